@@ -1,0 +1,160 @@
+/*
+ * relu_field.h -- C ABI of the MI355X (gfx950) ReLU-Fields render hot path.
+ *
+ * Shared library: thr3ed_atom_amd/csrc/librelu_field_hip.so (built by __graft_entry__.build()).
+ *
+ * The reference (akanimax/thr3ed_atom) is pure Python on PyTorch and has no FFI; its plug-in point for
+ * this path is the Python callable type
+ *     RenderProcedure = Callable[[Module, Rays, RenderConfig, Optional[int]], RenderOut]
+ *     (thre3d_atom/thre3d_reprs/renderers.py:22-25), invoked only at
+ *     thre3d_atom/modules/volumetric_model.py:112-114.
+ * The entry points below are what a binding for that path binds to (INTEGRATION.md shows the ctypes stub);
+ * each one names the reference code it replaces.
+ *
+ * Conventions
+ *  - All pointers named *_dev are DEVICE pointers owned by the caller (PyTorch allocations); the library
+ *    never allocates, frees or retains them.  All tensors are contiguous float32 unless a stride is given.
+ *  - Every call only ENQUEUES work on `stream` (a hipStream_t passed as void*); no implicit synchronisation.
+ *  - Re-entrant, no global state.  Return value: RF_OK (0) or a negative RF_ERR_* code; nothing is thrown
+ *    across the ABI.  rf_error_string() maps a code to text.
+ *  - Gradient buffers are ACCUMULATED into (+=) with float32 hardware atomics; the caller zero-fills them
+ *    (or keeps accumulating across several renders, which is autograd's semantics).
+ */
+#ifndef RELU_FIELD_H_
+#define RELU_FIELD_H_
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define RF_ABI_VERSION 1
+
+enum {
+  RF_OK = 0,
+  RF_ERR_NULL_POINTER = -1,
+  RF_ERR_BAD_SHAPE = -2,
+  RF_ERR_UNSUPPORTED = -3,
+  RF_ERR_LAUNCH = -4
+};
+
+/* density activation variants of VoxelGrid (thre3d_reprs/voxels.py:292-309; the three configurations the
+ * reference's trainer script builds: train_sh_based_voxel_grid_with_posed_images.py:169-192) */
+enum {
+  RF_DENSITY_RELU = 0,     /* pre = identity, post = ReLU      (the ReLU field)       */
+  RF_DENSITY_SOFTPLUS = 1, /* pre = identity, post = softplus(beta=1, threshold=20)   */
+  RF_DENSITY_ABS = 2,      /* pre = |.|,      post = identity  (traditional grid)     */
+  RF_DENSITY_IDENTITY = 3  /* pre = identity, post = identity                         */
+};
+
+/* render flags (SHVoxGridRenderConfig fields, thre3d_reprs/renderers.py:28-45) */
+enum {
+  RF_FLAG_WHITE_BKGD = 1,     /* white_bkgd                                                        */
+  RF_FLAG_RENDER_DIFFUSE = 2, /* render_diffuse: only the degree-0 SH coefficient of each colour   */
+  RF_FLAG_AABB_SAMPLING = 4,  /* optimized_sampling: per-ray [t_enter, t_exit] from the slab test  */
+  RF_FLAG_OCCUPANCY_SKIP = 8  /* use RFGrid.occupancy_dev to skip provably-empty cells (exact)     */
+};
+
+/* The dense SH + density voxel grid: VoxelGrid (thre3d_reprs/voxels.py:46-331). */
+typedef struct RFGrid {
+  const float* densities_dev; /* [X, Y, Z, 1]; z fastest                                              */
+  const float* features_dev;  /* [X, Y, Z, F]; F = 3 * (deg+1)^2, channel-major: index = colour*K + k  */
+  int32_t dims[3];            /* X, Y, Z                                                               */
+  int32_t num_features;       /* F in {3, 12, 27, 48}                                                  */
+  int64_t density_stride;     /* floats between consecutive voxels of densities_dev (1 = reference)   */
+  int64_t feature_stride;     /* floats between consecutive voxels of features_dev  (F = reference)   */
+  float aabb_min[3];          /* float32 planes of the bounding box (voxels.py:187-212)                */
+  float aabb_max[3];
+  float norm_scale[3];        /* q = p * scale + bias maps the AABB to [-1, 1] (voxels.py:214-223,     */
+  float norm_bias[3];         /*   utils/imaging_utils.py:58-63); computed by the host in float32      */
+  float density_scale;        /* expected_density_scale rho, applied BEFORE interpolation              */
+  int32_t density_mode;       /* RF_DENSITY_*                                                          */
+  const uint32_t* occupancy_dev; /* optional bit mask, one bit per cell incl. the border cells:
+                                    (X+1)*(Y+1)*(Z+1) bits, see rf_build_occupancy; may be NULL      */
+} RFGrid;
+
+/* Flat rays + sampling parameters: Rays (rendering/volumetric/render_interface.py:13-44),
+ * sample_uniform_points_on_rays (rendering/volumetric/sample.py:15-68). */
+typedef struct RFRayBatch {
+  const float* origins_dev;    /* [N, 3]                                                               */
+  const float* directions_dev; /* [N, 3], not normalised                                               */
+  int64_t num_rays;            /* N                                                                    */
+  int32_t num_samples;         /* S >= 1                                                               */
+  float near;                  /* CameraBounds.near / far (float32)                                    */
+  float far;
+  const float* t_vals_dev;     /* [S] = linspace(0, 1, S) (sample.py:46)                               */
+  const float* t_rand_dev;     /* [N, S] jitter in [0,1) (sample.py:63) or NULL = perturb off          */
+} RFRayBatch;
+
+/* Per-ray outputs: RenderOut (render_interface.py:47-83) + extra {"disparity", "accumulated_weight"}. */
+typedef struct RFRenderOut {
+  float* colour_dev;    /* [N, 3]                                                                      */
+  float* depth_dev;     /* [N]                                                                         */
+  float* acc_dev;       /* [N]                                                                         */
+  float* disparity_dev; /* [N]   (NaN where acc == 0, like the reference)                              */
+  /* Optional per-sample cache written by the forward pass and consumed by rf_render_backward
+   * (all three NULL for inference): */
+  float* sample_cache_dev; /* [N, S, 4] = (raw r, raw g, raw b, sigma)                                 */
+  float* trans_cache_dev;  /* [N, S]    = transmittance T_i                                            */
+  int32_t* stop_cache_dev; /* [N]       = number of samples the forward pass processed                 */
+} RFRenderOut;
+
+/* Upstream gradients of a render (all [N, ...] device arrays; any may be NULL = zero). */
+typedef struct RFRenderGrads {
+  const float* grad_colour_dev; /* [N, 3] */
+  const float* grad_depth_dev;  /* [N]    */
+  const float* grad_acc_dev;    /* [N]    */
+} RFRenderGrads;
+
+int rf_abi_version(void);
+const char* rf_error_string(int code);
+
+/* cast_rays (rendering/volumetric/utils/misc.py:12-50) + flatten_rays (:53-57):
+ * all H*W pixel-centre rays of one camera, row-major (ray = i*W + j).  rotation/translation are HOST
+ * pointers to 9 / 3 floats (camera-to-world). */
+int rf_cast_rays(int32_t height, int32_t width, float focal, const float* rotation_host,
+                 const float* translation_host, float* origins_dev, float* directions_dev, void* stream);
+
+/* The training-iteration ray source (modules/trainers.py:281-303): rays of the selected pixels only.
+ * pixel_index_dev[r] indexes the concatenation of B images: b*H*W + i*W + j; poses_dev is [B, 3, 4]
+ * (rotation | translation) on the device. */
+int rf_cast_selected_rays(int32_t height, int32_t width, float focal, const float* poses_dev,
+                          int32_t num_poses, const int64_t* pixel_index_dev, int64_t num_rays,
+                          float* origins_dev, float* directions_dev, void* stream);
+
+/* _ray_aabb_intersection (rendering/volumetric/sample.py:71-184): bounds_dev [N, 2], hit_dev [N] (0/1,
+ * may be NULL). */
+int rf_ray_aabb_bounds(const float* origins_dev, const float* directions_dev, int64_t num_rays, float near,
+                       float far, const float* aabb_min_host, const float* aabb_max_host,
+                       float* bounds_dev, float* hit_dev, void* stream);
+
+/* render_sh_voxel_grid (thre3d_reprs/renderers.py:48-102) = sampler (sample.py) -> VoxelGrid.forward
+ * (voxels.py:276-331) -> SH (utils/spherical_harmonics.py:64-116) -> AABB mask (process.py:80-84) ->
+ * compositing (accumulate.py:31-113), fused in one launch. */
+int rf_render_forward(const RFGrid* grid, const RFRayBatch* rays, uint32_t flags, const RFRenderOut* out,
+                      void* stream);
+
+/* The adjoint of rf_render_forward into the grid (the reference gets it from autograd:
+ * grid_sampler_3d_backward, cumprod_backward, ...).  `fwd` must hold the caches written by the matching
+ * forward call.  grad_densities_dev [X,Y,Z,1] and grad_features_dev [X,Y,Z,F] are accumulated into. */
+int rf_render_backward(const RFGrid* grid, const RFRayBatch* rays, uint32_t flags, const RFRenderOut* fwd,
+                       const RFRenderGrads* grads, float* grad_densities_dev, float* grad_features_dev,
+                       void* stream);
+
+/* Exact empty-cell mask for RF_FLAG_OCCUPANCY_SKIP (BASELINE.json configs[4]):
+ * bit (cx, cy, cz), cx in [0, X] etc., is set iff any of the (up to 8) grid nodes
+ * (cx-1..cx, cy-1..cy, cz-1..cz) that exist has a raw density that can yield sigma != 0 under
+ * `density_mode` (ReLU: D*rho > threshold; other modes: every cell is occupied).  With threshold = 0 and
+ * ReLU the skip is bit-exact.  occupancy_dev holds ceil((X+1)(Y+1)(Z+1)/32) words. */
+int rf_build_occupancy(const RFGrid* grid, float threshold, uint32_t* occupancy_dev, void* stream);
+
+/* Fused Adam step on a flat float32 parameter buffer (torch.optim.Adam semantics, betas/eps/lr given;
+ * modules/trainers.py:242-250,339-341).  step is the 1-based step count used for bias correction. */
+int rf_adam_step(float* param_dev, const float* grad_dev, float* exp_avg_dev, float* exp_avg_sq_dev,
+                 int64_t numel, float lr, float beta1, float beta2, float eps, int32_t step, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RELU_FIELD_H_ */

@@ -1,0 +1,156 @@
+"""ctypes binding of the C ABI in include/relu_field.h (thr3ed_atom_amd/csrc/librelu_field_hip.so).
+
+The library is the product: there is NO fallback.  ``load()`` raises when the shared object is
+missing and every wrapper raises ``RuntimeError`` on a non-zero return code.
+"""
+import ctypes as C
+import os
+import subprocess
+from typing import Optional
+
+CSRC_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc")
+INCLUDE_DIR = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "include")
+LIB_NAME = "librelu_field_hip.so"
+LIB_PATH = os.path.join(CSRC_DIR, LIB_NAME)
+SOURCES = ["relu_field_kernels.hip"]
+HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared"]
+
+# enums of relu_field.h
+DENSITY_MODES = {"relu": 0, "softplus": 1, "abs": 2, "identity": 3}
+FLAG_WHITE_BKGD = 1
+FLAG_RENDER_DIFFUSE = 2
+FLAG_AABB_SAMPLING = 4
+FLAG_OCCUPANCY_SKIP = 8
+
+EXPORTED_SYMBOLS = [
+    "rf_abi_version",
+    "rf_error_string",
+    "rf_cast_rays",
+    "rf_cast_selected_rays",
+    "rf_ray_aabb_bounds",
+    "rf_render_forward",
+    "rf_render_backward",
+    "rf_build_occupancy",
+    "rf_adam_step",
+]
+
+
+class RFGrid(C.Structure):
+    _fields_ = [
+        ("densities_dev", C.c_void_p),
+        ("features_dev", C.c_void_p),
+        ("dims", C.c_int32 * 3),
+        ("num_features", C.c_int32),
+        ("density_stride", C.c_int64),
+        ("feature_stride", C.c_int64),
+        ("aabb_min", C.c_float * 3),
+        ("aabb_max", C.c_float * 3),
+        ("norm_scale", C.c_float * 3),
+        ("norm_bias", C.c_float * 3),
+        ("density_scale", C.c_float),
+        ("density_mode", C.c_int32),
+        ("occupancy_dev", C.c_void_p),
+    ]
+
+
+class RFRayBatch(C.Structure):
+    _fields_ = [
+        ("origins_dev", C.c_void_p),
+        ("directions_dev", C.c_void_p),
+        ("num_rays", C.c_int64),
+        ("num_samples", C.c_int32),
+        ("near", C.c_float),
+        ("far", C.c_float),
+        ("t_vals_dev", C.c_void_p),
+        ("t_rand_dev", C.c_void_p),
+    ]
+
+
+class RFRenderOut(C.Structure):
+    _fields_ = [
+        ("colour_dev", C.c_void_p),
+        ("depth_dev", C.c_void_p),
+        ("acc_dev", C.c_void_p),
+        ("disparity_dev", C.c_void_p),
+        ("sample_cache_dev", C.c_void_p),
+        ("trans_cache_dev", C.c_void_p),
+        ("stop_cache_dev", C.c_void_p),
+    ]
+
+
+class RFRenderGrads(C.Structure):
+    _fields_ = [
+        ("grad_colour_dev", C.c_void_p),
+        ("grad_depth_dev", C.c_void_p),
+        ("grad_acc_dev", C.c_void_p),
+    ]
+
+
+def build(force: bool = False, verbose: bool = False) -> str:
+    """Cross-compile the HIP sources for gfx950 into csrc/librelu_field_hip.so (hipcc needs no GPU)."""
+    srcs = [os.path.join(CSRC_DIR, s) for s in SOURCES]
+    deps = srcs + [os.path.join(INCLUDE_DIR, "relu_field.h")]
+    if not force and os.path.exists(LIB_PATH):
+        if os.path.getmtime(LIB_PATH) >= max(os.path.getmtime(d) for d in deps):
+            return LIB_PATH
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    cmd = [hipcc] + HIPCC_FLAGS + ["-I", INCLUDE_DIR] + srcs + ["-o", LIB_PATH]
+    if verbose:
+        print(" ".join(cmd))
+    subprocess.run(cmd, check=True)
+    return LIB_PATH
+
+
+_LIB: Optional[C.CDLL] = None
+
+
+def load() -> C.CDLL:
+    """dlopen the HIP library; raises (never falls back) when it has not been built."""
+    global _LIB
+    if _LIB is not None:
+        return _LIB
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(
+            f"{LIB_PATH} is missing: the HIP render library has not been built. "
+            f"Run `python -c 'import __graft_entry__ as g; g.build()'` (needs hipcc). "
+            f"There is no CPU fallback for the render path."
+        )
+    lib = C.CDLL(LIB_PATH)
+    lib.rf_abi_version.restype = C.c_int
+    lib.rf_error_string.restype = C.c_char_p
+    lib.rf_error_string.argtypes = [C.c_int]
+    vp, i32, i64, f32, u32 = C.c_void_p, C.c_int32, C.c_int64, C.c_float, C.c_uint32
+    fp = C.POINTER(C.c_float)
+    lib.rf_cast_rays.argtypes = [i32, i32, f32, fp, fp, vp, vp, vp]
+    lib.rf_cast_selected_rays.argtypes = [i32, i32, f32, vp, i32, vp, i64, vp, vp, vp]
+    lib.rf_ray_aabb_bounds.argtypes = [vp, vp, i64, f32, f32, fp, fp, vp, vp, vp]
+    lib.rf_render_forward.argtypes = [C.POINTER(RFGrid), C.POINTER(RFRayBatch), u32, C.POINTER(RFRenderOut), vp]
+    lib.rf_render_backward.argtypes = [
+        C.POINTER(RFGrid),
+        C.POINTER(RFRayBatch),
+        u32,
+        C.POINTER(RFRenderOut),
+        C.POINTER(RFRenderGrads),
+        vp,
+        vp,
+        vp,
+    ]
+    lib.rf_build_occupancy.argtypes = [C.POINTER(RFGrid), f32, vp, vp]
+    lib.rf_adam_step.argtypes = [vp, vp, vp, vp, i64, f32, f32, f32, f32, i32, vp]
+    for name in EXPORTED_SYMBOLS:
+        if name not in ("rf_error_string",):
+            getattr(lib, name).restype = C.c_int
+    if lib.rf_abi_version() != 1:
+        raise RuntimeError(f"{LIB_PATH}: ABI version {lib.rf_abi_version()} != 1")
+    _LIB = lib
+    return lib
+
+
+def check(code: int, what: str) -> None:
+    if code != 0:
+        msg = load().rf_error_string(code).decode()
+        raise RuntimeError(f"{what} failed: {msg} (code {code})")
+
+
+def float3(values):
+    return (C.c_float * 3)(*[float(v) for v in values])

@@ -1,0 +1,1149 @@
+// relu_field_kernels.hip -- hand-written CDNA4 (gfx950, wave64) kernels of the ReLU-Fields render path.
+//
+// One wavefront renders one ray.  A ray is processed in chunks of 64 samples; each chunk runs three
+// phases that re-shape the wave instead of launching separate kernels:
+//
+//   P0  lanes = samples   z, point, AABB test, 8-corner density gather (+rho, +ReLU), alpha, wave-level
+//                         exclusive product scan -> transmittance T and weight w.  Samples whose
+//                         contribution is exactly zero (outside the box, sigma == 0 under ReLU, T == 0)
+//                         are dropped; the survivors are compacted into an LDS work list.
+//   P1  lanes = channels  LPS lanes cooperate on one sample: each lane fetches 4 consecutive feature
+//                         channels (16 B) of each of the 8 corners, so one corner is a contiguous 108-112 B
+//                         read.  Interpolate, apply the per-ray SH basis, butterfly-reduce to raw RGB.
+//   P2  lanes = samples   sigmoid, accumulate colour / acc / depth, optionally store the per-sample cache.
+//
+// Numerics follow the reference's CPU path operation by operation where it is cheap (this file is built
+// with -ffp-contract=off: every multiply and add below rounds separately unless fmaf is written):
+// the interpolation is the ATen grid_sample(align_corners=False, zeros padding) recipe restated in
+// oracle/relu_field_oracle.py:trilinear_recipe.
+//
+// Reference behaviour being replaced (paths relative to the reference repo):
+//   thre3d_atom/rendering/volumetric/sample.py, process.py, accumulate.py, utils/spherical_harmonics.py,
+//   utils/misc.py:12-50, thre3d_atom/thre3d_reprs/voxels.py:214-331, thre3d_reprs/renderers.py:48-102.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "relu_field.h"
+
+namespace {
+
+constexpr int kWave = 64;
+constexpr int kWavesPerBlock = 4;
+constexpr int kBlock = kWave * kWavesPerBlock;
+constexpr float kInfinity = 1e10f;   // thre3d_atom/utils/constants.py:8
+constexpr float kZeroPlus = 1e-10f;  // thre3d_atom/utils/constants.py:7
+
+// real SH constants (utils/spherical_harmonics.py:33-52), rounded to float32 like torch does when a
+// Python float multiplies a float32 tensor
+constexpr float kC0 = 0.28209479177387814f;
+constexpr float kC1 = 0.4886025119029199f;
+constexpr float kC2_0 = 1.0925484305920792f;
+constexpr float kC2_1 = -1.0925484305920792f;
+constexpr float kC2_2 = 0.31539156525252005f;
+constexpr float kC2_3 = -1.0925484305920792f;
+constexpr float kC2_4 = 0.5462742152960396f;
+constexpr float kC3_0 = -0.5900435899266435f;
+constexpr float kC3_1 = 2.890611442640554f;
+constexpr float kC3_2 = -0.4570457994644658f;
+constexpr float kC3_3 = 0.3731763325901154f;
+constexpr float kC3_4 = -0.4570457994644658f;
+constexpr float kC3_5 = 1.445305721320277f;
+constexpr float kC3_6 = -0.5900435899266435f;
+
+struct GridArgs {
+  const float* dens;
+  const float* feat;
+  const uint32_t* occ;
+  int X, Y, Z, F;
+  long long dstride, fstride;
+  float amin[3], amax[3], nscale[3], nbias[3];
+  float rho;
+  int mode;
+};
+
+struct RayArgs {
+  const float* origins;
+  const float* directions;
+  long long n;
+  int S;
+  float near, far;
+  const float* tvals;
+  const float* trand;
+};
+
+struct OutArgs {
+  float* colour;
+  float* depth;
+  float* acc;
+  float* disparity;
+  float* cache;   // [N,S,4]
+  float* tcache;  // [N,S]
+  int* stop;      // [N]
+};
+
+struct GradArgs {
+  const float* gcolour;
+  const float* gdepth;
+  const float* gacc;
+  float* gdens;
+  float* gfeat;
+};
+
+// 16-byte load/store at 4-byte alignment (a corner's 27 features start at a multiple of 108 B)
+struct __attribute__((packed, aligned(4))) f4u {
+  float v[4];
+};
+struct __attribute__((packed, aligned(4))) f3u {
+  float v[3];
+};
+
+// ---------------------------------------------------------------------------------------------
+// wave-level helpers (64 lanes)
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ void wave_lds_fence() {
+  // LDS traffic of one wave is executed in order; this only stops the compiler from moving LDS accesses
+  // across the phase boundary.
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+__device__ __forceinline__ float wave_incl_scan_mul(float x, int lane) {
+#pragma unroll
+  for (int off = 1; off < kWave; off <<= 1) {
+    float y = __shfl_up(x, off, kWave);
+    if (lane >= off) x = x * y;
+  }
+  return x;
+}
+
+// inclusive SUFFIX sum: result[lane] = sum_{l >= lane} x[l]
+__device__ __forceinline__ float wave_incl_rscan_add(float x, int lane) {
+#pragma unroll
+  for (int off = 1; off < kWave; off <<= 1) {
+    float y = __shfl_down(x, off, kWave);
+    if (lane + off < kWave) x = x + y;
+  }
+  return x;
+}
+
+__device__ __forceinline__ float wave_sum(float x) {
+#pragma unroll
+  for (int off = kWave / 2; off > 0; off >>= 1) x += __shfl_xor(x, off, kWave);
+  return x;
+}
+
+__device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + expf(-x)); }
+
+// ---------------------------------------------------------------------------------------------
+// sampling (rendering/volumetric/sample.py:39-68)
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ float z_uniform(float near, float far, float t) { return near * (1.0f - t) + far * t; }
+
+__device__ __forceinline__ float z_sample(const float* __restrict__ tv, const float* __restrict__ tr, int s, int S,
+                                          float near, float far) {
+  const float zc = z_uniform(near, far, tv[s]);
+  if (tr == nullptr) return zc;
+  // stratified jitter: lower/upper = neighbouring mid-points (sample.py:57-64)
+  const float lo = (s > 0) ? 0.5f * (zc + z_uniform(near, far, tv[s - 1])) : zc;
+  const float hi = (s < S - 1) ? 0.5f * (z_uniform(near, far, tv[s + 1]) + zc) : zc;
+  return lo + (hi - lo) * tr[s];
+}
+
+// slab test of sample.py:71-184; returns true when the ray hits, writes the (clamped) bounds either way
+__device__ __forceinline__ bool ray_box(const float o[3], const float d[3], const float bmin[3], const float bmax[3],
+                                        float near, float far, float& t0, float& t1) {
+  float lo_run = 0.f, hi_run = 0.f;
+  bool hit = true;
+#pragma unroll
+  for (int a = 0; a < 3; ++a) {
+    const float den = d[a] + kZeroPlus;
+    const float ta = (bmin[a] - o[a]) / den;
+    const float tb = (bmax[a] - o[a]) / den;
+    const bool swap = ta > tb;
+    const float lo = swap ? tb : ta;
+    const float hi = swap ? ta : tb;
+    if (a == 0) {
+      lo_run = lo;
+      hi_run = hi;
+    } else {
+      hit = hit && !((lo_run > hi) || (lo > hi_run));
+      lo_run = (lo > lo_run) ? lo : lo_run;
+      hi_run = (hi < hi_run) ? hi : hi_run;
+    }
+  }
+  t0 = hit ? lo_run : near;
+  t1 = hit ? hi_run : far;
+  t0 = (t0 < 0.f) ? 0.f : t0;  // torch.clip(min=0): NaN stays NaN, like the reference
+  t1 = (t1 < 0.f) ? 0.f : t1;
+  return hit;
+}
+
+// ---------------------------------------------------------------------------------------------
+// per-sample geometry (voxels.py:214-223 normalise, GridSampler.h:27-36 un-normalise)
+// ---------------------------------------------------------------------------------------------
+struct Cell {
+  int i0[3];     // floor of the continuous index (may be -1)
+  float w0[3];   // weight of the lower node along each axis  = (i0 + 1) - idx
+  float w1[3];   // weight of the upper node                   = idx - i0
+};
+
+__device__ __forceinline__ Cell locate(const float p[3], const GridArgs& g) {
+  Cell c;
+  const int dims[3] = {g.X, g.Y, g.Z};
+#pragma unroll
+  for (int a = 0; a < 3; ++a) {
+    const float q = p[a] * g.nscale[a] + g.nbias[a];
+    const float idx = ((q + 1.0f) * (float)dims[a] - 1.0f) / 2.0f;
+    const float fl = floorf(idx);
+    c.i0[a] = (int)fl;
+    c.w1[a] = idx - fl;
+    c.w0[a] = (fl + 1.0f) - idx;
+  }
+  return c;
+}
+
+// LDS work-list entry: 8 dwords (forward) / 12 dwords (backward)
+//   [0] (ix0+1) | (iy0+1) << 11 | (iz0+1) << 22      (grid dims <= 2046)
+//   [1] sample lane in the chunk
+//   [2..7] w0x w1x w0y w1y w0z w1z
+//   [8..11] backward only: dL/d(pre-activation density), dL/d(raw r, g, b)
+constexpr int kEntryFwd = 8;
+constexpr int kEntryBwd = 12;
+
+__device__ __forceinline__ uint32_t pack_cell(const Cell& c) {
+  return (uint32_t)(c.i0[0] + 1) | ((uint32_t)(c.i0[1] + 1) << 11) | ((uint32_t)(c.i0[2] + 1) << 22);
+}
+
+struct Corners {
+  long long lin[8];  // linear voxel index of the (clamped) corner, order dx fastest, then dy, then dz
+  float w[8];        // trilinear weight, forced to 0 for corners outside the grid
+};
+
+__device__ __forceinline__ Corners corners_of(uint32_t packed, const float wts[6], const GridArgs& g) {
+  const int ix0 = (int)(packed & 0x7ffu) - 1, iy0 = (int)((packed >> 11) & 0x7ffu) - 1, iz0 = (int)(packed >> 22) - 1;
+  const bool okx[2] = {ix0 >= 0 && ix0 < g.X, ix0 + 1 >= 0 && ix0 + 1 < g.X};
+  const bool oky[2] = {iy0 >= 0 && iy0 < g.Y, iy0 + 1 >= 0 && iy0 + 1 < g.Y};
+  const bool okz[2] = {iz0 >= 0 && iz0 < g.Z, iz0 + 1 >= 0 && iz0 + 1 < g.Z};
+  const int cx[2] = {min(max(ix0, 0), g.X - 1), min(max(ix0 + 1, 0), g.X - 1)};
+  const int cy[2] = {min(max(iy0, 0), g.Y - 1), min(max(iy0 + 1, 0), g.Y - 1)};
+  const int cz[2] = {min(max(iz0, 0), g.Z - 1), min(max(iz0 + 1, 0), g.Z - 1)};
+  Corners c;
+#pragma unroll
+  for (int k = 0; k < 8; ++k) {
+    const int dx = k & 1, dy = (k >> 1) & 1, dz = k >> 2;
+    c.lin[k] = ((long long)cx[dx] * g.Y + cy[dy]) * g.Z + cz[dz];
+    const float w = (wts[0 + dx] * wts[2 + dy]) * wts[4 + dz];
+    c.w[k] = (okx[dx] && oky[dy] && okz[dz]) ? w : 0.0f;
+  }
+  return c;
+}
+
+// density: post( interp( pre(D * rho) ) )  (voxels.py:292-309)
+__device__ __forceinline__ float interp_density(const Corners& c, const GridArgs& g, float& pre_out) {
+  float acc = 0.0f;
+#pragma unroll
+  for (int k = 0; k < 8; ++k) {
+    float v = g.dens[c.lin[k] * g.dstride] * g.rho;
+    if (g.mode == RF_DENSITY_ABS) v = fabsf(v);
+    acc = acc + v * c.w[k];
+  }
+  pre_out = acc;
+  if (g.mode == RF_DENSITY_RELU) return fmaxf(acc, 0.0f);
+  if (g.mode == RF_DENSITY_SOFTPLUS) return (acc > 20.0f) ? acc : log1pf(expf(acc));
+  return acc;
+}
+
+// signed SH basis in the reference's operation order (utils/spherical_harmonics.py:86-116)
+template <int K>
+__device__ __forceinline__ void sh_basis(float x, float y, float z, float Y[16]) {
+  Y[0] = kC0;
+  if (K > 1) {
+    Y[1] = -(kC1 * y);
+    Y[2] = kC1 * z;
+    Y[3] = -(kC1 * x);
+  }
+  if (K > 4) {
+    const float xx = x * x, yy = y * y, zz = z * z, xy = x * y, yz = y * z, xz = x * z;
+    Y[4] = kC2_0 * xy;
+    Y[5] = kC2_1 * yz;
+    Y[6] = kC2_2 * ((2.0f * zz - xx) - yy);
+    Y[7] = kC2_3 * xz;
+    Y[8] = kC2_4 * (xx - yy);
+    if (K > 9) {
+      Y[9] = (kC3_0 * y) * (3.0f * xx - yy);
+      Y[10] = (kC3_1 * xy) * z;
+      Y[11] = (kC3_2 * y) * ((4.0f * zz - xx) - yy);
+      Y[12] = (kC3_3 * z) * ((2.0f * zz - 3.0f * xx) - 3.0f * yy);
+      Y[13] = (kC3_4 * x) * ((4.0f * zz - xx) - yy);
+      Y[14] = (kC3_5 * z) * (xx - yy);
+      Y[15] = (kC3_6 * x) * (xx - 3.0f * yy);
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// per-ray state shared by forward and backward
+// ---------------------------------------------------------------------------------------------
+struct RayState {
+  float o[3], d[3];
+  float dnorm;
+  float near, far;
+};
+
+__device__ __forceinline__ RayState load_ray(const RayArgs& r, const GridArgs& g, long long ray, uint32_t flags) {
+  RayState st;
+#pragma unroll
+  for (int a = 0; a < 3; ++a) {
+    st.o[a] = r.origins[ray * 3 + a];
+    st.d[a] = r.directions[ray * 3 + a];
+  }
+  st.dnorm = sqrtf((st.d[0] * st.d[0] + st.d[1] * st.d[1]) + st.d[2] * st.d[2]);
+  st.near = r.near;
+  st.far = r.far;
+  if (flags & RF_FLAG_AABB_SAMPLING) {
+    float t0, t1;
+    ray_box(st.o, st.d, g.amin, g.amax, r.near, r.far, t0, t1);
+    st.near = t0;
+    st.far = t1;
+  }
+  return st;
+}
+
+// everything P0 knows about one sample
+struct Sample {
+  float z, delta;
+  bool valid, inside;
+  Cell cell;
+};
+
+__device__ __forceinline__ Sample make_sample(const RayState& st, const RayArgs& r, const GridArgs& g, long long ray,
+                                              int s) {
+  Sample sm;
+  sm.valid = s < r.S;
+  const int sc = sm.valid ? s : r.S - 1;
+  const float* tr = r.trand ? r.trand + ray * (long long)r.S : nullptr;
+  sm.z = z_sample(r.tvals, tr, sc, r.S, st.near, st.far);
+  if (sc < r.S - 1) {
+    const float zn = z_sample(r.tvals, tr, sc + 1, r.S, st.near, st.far);
+    sm.delta = (zn - sm.z) * st.dnorm;
+  } else {
+    sm.delta = kInfinity * st.dnorm;  // accumulate.py:50-55
+  }
+  float p[3];
+#pragma unroll
+  for (int a = 0; a < 3; ++a) p[a] = st.o[a] + st.d[a] * sm.z;
+  sm.inside = sm.valid && p[0] > g.amin[0] && p[0] < g.amax[0] && p[1] > g.amin[1] && p[1] < g.amax[1] &&
+              p[2] > g.amin[2] && p[2] < g.amax[2];  // strict, voxels.py:252-274
+  sm.cell = locate(p, g);
+  return sm;
+}
+
+__device__ __forceinline__ bool cell_occupied(const Cell& c, const GridArgs& g) {
+  // bit index over the (X+1)(Y+1)(Z+1) cells whose lower node is i0 in [-1, dim-1]
+  const long long bit = ((long long)(c.i0[0] + 1) * (g.Y + 1) + (c.i0[1] + 1)) * (g.Z + 1) + (c.i0[2] + 1);
+  return (g.occ[bit >> 5] >> (bit & 31)) & 1u;
+}
+
+// ---------------------------------------------------------------------------------------------
+// feature gather for LPS lanes per sample (P1).  Returns raw RGB in every lane of the group.
+//   CORNER mode (K_READ == 1; SH degree 0 or render_diffuse): lane = corner, 3 channels per lane.
+//   CHANNEL mode: lane l owns features [fb, fb+4), fb = min(4l, F-4); first owned element j0 = 4l - fb.
+// ---------------------------------------------------------------------------------------------
+template <int K, bool DIFFUSE>
+struct Layout {
+  static constexpr bool kCorner = DIFFUSE || K == 1;
+  static constexpr int kF = 3 * K;
+  static constexpr int kLPS = kCorner ? 8 : (K == 4 ? 4 : (K == 9 ? 8 : 16));
+  static constexpr int kGroups = kWave / kLPS;
+};
+
+template <int LPS>
+__device__ __forceinline__ float group_sum(float x) {
+#pragma unroll
+  for (int off = 1; off < LPS; off <<= 1) x += __shfl_xor(x, off, kWave);
+  return x;
+}
+
+
+// The slice of the per-ray SH basis a P1 lane needs: lane `sub` of a group owns features [fb, fb+4) with
+// fb = min(4 sub, F-4) (the last lane is shifted back so that it never reads past the corner's features;
+// its first `j0` elements belong to the previous lane and are ignored).  The basis is staged through a
+// 16-float LDS row of the wave so that the dynamic index (f % K) never touches scratch memory.
+template <int K, int LPS>
+__device__ __forceinline__ void lane_basis(const float d[3], float dnorm, int lane, float* ldsY, float yb[4],
+                                           int chan[4], int& fb) {
+  constexpr int F = 3 * K;
+  float Y[16];
+  sh_basis<K>(d[0] / dnorm, d[1] / dnorm, d[2] / dnorm, Y);  // v = d / |d| (process.py:53)
+  if (lane == 0) {
+#pragma unroll
+    for (int k = 0; k < K; ++k) ldsY[k] = Y[k];
+  }
+  wave_lds_fence();
+  const int sub = lane % LPS;
+  fb = min(4 * sub, F - 4);
+  const int j0 = 4 * sub - fb;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int f = fb + j;
+    const bool own = (4 * sub < F) && (j >= j0);
+    chan[j] = own ? f / K : -1;
+    yb[j] = own ? ldsY[f % K] : 0.0f;
+  }
+}
+
+// =============================================================================================
+// forward
+// =============================================================================================
+template <int K, bool DIFFUSE, bool SAVE>
+__global__ __launch_bounds__(kBlock) void render_forward_kernel(GridArgs g, RayArgs r, OutArgs out, uint32_t flags) {
+  using L = Layout<K, DIFFUSE>;
+  constexpr int LPS = L::kLPS;
+  constexpr int GROUPS = L::kGroups;
+
+  __shared__ __attribute__((aligned(16))) uint32_t s_entry[kWavesPerBlock][kWave * kEntryFwd];
+  __shared__ __attribute__((aligned(16))) float s_rgb[kWavesPerBlock][kWave * 4];
+
+  const int lane = threadIdx.x & (kWave - 1);
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const long long ray = (long long)blockIdx.x * kWavesPerBlock + wave;
+  if (ray >= r.n) return;
+
+  const RayState st = load_ray(r, g, ray, flags);
+  const bool white = flags & RF_FLAG_WHITE_BKGD;
+  const bool use_occ = (flags & RF_FLAG_OCCUPANCY_SKIP) && g.occ != nullptr;
+
+  // per-ray SH basis, then the per-lane slice of it used in P1
+  const int sub = lane % LPS;
+  const int group = lane / LPS;
+  float yb[4] = {0.f, 0.f, 0.f, 0.f};
+  int chan[4] = {-1, -1, -1, -1};
+  int fb = 0;
+  if constexpr (!L::kCorner) lane_basis<K, LPS>(st.d, st.dnorm, lane, s_rgb[wave], yb, chan, fb);
+
+  uint32_t* my_entry = s_entry[wave];
+  float* my_rgb = s_rgb[wave];
+
+  float T_carry = 1.0f;
+  float part_c[3] = {0.f, 0.f, 0.f};
+  float part_acc = 0.f, part_depth = 0.f;
+  int processed = 0;
+
+  const int nchunks = (r.S + kWave - 1) / kWave;
+  for (int chunk = 0; chunk < nchunks; ++chunk) {
+    const int s = chunk * kWave + lane;
+    // ---------------- P0: lanes = samples ----------------
+    Sample sm = make_sample(st, r, g, ray, s);
+    bool live = sm.inside;
+    if (use_occ && live) live = cell_occupied(sm.cell, g);
+    float sigma = 0.0f;
+    Corners cn;
+    float wts[6] = {sm.cell.w0[0], sm.cell.w1[0], sm.cell.w0[1], sm.cell.w1[1], sm.cell.w0[2], sm.cell.w1[2]};
+    const uint32_t packed = pack_cell(sm.cell);
+    if (live) {
+      cn = corners_of(packed, wts, g);
+      float pre;
+      sigma = interp_density(cn, g, pre);
+    }
+    const float alpha = 1.0f - expf(-(sigma * sm.delta));  // density2occupancy_pb, accumulate.py:24-28
+    const float one_minus = 1.0f - alpha;
+    const float incl = wave_incl_scan_mul(sm.valid ? one_minus : 1.0f, lane);
+    float excl = __shfl_up(incl, 1, kWave);
+    if (lane == 0) excl = 1.0f;
+    const float T = T_carry * excl;
+    const float w = alpha * T;
+    T_carry = T_carry * __shfl(incl, kWave - 1, kWave);
+    processed = min(r.S, (chunk + 1) * kWave);
+
+    // a sample needs its colour only if it can contribute: inside, T != 0 and (under ReLU) sigma != 0
+    const bool need = live && (T != 0.0f) && !(g.mode == RF_DENSITY_RELU && sigma == 0.0f);
+    const unsigned long long mask = __ballot(need);
+    const int count = __popcll(mask);
+    if (need) {
+      const int slot = __popcll(mask & ((1ull << lane) - 1ull));
+      uint32_t* e = my_entry + slot * kEntryFwd;
+      e[0] = packed;
+      e[1] = (uint32_t)lane;
+#pragma unroll
+      for (int i = 0; i < 6; ++i) e[2 + i] = __float_as_uint(wts[i]);
+    }
+    my_rgb[lane * 4 + 0] = 0.f;
+    my_rgb[lane * 4 + 1] = 0.f;
+    my_rgb[lane * 4 + 2] = 0.f;
+    wave_lds_fence();
+
+    // ---------------- P1: LPS lanes per sample ----------------
+    for (int base = 0; base < count; base += GROUPS) {
+      const int slot = base + group;
+      const bool has = slot < count;
+      float rgb[3] = {0.f, 0.f, 0.f};
+      int dst_lane = 0;
+      if (has) {
+        const uint32_t* e = my_entry + slot * kEntryFwd;
+        const uint32_t pk = e[0];
+        dst_lane = (int)e[1];
+        float ew[6];
+#pragma unroll
+        for (int i = 0; i < 6; ++i) ew[i] = __uint_as_float(e[2 + i]);
+        const Corners c = corners_of(pk, ew, g);
+        if constexpr (L::kCorner) {
+          // lane = corner `sub`; channels 0, K_full, 2*K_full of that corner
+          const int kfull = g.F / 3;
+          long long lin = c.lin[0];
+          float wk = c.w[0];
+#pragma unroll
+          for (int k = 1; k < 8; ++k) {
+            lin = (sub == k) ? c.lin[k] : lin;
+            wk = (sub == k) ? c.w[k] : wk;
+          }
+          const float* fp = g.feat + lin * g.fstride;
+          float v0, v1, v2;
+          if (kfull == 1) {
+            const f3u t = *reinterpret_cast<const f3u*>(fp);
+            v0 = t.v[0];
+            v1 = t.v[1];
+            v2 = t.v[2];
+          } else {
+            v0 = fp[0];
+            v1 = fp[kfull];
+            v2 = fp[2 * kfull];
+          }
+          rgb[0] = v0 * wk;
+          rgb[1] = v1 * wk;
+          rgb[2] = v2 * wk;
+        } else {
+          float a4[4] = {0.f, 0.f, 0.f, 0.f};
+          if (4 * sub < L::kF) {
+            f4u v[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) v[k] = *reinterpret_cast<const f4u*>(g.feat + c.lin[k] * g.fstride + fb);
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+#pragma unroll
+              for (int j = 0; j < 4; ++j) a4[j] = a4[j] + v[k].v[j] * c.w[k];
+            }
+          }
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            const float term = yb[j] * a4[j];
+#pragma unroll
+            for (int ch = 0; ch < 3; ++ch) rgb[ch] += (chan[j] == ch) ? term : 0.0f;
+          }
+        }
+      }
+#pragma unroll
+      for (int ch = 0; ch < 3; ++ch) rgb[ch] = group_sum<LPS>(rgb[ch]);
+      if (has && sub == 0) {
+        if constexpr (L::kCorner) {
+#pragma unroll
+          for (int ch = 0; ch < 3; ++ch) rgb[ch] = kC0 * rgb[ch];
+        }
+        my_rgb[dst_lane * 4 + 0] = rgb[0];
+        my_rgb[dst_lane * 4 + 1] = rgb[1];
+        my_rgb[dst_lane * 4 + 2] = rgb[2];
+      }
+    }
+    wave_lds_fence();
+
+    // ---------------- P2: lanes = samples ----------------
+    const float raw_r = my_rgb[lane * 4 + 0], raw_g = my_rgb[lane * 4 + 1], raw_b = my_rgb[lane * 4 + 2];
+    if (need) {
+      part_c[0] += w * sigmoidf_(raw_r);
+      part_c[1] += w * sigmoidf_(raw_g);
+      part_c[2] += w * sigmoidf_(raw_b);
+    }
+    if (sm.valid) {
+      part_acc += w;
+      part_depth += w * sm.z;
+    }
+    if constexpr (SAVE) {
+      if (sm.valid) {
+        const long long idx = ray * (long long)r.S + s;
+        float4 cv;
+        cv.x = raw_r;
+        cv.y = raw_g;
+        cv.z = raw_b;
+        cv.w = sigma;
+        reinterpret_cast<float4*>(out.cache)[idx] = cv;
+        out.tcache[idx] = T;
+      }
+    }
+    wave_lds_fence();
+    if (T_carry == 0.0f) break;  // every later weight is exactly 0
+  }
+
+  const float cr = wave_sum(part_c[0]), cg = wave_sum(part_c[1]), cb = wave_sum(part_c[2]);
+  const float acc = wave_sum(part_acc), depth = wave_sum(part_depth);
+  if (lane == 0) {
+    const float bg = white ? (1.0f - acc) : 0.0f;
+    out.colour[ray * 3 + 0] = white ? cr + bg : cr;
+    out.colour[ray * 3 + 1] = white ? cg + bg : cg;
+    out.colour[ray * 3 + 2] = white ? cb + bg : cb;
+    out.depth[ray] = depth;
+    out.acc[ray] = acc;
+    const float q = depth / acc;  // 0/0 = NaN propagates like torch.maximum (accumulate.py:85-88)
+    out.disparity[ray] = 1.0f / ((q != q) ? q : fmaxf(kZeroPlus, q));
+    if constexpr (SAVE) out.stop[ray] = processed;
+  }
+}
+
+// =============================================================================================
+// backward: dL/d(densities), dL/d(features) from dL/d(colour, depth, acc)
+//
+// With e_i = sum_ch gC[ch] (c_i[ch] - [white]) + gD z_i + gA :
+//   dL/dR_i[ch] = w_i gC[ch] c_i (1 - c_i)
+//   dL/dsigma_i = delta_i ( T_{i+1} e_i - sum_{j>i} w_j e_j ),   T_{i+1} = T_i (1 - alpha_i)   (division-free)
+// Chunks are walked from the far end so that the suffix sum is an exact running sum.
+// =============================================================================================
+template <int K, bool DIFFUSE>
+__global__ __launch_bounds__(kBlock) void render_backward_kernel(GridArgs g, RayArgs r, OutArgs fwd, GradArgs gr,
+                                                                 uint32_t flags) {
+  using L = Layout<K, DIFFUSE>;
+  constexpr int LPS = L::kLPS;
+  constexpr int GROUPS = L::kGroups;
+
+  __shared__ __attribute__((aligned(16))) uint32_t s_entry[kWavesPerBlock][kWave * kEntryBwd];
+
+  const int lane = threadIdx.x & (kWave - 1);
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const long long ray = (long long)blockIdx.x * kWavesPerBlock + wave;
+  if (ray >= r.n) return;
+
+  const RayState st = load_ray(r, g, ray, flags);
+  const float white = (flags & RF_FLAG_WHITE_BKGD) ? 1.0f : 0.0f;
+  float gC[3] = {0.f, 0.f, 0.f};
+  if (gr.gcolour) {
+    gC[0] = gr.gcolour[ray * 3 + 0];
+    gC[1] = gr.gcolour[ray * 3 + 1];
+    gC[2] = gr.gcolour[ray * 3 + 2];
+  }
+  const float gD = gr.gdepth ? gr.gdepth[ray] : 0.0f;
+  const float gA = gr.gacc ? gr.gacc[ray] : 0.0f;
+  if (gC[0] == 0.f && gC[1] == 0.f && gC[2] == 0.f && gD == 0.f && gA == 0.f) return;
+
+  const int sub = lane % LPS;
+  const int group = lane / LPS;
+  float yb[4] = {0.f, 0.f, 0.f, 0.f};
+  int chan[4] = {-1, -1, -1, -1};
+  int fb = 0;
+  if constexpr (!L::kCorner)
+    lane_basis<K, LPS>(st.d, st.dnorm, lane, reinterpret_cast<float*>(s_entry[wave]), yb, chan, fb);
+  uint32_t* my_entry = s_entry[wave];
+
+  const int processed = fwd.stop[ray];
+  const int nchunks = (processed + kWave - 1) / kWave;
+  float suffix = 0.0f;  // sum of w_j e_j over all samples beyond the current chunk
+
+  for (int chunk = nchunks - 1; chunk >= 0; --chunk) {
+    const int s = chunk * kWave + lane;
+    Sample sm = make_sample(st, r, g, ray, s);
+    const bool have = sm.valid && s < processed;
+    float raw[3] = {0.f, 0.f, 0.f};
+    float sigma = 0.f, T = 0.f;
+    if (have) {
+      const long long idx = ray * (long long)r.S + s;
+      const float4 cv = reinterpret_cast<const float4*>(fwd.cache)[idx];
+      raw[0] = cv.x;
+      raw[1] = cv.y;
+      raw[2] = cv.z;
+      sigma = cv.w;
+      T = fwd.tcache[idx];
+    }
+    const float alpha = 1.0f - expf(-(sigma * sm.delta));
+    const float w = alpha * T;
+    const float Tn = T * (1.0f - alpha);
+    float c[3], e = gD * sm.z + gA;
+#pragma unroll
+    for (int ch = 0; ch < 3; ++ch) {
+      c[ch] = sigmoidf_(raw[ch]);
+      e += gC[ch] * (c[ch] - white);
+    }
+    const float we = have ? w * e : 0.0f;
+    const float incl = wave_incl_rscan_add(we, lane);
+    const float after = (incl - we) + suffix;  // sum over samples strictly behind this one
+    suffix += __shfl(incl, 0, kWave);
+
+    float g_sigma = sm.delta * (Tn * e - after);
+    float g_pre;
+    if (g.mode == RF_DENSITY_RELU)
+      g_pre = (sigma > 0.0f) ? g_sigma : 0.0f;
+    else if (g.mode == RF_DENSITY_SOFTPLUS)
+      g_pre = g_sigma * (1.0f - expf(-sigma));  // softplus'(x) = sigmoid(x) = 1 - exp(-softplus(x))
+    else
+      g_pre = g_sigma;
+    float g_raw[3];
+#pragma unroll
+    for (int ch = 0; ch < 3; ++ch) g_raw[ch] = (w * gC[ch]) * (c[ch] * (1.0f - c[ch]));
+
+    const bool live = have && sm.inside;
+    const bool need = live && (g_pre != 0.f || g_raw[0] != 0.f || g_raw[1] != 0.f || g_raw[2] != 0.f);
+    const unsigned long long mask = __ballot(need);
+    const int count = __popcll(mask);
+    if (need) {
+      const int slot = __popcll(mask & ((1ull << lane) - 1ull));
+      uint32_t* en = my_entry + slot * kEntryBwd;
+      en[0] = pack_cell(sm.cell);
+      en[1] = (uint32_t)lane;
+      en[2] = __float_as_uint(sm.cell.w0[0]);
+      en[3] = __float_as_uint(sm.cell.w1[0]);
+      en[4] = __float_as_uint(sm.cell.w0[1]);
+      en[5] = __float_as_uint(sm.cell.w1[1]);
+      en[6] = __float_as_uint(sm.cell.w0[2]);
+      en[7] = __float_as_uint(sm.cell.w1[2]);
+      en[8] = __float_as_uint(g_pre);
+      en[9] = __float_as_uint(g_raw[0]);
+      en[10] = __float_as_uint(g_raw[1]);
+      en[11] = __float_as_uint(g_raw[2]);
+    }
+    wave_lds_fence();
+
+    // scatter: LPS lanes per sample
+    for (int base = 0; base < count; base += GROUPS) {
+      const int slot = base + group;
+      if (slot < count) {
+        const uint32_t* en = my_entry + slot * kEntryBwd;
+        float ew[6];
+#pragma unroll
+        for (int i = 0; i < 6; ++i) ew[i] = __uint_as_float(en[2 + i]);
+        const Corners cn = corners_of(en[0], ew, g);
+        const float gp = __uint_as_float(en[8]);
+        const float gr3[3] = {__uint_as_float(en[9]), __uint_as_float(en[10]), __uint_as_float(en[11])};
+
+        // density: corner `k` handled by lane k % LPS
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+          if ((k % LPS) == sub && cn.w[k] != 0.0f && gp != 0.0f) {
+            float gv = (cn.w[k] * gp) * g.rho;
+            if (g.mode == RF_DENSITY_ABS) {
+              const float dv = g.dens[cn.lin[k] * g.dstride] * g.rho;
+              gv = (dv > 0.f) ? gv : ((dv < 0.f) ? -gv : 0.0f);
+            }
+            unsafeAtomicAdd(gr.gdens + cn.lin[k] * g.dstride, gv);
+          }
+        }
+        if constexpr (L::kCorner) {
+          const int kfull = g.F / 3;
+          long long lin = cn.lin[0];
+          float wk = cn.w[0];
+#pragma unroll
+          for (int k = 1; k < 8; ++k) {
+            lin = (sub == k) ? cn.lin[k] : lin;
+            wk = (sub == k) ? cn.w[k] : wk;
+          }
+          if (wk != 0.0f) {
+            float* fp = gr.gfeat + lin * g.fstride;
+#pragma unroll
+            for (int ch = 0; ch < 3; ++ch) {
+              const float gv = wk * (gr3[ch] * kC0);
+              if (gv != 0.0f) unsafeAtomicAdd(fp + ch * kfull, gv);
+            }
+          }
+        } else {
+          if (4 * sub < L::kF) {
+            float gf[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+              float gsel = 0.0f;
+#pragma unroll
+              for (int ch = 0; ch < 3; ++ch) gsel = (chan[j] == ch) ? gr3[ch] : gsel;
+              gf[j] = gsel * yb[j];
+            }
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+              if (cn.w[k] != 0.0f) {
+                float* fp = gr.gfeat + cn.lin[k] * g.fstride + fb;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                  if (chan[j] >= 0) unsafeAtomicAdd(fp + j, cn.w[k] * gf[j]);
+                }
+              }
+            }
+          }
+        }
+      }
+    }
+    wave_lds_fence();
+  }
+}
+
+// =============================================================================================
+// ray generation (rendering/volumetric/utils/misc.py:12-50)
+// =============================================================================================
+struct Pose {
+  float r[9];
+  float t[3];
+};
+
+__device__ __forceinline__ void pixel_ray(int i, int j, int H, int W, float focal, const float* R, float d[3]) {
+  // pixel centres; camera looks along -z, y up
+  const float cx = (((float)j + 0.5f) - (float)W * 0.5f) / focal;
+  const float cy = -((((float)i + 0.5f) - (float)H * 0.5f) / focal);
+  const float cz = -1.0f;
+#pragma unroll
+  for (int a = 0; a < 3; ++a) d[a] = (R[a * 3 + 0] * cx + R[a * 3 + 1] * cy) + R[a * 3 + 2] * cz;
+}
+
+__global__ void cast_rays_kernel(int H, int W, float focal, Pose pose, float* origins, float* dirs) {
+  const long long n = (long long)H * W;
+  for (long long p = (long long)blockIdx.x * blockDim.x + threadIdx.x; p < n; p += (long long)gridDim.x * blockDim.x) {
+    const int i = (int)(p / W), j = (int)(p % W);
+    float d[3];
+    pixel_ray(i, j, H, W, focal, pose.r, d);
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+      origins[p * 3 + a] = pose.t[a];
+      dirs[p * 3 + a] = d[a];
+    }
+  }
+}
+
+__global__ void cast_selected_rays_kernel(int H, int W, float focal, const float* poses, int num_poses,
+                                          const int64_t* pix, long long n, float* origins, float* dirs) {
+  const long long hw = (long long)H * W;
+  for (long long q = (long long)blockIdx.x * blockDim.x + threadIdx.x; q < n; q += (long long)gridDim.x * blockDim.x) {
+    const long long p = pix[q];
+    int b = (int)(p / hw);
+    b = min(max(b, 0), num_poses - 1);
+    const long long rem = p - (long long)b * hw;
+    const int i = (int)(rem / W), j = (int)(rem % W);
+    const float* P = poses + b * 12;  // [3, 4] = rotation | translation
+    const float R[9] = {P[0], P[1], P[2], P[4], P[5], P[6], P[8], P[9], P[10]};
+    float d[3];
+    pixel_ray(i, j, H, W, focal, R, d);
+    origins[q * 3 + 0] = P[3];
+    origins[q * 3 + 1] = P[7];
+    origins[q * 3 + 2] = P[11];
+#pragma unroll
+    for (int a = 0; a < 3; ++a) dirs[q * 3 + a] = d[a];
+  }
+}
+
+struct Box {
+  float lo[3], hi[3];
+};
+
+__global__ void ray_aabb_bounds_kernel(const float* origins, const float* dirs, long long n, float near, float far,
+                                       Box box, float* bounds, float* hit) {
+  for (long long q = (long long)blockIdx.x * blockDim.x + threadIdx.x; q < n; q += (long long)gridDim.x * blockDim.x) {
+    const float o[3] = {origins[q * 3], origins[q * 3 + 1], origins[q * 3 + 2]};
+    const float d[3] = {dirs[q * 3], dirs[q * 3 + 1], dirs[q * 3 + 2]};
+    float t0, t1;
+    const bool h = ray_box(o, d, box.lo, box.hi, near, far, t0, t1);
+    bounds[q * 2] = t0;
+    bounds[q * 2 + 1] = t1;
+    if (hit) hit[q] = h ? 1.0f : 0.0f;
+  }
+}
+
+// =============================================================================================
+// occupancy mask (exact empty-space skipping for the ReLU field)
+// =============================================================================================
+__global__ void build_occupancy_kernel(GridArgs g, float threshold, uint32_t* occ, long long nwords) {
+  const long long ncell = (long long)(g.X + 1) * (g.Y + 1) * (g.Z + 1);
+  for (long long wd = (long long)blockIdx.x * blockDim.x + threadIdx.x; wd < nwords;
+       wd += (long long)gridDim.x * blockDim.x) {
+    uint32_t bits = 0;
+    for (int b = 0; b < 32; ++b) {
+      const long long cell = wd * 32 + b;
+      if (cell >= ncell) break;
+      const int cz = (int)(cell % (g.Z + 1));
+      const int cy = (int)((cell / (g.Z + 1)) % (g.Y + 1));
+      const int cx = (int)(cell / ((long long)(g.Z + 1) * (g.Y + 1)));
+      bool occ_cell = (g.mode != RF_DENSITY_RELU);
+      for (int k = 0; k < 8 && !occ_cell; ++k) {
+        const int x = cx - 1 + (k & 1), y = cy - 1 + ((k >> 1) & 1), z = cz - 1 + (k >> 2);
+        if (x < 0 || x >= g.X || y < 0 || y >= g.Y || z < 0 || z >= g.Z) continue;
+        const float v = g.dens[(((long long)x * g.Y + y) * g.Z + z) * g.dstride] * g.rho;
+        occ_cell = v > threshold;
+      }
+      bits |= (occ_cell ? 1u : 0u) << b;
+    }
+    occ[wd] = bits;
+  }
+}
+
+// =============================================================================================
+// fused Adam (torch.optim.Adam, no weight decay, no amsgrad)
+// =============================================================================================
+__global__ void adam_kernel(float* __restrict__ p, const float* __restrict__ gradp, float* __restrict__ m,
+                            float* __restrict__ v, long long n, float lr, float b1, float b2, float eps, float bc1,
+                            float bc2_sqrt) {
+  const long long n4 = n / 4;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long long)gridDim.x * blockDim.x) {
+    // 16-byte accesses that only assume 4-byte alignment (the flat buffer may hold odd-sized tensors)
+    const f4u gg = reinterpret_cast<const f4u*>(gradp)[i];
+    f4u pp = reinterpret_cast<f4u*>(p)[i];
+    f4u mm = reinterpret_cast<f4u*>(m)[i];
+    f4u vv = reinterpret_cast<f4u*>(v)[i];
+    const float step = lr / bc1;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      mm.v[c] = mm.v[c] + (gg.v[c] - mm.v[c]) * (1.0f - b1);
+      vv.v[c] = vv.v[c] * b2 + (gg.v[c] * gg.v[c]) * (1.0f - b2);
+      pp.v[c] = pp.v[c] - step * (mm.v[c] / (sqrtf(vv.v[c]) / bc2_sqrt + eps));
+    }
+    reinterpret_cast<f4u*>(p)[i] = pp;
+    reinterpret_cast<f4u*>(m)[i] = mm;
+    reinterpret_cast<f4u*>(v)[i] = vv;
+  }
+  // tail
+  const long long i = n4 * 4 + (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) {
+    const float gg = gradp[i];
+    const float mm = m[i] + (gg - m[i]) * (1.0f - b1);
+    const float vv = v[i] * b2 + (gg * gg) * (1.0f - b2);
+    p[i] = p[i] - (lr / bc1) * (mm / (sqrtf(vv) / bc2_sqrt + eps));
+    m[i] = mm;
+    v[i] = vv;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// host side of the C ABI
+// ---------------------------------------------------------------------------------------------
+int check_grid(const RFGrid* g) {
+  if (!g || !g->densities_dev || !g->features_dev) return RF_ERR_NULL_POINTER;
+  for (int a = 0; a < 3; ++a)
+    if (g->dims[a] < 1 || g->dims[a] > 2046) return RF_ERR_BAD_SHAPE;
+  const int F = g->num_features;
+  if (!(F == 3 || F == 12 || F == 27 || F == 48)) return RF_ERR_UNSUPPORTED;  // SH degree 0..3
+  if (g->density_mode < RF_DENSITY_RELU || g->density_mode > RF_DENSITY_IDENTITY) return RF_ERR_UNSUPPORTED;
+  if (g->density_stride < 1 || g->feature_stride < F) return RF_ERR_BAD_SHAPE;
+  return RF_OK;
+}
+
+GridArgs to_args(const RFGrid* g) {
+  GridArgs a;
+  a.dens = g->densities_dev;
+  a.feat = g->features_dev;
+  a.occ = g->occupancy_dev;
+  a.X = g->dims[0];
+  a.Y = g->dims[1];
+  a.Z = g->dims[2];
+  a.F = g->num_features;
+  a.dstride = g->density_stride;
+  a.fstride = g->feature_stride;
+  for (int i = 0; i < 3; ++i) {
+    a.amin[i] = g->aabb_min[i];
+    a.amax[i] = g->aabb_max[i];
+    a.nscale[i] = g->norm_scale[i];
+    a.nbias[i] = g->norm_bias[i];
+  }
+  a.rho = g->density_scale;
+  a.mode = g->density_mode;
+  return a;
+}
+
+int check_rays(const RFRayBatch* r) {
+  if (!r) return RF_ERR_NULL_POINTER;
+  if (r->num_rays < 0 || r->num_samples < 1) return RF_ERR_BAD_SHAPE;
+  if (r->num_rays > 0 && (!r->origins_dev || !r->directions_dev || !r->t_vals_dev)) return RF_ERR_NULL_POINTER;
+  return RF_OK;
+}
+
+RayArgs to_args(const RFRayBatch* r) {
+  RayArgs a;
+  a.origins = r->origins_dev;
+  a.directions = r->directions_dev;
+  a.n = r->num_rays;
+  a.S = r->num_samples;
+  a.near = r->near;
+  a.far = r->far;
+  a.tvals = r->t_vals_dev;
+  a.trand = r->t_rand_dev;
+  return a;
+}
+
+OutArgs to_args(const RFRenderOut* o) {
+  OutArgs a;
+  a.colour = o->colour_dev;
+  a.depth = o->depth_dev;
+  a.acc = o->acc_dev;
+  a.disparity = o->disparity_dev;
+  a.cache = o->sample_cache_dev;
+  a.tcache = o->trans_cache_dev;
+  a.stop = o->stop_cache_dev;
+  return a;
+}
+
+int launch_status() { return hipGetLastError() == hipSuccess ? RF_OK : RF_ERR_LAUNCH; }
+
+template <int K, bool DIFFUSE>
+void launch_forward(bool save, unsigned blocks, hipStream_t st, const GridArgs& g, const RayArgs& r, const OutArgs& o,
+                    uint32_t flags) {
+  if (save)
+    hipLaunchKernelGGL((render_forward_kernel<K, DIFFUSE, true>), dim3(blocks), dim3(kBlock), 0, st, g, r, o, flags);
+  else
+    hipLaunchKernelGGL((render_forward_kernel<K, DIFFUSE, false>), dim3(blocks), dim3(kBlock), 0, st, g, r, o, flags);
+}
+
+template <int K, bool DIFFUSE>
+void launch_backward(unsigned blocks, hipStream_t st, const GridArgs& g, const RayArgs& r, const OutArgs& o,
+                     const GradArgs& gr, uint32_t flags) {
+  hipLaunchKernelGGL((render_backward_kernel<K, DIFFUSE>), dim3(blocks), dim3(kBlock), 0, st, g, r, o, gr, flags);
+}
+
+unsigned grid_1d(long long n, int block, long long cap = 256LL * 16) {
+  long long b = (n + block - 1) / block;
+  if (b < 1) b = 1;
+  if (b > cap) b = cap;
+  return (unsigned)b;
+}
+
+}  // namespace
+
+extern "C" {
+
+int rf_abi_version(void) { return RF_ABI_VERSION; }
+
+const char* rf_error_string(int code) {
+  switch (code) {
+    case RF_OK:
+      return "ok";
+    case RF_ERR_NULL_POINTER:
+      return "null pointer";
+    case RF_ERR_BAD_SHAPE:
+      return "bad shape, size or stride";
+    case RF_ERR_UNSUPPORTED:
+      return "unsupported configuration (SH degree must be 0..3, density mode must be a RF_DENSITY_* value)";
+    case RF_ERR_LAUNCH:
+      return "HIP kernel launch failed";
+    default:
+      return "unknown error code";
+  }
+}
+
+int rf_cast_rays(int32_t height, int32_t width, float focal, const float* rotation_host, const float* translation_host,
+                 float* origins_dev, float* directions_dev, void* stream) {
+  if (!rotation_host || !translation_host || !origins_dev || !directions_dev) return RF_ERR_NULL_POINTER;
+  if (height < 1 || width < 1) return RF_ERR_BAD_SHAPE;
+  Pose pose;
+  for (int i = 0; i < 9; ++i) pose.r[i] = rotation_host[i];
+  for (int i = 0; i < 3; ++i) pose.t[i] = translation_host[i];
+  const long long n = (long long)height * width;
+  hipLaunchKernelGGL(cast_rays_kernel, dim3(grid_1d(n, 256)), dim3(256), 0, (hipStream_t)stream, height, width, focal,
+                     pose, origins_dev, directions_dev);
+  return launch_status();
+}
+
+int rf_cast_selected_rays(int32_t height, int32_t width, float focal, const float* poses_dev, int32_t num_poses,
+                          const int64_t* pixel_index_dev, int64_t num_rays, float* origins_dev, float* directions_dev,
+                          void* stream) {
+  if (num_rays == 0) return RF_OK;
+  if (!poses_dev || !pixel_index_dev || !origins_dev || !directions_dev) return RF_ERR_NULL_POINTER;
+  if (height < 1 || width < 1 || num_poses < 1 || num_rays < 0) return RF_ERR_BAD_SHAPE;
+  hipLaunchKernelGGL(cast_selected_rays_kernel, dim3(grid_1d(num_rays, 256)), dim3(256), 0, (hipStream_t)stream, height,
+                     width, focal, poses_dev, num_poses, pixel_index_dev, (long long)num_rays, origins_dev,
+                     directions_dev);
+  return launch_status();
+}
+
+int rf_ray_aabb_bounds(const float* origins_dev, const float* directions_dev, int64_t num_rays, float near, float far,
+                       const float* aabb_min_host, const float* aabb_max_host, float* bounds_dev, float* hit_dev,
+                       void* stream) {
+  if (num_rays == 0) return RF_OK;
+  if (!origins_dev || !directions_dev || !aabb_min_host || !aabb_max_host || !bounds_dev) return RF_ERR_NULL_POINTER;
+  if (num_rays < 0) return RF_ERR_BAD_SHAPE;
+  Box box;
+  for (int i = 0; i < 3; ++i) {
+    box.lo[i] = aabb_min_host[i];
+    box.hi[i] = aabb_max_host[i];
+  }
+  hipLaunchKernelGGL(ray_aabb_bounds_kernel, dim3(grid_1d(num_rays, 256)), dim3(256), 0, (hipStream_t)stream,
+                     origins_dev, directions_dev, (long long)num_rays, near, far, box, bounds_dev, hit_dev);
+  return launch_status();
+}
+
+int rf_render_forward(const RFGrid* grid, const RFRayBatch* rays, uint32_t flags, const RFRenderOut* out,
+                      void* stream) {
+  int rc = check_grid(grid);
+  if (rc != RF_OK) return rc;
+  rc = check_rays(rays);
+  if (rc != RF_OK) return rc;
+  if (!out) return RF_ERR_NULL_POINTER;
+  if (rays->num_rays == 0) return RF_OK;
+  if (!out->colour_dev || !out->depth_dev || !out->acc_dev || !out->disparity_dev) return RF_ERR_NULL_POINTER;
+  const bool save = out->sample_cache_dev != nullptr;
+  if (save && (!out->trans_cache_dev || !out->stop_cache_dev)) return RF_ERR_NULL_POINTER;
+  if ((flags & RF_FLAG_OCCUPANCY_SKIP) && !grid->occupancy_dev) return RF_ERR_NULL_POINTER;
+
+  const GridArgs g = to_args(grid);
+  const RayArgs r = to_args(rays);
+  const OutArgs o = to_args(out);
+  const unsigned blocks = (unsigned)((rays->num_rays + kWavesPerBlock - 1) / kWavesPerBlock);
+  hipStream_t st = (hipStream_t)stream;
+  const bool diffuse = flags & RF_FLAG_RENDER_DIFFUSE;
+  const int K = grid->num_features / 3;
+  if (diffuse || K == 1)
+    launch_forward<1, true>(save, blocks, st, g, r, o, flags);
+  else if (K == 4)
+    launch_forward<4, false>(save, blocks, st, g, r, o, flags);
+  else if (K == 9)
+    launch_forward<9, false>(save, blocks, st, g, r, o, flags);
+  else
+    launch_forward<16, false>(save, blocks, st, g, r, o, flags);
+  return launch_status();
+}
+
+int rf_render_backward(const RFGrid* grid, const RFRayBatch* rays, uint32_t flags, const RFRenderOut* fwd,
+                       const RFRenderGrads* grads, float* grad_densities_dev, float* grad_features_dev, void* stream) {
+  int rc = check_grid(grid);
+  if (rc != RF_OK) return rc;
+  rc = check_rays(rays);
+  if (rc != RF_OK) return rc;
+  if (!fwd || !grads) return RF_ERR_NULL_POINTER;
+  if (rays->num_rays == 0) return RF_OK;
+  if (!fwd->sample_cache_dev || !fwd->trans_cache_dev || !fwd->stop_cache_dev) return RF_ERR_NULL_POINTER;
+  if (!grad_densities_dev || !grad_features_dev) return RF_ERR_NULL_POINTER;
+
+  const GridArgs g = to_args(grid);
+  const RayArgs r = to_args(rays);
+  const OutArgs o = to_args(fwd);
+  GradArgs gr;
+  gr.gcolour = grads->grad_colour_dev;
+  gr.gdepth = grads->grad_depth_dev;
+  gr.gacc = grads->grad_acc_dev;
+  gr.gdens = grad_densities_dev;
+  gr.gfeat = grad_features_dev;
+  const unsigned blocks = (unsigned)((rays->num_rays + kWavesPerBlock - 1) / kWavesPerBlock);
+  hipStream_t st = (hipStream_t)stream;
+  const bool diffuse = flags & RF_FLAG_RENDER_DIFFUSE;
+  const int K = grid->num_features / 3;
+  if (diffuse || K == 1)
+    launch_backward<1, true>(blocks, st, g, r, o, gr, flags);
+  else if (K == 4)
+    launch_backward<4, false>(blocks, st, g, r, o, gr, flags);
+  else if (K == 9)
+    launch_backward<9, false>(blocks, st, g, r, o, gr, flags);
+  else
+    launch_backward<16, false>(blocks, st, g, r, o, gr, flags);
+  return launch_status();
+}
+
+int rf_build_occupancy(const RFGrid* grid, float threshold, uint32_t* occupancy_dev, void* stream) {
+  const int rc = check_grid(grid);
+  if (rc != RF_OK) return rc;
+  if (!occupancy_dev) return RF_ERR_NULL_POINTER;
+  const GridArgs g = to_args(grid);
+  const long long ncell = (long long)(g.X + 1) * (g.Y + 1) * (g.Z + 1);
+  const long long nwords = (ncell + 31) / 32;
+  hipLaunchKernelGGL(build_occupancy_kernel, dim3(grid_1d(nwords, 256)), dim3(256), 0, (hipStream_t)stream, g,
+                     threshold, occupancy_dev, nwords);
+  return launch_status();
+}
+
+int rf_adam_step(float* param_dev, const float* grad_dev, float* exp_avg_dev, float* exp_avg_sq_dev, int64_t numel,
+                 float lr, float beta1, float beta2, float eps, int32_t step, void* stream) {
+  if (numel == 0) return RF_OK;
+  if (!param_dev || !grad_dev || !exp_avg_dev || !exp_avg_sq_dev) return RF_ERR_NULL_POINTER;
+  if (numel < 0 || step < 1) return RF_ERR_BAD_SHAPE;
+  const double bc1 = 1.0 - pow((double)beta1, (double)step);
+  const double bc2 = 1.0 - pow((double)beta2, (double)step);
+  hipLaunchKernelGGL(adam_kernel, dim3(grid_1d(numel / 4 + 1, 256, 256LL * 32)), dim3(256), 0, (hipStream_t)stream,
+                     param_dev, grad_dev, exp_avg_dev, exp_avg_sq_dev, (long long)numel, lr, beta1, beta2, eps,
+                     (float)bc1, (float)sqrt(bc2));
+  return launch_status();
+}
+
+}  // extern "C"

@@ -1,0 +1,267 @@
+"""torch-facing operators over the C ABI (include/relu_field.h).
+
+``relu_field_render`` is the ``torch.autograd.Function`` that replaces the reference's whole
+sample -> VoxelGrid.forward -> SH -> mask -> accumulate composition
+(thre3d_atom/thre3d_reprs/renderers.py:48-102) and its autograd graph: forward enqueues
+rf_render_forward, backward enqueues rf_render_backward on the current HIP stream.  Tensors cross
+the boundary as raw device pointers; PyTorch is only the allocator and the stream owner.
+
+Nothing here computes on the CPU and nothing falls back: CPU tensors or a missing library raise.
+"""
+import ctypes as C
+from typing import Dict, Optional, Tuple
+
+import numpy as np
+import torch
+from torch import Tensor
+
+from . import _lib
+from .voxels import VoxelGrid
+
+_T_VALS_CACHE: Dict[Tuple[int, str], Tensor] = {}
+
+
+def _stream(device) -> int:
+    return torch.cuda.current_stream(device).cuda_stream
+
+
+def _require_hip(t: Tensor, name: str) -> None:
+    if not t.is_cuda:
+        raise RuntimeError(f"{name} must live on a HIP device (got {t.device}); the render path has no CPU fallback")
+
+
+def t_vals_for(num_samples: int, device) -> Tensor:
+    """linspace(0, 1, S) as the reference's CPU path computes it (sample.py:46), evaluated once on the
+    host so that every device sees bit-identical sample parameters, then cached on the device."""
+    key = (int(num_samples), str(device))
+    t = _T_VALS_CACHE.get(key)
+    if t is None:
+        t = torch.linspace(0.0, 1.0, int(num_samples), dtype=torch.float32).to(device)
+        _T_VALS_CACHE[key] = t
+    return t
+
+
+def _ptr(t: Optional[Tensor]):
+    return None if t is None else t.data_ptr()
+
+
+def _ray_batch(origins: Tensor, directions: Tensor, num_samples: int, near: float, far: float, t_rand: Optional[Tensor]):
+    rb = _lib.RFRayBatch()
+    rb.origins_dev = origins.data_ptr()
+    rb.directions_dev = directions.data_ptr()
+    rb.num_rays = origins.shape[0]
+    rb.num_samples = int(num_samples)
+    rb.near = float(np.float32(near))
+    rb.far = float(np.float32(far))
+    tv = t_vals_for(num_samples, origins.device)
+    rb.t_vals_dev = tv.data_ptr()
+    rb.t_rand_dev = _ptr(t_rand)
+    return rb, tv
+
+
+class _ReluFieldRender(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, densities, features, origins, directions, t_rand, grid: VoxelGrid, num_samples, near, far, flags):
+        lib = _lib.load()
+        for name, t in (("densities", densities), ("features", features), ("ray origins", origins), ("ray directions", directions)):
+            _require_hip(t, name)
+        origins = origins.detach().to(torch.float32).contiguous()
+        directions = directions.detach().to(torch.float32).contiguous()
+        n = origins.shape[0]
+        if t_rand is not None:
+            _require_hip(t_rand, "t_rand")
+            t_rand = t_rand.detach().to(torch.float32).contiguous()
+            if tuple(t_rand.shape) != (n, num_samples):
+                raise ValueError(f"t_rand must be [{n}, {num_samples}], got {tuple(t_rand.shape)}")
+        dev = origins.device
+        need_grad = densities.requires_grad or features.requires_grad
+        rf_grid = grid.to_rf_grid(use_occupancy=bool(flags & _lib.FLAG_OCCUPANCY_SKIP))
+        rb, tv = _ray_batch(origins, directions, num_samples, near, far, t_rand)
+
+        colour = torch.empty((n, 3), dtype=torch.float32, device=dev)
+        depth = torch.empty((n, 1), dtype=torch.float32, device=dev)
+        acc = torch.empty((n, 1), dtype=torch.float32, device=dev)
+        disparity = torch.empty((n, 1), dtype=torch.float32, device=dev)
+        out = _lib.RFRenderOut()
+        out.colour_dev, out.depth_dev, out.acc_dev, out.disparity_dev = (
+            colour.data_ptr(),
+            depth.data_ptr(),
+            acc.data_ptr(),
+            disparity.data_ptr(),
+        )
+        cache = tcache = stop = None
+        if need_grad:
+            cache = torch.empty((n, num_samples, 4), dtype=torch.float32, device=dev)
+            tcache = torch.empty((n, num_samples), dtype=torch.float32, device=dev)
+            stop = torch.empty((n,), dtype=torch.int32, device=dev)
+            out.sample_cache_dev, out.trans_cache_dev, out.stop_cache_dev = cache.data_ptr(), tcache.data_ptr(), stop.data_ptr()
+        _lib.check(lib.rf_render_forward(C.byref(rf_grid), C.byref(rb), int(flags), C.byref(out), _stream(dev)), "rf_render_forward")
+
+        ctx.grid, ctx.flags = grid, int(flags)
+        ctx.num_samples, ctx.near, ctx.far = int(num_samples), float(near), float(far)
+        ctx.has_rand = t_rand is not None
+        saved = [densities, features, origins, directions, depth, acc]
+        if need_grad:
+            saved += [cache, tcache, stop]
+        if t_rand is not None:
+            saved.append(t_rand)
+        ctx.need_grad = need_grad
+        ctx.save_for_backward(*saved)
+        ctx.mark_non_differentiable(disparity)
+        return colour, depth, acc, disparity
+
+    @staticmethod
+    def backward(ctx, g_colour, g_depth, g_acc, _g_disparity):
+        if not ctx.need_grad:
+            return (None,) * 10
+        lib = _lib.load()
+        saved = list(ctx.saved_tensors)
+        densities, features, origins, directions, depth, acc, cache, tcache, stop = saved[:9]
+        t_rand = saved[9] if ctx.has_rand else None
+        dev = origins.device
+        grid: VoxelGrid = ctx.grid
+        # the kernels read the grid through the module's own tensors; make sure those are the ones saved
+        rf_grid = grid.to_rf_grid(use_occupancy=bool(ctx.flags & _lib.FLAG_OCCUPANCY_SKIP))
+        rf_grid.densities_dev, rf_grid.features_dev = densities.data_ptr(), features.data_ptr()
+        rb, tv = _ray_batch(origins, directions, ctx.num_samples, ctx.near, ctx.far, t_rand)
+
+        def prep(g):
+            return None if g is None else g.detach().to(torch.float32).contiguous()
+
+        g_colour, g_depth, g_acc = prep(g_colour), prep(g_depth), prep(g_acc)
+        grads = _lib.RFRenderGrads()
+        grads.grad_colour_dev, grads.grad_depth_dev, grads.grad_acc_dev = _ptr(g_colour), _ptr(g_depth), _ptr(g_acc)
+        fwd = _lib.RFRenderOut()
+        fwd.sample_cache_dev, fwd.trans_cache_dev, fwd.stop_cache_dev = cache.data_ptr(), tcache.data_ptr(), stop.data_ptr()
+
+        # gradient buffers: reuse a caller-provided flat bucket when there is one (see GradBucket), else
+        # fresh zero-filled tensors.  The kernel accumulates with atomics.
+        bucket = getattr(grid, "_grad_bucket", None)
+        if bucket is not None and bucket.matches(densities, features):
+            gd, gf = bucket.views_for_accumulation()
+            ret_d, ret_f = bucket.autograd_return()
+        else:
+            gd = torch.zeros_like(densities)
+            gf = torch.zeros_like(features)
+            ret_d, ret_f = gd, gf
+        _lib.check(
+            lib.rf_render_backward(
+                C.byref(rf_grid), C.byref(rb), ctx.flags, C.byref(fwd), C.byref(grads), gd.data_ptr(), gf.data_ptr(), _stream(dev)
+            ),
+            "rf_render_backward",
+        )
+        return ret_d, ret_f, None, None, None, None, None, None, None, None
+
+
+def relu_field_render(
+    grid: VoxelGrid,
+    origins: Tensor,
+    directions: Tensor,
+    num_samples: int,
+    near: float,
+    far: float,
+    t_rand: Optional[Tensor] = None,
+    white_bkgd: bool = False,
+    render_diffuse: bool = False,
+    optimized_sampling: bool = False,
+    use_occupancy: bool = False,
+) -> Tuple[Tensor, Tensor, Tensor, Tensor]:
+    """colour [N,3], depth [N,1], accumulated weight [N,1], disparity [N,1] for flat rays [N,3].
+    Differentiable w.r.t. ``grid.densities`` and ``grid.features`` only (like every reference use)."""
+    if origins.dim() != 2 or origins.shape != directions.shape or origins.shape[-1] != 3:
+        raise AssertionError("the render op works with FLAT rays [N, 3] only")
+    if int(num_samples) < 1:
+        raise ValueError("num_samples must be >= 1")
+    flags = 0
+    flags |= _lib.FLAG_WHITE_BKGD if white_bkgd else 0
+    flags |= _lib.FLAG_RENDER_DIFFUSE if render_diffuse else 0
+    flags |= _lib.FLAG_AABB_SAMPLING if optimized_sampling else 0
+    if use_occupancy:
+        if grid.occupancy is None:
+            grid.build_occupancy()
+        flags |= _lib.FLAG_OCCUPANCY_SKIP
+    return _ReluFieldRender.apply(
+        grid.densities, grid.features, origins, directions, t_rand, grid, int(num_samples), float(near), float(far), flags
+    )
+
+
+# --------------------------------------------------------------------------------------------
+# ray generation
+# --------------------------------------------------------------------------------------------
+def _pose_to_host(rotation, translation):
+    rot = torch.as_tensor(rotation).detach().to("cpu", torch.float32).reshape(9).tolist()
+    trans = torch.as_tensor(translation).detach().to("cpu", torch.float32).reshape(3).tolist()
+    return (C.c_float * 9)(*rot), (C.c_float * 3)(*trans)
+
+
+def cast_rays_hip(height: int, width: int, focal: float, rotation, translation, device) -> Tuple[Tensor, Tensor]:
+    """All pixel-centre rays of one camera -> (origins, directions) [H, W, 3] float32 on ``device``
+    (reference rendering/volumetric/utils/misc.py:12-50)."""
+    device = torch.device(device)
+    if device.type != "cuda":
+        raise RuntimeError(f"cast_rays runs on a HIP device only (got {device})")
+    lib = _lib.load()
+    rot, trans = _pose_to_host(rotation, translation)
+    o = torch.empty((height, width, 3), dtype=torch.float32, device=device)
+    d = torch.empty((height, width, 3), dtype=torch.float32, device=device)
+    _lib.check(
+        lib.rf_cast_rays(int(height), int(width), float(np.float32(focal)), rot, trans, o.data_ptr(), d.data_ptr(), _stream(device)),
+        "rf_cast_rays",
+    )
+    return o, d
+
+
+def cast_selected_rays_hip(height: int, width: int, focal: float, poses: Tensor, pixel_index: Tensor) -> Tuple[Tensor, Tensor]:
+    """Rays of selected pixels of a batch of cameras: ``poses`` [B, 3, 4] (rotation | translation) and
+    ``pixel_index`` [R] int64 into the B*H*W concatenated pixels (the ray set the reference builds per
+    training iteration at modules/trainers.py:281-303, without materialising the other rays)."""
+    _require_hip(poses, "poses")
+    _require_hip(pixel_index, "pixel_index")
+    lib = _lib.load()
+    poses = poses.detach().to(torch.float32).contiguous()
+    pixel_index = pixel_index.detach().to(torch.int64).contiguous()
+    n = pixel_index.shape[0]
+    o = torch.empty((n, 3), dtype=torch.float32, device=poses.device)
+    d = torch.empty((n, 3), dtype=torch.float32, device=poses.device)
+    _lib.check(
+        lib.rf_cast_selected_rays(
+            int(height), int(width), float(np.float32(focal)), poses.data_ptr(), int(poses.shape[0]), pixel_index.data_ptr(), n, o.data_ptr(), d.data_ptr(), _stream(poses.device)
+        ),
+        "rf_cast_selected_rays",
+    )
+    return o, d
+
+
+def ray_aabb_bounds_hip(origins: Tensor, directions: Tensor, near: float, far: float, aabb) -> Tuple[Tensor, Tensor]:
+    """Per-ray [t_enter, t_exit] and hit flags (reference rendering/volumetric/sample.py:71-184)."""
+    _require_hip(origins, "ray origins")
+    lib = _lib.load()
+    origins = origins.detach().to(torch.float32).contiguous()
+    directions = directions.detach().to(torch.float32).contiguous()
+    n = origins.shape[0]
+    bounds = torch.empty((n, 2), dtype=torch.float32, device=origins.device)
+    hit = torch.empty((n, 1), dtype=torch.float32, device=origins.device)
+    lo = _lib.float3([np.float32(r[0]) for r in aabb])
+    hi = _lib.float3([np.float32(r[1]) for r in aabb])
+    _lib.check(
+        lib.rf_ray_aabb_bounds(
+            origins.data_ptr(), directions.data_ptr(), n, float(np.float32(near)), float(np.float32(far)), lo, hi, bounds.data_ptr(), hit.data_ptr(), _stream(origins.device)
+        ),
+        "rf_ray_aabb_bounds",
+    )
+    return bounds, hit
+
+
+def adam_step_hip(param: Tensor, grad: Tensor, exp_avg: Tensor, exp_avg_sq: Tensor, lr: float, beta1: float, beta2: float, eps: float, step: int) -> None:
+    """In-place fused Adam update of a flat float32 buffer (torch.optim.Adam arithmetic)."""
+    for name, t in (("param", param), ("grad", grad), ("exp_avg", exp_avg), ("exp_avg_sq", exp_avg_sq)):
+        _require_hip(t, name)
+        if not (t.is_contiguous() and t.dtype == torch.float32 and t.numel() == param.numel()):
+            raise ValueError(f"{name} must be a contiguous float32 tensor with {param.numel()} elements")
+    lib = _lib.load()
+    _lib.check(
+        lib.rf_adam_step(
+            param.data_ptr(), grad.data_ptr(), exp_avg.data_ptr(), exp_avg_sq.data_ptr(), param.numel(), float(lr), float(beta1), float(beta2), float(eps), int(step), _stream(param.device)
+        ),
+        "rf_adam_step",
+    )

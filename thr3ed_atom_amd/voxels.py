@@ -1,0 +1,283 @@
+"""Dense SH + density voxel grid (the ReLU Field) -- host-side mirror of the reference's
+thre3d_atom/thre3d_reprs/voxels.py (VoxelGrid :46-331, scale_voxel_grid_with_required_output_size
+:334-373, create_voxel_grid_from_saved_info_dict :376-383).
+
+Same constructor arguments, properties, state_dict keys (``_densities`` / ``_features``) and config
+dictionaries as the reference, so trainers and checkpoints written against it keep working.  The
+arithmetic itself (normalise -> trilinear gather -> ReLU) lives in the HIP kernels
+(csrc/relu_field_kernels.hip); this class only owns the tensors and describes them to the C ABI.
+"""
+from typing import Any, Callable, Dict, NamedTuple, Optional, Tuple
+
+import numpy as np
+import torch
+from torch import Tensor
+from torch.nn import Module
+
+from . import _lib
+from .camera import slack_range_map
+from .constants import CONFIG_DICT, STATE_DICT, THRE3D_REPR, u_DENSITIES, u_FEATURES
+
+
+class VoxelSize(NamedTuple):
+    x_size: float = 1.0
+    y_size: float = 1.0
+    z_size: float = 1.0
+
+
+class VoxelGridLocation(NamedTuple):
+    x_coord: float = 0.0
+    y_coord: float = 0.0
+    z_coord: float = 0.0
+
+
+class AxisAlignedBoundingBox(NamedTuple):
+    x_range: Tuple[float, float]
+    y_range: Tuple[float, float]
+    z_range: Tuple[float, float]
+
+
+def _is_identity(fn) -> bool:
+    return fn is None or isinstance(fn, torch.nn.Identity)
+
+
+def resolve_density_mode(pre: Callable, post: Callable) -> str:
+    """Map the reference's (pre-activation, post-activation) callables onto the kernel's density mode.
+    Supported pairs are the three the reference's trainer script builds
+    (train_sh_based_voxel_grid_with_posed_images.py:169-192) plus plain identity."""
+    pre_abs = pre is torch.abs or getattr(pre, "__name__", "") in ("abs", "absolute")
+    if _is_identity(pre):
+        if isinstance(post, torch.nn.ReLU) or post is torch.relu or post is torch.nn.functional.relu:
+            return "relu"
+        if isinstance(post, torch.nn.Softplus):
+            if post.beta != 1 or post.threshold != 20:
+                raise ValueError("only Softplus(beta=1, threshold=20) is supported by the HIP kernels")
+            return "softplus"
+        if _is_identity(post):
+            return "identity"
+    elif pre_abs and _is_identity(post):
+        return "abs"
+    raise ValueError(
+        f"unsupported density activation pair (pre={pre}, post={post}); supported: "
+        f"Identity/ReLU, Identity/Softplus, torch.abs/Identity, Identity/Identity"
+    )
+
+
+class VoxelGrid(Module):
+    def __init__(
+        self,
+        densities: Tensor,
+        features: Tensor,
+        voxel_size: VoxelSize,
+        grid_location: Optional[VoxelGridLocation] = VoxelGridLocation(),
+        density_preactivation: Callable[[Tensor], Tensor] = torch.abs,
+        density_postactivation: Callable[[Tensor], Tensor] = torch.nn.Identity(),
+        feature_preactivation: Callable[[Tensor], Tensor] = torch.nn.Identity(),
+        feature_postactivation: Callable[[Tensor], Tensor] = torch.nn.Identity(),
+        radiance_transfer_function: Callable[[Tensor, Tensor], Tensor] = None,
+        expected_density_scale: float = 1.0,
+        tunable: bool = False,
+    ):
+        if densities.dim() != 4 or densities.shape[-1] != 1:
+            raise AssertionError(f"densities should be [W x D x H x 1], got {tuple(densities.shape)}")
+        if features.dim() != 4 or features.shape[:3] != densities.shape[:3]:
+            raise AssertionError(f"features should be [W x D x H x F], got {tuple(features.shape)}")
+        if densities.device != features.device:
+            raise AssertionError("densities and features are not on the same device")
+        if not (_is_identity(feature_preactivation) and _is_identity(feature_postactivation)):
+            raise ValueError("the HIP render path supports identity feature activations only")
+        if radiance_transfer_function is not None:
+            raise ValueError("radiance_transfer_function is not used on the SH render path")
+        super().__init__()
+        self._density_preactivation = density_preactivation
+        self._density_postactivation = density_postactivation
+        self._feature_preactivation = feature_preactivation
+        self._feature_postactivation = feature_postactivation
+        self._radiance_transfer_function = radiance_transfer_function
+        self._grid_location = grid_location
+        self._voxel_size = voxel_size
+        self._expected_density_scale = expected_density_scale
+        self._tunable = tunable
+        self.density_mode = resolve_density_mode(density_preactivation, density_postactivation)
+
+        densities = densities.to(torch.float32).contiguous()
+        features = features.to(torch.float32).contiguous()
+        if tunable:
+            self._densities = torch.nn.Parameter(densities)
+            self._features = torch.nn.Parameter(features)
+        else:
+            # buffers, so that Module.to(device) moves a frozen grid as well
+            self.register_buffer("_densities", densities)
+            self.register_buffer("_features", features)
+        self.width_x, self.depth_y, self.height_z = (int(v) for v in features.shape[:3])
+        self._aabb = self._setup_bounding_box_planes()
+        self._occupancy: Optional[Tensor] = None
+
+    # ----- reference-compatible accessors -------------------------------------------------
+    @property
+    def densities(self) -> Tensor:
+        return self._densities
+
+    @densities.setter
+    def densities(self, value: Tensor) -> None:
+        assert value.shape == self._densities.shape, "new densities don't match the grid's dimensions"
+        self._densities = torch.nn.Parameter(value) if self._tunable and not isinstance(value, torch.nn.Parameter) else value
+        self._occupancy = None
+
+    @property
+    def features(self) -> Tensor:
+        return self._features
+
+    @features.setter
+    def features(self, value: Tensor) -> None:
+        assert value.shape == self._features.shape, "new features don't match the grid's dimensions"
+        self._features = torch.nn.Parameter(value) if self._tunable and not isinstance(value, torch.nn.Parameter) else value
+
+    @property
+    def aabb(self) -> AxisAlignedBoundingBox:
+        return self._aabb
+
+    @property
+    def grid_dims(self) -> Tuple[int, int, int]:
+        return self.width_x, self.depth_y, self.height_z
+
+    @property
+    def voxel_size(self) -> VoxelSize:
+        return self._voxel_size
+
+    @voxel_size.setter
+    def voxel_size(self, voxel_size: VoxelSize) -> None:
+        self._voxel_size = voxel_size
+        self._aabb = self._setup_bounding_box_planes()
+
+    @property
+    def expected_density_scale(self) -> float:
+        return self._expected_density_scale
+
+    @property
+    def sh_degree(self) -> int:
+        return int(np.sqrt(self._features.shape[-1] // 3)) - 1
+
+    def get_config_dict(self) -> Dict[str, Any]:
+        return {
+            "grid_location": self._grid_location,
+            "density_preactivation": self._density_preactivation,
+            "density_postactivation": self._density_postactivation,
+            "feature_preactivation": self._feature_preactivation,
+            "feature_postactivation": self._feature_postactivation,
+            "radiance_transfer_function": self._radiance_transfer_function,
+            "expected_density_scale": self._expected_density_scale,
+            "tunable": self._tunable,
+        }
+
+    def get_save_config_dict(self) -> Dict[str, Any]:
+        out = self.get_config_dict()
+        out["voxel_size"] = self._voxel_size
+        return out
+
+    def _setup_bounding_box_planes(self) -> AxisAlignedBoundingBox:
+        """centre +- dims * voxel_size / 2 in Python floats (reference voxels.py:187-212)."""
+        ranges = []
+        for n, v, c in zip(self.grid_dims, self._voxel_size, self._grid_location):
+            half = (n * v) / 2
+            ranges.append((c - half, c + half))
+        return AxisAlignedBoundingBox(*ranges)
+
+    def extra_repr(self) -> str:
+        return (
+            f"grid_dims: {self.grid_dims}, feature_dims: {self._features.shape[-1]}, "
+            f"voxel_size: {self._voxel_size}, grid_location: {self._grid_location}, "
+            f"density: {self.density_mode}, tunable: {self._tunable}"
+        )
+
+    def test_inside_volume(self, points: Tensor) -> Tensor:
+        """[N, 3] -> [N, 1] bool, strict inequalities (reference voxels.py:252-274)."""
+        m = torch.ones_like(points[..., 0:1], dtype=torch.bool)
+        for a, (lo, hi) in enumerate(self._aabb):
+            m = m & (points[..., a : a + 1] > lo) & (points[..., a : a + 1] < hi)
+        return m
+
+    # ----- description for the C ABI -------------------------------------------------------
+    def to_rf_grid(self, use_occupancy: bool = False) -> "_lib.RFGrid":
+        d, f = self._densities, self._features
+        if not (d.is_cuda and f.is_cuda):
+            raise RuntimeError(
+                "the ReLU-field render path runs on the GPU only: move the VoxelGrid to a HIP device "
+                "(there is no CPU fallback)"
+            )
+        if not (d.is_contiguous() and f.is_contiguous() and d.dtype == torch.float32 and f.dtype == torch.float32):
+            raise RuntimeError("grid tensors must be contiguous float32")
+        g = _lib.RFGrid()
+        g.densities_dev = d.data_ptr()
+        g.features_dev = f.data_ptr()
+        for a in range(3):
+            g.dims[a] = self.grid_dims[a]
+            lo, hi = self._aabb[a]
+            g.aabb_min[a] = float(np.float32(lo))
+            g.aabb_max[a] = float(np.float32(hi))
+            scale, bias = slack_range_map((lo, hi))
+            g.norm_scale[a] = float(scale)
+            g.norm_bias[a] = float(bias)
+        g.num_features = int(f.shape[-1])
+        g.density_stride = 1
+        g.feature_stride = int(f.shape[-1])
+        g.density_scale = float(self._expected_density_scale)
+        g.density_mode = _lib.DENSITY_MODES[self.density_mode]
+        g.occupancy_dev = self._occupancy.data_ptr() if (use_occupancy and self._occupancy is not None) else None
+        return g
+
+    def build_occupancy(self, threshold: float = 0.0) -> Tensor:
+        """(Re)build the exact empty-cell bit mask used by RF_FLAG_OCCUPANCY_SKIP.  Must be called again
+        whenever the densities change."""
+        ncell = (self.width_x + 1) * (self.depth_y + 1) * (self.height_z + 1)
+        occ = torch.empty((ncell + 31) // 32, dtype=torch.int32, device=self._densities.device)
+        grid = self.to_rf_grid()
+        stream = torch.cuda.current_stream(self._densities.device).cuda_stream
+        _lib.check(_lib.load().rf_build_occupancy(grid, float(threshold), occ.data_ptr(), stream), "rf_build_occupancy")
+        self._occupancy = occ
+        return occ
+
+    @property
+    def occupancy(self) -> Optional[Tensor]:
+        return self._occupancy
+
+
+def scale_voxel_grid_with_required_output_size(
+    voxel_grid: VoxelGrid, output_size: Tuple[int, int, int], mode: str = "trilinear"
+) -> VoxelGrid:
+    """Trilinear (align_corners=False) resampling of the whole [F+1]-channel volume, the voxel size
+    shrinking so that the world extent is unchanged (reference voxels.py:334-373).  One-off per training
+    stage; stays a PyTorch-ROCm op."""
+    unified = torch.cat([voxel_grid.features, voxel_grid.densities], dim=-1).detach()
+    new = torch.nn.functional.interpolate(
+        unified.permute(3, 0, 1, 2)[None],
+        size=tuple(output_size),
+        mode=mode,
+        align_corners=False,
+        recompute_scale_factor=False,
+    )[0].permute(1, 2, 3, 0)
+    assert tuple(new.shape[:-1]) == tuple(output_size)
+    old = voxel_grid.voxel_size
+    new_voxel = VoxelSize(
+        (old.x_size * voxel_grid.width_x) / output_size[0],
+        (old.y_size * voxel_grid.depth_y) / output_size[1],
+        (old.z_size * voxel_grid.height_z) / output_size[2],
+    )
+    return VoxelGrid(
+        densities=new[..., -1:].contiguous(),
+        features=new[..., :-1].contiguous(),
+        voxel_size=new_voxel,
+        **voxel_grid.get_config_dict(),
+    )
+
+
+def create_voxel_grid_from_saved_info_dict(saved_info: Dict[str, Any]) -> VoxelGrid:
+    """Rebuild a grid from the ``thre3d_repr`` entry of a checkpoint (reference voxels.py:376-383)."""
+    state = saved_info[THRE3D_REPR][STATE_DICT]
+    grid = VoxelGrid(
+        densities=torch.empty_like(state[u_DENSITIES]),
+        features=torch.empty_like(state[u_FEATURES]),
+        **saved_info[THRE3D_REPR][CONFIG_DICT],
+    )
+    grid.load_state_dict(state)
+    return grid
