@@ -1,0 +1,310 @@
+#!/usr/bin/env python
+"""Headline benchmark of the MI355X ReLU-Fields render path.
+
+    python bench.py --gpus N --steps K --warmup W          (N > 1: launched by torch.distributed.run)
+
+Workload (BASELINE.json: "ray-samples/sec (fwd+bwd) ... 800x800 @ 128^3 grid", configs[2]/[3]):
+one STEP = one training iteration of the posed-image trainer on a 128^3 SH-degree-2 ReLU field --
+random 16384-ray batch out of 8 synthetic 800x800 images (randperm + ray generation), specular render
+fwd, diffuse render fwd, L1 + L1, backward of both, [gradient all-reduce over RCCL when N > 1], Adam --
+with 256 stratified (jittered) samples per ray.  ``value`` = nominal ray-samples/s over the whole job
+= N * 2 renders * 16384 rays * 256 samples * K / time, inputs resident in HBM, nothing skipped.
+Weak scaling: every rank draws its own 16384-ray batch.
+
+Also reported in the same JSON line: the forward-only full-frame render of configs[1]
+(``fwd_render``), the HBM roofline of the dominant kernel (``roofline``) and the oracle timed on the
+host cores (``cpu_baseline``).  The oracle is used ONLY in that last leg.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import thr3ed_atom_amd as rf  # noqa: E402
+from thr3ed_atom_amd import distributed as rfdist  # noqa: E402
+from thr3ed_atom_amd import ops  # noqa: E402
+from thr3ed_atom_amd.trainers import PosedImagesInMemory, TrainStepper  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md)
+NEAR = float(np.float32(2.0) * 0.9)  # hotdog-like bounds, SURVEY.md 8d
+FAR = float(np.float32(6.0) * 1.1)
+RADIUS = 4.0311
+WORLD = 3.0
+
+
+def make_grid(dev, G, sh_degree, seed, sparse=False):
+    gen = torch.Generator(device=dev)
+    gen.manual_seed(seed)
+    F = 3 * (sh_degree + 1) ** 2
+    dens = torch.empty((G, G, G, 1), device=dev).uniform_(-1.0, 1.0, generator=gen)
+    feat = torch.empty((G, G, G, F), device=dev).uniform_(-1.0, 1.0, generator=gen)
+    if sparse:  # a blob: positive raw density inside radius ~0.75 (SURVEY.md 8d cfg5 recipe)
+        ax = ((torch.arange(G, device=dev, dtype=torch.float32) + 0.5) / G * WORLD - WORLD / 2) / (WORLD / 2)
+        r = torch.sqrt(ax[:, None, None] ** 2 + ax[None, :, None] ** 2 + ax[None, None, :] ** 2)
+        dens = (0.5 - r + 0.05 * dens[..., 0])[..., None].contiguous()
+    return rf.VoxelGrid(
+        dens,
+        feat,
+        rf.VoxelSize(WORLD / G, WORLD / G, WORLD / G),
+        density_preactivation=torch.nn.Identity(),
+        density_postactivation=torch.nn.ReLU(),
+        expected_density_scale=rf.compute_expected_density_scale_for_relu_field_grid((WORLD,) * 3),
+        tunable=True,
+    )
+
+
+def count_inside(origins, directions, num_samples, aabb):
+    """samples strictly inside the AABB at the un-jittered sample positions (harness-side, torch ops)"""
+    t = torch.linspace(0.0, 1.0, num_samples, device=origins.device)
+    z = NEAR * (1.0 - t) + FAR * t
+    total = 0
+    for s in range(0, origins.shape[0], 65536):
+        o, d = origins[s : s + 65536], directions[s : s + 65536]
+        p = o[:, None, :] + d[:, None, :] * z[None, :, None]
+        m = torch.ones(p.shape[:2], dtype=torch.bool, device=p.device)
+        for a, (lo, hi) in enumerate(aabb):
+            m &= (p[..., a] > lo) & (p[..., a] < hi)
+        total += int(m.sum().item())
+    return total
+
+
+def cpu_baseline(grid, rays_cpu, pixels_cpu, num_samples, n_rays, threads=0):
+    """The oracle's float32 CPU path (same ATen ops the reference calls) on a bounded sample of the same
+    workload: fwd+bwd of the specular and the diffuse render of ``n_rays`` rays, all host cores."""
+    from oracle import relu_field_oracle as orc  # checker / baseline only
+
+    # measured on the MI355X host (256 logical cores): 16 threads 4.2e5, 64 threads 3.8e5, 256 threads 0.5e5
+    # ray-samples/s -- the ATen ops of this path do not scale past a few tens of threads, so the default is
+    # capped at 16 (the count actually used is reported as "cores")
+    cores = threads if threads > 0 else min(os.cpu_count() or 1, 16)
+    torch.set_num_threads(cores)
+    dens = grid.densities.detach().cpu().clone().requires_grad_(True)
+    feat = grid.features.detach().cpu().clone().requires_grad_(True)
+    aabb = tuple(tuple(r) for r in grid.aabb)
+    rho = grid.expected_density_scale
+
+    def step(n):
+        o, d, px = rays_cpu[0][:n], rays_cpu[1][:n], pixels_cpu[:n]
+        dens.grad = feat.grad = None
+        total = 0.0
+        for diffuse in (False, True):
+            t_rand = torch.rand(n, num_samples)
+            out = orc.render(
+                dens, feat, o, d, aabb, NEAR, FAR, num_samples, rho, "relu", white_bkgd=True,
+                render_diffuse=diffuse, t_rand=t_rand, interp="aten",
+            )
+            total = total + torch.nn.functional.l1_loss(out["colour"], px)
+        total.backward()
+
+    step(min(256, n_rays))  # warm-up (thread pool, page-in)
+    reps = 1
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        step(n_rays)
+    dt = (time.perf_counter() - t0) / reps
+    return {
+        "value": 2 * n_rays * num_samples / dt,
+        "unit": "ray-samples/s",
+        "cores": cores,
+        "kind": "port",
+        "sample": f"{reps} training-step cores (specular+diffuse fwd+bwd, no optimiser) of {n_rays} rays x {num_samples} samples "
+        f"on the same 128^3 SH-2 grid, oracle with interp='aten' (F.grid_sample), torch {torch.__version__} CPU fp32; {dt:.2f} s/step",
+    }
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--grid", type=int, default=128)
+    ap.add_argument("--sh-degree", type=int, default=2)
+    ap.add_argument("--rays", type=int, default=16384, help="ray batch per GPU (reference CLI default)")
+    ap.add_argument("--samples", type=int, default=256)
+    ap.add_argument("--image-size", type=int, default=800)
+    ap.add_argument("--images", type=int, default=8)
+    ap.add_argument("--render-frames", type=int, default=3, help="full-frame forward renders timed for fwd_render (0 = skip)")
+    ap.add_argument("--cpu-rays", type=int, default=2048, help="rays of the cpu_baseline sample (0 = skip)")
+    ap.add_argument("--cpu-threads", type=int, default=0, help="torch CPU threads for cpu_baseline (0 = all host cores)")
+    args = ap.parse_args()
+
+    rank, local_rank, world = rfdist.init_from_env()
+    if world != args.gpus and world > 1:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    assert torch.cuda.is_available(), "bench.py needs a GPU (the render path has no CPU fallback)"
+    dev = torch.device("cuda", local_rank)
+    torch.cuda.set_device(dev)
+
+    H = W = args.image_size
+    focal = 1111.111 * (W / 800.0)
+    intr = rf.CameraIntrinsics(H, W, focal)
+    S, R, G = args.samples, args.rays, args.grid
+    bounds = rf.CameraBounds(NEAR, FAR)
+
+    # ---- synthetic dataset: images of a procedural ground-truth field rendered once (untimed) -------
+    gt = make_grid(dev, G, args.sh_degree, seed=7, sparse=True)
+    gt_cfg = rf.SHVoxGridRenderConfig(S, bounds, perturb_sampled_points=False, white_bkgd=True)
+    gt_model = rf.VolumetricModel(gt, rf.render_sh_voxel_grid, gt_cfg, device=dev)
+    poses = [rf.pose_spherical(45.0 * k, -30.0, RADIUS) for k in range(args.images)]
+    images = torch.stack([gt_model.render(p, intr).colour.permute(2, 0, 1) for p in poses])
+    pose_mat = torch.stack([torch.cat([p.rotation, p.translation], dim=1) for p in poses]).to(dev)
+    dataset = PosedImagesInMemory(images, pose_mat, intr, bounds)
+    del gt_model, gt
+
+    # ---- model under training: U(-1,1) grid, the reference's initialisation -----------------------
+    grid = make_grid(dev, G, args.sh_degree, seed=42)
+    cfg = rf.SHVoxGridRenderConfig(S, bounds, perturb_sampled_points=True, white_bkgd=True)
+    model = rf.VolumetricModel(grid, rf.render_sh_voxel_grid, cfg, device=dev)
+
+    # ---- forward-only full-frame render (configs[1]), timed separately, before training -----------
+    fwd_render = None
+    if args.render_frames > 0 and rank == 0:
+        pose = rf.pose_spherical(30.0, -30.0, RADIUS)
+        model.render(pose, intr)  # warm-up
+        timer = ops.KernelTimer()
+        ops.KERNEL_TIMER = timer
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(args.render_frames):
+            model.render(pose, intr)
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t0) / args.render_frames
+        ops.KERNEL_TIMER = None
+        rays = rf.flatten_rays(rf.cast_rays(intr, pose, dev))
+        n_in = count_inside(rays.origins, rays.directions, S, grid.aabb)
+        ksum = timer.summary()
+        kname = f"render_forward[sh{args.sh_degree}]"
+        kms = ksum[kname]["total_ms"] / args.render_frames
+        alg = n_in * 8 * (grid.features.shape[-1] + 1) * 4 + H * W * 48
+        fwd_render = {
+            "workload": f"{G}^3 SH-{args.sh_degree} ReLU field, {H}x{W}, {S} samples/ray, jittered, VolumetricModel.render (32768-ray chunks)",
+            "ms_per_frame": dt * 1e3,
+            "ray_samples_per_s": H * W * S / dt,
+            "rays_per_s": H * W / dt,
+            "kernel_ms_per_frame": kms,
+            "inside_fraction": n_in / (H * W * S),
+            "algorithmic_GB_per_frame": alg / 1e9,
+            "effective_GBps_kernel": alg / 1e9 / (kms / 1e3),
+            "frac_of_hbm_peak": alg / 1e9 / (kms / 1e3) / HBM_PEAK_GBS,
+        }
+
+    # ---- training steps: the headline ---------------------------------------------------------------
+    stepper = TrainStepper(model, R, learning_rate=0.03, apply_diffuse_render_regularization=True)
+    torch.manual_seed(1234 + rank)  # every rank draws its own rays
+    batches = dataset.image_batches(args.images)
+    for _ in range(args.warmup):
+        stepper.step(dataset, next(batches))
+    timer = ops.KernelTimer()
+    ops.KERNEL_TIMER = timer
+    if world > 1:
+        torch.distributed.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        stats = stepper.step(dataset, next(batches))
+    torch.cuda.synchronize()
+    if world > 1:
+        torch.distributed.barrier()
+    elapsed = time.perf_counter() - t0
+    ops.KERNEL_TIMER = None
+    if world > 1:
+        te = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        torch.distributed.all_reduce(te, op=torch.distributed.ReduceOp.MAX)
+        elapsed = float(te.item())
+
+    if rank != 0:
+        return
+    ms_per_step = elapsed / args.steps * 1e3
+    value = world * 2 * R * S * args.steps / elapsed
+
+    # ---- roofline of the dominant kernel (HIP events recorded inside the timed region) ------------
+    ksum = timer.summary()
+    rays, pixels = stepper.select(dataset, next(batches))
+    n_in = count_inside(rays.origins, rays.directions, S, grid.aabb)
+    C = grid.features.shape[-1] + 1
+    alg_bytes = {
+        f"render_forward[sh{args.sh_degree},save]": n_in * 8 * C * 4 + R * 48,
+        "render_forward[diffuse,save]": n_in * 8 * 4 * 4 + R * 48,
+        f"render_backward[sh{args.sh_degree}]": n_in * 8 * C * 4 + R * 48,
+        "render_backward[diffuse]": n_in * 8 * 4 * 4 + R * 48,
+        "adam_step": grid.densities.numel() * C * 4 * 7,
+    }
+    kernels = {}
+    for name, rec in ksum.items():
+        b = alg_bytes.get(name)
+        kernels[name] = {"avg_ms": rec["avg_ms"], "launches": rec["launches"]}
+        if b:
+            kernels[name]["algorithmic_GB"] = b / 1e9
+            kernels[name]["effective_GBps"] = b / 1e9 / (rec["avg_ms"] / 1e3)
+    render_kernels = {k: v for k, v in ksum.items() if k.startswith("render_")}
+    dom = max(render_kernels, key=lambda k: render_kernels[k]["total_ms"])
+    achieved = alg_bytes[dom] / 1e9 / (ksum[dom]["avg_ms"] / 1e3)
+    roofline = {
+        "kernel": dom,
+        "bound": "hbm",
+        "achieved": achieved,
+        "peak": HBM_PEAK_GBS,
+        "unit": "GB/s",
+        "frac": achieved / HBM_PEAK_GBS,
+        "traffic": None,
+        "algorithmic_bytes_per_launch": alg_bytes[dom],
+        "avg_launch_ms": ksum[dom]["avg_ms"],
+        "note": "effective bandwidth: algorithmic gather/scatter bytes (8 corners x C x 4 B per in-AABB sample, SURVEY 8d), "
+        "not credited for cache reuse or skipped zero-weight samples, so it can exceed DRAM traffic",
+    }
+    prof = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+    if os.path.exists(prof):
+        try:
+            table = json.load(open(prof))
+            roofline["traffic"] = table.get(dom, {}).get("hbm_bytes_per_launch")
+            roofline["traffic_source"] = table.get("_source")
+        except Exception:
+            pass
+
+    baseline = None
+    if args.cpu_rays > 0:
+        baseline = cpu_baseline(grid, (rays.origins.cpu(), rays.directions.cpu()), pixels.cpu(), S, args.cpu_rays, args.cpu_threads)
+
+    line = {
+        "metric": "ray-samples/sec (fwd+bwd) training step, 800x800 images @ 128^3 SH-2 ReLU field",
+        "value": value,
+        "unit": "ray-samples/s",
+        "n_gpus": world,
+        "steps": args.steps,
+        "warmup": args.warmup,
+        "ms_per_step": ms_per_step,
+        "higher_is_better": True,
+        "scaling": "weak",
+        "vs_baseline": None,
+        "dtype": "f32",
+        "data": "synthetic",
+        "config": {
+            "workload": f"configs[2]: train step on {G}^3 SH-degree-{args.sh_degree} ReLU field (U(-1,1) init), {args.images} synthetic {H}x{W} images, "
+            f"{R} random rays/GPU/step (randperm over all pixels), {S} jittered samples/ray, specular+diffuse fwd+bwd, L1+L1, fused Adam"
+            + (", gradient all-reduce over RCCL" if world > 1 else ""),
+            "rays_per_gpu_per_step": R,
+            "samples_per_ray": S,
+            "renders_per_step": 2,
+            "parallelism": f"dp{world}",
+        },
+        "rays_per_s": world * 2 * R * args.steps / elapsed,
+        "final_specular_psnr": stats.psnr()["specular_psnr"],
+        "inside_fraction": n_in / (R * S),
+        "kernels": kernels,
+        "roofline": roofline,
+        "cpu_baseline": baseline,
+        "fwd_render": fwd_render,
+    }
+    print(json.dumps(line))
+
+
+if __name__ == "__main__":
+    main()

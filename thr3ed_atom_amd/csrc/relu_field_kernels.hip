@@ -588,6 +588,14 @@ __global__ __launch_bounds__(kBlock) void render_forward_kernel(GridArgs g, RayA
   }
 }
 
+// lanes per corner for the backward scatter: F features + 1 density, rounded up to a power of two
+template <int K, bool DIFFUSE>
+struct ScatterLayout {
+  static constexpr bool kCorner = DIFFUSE || K == 1;  // only the degree-0 coefficient of each colour
+  static constexpr int kF = 3 * K;
+  static constexpr int kLPC = kCorner ? 4 : (kF + 1 <= 16 ? 16 : (kF + 1 <= 32 ? 32 : 64));
+};
+
 // =============================================================================================
 // backward: dL/d(densities), dL/d(features) from dL/d(colour, depth, acc)
 //
@@ -599,9 +607,7 @@ __global__ __launch_bounds__(kBlock) void render_forward_kernel(GridArgs g, RayA
 template <int K, bool DIFFUSE>
 __global__ __launch_bounds__(kBlock) void render_backward_kernel(GridArgs g, RayArgs r, OutArgs fwd, GradArgs gr,
                                                                  uint32_t flags) {
-  using L = Layout<K, DIFFUSE>;
-  constexpr int LPS = L::kLPS;
-  constexpr int GROUPS = L::kGroups;
+  using SL = ScatterLayout<K, DIFFUSE>;
 
   __shared__ __attribute__((aligned(16))) uint32_t s_entry[kWavesPerBlock][kWave * kEntryBwd];
 
@@ -622,13 +628,44 @@ __global__ __launch_bounds__(kBlock) void render_backward_kernel(GridArgs g, Ray
   const float gA = gr.gacc ? gr.gacc[ray] : 0.0f;
   if (gC[0] == 0.f && gC[1] == 0.f && gC[2] == 0.f && gD == 0.f && gA == 0.f) return;
 
-  const int sub = lane % LPS;
-  const int group = lane / LPS;
-  float yb[4] = {0.f, 0.f, 0.f, 0.f};
-  int chan[4] = {-1, -1, -1, -1};
-  int fb = 0;
-  if constexpr (!L::kCorner)
-    lane_basis<K, LPS>(st.d, st.dnorm, lane, reinterpret_cast<float*>(s_entry[wave]), yb, chan, fb);
+  // Scatter layout (measured on MI355X, tools/atomic_microbench.hip): float32 atomics retire at a fixed rate of
+  // ~21 G 64-byte-sector requests/s however many dwords a request carries, so one instruction should cover as
+  // many CONSECUTIVE dwords as possible.  Lane = channel: LPC lanes span one corner's F features + its density,
+  // and the two z-neighbours (adjacent records in memory) always share an instruction.
+  //   unit = (sample, corner);  corner q: bit0 = dz, bit1 = dy, bit2 = dx
+  constexpr int LPC = SL::kLPC;          // lanes per corner
+  constexpr int UPI = kWave / LPC;       // units per instruction
+  constexpr int SPI = UPI >= 8 ? UPI / 8 : 1;  // samples per scatter iteration
+  constexpr int NPASS = UPI >= 8 ? 1 : 8 / UPI;
+  const int c = lane % LPC;   // channel slot of this lane
+  const int unit = lane / LPC;
+  // per-lane, per-ray constants: which colour feeds this channel, its SH weight, its offset in the record
+  int lane_colour = -1;       // 0..2 feature of that colour, 3 = density lane, -1 = idle
+  float lane_basis_w = 0.0f;
+  int lane_feat_off = 0;
+  if constexpr (SL::kCorner) {
+    const int kfull = g.F / 3;
+    lane_colour = c;          // 0,1,2 colour; 3 density
+    lane_basis_w = kC0;
+    lane_feat_off = (c < 3) ? c * kfull : 0;
+  } else {
+    float Y[16];
+    sh_basis<K>(st.d[0] / st.dnorm, st.d[1] / st.dnorm, st.d[2] / st.dnorm, Y);
+    float* ldsY = reinterpret_cast<float*>(s_entry[wave]);
+    if (lane == 0) {
+#pragma unroll
+      for (int k = 0; k < K; ++k) ldsY[k] = Y[k];
+    }
+    wave_lds_fence();
+    if (c < SL::kF) {
+      lane_colour = c / K;
+      lane_basis_w = ldsY[c % K];
+      lane_feat_off = c;
+    } else if (c == SL::kF) {
+      lane_colour = 3;
+    }
+    wave_lds_fence();
+  }
   uint32_t* my_entry = s_entry[wave];
 
   const int processed = fwd.stop[ray];
@@ -698,66 +735,34 @@ __global__ __launch_bounds__(kBlock) void render_backward_kernel(GridArgs g, Ray
     }
     wave_lds_fence();
 
-    // scatter: LPS lanes per sample
-    for (int base = 0; base < count; base += GROUPS) {
-      const int slot = base + group;
-      if (slot < count) {
-        const uint32_t* en = my_entry + slot * kEntryBwd;
-        float ew[6];
+    // scatter: lane = channel
+    for (int base = 0; base < count; base += SPI) {
 #pragma unroll
-        for (int i = 0; i < 6; ++i) ew[i] = __uint_as_float(en[2 + i]);
-        const Corners cn = corners_of(en[0], ew, g);
-        const float gp = __uint_as_float(en[8]);
-        const float gr3[3] = {__uint_as_float(en[9]), __uint_as_float(en[10]), __uint_as_float(en[11])};
-
-        // density: corner `k` handled by lane k % LPS
-#pragma unroll
-        for (int k = 0; k < 8; ++k) {
-          if ((k % LPS) == sub && cn.w[k] != 0.0f && gp != 0.0f) {
-            float gv = (cn.w[k] * gp) * g.rho;
-            if (g.mode == RF_DENSITY_ABS) {
-              const float dv = g.dens[cn.lin[k] * g.dstride] * g.rho;
-              gv = (dv > 0.f) ? gv : ((dv < 0.f) ? -gv : 0.0f);
-            }
-            unsafeAtomicAdd(gr.gdens + cn.lin[k] * g.dstride, gv);
-          }
-        }
-        if constexpr (L::kCorner) {
-          const int kfull = g.F / 3;
-          long long lin = cn.lin[0];
-          float wk = cn.w[0];
-#pragma unroll
-          for (int k = 1; k < 8; ++k) {
-            lin = (sub == k) ? cn.lin[k] : lin;
-            wk = (sub == k) ? cn.w[k] : wk;
-          }
-          if (wk != 0.0f) {
-            float* fp = gr.gfeat + lin * g.fstride;
-#pragma unroll
-            for (int ch = 0; ch < 3; ++ch) {
-              const float gv = wk * (gr3[ch] * kC0);
-              if (gv != 0.0f) unsafeAtomicAdd(fp + ch * kfull, gv);
-            }
-          }
-        } else {
-          if (4 * sub < L::kF) {
-            float gf[4];
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-              float gsel = 0.0f;
-#pragma unroll
-              for (int ch = 0; ch < 3; ++ch) gsel = (chan[j] == ch) ? gr3[ch] : gsel;
-              gf[j] = gsel * yb[j];
-            }
-#pragma unroll
-            for (int k = 0; k < 8; ++k) {
-              if (cn.w[k] != 0.0f) {
-                float* fp = gr.gfeat + cn.lin[k] * g.fstride + fb;
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                  if (chan[j] >= 0) unsafeAtomicAdd(fp + j, cn.w[k] * gf[j]);
-                }
+      for (int pass = 0; pass < NPASS; ++pass) {
+        const int u = pass * UPI + unit;     // unit index within this group of SPI samples
+        const int slot = base + (u >> 3);
+        const int q = u & 7;
+        if (slot < count && lane_colour >= 0) {
+          const uint32_t* en = my_entry + slot * kEntryBwd;
+          const uint32_t pk = en[0];
+          const int dx = (q >> 2) & 1, dy = (q >> 1) & 1, dz = q & 1;
+          const int ix = (int)(pk & 0x7ffu) - 1 + dx, iy = (int)((pk >> 11) & 0x7ffu) - 1 + dy, iz = (int)(pk >> 22) - 1 + dz;
+          const bool ok = ix >= 0 && ix < g.X && iy >= 0 && iy < g.Y && iz >= 0 && iz < g.Z;
+          const float wx = __uint_as_float(en[2 + dx]), wy = __uint_as_float(en[4 + dy]), wz = __uint_as_float(en[6 + dz]);
+          const float wc = (wx * wy) * wz;
+          if (ok) {
+            const long long lin = ((long long)ix * g.Y + iy) * g.Z + iz;
+            if (lane_colour == 3) {
+              float gv = (wc * __uint_as_float(en[8])) * g.rho;
+              if (g.mode == RF_DENSITY_ABS) {
+                const float dv = g.dens[lin * g.dstride] * g.rho;
+                gv = (dv > 0.f) ? gv : ((dv < 0.f) ? -gv : 0.0f);
               }
+              if (gv != 0.0f) unsafeAtomicAdd(gr.gdens + lin * g.dstride, gv);
+            } else {
+              const float gsel = __uint_as_float(en[9 + lane_colour]);
+              const float gv = wc * (gsel * lane_basis_w);
+              if (gv != 0.0f) unsafeAtomicAdd(gr.gfeat + lin * g.fstride + lane_feat_off, gv);
             }
           }
         }

@@ -1,0 +1,85 @@
+"""Data-parallel rendering/training across the GPUs of one node: one process per GPU over RCCL/xGMI.
+
+The reference has no distributed code at all (single process, single device).  Rays are independent, so
+the path shards naturally: every rank renders its own ray batch against a replicated grid; training adds
+exactly ONE exchange step per iteration -- an all-reduce (average) of the flat gradient bucket
+(``FlatGrid.flat_grad``: 234.9 MB at 128^3 / SH degree 2), after which every rank applies the identical
+Adam update, so parameters stay bit-identical replicas without ever being broadcast again.
+
+Backend "nccl" is RCCL on ROCm; "gloo" is used by the CPU tests of the collective wiring.
+"""
+import os
+from typing import Optional
+
+import torch
+import torch.distributed as dist
+from torch import Tensor
+
+
+def env_world() -> tuple:
+    return int(os.environ.get("RANK", "0")), int(os.environ.get("LOCAL_RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
+
+
+def init_from_env(backend: Optional[str] = None) -> tuple:
+    """Join the process group described by torchrun's environment (RANK / LOCAL_RANK / WORLD_SIZE /
+    MASTER_ADDR / MASTER_PORT).  Returns (rank, local_rank, world_size); a world of 1 initialises nothing."""
+    rank, local_rank, world = env_world()
+    if world > 1 and not dist.is_initialized():
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        if backend is None:
+            backend = "nccl" if torch.cuda.is_available() else "gloo"
+        if backend == "nccl":
+            torch.cuda.set_device(local_rank)
+        dist.init_process_group(backend=backend, rank=rank, world_size=world)
+    return rank, local_rank, world
+
+
+def world_size() -> int:
+    return dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
+
+
+def rank() -> int:
+    return dist.get_rank() if dist.is_available() and dist.is_initialized() else 0
+
+
+def all_reduce_mean_(bucket: Tensor) -> Tensor:
+    """In-place average of one flat bucket over all ranks (no-op for a world of 1).  One collective per
+    training step; RCCL picks ring / direct over the xGMI mesh."""
+    n = world_size()
+    if n > 1:
+        dist.all_reduce(bucket, op=dist.ReduceOp.SUM)
+        bucket.mul_(1.0 / n)
+    return bucket
+
+
+def broadcast_(tensor: Tensor, src: int = 0) -> Tensor:
+    if world_size() > 1:
+        dist.broadcast(tensor, src=src)
+    return tensor
+
+
+def shard_range(total: int, rank_: Optional[int] = None, world: Optional[int] = None) -> tuple:
+    """[start, stop) of this rank's contiguous shard of ``total`` items (remainder spread over the first
+    ranks) -- used to split the rays of a full-image render."""
+    r = rank() if rank_ is None else rank_
+    w = world_size() if world is None else world
+    base, rem = divmod(total, w)
+    start = r * base + min(r, rem)
+    return start, start + base + (1 if r < rem else 0)
+
+
+def all_gather_rows(local: Tensor) -> Tensor:
+    """Concatenate per-rank row blocks (possibly of different lengths) along dim 0 on every rank."""
+    w = world_size()
+    if w == 1:
+        return local
+    sizes = [torch.zeros(1, dtype=torch.int64, device=local.device) for _ in range(w)]
+    dist.all_gather(sizes, torch.tensor([local.shape[0]], dtype=torch.int64, device=local.device))
+    sizes = [int(s.item()) for s in sizes]
+    width = max(sizes)
+    padded = torch.zeros((width,) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
+    padded[: local.shape[0]] = local
+    parts = [torch.empty_like(padded) for _ in range(w)]
+    dist.all_gather(parts, padded)
+    return torch.cat([p[:s] for p, s in zip(parts, sizes)], dim=0)

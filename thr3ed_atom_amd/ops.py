@@ -21,6 +21,62 @@ from .voxels import VoxelGrid
 _T_VALS_CACHE: Dict[Tuple[int, str], Tensor] = {}
 
 
+class KernelTimer:
+    """Optional HIP-event timing of the render launches (bench.py's roofline leg).  Events are recorded
+    on the stream the kernels are enqueued on; reading them needs a device synchronise, which the caller
+    does once after the timed region."""
+
+    def __init__(self):
+        self.records: Dict[str, list] = {}
+
+    def span(self, name: str, device):
+        return _TimedSpan(self, name, device)
+
+    def summary(self) -> Dict[str, dict]:
+        out = {}
+        for name, spans in self.records.items():
+            ms = [a.elapsed_time(b) for a, b in spans]
+            out[name] = {"launches": len(ms), "avg_ms": sum(ms) / max(len(ms), 1), "total_ms": sum(ms)}
+        return out
+
+    def reset(self) -> None:
+        self.records.clear()
+
+
+class _TimedSpan:
+    def __init__(self, timer, name, device):
+        self.timer, self.name, self.device = timer, name, device
+
+    def __enter__(self):
+        self.a = torch.cuda.Event(enable_timing=True)
+        self.b = torch.cuda.Event(enable_timing=True)
+        self.a.record(torch.cuda.current_stream(self.device))
+
+    def __exit__(self, *exc):
+        self.b.record(torch.cuda.current_stream(self.device))
+        self.timer.records.setdefault(self.name, []).append((self.a, self.b))
+        return False
+
+
+class _NoSpan:
+    def __enter__(self):
+        return None
+
+    def __exit__(self, *exc):
+        return False
+
+
+KERNEL_TIMER: Optional[KernelTimer] = None
+
+
+def _span(name: str, device):
+    return KERNEL_TIMER.span(name, device) if KERNEL_TIMER is not None else _NoSpan()
+
+
+def _variant(grid: "VoxelGrid", flags: int) -> str:
+    return "diffuse" if (flags & _lib.FLAG_RENDER_DIFFUSE) else f"sh{grid.sh_degree}"
+
+
 def _stream(device) -> int:
     return torch.cuda.current_stream(device).cuda_stream
 
@@ -61,7 +117,7 @@ def _ray_batch(origins: Tensor, directions: Tensor, num_samples: int, near: floa
 
 class _ReluFieldRender(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, densities, features, origins, directions, t_rand, grid: VoxelGrid, num_samples, near, far, flags):
+    def forward(ctx, densities, features, origins, directions, t_rand, grid: VoxelGrid, num_samples, near, far, flags, need_grad):
         lib = _lib.load()
         for name, t in (("densities", densities), ("features", features), ("ray origins", origins), ("ray directions", directions)):
             _require_hip(t, name)
@@ -74,7 +130,6 @@ class _ReluFieldRender(torch.autograd.Function):
             if tuple(t_rand.shape) != (n, num_samples):
                 raise ValueError(f"t_rand must be [{n}, {num_samples}], got {tuple(t_rand.shape)}")
         dev = origins.device
-        need_grad = densities.requires_grad or features.requires_grad
         rf_grid = grid.to_rf_grid(use_occupancy=bool(flags & _lib.FLAG_OCCUPANCY_SKIP))
         rb, tv = _ray_batch(origins, directions, num_samples, near, far, t_rand)
 
@@ -95,7 +150,9 @@ class _ReluFieldRender(torch.autograd.Function):
             tcache = torch.empty((n, num_samples), dtype=torch.float32, device=dev)
             stop = torch.empty((n,), dtype=torch.int32, device=dev)
             out.sample_cache_dev, out.trans_cache_dev, out.stop_cache_dev = cache.data_ptr(), tcache.data_ptr(), stop.data_ptr()
-        _lib.check(lib.rf_render_forward(C.byref(rf_grid), C.byref(rb), int(flags), C.byref(out), _stream(dev)), "rf_render_forward")
+        with _span(f"render_forward[{_variant(grid, flags)}{',save' if need_grad else ''}]", dev):
+            rc = lib.rf_render_forward(C.byref(rf_grid), C.byref(rb), int(flags), C.byref(out), _stream(dev))
+        _lib.check(rc, "rf_render_forward")
 
         ctx.grid, ctx.flags = grid, int(flags)
         ctx.num_samples, ctx.near, ctx.far = int(num_samples), float(near), float(far)
@@ -113,7 +170,7 @@ class _ReluFieldRender(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g_colour, g_depth, g_acc, _g_disparity):
         if not ctx.need_grad:
-            return (None,) * 10
+            return (None,) * 11
         lib = _lib.load()
         saved = list(ctx.saved_tensors)
         densities, features, origins, directions, depth, acc, cache, tcache, stop = saved[:9]
@@ -144,13 +201,12 @@ class _ReluFieldRender(torch.autograd.Function):
             gd = torch.zeros_like(densities)
             gf = torch.zeros_like(features)
             ret_d, ret_f = gd, gf
-        _lib.check(
-            lib.rf_render_backward(
+        with _span(f"render_backward[{_variant(grid, ctx.flags)}]", dev):
+            rc = lib.rf_render_backward(
                 C.byref(rf_grid), C.byref(rb), ctx.flags, C.byref(fwd), C.byref(grads), gd.data_ptr(), gf.data_ptr(), _stream(dev)
-            ),
-            "rf_render_backward",
-        )
-        return ret_d, ret_f, None, None, None, None, None, None, None, None
+            )
+        _lib.check(rc, "rf_render_backward")
+        return ret_d, ret_f, None, None, None, None, None, None, None, None, None
 
 
 def relu_field_render(
@@ -180,8 +236,10 @@ def relu_field_render(
         if grid.occupancy is None:
             grid.build_occupancy()
         flags |= _lib.FLAG_OCCUPANCY_SKIP
+    # the per-sample cache for the backward pass is only written when a gradient can be asked for
+    need_grad = torch.is_grad_enabled() and (grid.densities.requires_grad or grid.features.requires_grad)
     return _ReluFieldRender.apply(
-        grid.densities, grid.features, origins, directions, t_rand, grid, int(num_samples), float(near), float(far), flags
+        grid.densities, grid.features, origins, directions, t_rand, grid, int(num_samples), float(near), float(far), flags, need_grad
     )
 
 
@@ -259,9 +317,8 @@ def adam_step_hip(param: Tensor, grad: Tensor, exp_avg: Tensor, exp_avg_sq: Tens
         if not (t.is_contiguous() and t.dtype == torch.float32 and t.numel() == param.numel()):
             raise ValueError(f"{name} must be a contiguous float32 tensor with {param.numel()} elements")
     lib = _lib.load()
-    _lib.check(
-        lib.rf_adam_step(
+    with _span("adam_step", param.device):
+        rc = lib.rf_adam_step(
             param.data_ptr(), grad.data_ptr(), exp_avg.data_ptr(), exp_avg_sq.data_ptr(), param.numel(), float(lr), float(beta1), float(beta2), float(eps), int(step), _stream(param.device)
-        ),
-        "rf_adam_step",
-    )
+        )
+    _lib.check(rc, "rf_adam_step")
