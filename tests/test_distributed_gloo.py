@@ -1,0 +1,89 @@
+"""World-size-2 tests of the data-parallel wiring on the gloo backend (CPU, runs everywhere).
+
+The GPU path uses the same helpers with backend "nccl" (= RCCL): one all-reduce of the flat gradient bucket
+per step, identical optimiser state on every rank, ray shards by contiguous range."""
+import os
+import socket
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from thr3ed_atom_amd import distributed as rfdist
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _worker(rank, world, port, result_dir):
+    os.environ.update(
+        RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port)
+    )
+    r, lr, w = rfdist.init_from_env(backend="gloo")
+    assert (r, w) == (rank, world) and rfdist.rank() == rank and rfdist.world_size() == world
+
+    # 1. flat-bucket gradient average == gradient of the concatenated batch
+    torch.manual_seed(0)
+    params = torch.randn(1000)
+    data = torch.randn(world * 8, 1000)
+    target = torch.randn(world * 8)
+    p = params.clone().requires_grad_(True)
+    lo, hi = rfdist.shard_range(world * 8)
+    assert hi - lo == 8
+    loss = ((data[lo:hi] @ p - target[lo:hi]) ** 2).mean()
+    loss.backward()
+    bucket = p.grad.clone()
+    rfdist.all_reduce_mean_(bucket)
+    pf = params.clone().requires_grad_(True)
+    ((data @ pf - target) ** 2).mean().backward()
+    assert torch.allclose(bucket, pf.grad, rtol=1e-5, atol=1e-6)
+
+    # 2. identical Adam on every rank keeps replicas bit-identical after several steps
+    m, v = torch.zeros_like(params), torch.zeros_like(params)
+    q = params.clone()
+    for step in range(1, 4):
+        g = bucket * step
+        m = m + (g - m) * 0.1
+        v = v * 0.999 + g * g * 0.001
+        q = q - 0.03 / (1 - 0.9**step) * (m / (v.sqrt() / (1 - 0.999**step) ** 0.5 + 1e-8))
+    gathered = [torch.empty_like(q) for _ in range(world)]
+    dist.all_gather(gathered, q)
+    assert all(torch.equal(gathered[0], t) for t in gathered)
+
+    # 3. ragged row gather (rays of a frame split over ranks) and broadcast
+    rows = torch.arange(10 * 3, dtype=torch.float32).reshape(10, 3)
+    lo, hi = rfdist.shard_range(10)
+    full = rfdist.all_gather_rows(rows[lo:hi] * 1.0)
+    assert torch.equal(full, rows)
+    b = torch.full((4,), float(rank))
+    rfdist.broadcast_(b, src=0)
+    assert torch.equal(b, torch.zeros(4))
+    open(os.path.join(result_dir, f"ok{rank}"), "w").write("ok")
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2])
+def test_gradient_bucket_allreduce_and_sharding(tmp_path, world):
+    mp.spawn(_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    assert sorted(os.listdir(tmp_path)) == [f"ok{r}" for r in range(world)]
+
+
+def test_shard_range_covers_everything():
+    for total in (0, 1, 7, 16384, 640000):
+        for world in (1, 2, 3, 8):
+            spans = [rfdist.shard_range(total, r, world) for r in range(world)]
+            assert spans[0][0] == 0 and spans[-1][1] == total
+            assert all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
+            sizes = [b - a for a, b in spans]
+            assert max(sizes) - min(sizes) <= 1
+
+
+def test_single_process_helpers_are_noops():
+    t = torch.ones(5)
+    assert rfdist.world_size() == 1 and rfdist.rank() == 0
+    assert torch.equal(rfdist.all_reduce_mean_(t.clone()), t)
+    assert torch.equal(rfdist.all_gather_rows(t), t)
