@@ -266,3 +266,35 @@ def test_hash_uniform_is_stable():
     v = hash_uniform((4,), 71)
     assert v.dtype == np.float32 and np.all(np.abs(v) <= 1.0)
     np.testing.assert_array_equal(v, hash_uniform((2, 2), 71).reshape(-1))
+
+
+def test_g9_training_trajectory_of_the_real_reference_trainer():
+    """Row 12: the oracle + torch.optim.Adam, fed the ray/pixel batches the REAL reference trainer selected
+    (oracle/gen_golden_trainer.py), reproduces its losses and its parameters after 1 and 5 Adam steps."""
+    g = load_golden("g9_trainer_trajectory.npz")
+    G, deg, hw, n_img, n_rays, steps, S = (int(v) for v in g["config"])
+    F = 3 * (deg + 1) ** 2
+    dens = torch.from_numpy(hash_uniform((G, G, G, 1), 900 + 1)).requires_grad_(True)
+    feat = torch.from_numpy(hash_uniform((G, G, G, F), 900 + F)).requires_grad_(True)
+    opt = torch.optim.Adam([{"params": [dens, feat], "lr": float(g["lr"])}], betas=(0.9, 0.999))
+    aabb = orc.make_aabb((G, G, G), (3.0 / G,) * 3)
+    for it in range(steps):
+        o, d, px = T(g["origins"][it]), T(g["directions"][it]), T(g["pixels"][it])
+        kw = dict(origins=o, directions=d, aabb=aabb, near=float(g["near"]), far=float(g["far"]), num_samples=S,
+                  density_scale=100.0 / 3.0, white_bkgd=True)
+        spec = torch.nn.functional.l1_loss(orc.render(dens, feat, **kw)["colour"], px)
+        diff = torch.nn.functional.l1_loss(orc.render(dens, feat, render_diffuse=True, **kw)["colour"], px)
+        np.testing.assert_allclose(spec.item(), g["specular_loss"][it], rtol=2e-6)
+        np.testing.assert_allclose(diff.item(), g["diffuse_loss"][it], rtol=2e-6)
+        opt.zero_grad()
+        (spec + diff).backward()
+        opt.step()
+        if it == 0:
+            # (the two autograd graphs sum the scatter in different orders: a few parameters move by ~1e-6)
+            np.testing.assert_allclose(dens.detach().numpy(), g["dens_after_step1"], rtol=0, atol=1e-5)
+            np.testing.assert_allclose(feat.detach().numpy(), g["feat_after_step1"], rtol=0, atol=1e-5)
+    # Adam's first steps move every touched parameter by ~lr regardless of gradient size, so tiny
+    # summation-order differences can flip the direction of near-zero gradients: compare in aggregate
+    dd = np.abs(dens.detach().numpy() - g["dens_final"])
+    df = np.abs(feat.detach().numpy() - g["feat_final"])
+    assert np.mean(dd < 1e-4) > 0.995 and np.mean(df < 1e-4) > 0.995
