@@ -40,7 +40,7 @@ RADIUS = 4.0311
 WORLD = 3.0
 
 
-def make_grid(dev, G, sh_degree, seed, sparse=False):
+def make_grid(dev, G, sh_degree, seed, sparse=False, storage="reference"):
     gen = torch.Generator(device=dev)
     gen.manual_seed(seed)
     F = 3 * (sh_degree + 1) ** 2
@@ -58,6 +58,7 @@ def make_grid(dev, G, sh_degree, seed, sparse=False):
         density_postactivation=torch.nn.ReLU(),
         expected_density_scale=rf.compute_expected_density_scale_for_relu_field_grid((WORLD,) * 3),
         tunable=True,
+        storage=storage,
     )
 
 
@@ -133,6 +134,8 @@ def main():
     ap.add_argument("--images", type=int, default=8)
     ap.add_argument("--render-frames", type=int, default=3, help="full-frame forward renders timed for fwd_render (0 = skip)")
     ap.add_argument("--cpu-rays", type=int, default=2048, help="rays of the cpu_baseline sample (0 = skip)")
+    ap.add_argument("--storage", choices=["split", "reference"], default="split",
+                    help="HBM layout of the grid: split = MI355X-native (what the trainer uses), reference = the reference's two tensors")
     ap.add_argument("--cpu-threads", type=int, default=0, help="torch CPU threads for cpu_baseline (0 = all host cores)")
     args = ap.parse_args()
 
@@ -160,7 +163,7 @@ def main():
     del gt_model, gt
 
     # ---- model under training: U(-1,1) grid, the reference's initialisation -----------------------
-    grid = make_grid(dev, G, args.sh_degree, seed=42)
+    grid = make_grid(dev, G, args.sh_degree, seed=42, storage=args.storage)
     cfg = rf.SHVoxGridRenderConfig(S, bounds, perturb_sampled_points=True, white_bkgd=True)
     model = rf.VolumetricModel(grid, rf.render_sh_voxel_grid, cfg, device=dev)
 
@@ -183,7 +186,7 @@ def main():
         ksum = timer.summary()
         kname = f"render_forward[sh{args.sh_degree}]"
         kms = ksum[kname]["total_ms"] / args.render_frames
-        alg = n_in * 8 * (grid.features.shape[-1] + 1) * 4 + H * W * 48
+        alg = n_in * 8 * (3 * (args.sh_degree + 1) ** 2 + 1) * 4 + H * W * 48
         fwd_render = {
             "workload": f"{G}^3 SH-{args.sh_degree} ReLU field, {H}x{W}, {S} samples/ray, jittered, VolumetricModel.render (32768-ray chunks)",
             "ms_per_frame": dt * 1e3,
@@ -229,13 +232,13 @@ def main():
     ksum = timer.summary()
     rays, pixels = stepper.select(dataset, next(batches))
     n_in = count_inside(rays.origins, rays.directions, S, grid.aabb)
-    C = grid.features.shape[-1] + 1
+    C = 3 * (args.sh_degree + 1) ** 2 + 1
     alg_bytes = {
         f"render_forward[sh{args.sh_degree},save]": n_in * 8 * C * 4 + R * 48,
         "render_forward[diffuse,save]": n_in * 8 * 4 * 4 + R * 48,
         f"render_backward[sh{args.sh_degree}]": n_in * 8 * C * 4 + R * 48,
         "render_backward[diffuse]": n_in * 8 * 4 * 4 + R * 48,
-        "adam_step": grid.densities.numel() * C * 4 * 7,
+        "adam_step": G**3 * C * 4 * 7,
     }
     kernels = {}
     for name, rec in ksum.items():
@@ -294,6 +297,7 @@ def main():
             "samples_per_ray": S,
             "renders_per_step": 2,
             "parallelism": f"dp{world}",
+            "grid_storage": args.storage,
         },
         "rays_per_s": world * 2 * R * args.steps / elapsed,
         "final_specular_psnr": stats.psnr()["specular_psnr"],

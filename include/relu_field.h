@@ -48,6 +48,16 @@ enum {
   RF_DENSITY_IDENTITY = 3  /* pre = identity, post = identity                         */
 };
 
+/* storage layout of the grid tensors handed to the kernels */
+enum {
+  RF_LAYOUT_REFERENCE = 0, /* the reference's two tensors: densities [X,Y,Z,1], features [X,Y,Z,F]
+                              (feature index = colour*K + k, thre3d_reprs/voxels.py:70-71)                 */
+  RF_LAYOUT_SPLIT = 1      /* MI355X-native: densities_dev -> base [X,Y,Z,4] = (density, sh0 r, sh0 g, sh0 b),
+                              features_dev -> rest [X,Y,Z,F-3] with index = colour*(K-1) + (k-1), k >= 1
+                              (NULL when F == 3).  The diffuse pass and the density gather touch only the
+                              16-byte base records; gradient buffers use the same layout.                 */
+};
+
 /* render flags (SHVoxGridRenderConfig fields, thre3d_reprs/renderers.py:28-45) */
 enum {
   RF_FLAG_WHITE_BKGD = 1,     /* white_bkgd                                                        */
@@ -70,6 +80,7 @@ typedef struct RFGrid {
   float norm_bias[3];         /*   utils/imaging_utils.py:58-63); computed by the host in float32      */
   float density_scale;        /* expected_density_scale rho, applied BEFORE interpolation              */
   int32_t density_mode;       /* RF_DENSITY_*                                                          */
+  int32_t layout;             /* RF_LAYOUT_*; strides above are then those of base / rest              */
   const uint32_t* occupancy_dev; /* optional bit mask, one bit per cell incl. the border cells:
                                     (X+1)*(Y+1)*(Z+1) bits, see rf_build_occupancy; may be NULL      */
 } RFGrid;

@@ -19,7 +19,7 @@ def T(a):
     return torch.from_numpy(np.asarray(a))
 
 
-def relu_grid(dev, dens, feat, G, rho=100.0 / 3.0, tunable=True):
+def relu_grid(dev, dens, feat, G, rho=100.0 / 3.0, tunable=True, storage="reference"):
     return rf.VoxelGrid(
         dens.clone().to(dev),
         feat.clone().to(dev),
@@ -28,15 +28,17 @@ def relu_grid(dev, dens, feat, G, rho=100.0 / 3.0, tunable=True):
         density_postactivation=torch.nn.ReLU(),
         expected_density_scale=rho,
         tunable=tunable,
+        storage=storage,
     )
 
 
-def test_g9_reference_trainer_trajectory(hip_device):
+@pytest.mark.parametrize("storage", ["reference", "split"])
+def test_g9_reference_trainer_trajectory(hip_device, storage):
     """TrainStepper fed the batches the REAL reference trainer selected reproduces its losses and parameters."""
     g = load_golden("g9_trainer_trajectory.npz")
     G, deg, hw, n_img, n_rays, steps, S = (int(v) for v in g["config"])
     F = 3 * (deg + 1) ** 2
-    grid = relu_grid(hip_device, T(hash_uniform((G, G, G, 1), 901)), T(hash_uniform((G, G, G, F), 900 + F)), G)
+    grid = relu_grid(hip_device, T(hash_uniform((G, G, G, 1), 901)), T(hash_uniform((G, G, G, F), 900 + F)), G, storage=storage)
     cfg = rf.SHVoxGridRenderConfig(S, rf.CameraBounds(float(g["near"]), float(g["far"])), perturb_sampled_points=False, white_bkgd=True)
     model = rf.VolumetricModel(grid, rf.render_sh_voxel_grid, cfg, device=hip_device)
     stepper = TrainStepper(model, n_rays, learning_rate=float(g["lr"]))
@@ -78,6 +80,41 @@ def test_flat_bucket_gradients_equal_plain_autograd(hip_device):
     assert float(flat.flat_grad.abs().max()) == 0.0
     # state_dict is still the reference's two tensors
     assert sorted(grids[1].state_dict().keys()) == ["_densities", "_features"]
+
+
+def test_split_storage_is_the_same_grid(hip_device, tmp_path):
+    """reference <-> split storage: same accessors, same state_dict keys/values, same renders (bit-exact
+    interpolation recipe in both layouts), checkpoints interchangeable."""
+    dens, feat = procedural_grid((9, 10, 11), 27, 13)
+    ref = relu_grid(hip_device, dens, feat, 9, storage="reference")
+    spl = relu_grid(hip_device, dens, feat, 9, storage="split")
+    assert torch.equal(spl.densities, ref.densities) and torch.equal(spl.features, ref.features)
+    sd_ref, sd_spl = ref.state_dict(), spl.state_dict()
+    assert sorted(sd_spl.keys()) == sorted(sd_ref.keys()) == ["_densities", "_features"]
+    assert all(torch.equal(sd_ref[k], sd_spl[k]) for k in sd_ref)
+    assert [tuple(p.shape) for p in spl.parameters()] == [(9, 10, 11, 4), (9, 10, 11, 24)]
+    cam = hotdog_like_camera()
+    g7 = load_golden("g7_grid16_render.npz")
+    rays = rf.Rays(T(g7["origins"]).to(hip_device), T(g7["directions"]).to(hip_device))
+    cfg = rf.SHVoxGridRenderConfig(40, rf.CameraBounds(cam["near"], cam["far"]), perturb_sampled_points=False, white_bkgd=True)
+    a, b = rf.render_sh_voxel_grid(ref, rays, cfg), rf.render_sh_voxel_grid(spl, rays, cfg)
+    assert torch.equal(a.depth, b.depth) and torch.equal(a.extra["accumulated_weight"], b.extra["accumulated_weight"])
+    np.testing.assert_allclose(a.colour.detach().cpu().numpy(), b.colour.detach().cpu().numpy(), rtol=0, atol=5e-7)
+    # a checkpoint written from split storage loads into reference storage and vice versa
+    model = rf.VolumetricModel(spl, rf.render_sh_voxel_grid, cfg, device=hip_device)
+    torch.save(model.get_save_info(extra_info={}), tmp_path / "m.pth")
+    for storage in ("reference", "split"):
+        creator = lambda info, st=storage: rf.create_voxel_grid_from_saved_info_dict(info, storage=st)
+        loaded, _ = rf.create_volumetric_model_from_saved_model(tmp_path / "m.pth", creator, device=hip_device)
+        assert loaded.thre3d_repr.storage == storage
+        assert torch.equal(loaded.thre3d_repr.features, ref.features) and torch.equal(loaded.thre3d_repr.densities, ref.densities)
+    # writing through the accessors reaches the split tensors
+    with torch.no_grad():
+        spl.densities.mul_(2.0)
+    spl.features = ref.features * 3.0
+    assert torch.equal(spl.densities, ref.densities * 2.0) and torch.equal(spl.features, ref.features * 3.0)
+    up = rf.scale_voxel_grid_with_required_output_size(spl, (12, 12, 12))
+    assert up.storage == "split" and up.features.shape == (12, 12, 12, 27)
 
 
 def test_fused_adam_matches_torch_adam(hip_device):
@@ -124,7 +161,7 @@ def test_psnr_after_equal_steps_matches_cpu_reference_path(hip_device):
     data, cfg, poses = _make_scene(hip_device, G, deg, 8, 40, S)
     F = 3 * (deg + 1) ** 2
     d0, f0 = procedural_grid((G, G, G), F, 77)
-    grid = relu_grid(hip_device, d0, f0, G)
+    grid = relu_grid(hip_device, d0, f0, G, storage="split")  # the layout the trainer and bench.py use
     model = rf.VolumetricModel(grid, rf.render_sh_voxel_grid, cfg, device=hip_device)
     stepper = TrainStepper(model, R, learning_rate=0.03)
     cd, cf = d0.clone().requires_grad_(True), f0.clone().requires_grad_(True)
@@ -178,7 +215,8 @@ def test_full_trainer_two_stages_and_checkpoint_roundtrip(hip_device, tmp_path):
     assert torch.equal(a, b)
 
 
-def test_occupancy_skipping_is_exact(hip_device):
+@pytest.mark.parametrize("storage", ["reference", "split"])
+def test_occupancy_skipping_is_exact(hip_device, storage):
     """BASELINE.json configs[4] at reduced size: density-threshold occupancy mask, ReLU field, threshold 0:
     outputs AND gradients are bit-identical with and without the mask on a sparse scene."""
     G, S = 48, 96
@@ -187,13 +225,14 @@ def test_occupancy_skipping_is_exact(hip_device):
     pose = rf.pose_spherical(40.0, -25.0, cam["radius"])
     outs = []
     for use in (False, True):
-        grid = relu_grid(hip_device, gd, gf, G)
+        grid = relu_grid(hip_device, gd, gf, G, storage=storage)
         cfg = rf.SHVoxGridRenderConfig(S, rf.CameraBounds(cam["near"], cam["far"]), perturb_sampled_points=False, white_bkgd=True, use_occupancy_mask=use)
         model = rf.VolumetricModel(grid, rf.render_sh_voxel_grid, cfg, device=hip_device)
         rays = rf.flatten_rays(rf.cast_rays(rf.CameraIntrinsics(48, 48, 60.0), pose, hip_device))
         out = model.render_rays(rays)
         out.colour.sum().backward()
-        outs.append((out.colour.detach(), out.depth.detach(), grid.densities.grad.clone(), grid.features.grad.clone(), grid))
+        rgd, rgf = grid.reference_gradients()
+        outs.append((out.colour.detach(), out.depth.detach(), rgd.clone(), rgf.clone(), grid))
     occ = outs[1][4].occupancy
     bits = sum(bin(int(w) & 0xFFFFFFFF).count("1") for w in occ.cpu().tolist())
     assert 0 < bits < 0.5 * (G + 1) ** 3, "the mask should mark most of this scene empty"

@@ -59,6 +59,7 @@ struct GridArgs {
   float amin[3], amax[3], nscale[3], nbias[3];
   float rho;
   int mode;
+  int layout;  // RF_LAYOUT_REFERENCE: dens[.,1] + feat[.,F];  RF_LAYOUT_SPLIT: dens = base[.,4], feat = rest[.,F-3]
 };
 
 struct RayArgs {
@@ -348,7 +349,7 @@ __device__ __forceinline__ bool cell_occupied(const Cell& c, const GridArgs& g) 
 // ---------------------------------------------------------------------------------------------
 // feature gather for LPS lanes per sample (P1).  Returns raw RGB in every lane of the group.
 //   CORNER mode (K_READ == 1; SH degree 0 or render_diffuse): lane = corner, 3 channels per lane.
-//   CHANNEL mode: lane l owns features [fb, fb+4), fb = min(4l, F-4); first owned element j0 = 4l - fb.
+//   CHANNEL mode: each lane gathers 4 consecutive floats per corner (see LaneSlice).
 // ---------------------------------------------------------------------------------------------
 template <int K, bool DIFFUSE>
 struct Layout {
@@ -366,14 +367,27 @@ __device__ __forceinline__ float group_sum(float x) {
 }
 
 
-// The slice of the per-ray SH basis a P1 lane needs: lane `sub` of a group owns features [fb, fb+4) with
-// fb = min(4 sub, F-4) (the last lane is shifted back so that it never reads past the corner's features;
-// its first `j0` elements belong to the previous lane and are ignored).  The basis is staged through a
-// 16-float LDS row of the wave so that the dynamic index (f % K) never touches scratch memory.
+// What one P1 lane gathers: 4 consecutive floats at `src + voxel * stride + off` of every corner, and for each of
+// the 4 elements which colour it feeds (chan, -1 = not owned) with which SH weight (yb).
+//   reference layout: lane `sub` owns features [off, off+4), off = min(4 sub, F-4): the last lane is shifted back so
+//     that it never reads past the corner's F features; its first j0 elements belong to the previous lane.
+//   split layout: lane 0 reads the 16-byte base record (sigma, sh0 r, g, b); lanes 1.. read the rest record
+//     (index = colour * (K-1) + (k-1)) four floats at a time, last lane shifted back likewise.
+// The per-ray basis is staged through a 16-float LDS row so that the dynamic index never touches scratch.
+struct LaneSlice {
+  const float* src;
+  long long stride;
+  int off;
+  bool active;
+  float yb[4];
+  int chan[4];
+};
+
 template <int K, int LPS>
-__device__ __forceinline__ void lane_basis(const float d[3], float dnorm, int lane, float* ldsY, float yb[4],
-                                           int chan[4], int& fb) {
+__device__ __forceinline__ LaneSlice lane_slice(const GridArgs& g, const float d[3], float dnorm, int lane,
+                                                float* ldsY) {
   constexpr int F = 3 * K;
+  constexpr int R = 3 * (K - 1);
   float Y[16];
   sh_basis<K>(d[0] / dnorm, d[1] / dnorm, d[2] / dnorm, Y);  // v = d / |d| (process.py:53)
   if (lane == 0) {
@@ -382,15 +396,49 @@ __device__ __forceinline__ void lane_basis(const float d[3], float dnorm, int la
   }
   wave_lds_fence();
   const int sub = lane % LPS;
-  fb = min(4 * sub, F - 4);
-  const int j0 = 4 * sub - fb;
+  LaneSlice ls;
+  if (g.layout == RF_LAYOUT_SPLIT) {
+    if (sub == 0) {
+      ls.src = g.dens;
+      ls.stride = g.dstride;
+      ls.off = 0;
+      ls.active = true;
 #pragma unroll
-  for (int j = 0; j < 4; ++j) {
-    const int f = fb + j;
-    const bool own = (4 * sub < F) && (j >= j0);
-    chan[j] = own ? f / K : -1;
-    yb[j] = own ? ldsY[f % K] : 0.0f;
+      for (int j = 0; j < 4; ++j) {
+        ls.chan[j] = j - 1;  // element 0 is sigma: chan = -1
+        ls.yb[j] = (j >= 1) ? ldsY[0] : 0.0f;
+      }
+    } else {
+      const int t = sub - 1;
+      ls.src = g.feat;
+      ls.stride = g.fstride;
+      ls.off = min(4 * t, R - 4);
+      ls.active = 4 * t < R;
+      const int j0 = 4 * t - ls.off;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int rr = ls.off + j;
+        const bool own = ls.active && (j >= j0);
+        ls.chan[j] = own ? rr / (K - 1) : -1;
+        ls.yb[j] = own ? ldsY[rr % (K - 1) + 1] : 0.0f;
+      }
+    }
+  } else {
+    ls.src = g.feat;
+    ls.stride = g.fstride;
+    ls.off = min(4 * sub, F - 4);
+    ls.active = 4 * sub < F;
+    const int j0 = 4 * sub - ls.off;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int f = ls.off + j;
+      const bool own = ls.active && (j >= j0);
+      ls.chan[j] = own ? f / K : -1;
+      ls.yb[j] = own ? ldsY[f % K] : 0.0f;
+    }
   }
+  wave_lds_fence();
+  return ls;
 }
 
 // =============================================================================================
@@ -417,10 +465,10 @@ __global__ __launch_bounds__(kBlock) void render_forward_kernel(GridArgs g, RayA
   // per-ray SH basis, then the per-lane slice of it used in P1
   const int sub = lane % LPS;
   const int group = lane / LPS;
-  float yb[4] = {0.f, 0.f, 0.f, 0.f};
-  int chan[4] = {-1, -1, -1, -1};
-  int fb = 0;
-  if constexpr (!L::kCorner) lane_basis<K, LPS>(st.d, st.dnorm, lane, s_rgb[wave], yb, chan, fb);
+  LaneSlice ls;
+  ls.src = nullptr;
+  ls.active = false;
+  if constexpr (!L::kCorner) ls = lane_slice<K, LPS>(g, st.d, st.dnorm, lane, s_rgb[wave]);
 
   uint32_t* my_entry = s_entry[wave];
   float* my_rgb = s_rgb[wave];
@@ -497,14 +545,21 @@ __global__ __launch_bounds__(kBlock) void render_forward_kernel(GridArgs g, RayA
             lin = (sub == k) ? c.lin[k] : lin;
             wk = (sub == k) ? c.w[k] : wk;
           }
-          const float* fp = g.feat + lin * g.fstride;
           float v0, v1, v2;
-          if (kfull == 1) {
+          if (g.layout == RF_LAYOUT_SPLIT) {
+            // base record = (sigma, sh0 r, sh0 g, sh0 b): one 16-byte load per corner
+            const f4u t = *reinterpret_cast<const f4u*>(g.dens + lin * g.dstride);
+            v0 = t.v[1];
+            v1 = t.v[2];
+            v2 = t.v[3];
+          } else if (kfull == 1) {
+            const float* fp = g.feat + lin * g.fstride;
             const f3u t = *reinterpret_cast<const f3u*>(fp);
             v0 = t.v[0];
             v1 = t.v[1];
             v2 = t.v[2];
           } else {
+            const float* fp = g.feat + lin * g.fstride;
             v0 = fp[0];
             v1 = fp[kfull];
             v2 = fp[2 * kfull];
@@ -514,10 +569,10 @@ __global__ __launch_bounds__(kBlock) void render_forward_kernel(GridArgs g, RayA
           rgb[2] = v2 * wk;
         } else {
           float a4[4] = {0.f, 0.f, 0.f, 0.f};
-          if (4 * sub < L::kF) {
+          if (ls.active) {
             f4u v[8];
 #pragma unroll
-            for (int k = 0; k < 8; ++k) v[k] = *reinterpret_cast<const f4u*>(g.feat + c.lin[k] * g.fstride + fb);
+            for (int k = 0; k < 8; ++k) v[k] = *reinterpret_cast<const f4u*>(ls.src + c.lin[k] * ls.stride + ls.off);
 #pragma unroll
             for (int k = 0; k < 8; ++k) {
 #pragma unroll
@@ -526,9 +581,9 @@ __global__ __launch_bounds__(kBlock) void render_forward_kernel(GridArgs g, RayA
           }
 #pragma unroll
           for (int j = 0; j < 4; ++j) {
-            const float term = yb[j] * a4[j];
+            const float term = ls.yb[j] * a4[j];
 #pragma unroll
-            for (int ch = 0; ch < 3; ++ch) rgb[ch] += (chan[j] == ch) ? term : 0.0f;
+            for (int ch = 0; ch < 3; ++ch) rgb[ch] += (ls.chan[j] == ch) ? term : 0.0f;
           }
         }
       }
@@ -639,15 +694,30 @@ __global__ __launch_bounds__(kBlock) void render_backward_kernel(GridArgs g, Ray
   constexpr int NPASS = UPI >= 8 ? 1 : 8 / UPI;
   const int c = lane % LPC;   // channel slot of this lane
   const int unit = lane / LPC;
-  // per-lane, per-ray constants: which colour feeds this channel, its SH weight, its offset in the record
-  int lane_colour = -1;       // 0..2 feature of that colour, 3 = density lane, -1 = idle
+  // per-lane, per-ray constants: destination (pointer, voxel stride, offset in the record), which colour feeds this
+  // channel (3 = density lane, -1 = idle) and its SH weight
+  int lane_colour = -1;
   float lane_basis_w = 0.0f;
-  int lane_feat_off = 0;
+  float* lane_dst = gr.gfeat;
+  long long lane_stride = g.fstride;
+  int lane_off = 0;
+  const bool split = g.layout == RF_LAYOUT_SPLIT;
   if constexpr (SL::kCorner) {
     const int kfull = g.F / 3;
-    lane_colour = c;          // 0,1,2 colour; 3 density
     lane_basis_w = kC0;
-    lane_feat_off = (c < 3) ? c * kfull : 0;
+    if (split) {  // base record: (sigma, r, g, b)
+      lane_colour = (c == 0) ? 3 : c - 1;
+      lane_dst = gr.gdens;
+      lane_stride = g.dstride;
+      lane_off = c;
+    } else {
+      lane_colour = c;  // 0,1,2 colour; 3 density
+      lane_off = (c < 3) ? c * kfull : 0;
+      if (c == 3) {
+        lane_dst = gr.gdens;
+        lane_stride = g.dstride;
+      }
+    }
   } else {
     float Y[16];
     sh_basis<K>(st.d[0] / st.dnorm, st.d[1] / st.dnorm, st.d[2] / st.dnorm, Y);
@@ -657,12 +727,29 @@ __global__ __launch_bounds__(kBlock) void render_backward_kernel(GridArgs g, Ray
       for (int k = 0; k < K; ++k) ldsY[k] = Y[k];
     }
     wave_lds_fence();
-    if (c < SL::kF) {
-      lane_colour = c / K;
-      lane_basis_w = ldsY[c % K];
-      lane_feat_off = c;
-    } else if (c == SL::kF) {
-      lane_colour = 3;
+    if (split) {
+      if (c < 4) {  // base record
+        lane_colour = (c == 0) ? 3 : c - 1;
+        lane_basis_w = ldsY[0];
+        lane_dst = gr.gdens;
+        lane_stride = g.dstride;
+        lane_off = c;
+      } else if (c <= SL::kF) {  // rest record, index = colour * (K-1) + (k-1)
+        const int rr = c - 4;
+        lane_colour = rr / (K - 1);
+        lane_basis_w = ldsY[rr % (K - 1) + 1];
+        lane_off = rr;
+      }
+    } else {
+      if (c < SL::kF) {
+        lane_colour = c / K;
+        lane_basis_w = ldsY[c % K];
+        lane_off = c;
+      } else if (c == SL::kF) {
+        lane_colour = 3;
+        lane_dst = gr.gdens;
+        lane_stride = g.dstride;
+      }
     }
     wave_lds_fence();
   }
@@ -758,11 +845,11 @@ __global__ __launch_bounds__(kBlock) void render_backward_kernel(GridArgs g, Ray
                 const float dv = g.dens[lin * g.dstride] * g.rho;
                 gv = (dv > 0.f) ? gv : ((dv < 0.f) ? -gv : 0.0f);
               }
-              if (gv != 0.0f) unsafeAtomicAdd(gr.gdens + lin * g.dstride, gv);
+              if (gv != 0.0f) unsafeAtomicAdd(lane_dst + lin * lane_stride + lane_off, gv);
             } else {
               const float gsel = __uint_as_float(en[9 + lane_colour]);
               const float gv = wc * (gsel * lane_basis_w);
-              if (gv != 0.0f) unsafeAtomicAdd(gr.gfeat + lin * g.fstride + lane_feat_off, gv);
+              if (gv != 0.0f) unsafeAtomicAdd(lane_dst + lin * lane_stride + lane_off, gv);
             }
           }
         }
@@ -908,13 +995,20 @@ __global__ void adam_kernel(float* __restrict__ p, const float* __restrict__ gra
 // host side of the C ABI
 // ---------------------------------------------------------------------------------------------
 int check_grid(const RFGrid* g) {
-  if (!g || !g->densities_dev || !g->features_dev) return RF_ERR_NULL_POINTER;
+  if (!g || !g->densities_dev) return RF_ERR_NULL_POINTER;
+  if (!g->features_dev && !(g->layout == RF_LAYOUT_SPLIT && g->num_features == 3)) return RF_ERR_NULL_POINTER;
   for (int a = 0; a < 3; ++a)
     if (g->dims[a] < 1 || g->dims[a] > 2046) return RF_ERR_BAD_SHAPE;
   const int F = g->num_features;
   if (!(F == 3 || F == 12 || F == 27 || F == 48)) return RF_ERR_UNSUPPORTED;  // SH degree 0..3
   if (g->density_mode < RF_DENSITY_RELU || g->density_mode > RF_DENSITY_IDENTITY) return RF_ERR_UNSUPPORTED;
-  if (g->density_stride < 1 || g->feature_stride < F) return RF_ERR_BAD_SHAPE;
+  if (g->layout == RF_LAYOUT_REFERENCE) {
+    if (g->density_stride < 1 || g->feature_stride < F) return RF_ERR_BAD_SHAPE;
+  } else if (g->layout == RF_LAYOUT_SPLIT) {
+    if (g->density_stride < 4 || (F > 3 && g->feature_stride < F - 3)) return RF_ERR_BAD_SHAPE;
+  } else {
+    return RF_ERR_UNSUPPORTED;
+  }
   return RF_OK;
 }
 
@@ -937,6 +1031,7 @@ GridArgs to_args(const RFGrid* g) {
   }
   a.rho = g->density_scale;
   a.mode = g->density_mode;
+  a.layout = g->layout;
   return a;
 }
 
@@ -1100,7 +1195,8 @@ int rf_render_backward(const RFGrid* grid, const RFRayBatch* rays, uint32_t flag
   if (!fwd || !grads) return RF_ERR_NULL_POINTER;
   if (rays->num_rays == 0) return RF_OK;
   if (!fwd->sample_cache_dev || !fwd->trans_cache_dev || !fwd->stop_cache_dev) return RF_ERR_NULL_POINTER;
-  if (!grad_densities_dev || !grad_features_dev) return RF_ERR_NULL_POINTER;
+  if (!grad_densities_dev) return RF_ERR_NULL_POINTER;
+  if (!grad_features_dev && !(grid->layout == RF_LAYOUT_SPLIT && grid->num_features == 3)) return RF_ERR_NULL_POINTER;
 
   const GridArgs g = to_args(grid);
   const RayArgs r = to_args(rays);

@@ -119,8 +119,9 @@ class _ReluFieldRender(torch.autograd.Function):
     @staticmethod
     def forward(ctx, densities, features, origins, directions, t_rand, grid: VoxelGrid, num_samples, near, far, flags, need_grad):
         lib = _lib.load()
-        for name, t in (("densities", densities), ("features", features), ("ray origins", origins), ("ray directions", directions)):
-            _require_hip(t, name)
+        for name, t in (("grid tensor", densities), ("grid tensor", features), ("ray origins", origins), ("ray directions", directions)):
+            if t is not None:
+                _require_hip(t, name)
         origins = origins.detach().to(torch.float32).contiguous()
         directions = directions.detach().to(torch.float32).contiguous()
         n = origins.shape[0]
@@ -157,7 +158,8 @@ class _ReluFieldRender(torch.autograd.Function):
         ctx.grid, ctx.flags = grid, int(flags)
         ctx.num_samples, ctx.near, ctx.far = int(num_samples), float(near), float(far)
         ctx.has_rand = t_rand is not None
-        saved = [densities, features, origins, directions, depth, acc]
+        ctx.has_second = features is not None
+        saved = [densities] + ([features] if features is not None else []) + [origins, directions, depth, acc]
         if need_grad:
             saved += [cache, tcache, stop]
         if t_rand is not None:
@@ -173,13 +175,15 @@ class _ReluFieldRender(torch.autograd.Function):
             return (None,) * 11
         lib = _lib.load()
         saved = list(ctx.saved_tensors)
-        densities, features, origins, directions, depth, acc, cache, tcache, stop = saved[:9]
-        t_rand = saved[9] if ctx.has_rand else None
+        densities = saved.pop(0)
+        features = saved.pop(0) if ctx.has_second else None
+        origins, directions, depth, acc, cache, tcache, stop = saved[:7]
+        t_rand = saved[7] if ctx.has_rand else None
         dev = origins.device
         grid: VoxelGrid = ctx.grid
         # the kernels read the grid through the module's own tensors; make sure those are the ones saved
         rf_grid = grid.to_rf_grid(use_occupancy=bool(ctx.flags & _lib.FLAG_OCCUPANCY_SKIP))
-        rf_grid.densities_dev, rf_grid.features_dev = densities.data_ptr(), features.data_ptr()
+        rf_grid.densities_dev, rf_grid.features_dev = densities.data_ptr(), _ptr(features)
         rb, tv = _ray_batch(origins, directions, ctx.num_samples, ctx.near, ctx.far, t_rand)
 
         def prep(g):
@@ -199,11 +203,11 @@ class _ReluFieldRender(torch.autograd.Function):
             ret_d, ret_f = bucket.autograd_return()
         else:
             gd = torch.zeros_like(densities)
-            gf = torch.zeros_like(features)
+            gf = None if features is None else torch.zeros_like(features)
             ret_d, ret_f = gd, gf
         with _span(f"render_backward[{_variant(grid, ctx.flags)}]", dev):
             rc = lib.rf_render_backward(
-                C.byref(rf_grid), C.byref(rb), ctx.flags, C.byref(fwd), C.byref(grads), gd.data_ptr(), gf.data_ptr(), _stream(dev)
+                C.byref(rf_grid), C.byref(rb), ctx.flags, C.byref(fwd), C.byref(grads), gd.data_ptr(), _ptr(gf), _stream(dev)
             )
         _lib.check(rc, "rf_render_backward")
         return ret_d, ret_f, None, None, None, None, None, None, None, None, None
@@ -237,9 +241,11 @@ def relu_field_render(
             grid.build_occupancy()
         flags |= _lib.FLAG_OCCUPANCY_SKIP
     # the per-sample cache for the backward pass is only written when a gradient can be asked for
-    need_grad = torch.is_grad_enabled() and (grid.densities.requires_grad or grid.features.requires_grad)
+    # grid tensors in storage order: (densities, features) or, for split storage, (base, rest)
+    ta, tb = grid.kernel_tensors()
+    need_grad = torch.is_grad_enabled() and (ta.requires_grad or (tb is not None and tb.requires_grad))
     return _ReluFieldRender.apply(
-        grid.densities, grid.features, origins, directions, t_rand, grid, int(num_samples), float(near), float(far), flags, need_grad
+        ta, tb, origins, directions, t_rand, grid, int(num_samples), float(near), float(far), flags, need_grad
     )
 
 

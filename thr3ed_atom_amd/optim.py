@@ -25,26 +25,32 @@ from .voxels import VoxelGrid
 
 class FlatGrid:
     def __init__(self, grid: VoxelGrid):
-        d, f = grid.densities, grid.features
-        if not (isinstance(d, torch.nn.Parameter) and isinstance(f, torch.nn.Parameter)):
+        d, f = grid.kernel_tensors()  # (densities, features) or (base, rest); f is None for split storage at degree 0
+        if not (isinstance(d, torch.nn.Parameter) and (f is None or isinstance(f, torch.nn.Parameter))):
             raise ValueError("FlatGrid needs a tunable VoxelGrid")
         self.grid = grid
-        nd, nf = d.numel(), f.numel()
+        self._d, self._f = d, f
+        nd, nf = d.numel(), (0 if f is None else f.numel())
         self.flat_param = torch.empty(nd + nf, dtype=torch.float32, device=d.device)
         self.flat_param[:nd].copy_(d.detach().reshape(-1))
-        self.flat_param[nd:].copy_(f.detach().reshape(-1))
         d.data = self.flat_param[:nd].view(d.shape)
-        f.data = self.flat_param[nd:].view(f.shape)
         self.flat_grad = torch.zeros_like(self.flat_param)
         self._gd = self.flat_grad[:nd].view(d.shape)
-        self._gf = self.flat_grad[nd:].view(f.shape)
-        d.grad, f.grad = self._gd, self._gf
+        self._gf = None
+        d.grad = self._gd
+        if f is not None:
+            self.flat_param[nd:].copy_(f.detach().reshape(-1))
+            f.data = self.flat_param[nd:].view(f.shape)
+            self._gf = self.flat_grad[nd:].view(f.shape)
+            f.grad = self._gf
         grid._grad_bucket = self
 
     # ---- protocol used by ops._ReluFieldRender.backward -------------------------------------
-    def matches(self, densities: Tensor, features: Tensor) -> bool:
-        g = self.grid
-        return densities.data_ptr() == g.densities.data_ptr() and features.data_ptr() == g.features.data_ptr()
+    def matches(self, first: Tensor, second: Optional[Tensor]) -> bool:
+        same = first.data_ptr() == self._d.data_ptr()
+        if self._f is not None:
+            same = same and second is not None and second.data_ptr() == self._f.data_ptr()
+        return same
 
     def views_for_accumulation(self) -> Tuple[Tensor, Tensor]:
         return self._gd, self._gf
@@ -57,11 +63,10 @@ class FlatGrid:
     # ---------------------------------------------------------------------------------------
     def zero_grad(self) -> None:
         self.flat_grad.zero_()
-        g = self.grid
-        if g.densities.grad is not self._gd:
-            g.densities.grad = self._gd
-        if g.features.grad is not self._gf:
-            g.features.grad = self._gf
+        if self._d.grad is not self._gd:
+            self._d.grad = self._gd
+        if self._f is not None and self._f.grad is not self._gf:
+            self._f.grad = self._gf
 
     def detach(self) -> None:
         if getattr(self.grid, "_grad_bucket", None) is self:

@@ -187,9 +187,12 @@ def train_sh_vox_grid_vol_mod_with_posed_images(
     apply_diffuse_render_regularization: bool = True,
     log: Callable[[str], None] = print,
     history: Optional[List[dict]] = None,
+    storage: Optional[str] = "split",
 ) -> VolumetricModel:
     """Same arguments (minus the feedback/visualisation ones) and same schedule as the reference's
-    trainer.  Returns the trained model; ``history`` (if given) collects the logged scalars."""
+    trainer.  Returns the trained model; ``history`` (if given) collects the logged scalars.
+    ``storage`` selects the HBM layout the grid is trained in ("split" = MI355X-native, "reference", or
+    None = keep the model's); checkpoints and ``.densities`` / ``.features`` stay in the reference layout."""
     grid = vol_mod.thre3d_repr
     assert isinstance(grid, VoxelGrid), f"cannot use a {type(grid)} with this TrainProcedure"
     assert vol_mod.render_procedure is render_sh_voxel_grid, "non SH-based VoxelGrids cannot be used with this TrainProcedure"
@@ -202,11 +205,12 @@ def train_sh_vox_grid_vol_mod_with_posed_images(
 
     with torch.no_grad():
         small = scale_voxel_grid_with_required_output_size(grid, stage_sizes[0])
-        random_initializer(small.densities)
-        random_initializer(small.features)
-        # every rank must start from the same parameters
-        rfdist.broadcast_(small.densities.data)
-        rfdist.broadcast_(small.features.data)
+        if storage is not None:
+            small = small.to_storage(storage)
+        for tensor in small.kernel_tensors():  # densities + features, in whatever layout they are stored
+            if tensor is not None:
+                random_initializer(tensor)
+                rfdist.broadcast_(tensor.data)  # every rank must start from the same parameters
         vol_mod.thre3d_repr = small.to(vol_mod.device)
 
     model_dir = None

@@ -37,6 +37,29 @@ class AxisAlignedBoundingBox(NamedTuple):
     z_range: Tuple[float, float]
 
 
+STORAGES = ("reference", "split")
+
+
+def pack_split(densities: Tensor, features: Tensor):
+    """reference tensors -> (base [..., 4] = (density, sh0 r, g, b), rest [..., 3(K-1)] or None)."""
+    K = features.shape[-1] // 3
+    f = features.unflatten(-1, (3, K))
+    base = torch.cat([densities, f[..., 0]], dim=-1).contiguous()
+    rest = f[..., 1:].reshape(*features.shape[:-1], 3 * (K - 1)).contiguous() if K > 1 else None
+    return base, rest
+
+
+def unpack_split(base: Tensor, rest: Optional[Tensor]):
+    """(base, rest) -> reference tensors (densities [..., 1], features [..., 3K], index = colour*K + k)."""
+    densities = base[..., :1].contiguous()
+    sh0 = base[..., 1:4]
+    if rest is None:
+        return densities, sh0.contiguous()
+    K = rest.shape[-1] // 3 + 1
+    f = torch.cat([sh0[..., None], rest.unflatten(-1, (3, K - 1))], dim=-1)
+    return densities, f.flatten(-2).contiguous()
+
+
 def _is_identity(fn) -> bool:
     return fn is None or isinstance(fn, torch.nn.Identity)
 
@@ -77,7 +100,14 @@ class VoxelGrid(Module):
         radiance_transfer_function: Callable[[Tensor, Tensor], Tensor] = None,
         expected_density_scale: float = 1.0,
         tunable: bool = False,
+        storage: str = "reference",
     ):
+        """``storage`` (extension of this build) selects how the grid lives in HBM:
+        "reference" keeps the reference's two tensors; "split" keeps the MI355X-native pair
+        base [X,Y,Z,4] = (density, degree-0 RGB) + rest [X,Y,Z,3(K-1)] (RF_LAYOUT_SPLIT).  Either way the
+        constructor takes, and state_dict / .densities / .features present, reference-layout tensors."""
+        if storage not in STORAGES:
+            raise ValueError(f"storage must be one of {STORAGES}")
         if densities.dim() != 4 or densities.shape[-1] != 1:
             raise AssertionError(f"densities should be [W x D x H x 1], got {tuple(densities.shape)}")
         if features.dim() != 4 or features.shape[:3] != densities.shape[:3]:
@@ -100,38 +130,108 @@ class VoxelGrid(Module):
         self._tunable = tunable
         self.density_mode = resolve_density_mode(density_preactivation, density_postactivation)
 
-        densities = densities.to(torch.float32).contiguous()
-        features = features.to(torch.float32).contiguous()
-        if tunable:
-            self._densities = torch.nn.Parameter(densities)
-            self._features = torch.nn.Parameter(features)
-        else:
-            # buffers, so that Module.to(device) moves a frozen grid as well
-            self.register_buffer("_densities", densities)
-            self.register_buffer("_features", features)
+        densities = densities.detach().to(torch.float32).contiguous()
+        features = features.detach().to(torch.float32).contiguous()
+        self.storage = storage
+        self._num_features = int(features.shape[-1])
         self.width_x, self.depth_y, self.height_z = (int(v) for v in features.shape[:3])
+        if storage == "reference":
+            self._register_grid_tensor("_densities", densities)
+            self._register_grid_tensor("_features", features)
+        else:
+            base, rest = pack_split(densities, features)
+            self._register_grid_tensor("_base", base)
+            if rest is not None:
+                self._register_grid_tensor("_rest", rest)
+            else:
+                self._rest = None
+            # checkpoints keep the reference's keys and layout
+            self._register_state_dict_hook(VoxelGrid._export_reference_state)
+            self._register_load_state_dict_pre_hook(self._import_reference_state)
         self._aabb = self._setup_bounding_box_planes()
         self._occupancy: Optional[Tensor] = None
+
+    def _register_grid_tensor(self, name: str, value: Tensor) -> None:
+        if self._tunable:
+            setattr(self, name, torch.nn.Parameter(value))
+        else:
+            # buffers, so that Module.to(device) moves a frozen grid as well
+            self.register_buffer(name, value)
+
+    @staticmethod
+    def _export_reference_state(module, state, prefix, local_metadata):
+        base = state.pop(prefix + "_base")
+        rest = state.pop(prefix + "_rest", None)
+        dens, feat = unpack_split(base, rest)
+        state[prefix + u_DENSITIES], state[prefix + u_FEATURES] = dens, feat
+        return state
+
+    def _import_reference_state(self, state, prefix, local_metadata, strict, missing, unexpected, errors):
+        if prefix + u_DENSITIES in state:
+            base, rest = pack_split(state.pop(prefix + u_DENSITIES), state.pop(prefix + u_FEATURES))
+            state[prefix + "_base"] = base
+            if rest is not None:
+                state[prefix + "_rest"] = rest
+
+    def kernel_tensors(self):
+        """The two tensors the kernels read, in storage order: (densities, features) or (base, rest)."""
+        if self.storage == "reference":
+            return self._densities, self._features
+        return self._base, self._rest
+
+    def reference_gradients(self):
+        """(dL/d densities, dL/d features) in the reference layout, whatever the storage."""
+        a, b = self.kernel_tensors()
+        if self.storage == "reference":
+            return a.grad, b.grad
+        if a.grad is None:
+            return None, None
+        return unpack_split(a.grad, None if b is None else b.grad)
+
+    def to_storage(self, storage: str) -> "VoxelGrid":
+        """A new grid with the same content and configuration in the requested storage."""
+        if storage == self.storage:
+            return self
+        return VoxelGrid(self.densities.detach(), self.features.detach(), self._voxel_size, **self.get_config_dict(), storage=storage)
 
     # ----- reference-compatible accessors -------------------------------------------------
     @property
     def densities(self) -> Tensor:
-        return self._densities
+        """[X,Y,Z,1].  The Parameter itself with reference storage; a strided VIEW of the base tensor with
+        split storage (in-place edits reach the grid, but it is not a leaf: use reference_gradients())."""
+        if self.storage == "reference":
+            return self._densities
+        return self._base[..., :1]
 
     @densities.setter
     def densities(self, value: Tensor) -> None:
-        assert value.shape == self._densities.shape, "new densities don't match the grid's dimensions"
-        self._densities = torch.nn.Parameter(value) if self._tunable and not isinstance(value, torch.nn.Parameter) else value
+        assert value.shape == (*self.grid_dims, 1), "new densities don't match the grid's dimensions"
+        if self.storage == "reference":
+            self._densities = torch.nn.Parameter(value) if self._tunable and not isinstance(value, torch.nn.Parameter) else value
+        else:
+            with torch.no_grad():
+                self._base[..., :1].copy_(value)
         self._occupancy = None
 
     @property
     def features(self) -> Tensor:
-        return self._features
+        """[X,Y,Z,F], index = colour*K + k.  The Parameter itself with reference storage; an assembled COPY
+        with split storage (assign to the property to write)."""
+        if self.storage == "reference":
+            return self._features
+        return unpack_split(self._base, self._rest)[1]
 
     @features.setter
     def features(self, value: Tensor) -> None:
-        assert value.shape == self._features.shape, "new features don't match the grid's dimensions"
-        self._features = torch.nn.Parameter(value) if self._tunable and not isinstance(value, torch.nn.Parameter) else value
+        assert value.shape == (*self.grid_dims, self._num_features), "new features don't match the grid's dimensions"
+        if self.storage == "reference":
+            self._features = torch.nn.Parameter(value) if self._tunable and not isinstance(value, torch.nn.Parameter) else value
+        else:
+            with torch.no_grad():
+                base, rest = pack_split(self._base[..., :1], value)
+                self._base.copy_(base)
+                if rest is not None:
+                    self._rest.copy_(rest)
 
     @property
     def aabb(self) -> AxisAlignedBoundingBox:
@@ -156,7 +256,7 @@ class VoxelGrid(Module):
 
     @property
     def sh_degree(self) -> int:
-        return int(np.sqrt(self._features.shape[-1] // 3)) - 1
+        return int(np.sqrt(self._num_features // 3)) - 1
 
     def get_config_dict(self) -> Dict[str, Any]:
         return {
@@ -185,9 +285,9 @@ class VoxelGrid(Module):
 
     def extra_repr(self) -> str:
         return (
-            f"grid_dims: {self.grid_dims}, feature_dims: {self._features.shape[-1]}, "
+            f"grid_dims: {self.grid_dims}, feature_dims: {self._num_features}, "
             f"voxel_size: {self._voxel_size}, grid_location: {self._grid_location}, "
-            f"density: {self.density_mode}, tunable: {self._tunable}"
+            f"density: {self.density_mode}, tunable: {self._tunable}, storage: {self.storage}"
         )
 
     def test_inside_volume(self, points: Tensor) -> Tensor:
@@ -199,17 +299,20 @@ class VoxelGrid(Module):
 
     # ----- description for the C ABI -------------------------------------------------------
     def to_rf_grid(self, use_occupancy: bool = False) -> "_lib.RFGrid":
-        d, f = self._densities, self._features
-        if not (d.is_cuda and f.is_cuda):
-            raise RuntimeError(
-                "the ReLU-field render path runs on the GPU only: move the VoxelGrid to a HIP device "
-                "(there is no CPU fallback)"
-            )
-        if not (d.is_contiguous() and f.is_contiguous() and d.dtype == torch.float32 and f.dtype == torch.float32):
-            raise RuntimeError("grid tensors must be contiguous float32")
+        d, f = self.kernel_tensors()
+        for t in (d, f):
+            if t is None:
+                continue
+            if not t.is_cuda:
+                raise RuntimeError(
+                    "the ReLU-field render path runs on the GPU only: move the VoxelGrid to a HIP device "
+                    "(there is no CPU fallback)"
+                )
+            if not (t.is_contiguous() and t.dtype == torch.float32):
+                raise RuntimeError("grid tensors must be contiguous float32")
         g = _lib.RFGrid()
         g.densities_dev = d.data_ptr()
-        g.features_dev = f.data_ptr()
+        g.features_dev = None if f is None else f.data_ptr()
         for a in range(3):
             g.dims[a] = self.grid_dims[a]
             lo, hi = self._aabb[a]
@@ -218,9 +321,10 @@ class VoxelGrid(Module):
             scale, bias = slack_range_map((lo, hi))
             g.norm_scale[a] = float(scale)
             g.norm_bias[a] = float(bias)
-        g.num_features = int(f.shape[-1])
-        g.density_stride = 1
-        g.feature_stride = int(f.shape[-1])
+        g.num_features = self._num_features
+        g.density_stride = int(d.shape[-1])
+        g.feature_stride = 0 if f is None else int(f.shape[-1])
+        g.layout = _lib.LAYOUTS[self.storage]
         g.density_scale = float(self._expected_density_scale)
         g.density_mode = _lib.DENSITY_MODES[self.density_mode]
         g.occupancy_dev = self._occupancy.data_ptr() if (use_occupancy and self._occupancy is not None) else None
@@ -230,9 +334,10 @@ class VoxelGrid(Module):
         """(Re)build the exact empty-cell bit mask used by RF_FLAG_OCCUPANCY_SKIP.  Must be called again
         whenever the densities change."""
         ncell = (self.width_x + 1) * (self.depth_y + 1) * (self.height_z + 1)
-        occ = torch.empty((ncell + 31) // 32, dtype=torch.int32, device=self._densities.device)
+        dev = self.kernel_tensors()[0].device
+        occ = torch.empty((ncell + 31) // 32, dtype=torch.int32, device=dev)
         grid = self.to_rf_grid()
-        stream = torch.cuda.current_stream(self._densities.device).cuda_stream
+        stream = torch.cuda.current_stream(dev).cuda_stream
         _lib.check(_lib.load().rf_build_occupancy(grid, float(threshold), occ.data_ptr(), stream), "rf_build_occupancy")
         self._occupancy = occ
         return occ
@@ -268,16 +373,18 @@ def scale_voxel_grid_with_required_output_size(
         features=new[..., :-1].contiguous(),
         voxel_size=new_voxel,
         **voxel_grid.get_config_dict(),
+        storage=voxel_grid.storage,
     )
 
 
-def create_voxel_grid_from_saved_info_dict(saved_info: Dict[str, Any]) -> VoxelGrid:
+def create_voxel_grid_from_saved_info_dict(saved_info: Dict[str, Any], storage: str = "reference") -> VoxelGrid:
     """Rebuild a grid from the ``thre3d_repr`` entry of a checkpoint (reference voxels.py:376-383)."""
     state = saved_info[THRE3D_REPR][STATE_DICT]
     grid = VoxelGrid(
         densities=torch.empty_like(state[u_DENSITIES]),
         features=torch.empty_like(state[u_FEATURES]),
         **saved_info[THRE3D_REPR][CONFIG_DICT],
+        storage=storage,
     )
     grid.load_state_dict(state)
     return grid
