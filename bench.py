@@ -136,6 +136,9 @@ def main():
     ap.add_argument("--cpu-rays", type=int, default=2048, help="rays of the cpu_baseline sample (0 = skip)")
     ap.add_argument("--storage", choices=["split", "reference"], default="split",
                     help="HBM layout of the grid: split = MI355X-native (what the trainer uses), reference = the reference's two tensors")
+    ap.add_argument("--ray-selection", choices=["keyed", "randperm"], default="keyed",
+                    help="how a step picks its 16384 random pixels: keyed = fused keyed-permutation kernel (trainer default), "
+                    "randperm = torch.randperm over all 5.12 M pixels like the reference")
     ap.add_argument("--cpu-threads", type=int, default=0, help="torch CPU threads for cpu_baseline (0 = all host cores)")
     args = ap.parse_args()
 
@@ -200,7 +203,7 @@ def main():
         }
 
     # ---- training steps: the headline ---------------------------------------------------------------
-    stepper = TrainStepper(model, R, learning_rate=0.03, apply_diffuse_render_regularization=True)
+    stepper = TrainStepper(model, R, learning_rate=0.03, apply_diffuse_render_regularization=True, ray_selection=args.ray_selection)
     torch.manual_seed(1234 + rank)  # every rank draws its own rays
     batches = dataset.image_batches(args.images)
     for _ in range(args.warmup):
@@ -291,13 +294,14 @@ def main():
         "data": "synthetic",
         "config": {
             "workload": f"configs[2]: train step on {G}^3 SH-degree-{args.sh_degree} ReLU field (U(-1,1) init), {args.images} synthetic {H}x{W} images, "
-            f"{R} random rays/GPU/step (randperm over all pixels), {S} jittered samples/ray, specular+diffuse fwd+bwd, L1+L1, fused Adam"
+            f"{R} random distinct pixels/GPU/step out of all {args.images}x{H}x{W} ({args.ray_selection} selection), {S} jittered samples/ray, specular+diffuse fwd+bwd, L1+L1, fused Adam"
             + (", gradient all-reduce over RCCL" if world > 1 else ""),
             "rays_per_gpu_per_step": R,
             "samples_per_ray": S,
             "renders_per_step": 2,
             "parallelism": f"dp{world}",
             "grid_storage": args.storage,
+            "ray_selection": args.ray_selection,
         },
         "rays_per_s": world * 2 * R * args.steps / elapsed,
         "final_specular_psnr": stats.psnr()["specular_psnr"],

@@ -134,6 +134,18 @@ int rf_cast_selected_rays(int32_t height, int32_t width, float focal, const floa
                           int32_t num_poses, const int64_t* pixel_index_dev, int64_t num_rays,
                           float* origins_dev, float* directions_dev, void* stream);
 
+/* sample_random_rays_and_pixels_synchronously (rendering/volumetric/utils/misc.py:117-129) fused with the ray
+ * casting and pixel gathering around it (modules/trainers.py:281-303): element r of the batch is pixel
+ * PRP_key(r) of the num_batch_images*H*W pixels of the image batch, PRP a keyed bijection of that range
+ * (distinct pixels, uniformly distributed: the law of torch.randperm(P)[:R], without sorting P keys).
+ * poses_dev [M,3,4] and pixel_table_dev [M*H*W,3] describe ALL images; image_ids_dev [num_batch_images]
+ * (int64, may be NULL = images 0..B-1) picks the batch.  pixel_index_dev [R] (may be NULL) receives
+ * b*H*W + i*W + j. */
+int rf_select_rays_and_pixels(int32_t height, int32_t width, float focal, const float* poses_dev,
+                              const int64_t* image_ids_dev, int32_t num_batch_images, const float* pixel_table_dev,
+                              uint64_t key, int64_t num_rays, float* origins_dev, float* directions_dev,
+                              float* pixels_dev, int64_t* pixel_index_dev, void* stream);
+
 /* _ray_aabb_intersection (rendering/volumetric/sample.py:71-184): bounds_dev [N, 2], hit_dev [N] (0/1,
  * may be NULL). */
 int rf_ray_aabb_bounds(const float* origins_dev, const float* directions_dev, int64_t num_rays, float near,

@@ -408,3 +408,42 @@ def trilinear_upsample(volume: Tensor, output_size) -> Tensor:
         recompute_scale_factor=False,
     )[0]
     return up.permute(1, 2, 3, 0)
+
+
+# --------------------------------------------------------------------------------------------
+# checker for the build's own batch selection (rf_select_rays_and_pixels) -- not reference behaviour
+# --------------------------------------------------------------------------------------------
+def keyed_permutation(index: np.ndarray, domain: int, key: int) -> np.ndarray:
+    """numpy restatement of the kernel's keyed bijection of [0, domain): 4-round Feistel network on
+    ceil(log2(domain)) bits (at least 2) with cycle walking."""
+    bits = 2
+    while (1 << bits) < domain:
+        bits += 1
+    hr = bits // 2
+    hl = bits - hr
+    k0, k1 = key & 0xFFFFFFFF, (key >> 32) & 0xFFFFFFFF
+    M32 = np.uint64(0xFFFFFFFF)
+
+    def mix32(x):
+        x = x & M32
+        x ^= x >> np.uint64(16)
+        x = (x * np.uint64(0x7FEB352D)) & M32
+        x ^= x >> np.uint64(15)
+        x = (x * np.uint64(0x846CA68B)) & M32
+        x ^= x >> np.uint64(16)
+        return x
+
+    x = np.asarray(index, dtype=np.uint64).copy()
+    todo = np.ones(x.shape, dtype=bool)
+    while todo.any():
+        xs = x[todo]
+        L, R = xs >> np.uint64(hr), xs & np.uint64((1 << hr) - 1)
+        for rnd in range(2):
+            c1 = np.uint64((0x9E3779B9 * (2 * rnd + 1)) & 0xFFFFFFFF)
+            c2 = np.uint64((0x85EBCA6B * (2 * rnd + 2)) & 0xFFFFFFFF)
+            L = L ^ (mix32(R ^ np.uint64(k0) ^ c1) & np.uint64((1 << hl) - 1))
+            R = R ^ (mix32(L ^ np.uint64(k1) ^ c2) & np.uint64((1 << hr) - 1))
+        xs = (L << np.uint64(hr)) | R
+        x[todo] = xs
+        todo[todo] = xs >= np.uint64(domain)
+    return x.astype(np.int64)

@@ -329,3 +329,44 @@ def test_backward_run_to_run_differences_are_rounding_only(full_size, hip_device
     scale = float(grads[0].abs().max())
     assert float((grads[0] - grads[1]).abs().max()) <= 1e-5 * scale
     grid.zero_grad()
+
+
+def test_keyed_ray_selection(hip_device):
+    """rf_select_rays_and_pixels: distinct pixels (a permutation prefix), the same indices as the numpy
+    restatement of the keyed bijection, rays identical to cast_rays at those pixels, pixels from the table,
+    and a uniform spread over images / image regions."""
+    data, cfg, poses = _make_scene(hip_device, 12, 0, 6, 40, 16)
+    hw, H, W, f = 1600, 40, 40, data.camera_intrinsics.focal
+    ids = torch.tensor([4, 0, 5, 2])
+    key = 0x0123456789ABCDEF
+    o, d, px, idx = ops.select_rays_and_pixels_hip(H, W, f, data.poses, ids, data.pixels, 3000, key, return_index=True)
+    idx_cpu = idx.cpu().numpy()
+    assert len(np.unique(idx_cpu)) == 3000 and idx_cpu.min() >= 0 and idx_cpu.max() < 4 * hw
+    np.testing.assert_array_equal(idx_cpu, orc.keyed_permutation(np.arange(3000), 4 * hw, key))
+    full = ops.select_rays_and_pixels_hip(H, W, f, data.poses, ids, data.pixels, 4 * hw, key, return_index=True)[3]
+    assert sorted(full.cpu().tolist()) == list(range(4 * hw))  # a bijection of the whole pixel range
+    # rays / pixels of the chosen entries
+    b = idx // hw
+    rem = idx - b * hw
+    img = ids.to(hip_device)[b]
+    ro, rd = ops.cast_selected_rays_hip(H, W, f, data.poses[ids.to(hip_device)], idx)
+    assert torch.equal(o, ro) and torch.equal(d, rd)
+    assert torch.equal(px, data.pixels[img * hw + rem])
+    # uniformity: image counts and 4x4 tile counts of a larger draw (chi-square, loose bound)
+    big = ops.select_rays_and_pixels_hip(H, W, f, data.poses, ids, data.pixels, 4800, 987654321, return_index=True)[3].cpu().numpy()
+    counts = np.bincount(big // hw, minlength=4)
+    assert np.all(np.abs(counts - 1200) < 5 * np.sqrt(1200 * 0.75))
+    rem = big % hw
+    tiles = np.bincount((rem // W // 10) * 4 + (rem % W) // 10, minlength=16)
+    assert np.all(np.abs(tiles - 300) < 5 * np.sqrt(300))
+    # different keys give different batches; the trainer draws its key from torch's CPU generator
+    other = ops.select_rays_and_pixels_hip(H, W, f, data.poses, ids, data.pixels, 3000, key + 1, return_index=True)[3]
+    assert not torch.equal(other, idx)
+    d0, f0 = procedural_grid((12, 12, 12), 3, 5)
+    model = rf.VolumetricModel(relu_grid(hip_device, d0, f0, 12), rf.render_sh_voxel_grid, cfg, device=hip_device)
+    stepper = TrainStepper(model, 512, 0.03, ray_selection="keyed")
+    torch.manual_seed(3)
+    r1, p1 = stepper.select(data, ids)
+    torch.manual_seed(3)
+    r2, p2 = stepper.select(data, ids)
+    assert torch.equal(r1.origins, r2.origins) and torch.equal(p1, p2) and len(r1) == 512

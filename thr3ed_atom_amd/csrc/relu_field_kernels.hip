@@ -204,12 +204,13 @@ __device__ __forceinline__ Cell locate(const float p[3], const GridArgs& g) {
   return c;
 }
 
-// LDS work-list entry: 8 dwords (forward) / 12 dwords (backward)
-//   [0] (ix0+1) | (iy0+1) << 11 | (iz0+1) << 22      (grid dims <= 2046)
-//   [1] sample lane in the chunk
-//   [2..7] w0x w1x w0y w1y w0z w1z
-//   [8..11] backward only: dL/d(pre-activation density), dL/d(raw r, g, b)
-constexpr int kEntryFwd = 8;
+// LDS work-list entries, 12 dwords each.
+// forward:  [0..1] linear voxel index of the (clamped) corner 000   [2] sample lane | step bits << 8
+//           [3] unused   [4..11] the 8 trilinear corner weights (0 for corners outside the grid)
+//           step bits: bit0/1/2 = the x/y/z upper node is a distinct voxel (clamping collapses it at the border)
+// backward: [0] (ix0+1) | (iy0+1) << 11 | (iz0+1) << 22 (grid dims <= 2046)   [1] sample lane
+//           [2..7] w0x w1x w0y w1y w0z w1z   [8..11] dL/d(pre-activation density), dL/d(raw r, g, b)
+constexpr int kEntryFwd = 12;
 constexpr int kEntryBwd = 12;
 
 __device__ __forceinline__ uint32_t pack_cell(const Cell& c) {
@@ -478,9 +479,34 @@ __global__ __launch_bounds__(kBlock) void render_forward_kernel(GridArgs g, RayA
   float part_acc = 0.f, part_depth = 0.f;
   int processed = 0;
 
+  // Parameter interval of the ray inside the box (same slab test as the AABB sampler).  A chunk whose samples all
+  // lie outside it by a safe margin contributes exactly nothing (sigma = 0 -> alpha = 0 -> T unchanged) and is
+  // skipped without evaluating a single sample.
+  float t_in, t_out;
+  const bool hits_box = ray_box(st.o, st.d, g.amin, g.amax, 0.0f, -1.0f, t_in, t_out);
+  const float zpad = fabsf(st.far - st.near) / (float)(r.S > 1 ? r.S - 1 : 1);  // jitter stays within one stratum
+
   const int nchunks = (r.S + kWave - 1) / kWave;
   for (int chunk = 0; chunk < nchunks; ++chunk) {
     const int s = chunk * kWave + lane;
+    {
+      const int s_first = chunk * kWave, s_last = min(r.S - 1, chunk * kWave + kWave - 1);
+      const float za = z_uniform(st.near, st.far, r.tvals[s_first]), zb = z_uniform(st.near, st.far, r.tvals[s_last]);
+      const float zlo = fminf(za, zb) - zpad, zhi = fmaxf(za, zb) + zpad;
+      const float margin = 1e-3f * (1.0f + fabsf(t_in) + fabsf(t_out));
+      const bool empty = !hits_box || zhi < t_in - margin || zlo > t_out + margin;
+      if (empty) {  // wave-uniform
+        processed = min(r.S, (chunk + 1) * kWave);
+        if constexpr (SAVE) {
+          if (s < r.S) {
+            const long long idx = ray * (long long)r.S + s;
+            reinterpret_cast<float4*>(out.cache)[idx] = make_float4(0.f, 0.f, 0.f, 0.f);
+            out.tcache[idx] = T_carry;
+          }
+        }
+        continue;
+      }
+    }
     // ---------------- P0: lanes = samples ----------------
     Sample sm = make_sample(st, r, g, ray, s);
     bool live = sm.inside;
@@ -511,10 +537,14 @@ __global__ __launch_bounds__(kBlock) void render_forward_kernel(GridArgs g, RayA
     if (need) {
       const int slot = __popcll(mask & ((1ull << lane) - 1ull));
       uint32_t* e = my_entry + slot * kEntryFwd;
-      e[0] = packed;
-      e[1] = (uint32_t)lane;
+      // corner k = dx + 2 dy + 4 dz (corners_of): lin[1] / lin[2] / lin[4] are the x / y / z upper neighbours
+      const uint32_t steps = (cn.lin[1] != cn.lin[0] ? 1u : 0u) | (cn.lin[2] != cn.lin[0] ? 2u : 0u) |
+                             (cn.lin[4] != cn.lin[0] ? 4u : 0u);
+      e[0] = (uint32_t)(unsigned long long)cn.lin[0];
+      e[1] = (uint32_t)((unsigned long long)cn.lin[0] >> 32);
+      e[2] = (uint32_t)lane | (steps << 8);
 #pragma unroll
-      for (int i = 0; i < 6; ++i) e[2 + i] = __float_as_uint(wts[i]);
+      for (int k = 0; k < 8; ++k) e[4 + k] = __float_as_uint(cn.w[k]);
     }
     my_rgb[lane * 4 + 0] = 0.f;
     my_rgb[lane * 4 + 1] = 0.f;
@@ -529,12 +559,19 @@ __global__ __launch_bounds__(kBlock) void render_forward_kernel(GridArgs g, RayA
       int dst_lane = 0;
       if (has) {
         const uint32_t* e = my_entry + slot * kEntryFwd;
-        const uint32_t pk = e[0];
-        dst_lane = (int)e[1];
-        float ew[6];
+        const long long lin0 = (long long)(((unsigned long long)e[1] << 32) | e[0]);
+        const uint32_t meta = e[2];
+        dst_lane = (int)(meta & 0xffu);
+        // corner k = dx + 2 dy + 4 dz; the steps to the upper nodes are whole voxels or 0 (clamped at the border)
+        const long long sx = (meta & (1u << 8)) ? (long long)g.Y * g.Z : 0;
+        const long long sy = (meta & (2u << 8)) ? (long long)g.Z : 0;
+        const long long sz = (meta & (4u << 8)) ? 1 : 0;
+        Corners c;
 #pragma unroll
-        for (int i = 0; i < 6; ++i) ew[i] = __uint_as_float(e[2 + i]);
-        const Corners c = corners_of(pk, ew, g);
+        for (int k = 0; k < 8; ++k) {
+          c.lin[k] = lin0 + ((k & 1) ? sx : 0) + ((k & 2) ? sy : 0) + ((k & 4) ? sz : 0);
+          c.w[k] = __uint_as_float(e[4 + k]);
+        }
         if constexpr (L::kCorner) {
           // lane = corner `sub`; channels 0, K_full, 2*K_full of that corner
           const int kfull = g.F / 3;
@@ -911,6 +948,68 @@ __global__ void cast_selected_rays_kernel(int H, int W, float focal, const float
   }
 }
 
+// ---------------------------------------------------------------------------------------------
+// fused batch selection: the r-th ray of the batch is pixel PRP_key(r) of the B*H*W pixels of the image batch,
+// where PRP is a keyed bijection of [0, P) (4-round Feistel network on ceil(log2 P) bits + cycle walking).
+// The first R values of a random permutation = R distinct uniformly random pixels: the same sampling law as
+// torch.randperm(P)[:R] (utils/misc.py:117-129) without sorting P keys.
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ uint32_t mix32(uint32_t x) {
+  x ^= x >> 16;
+  x *= 0x7feb352dU;
+  x ^= x >> 15;
+  x *= 0x846ca68bU;
+  x ^= x >> 16;
+  return x;
+}
+
+__device__ __forceinline__ unsigned long long keyed_permutation(unsigned long long i, unsigned long long P, int bits,
+                                                                unsigned long long key) {
+  const int hr = bits / 2, hl = bits - hr;  // x = L (hl bits) | R (hr bits)
+  const uint32_t k0 = (uint32_t)key, k1 = (uint32_t)(key >> 32);
+  unsigned long long x = i;
+  do {
+    uint32_t L = (uint32_t)(x >> hr), R = (uint32_t)(x & ((1ull << hr) - 1ull));
+    // two double-rounds; after each double-round the halves have their original widths again
+#pragma unroll
+    for (int rnd = 0; rnd < 2; ++rnd) {
+      L ^= mix32(R ^ k0 ^ (0x9E3779B9u * (2 * rnd + 1))) & (uint32_t)((1ull << hl) - 1ull);
+      R ^= mix32(L ^ k1 ^ (0x85EBCA6Bu * (2 * rnd + 2))) & (uint32_t)((1ull << hr) - 1ull);
+    }
+    x = ((unsigned long long)L << hr) | R;
+  } while (x >= P);  // cycle walking keeps it a bijection of [0, P); < 2 trips on average
+  return x;
+}
+
+__global__ void select_rays_and_pixels_kernel(int H, int W, float focal, const float* poses, const int64_t* image_ids,
+                                              int num_batch_images, const float* pixel_table, unsigned long long key,
+                                              int bits, long long n, float* origins, float* dirs, float* pixels,
+                                              int64_t* pixel_index) {
+  const long long hw = (long long)H * W;
+  const unsigned long long P = (unsigned long long)num_batch_images * hw;
+  for (long long q = (long long)blockIdx.x * blockDim.x + threadIdx.x; q < n; q += (long long)gridDim.x * blockDim.x) {
+    const long long p = (long long)keyed_permutation((unsigned long long)q, P, bits, key);
+    const int b = (int)(p / hw);
+    const long long rem = p - (long long)b * hw;
+    const int i = (int)(rem / W), j = (int)(rem % W);
+    const long long img = image_ids ? image_ids[b] : b;
+    const float* Pm = poses + img * 12;  // [3, 4] = rotation | translation
+    const float R[9] = {Pm[0], Pm[1], Pm[2], Pm[4], Pm[5], Pm[6], Pm[8], Pm[9], Pm[10]};
+    float d[3];
+    pixel_ray(i, j, H, W, focal, R, d);
+    origins[q * 3 + 0] = Pm[3];
+    origins[q * 3 + 1] = Pm[7];
+    origins[q * 3 + 2] = Pm[11];
+    const float* px = pixel_table + (img * hw + rem) * 3;
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+      dirs[q * 3 + a] = d[a];
+      pixels[q * 3 + a] = px[a];
+    }
+    if (pixel_index) pixel_index[q] = p;
+  }
+}
+
 struct Box {
   float lo[3], hi[3];
 };
@@ -1136,6 +1235,25 @@ int rf_cast_selected_rays(int32_t height, int32_t width, float focal, const floa
   hipLaunchKernelGGL(cast_selected_rays_kernel, dim3(grid_1d(num_rays, 256)), dim3(256), 0, (hipStream_t)stream, height,
                      width, focal, poses_dev, num_poses, pixel_index_dev, (long long)num_rays, origins_dev,
                      directions_dev);
+  return launch_status();
+}
+
+int rf_select_rays_and_pixels(int32_t height, int32_t width, float focal, const float* poses_dev,
+                              const int64_t* image_ids_dev, int32_t num_batch_images, const float* pixel_table_dev,
+                              uint64_t key, int64_t num_rays, float* origins_dev, float* directions_dev,
+                              float* pixels_dev, int64_t* pixel_index_dev, void* stream) {
+  if (num_rays == 0) return RF_OK;
+  if (!poses_dev || !pixel_table_dev || !origins_dev || !directions_dev || !pixels_dev) return RF_ERR_NULL_POINTER;
+  if (height < 1 || width < 1 || num_batch_images < 1 || num_rays < 0) return RF_ERR_BAD_SHAPE;
+  const unsigned long long P = (unsigned long long)num_batch_images * height * width;
+  if ((unsigned long long)num_rays > P) return RF_ERR_BAD_SHAPE;  // cannot draw more distinct pixels than exist
+  int bits = 2;
+  while ((1ull << bits) < P) ++bits;
+  if (bits > 62) return RF_ERR_BAD_SHAPE;
+  hipLaunchKernelGGL(select_rays_and_pixels_kernel, dim3(grid_1d(num_rays, 256)), dim3(256), 0, (hipStream_t)stream,
+                     height, width, focal, poses_dev, image_ids_dev, num_batch_images, pixel_table_dev,
+                     (unsigned long long)key, bits, (long long)num_rays, origins_dev, directions_dev, pixels_dev,
+                     pixel_index_dev);
   return launch_status();
 }
 

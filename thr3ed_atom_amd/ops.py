@@ -296,6 +296,29 @@ def cast_selected_rays_hip(height: int, width: int, focal: float, poses: Tensor,
     return o, d
 
 
+def select_rays_and_pixels_hip(height: int, width: int, focal: float, poses: Tensor, image_ids: Tensor, pixel_table: Tensor, num_rays: int, key: int, return_index: bool = False):
+    """Fused random batch selection: ``num_rays`` distinct pixels of the images ``image_ids`` chosen by a keyed
+    pseudo-random permutation, with their rays and target colours -> (origins, directions, pixels[, index]).
+    ``poses`` [M,3,4] and ``pixel_table`` [M*H*W,3] cover the whole dataset."""
+    _require_hip(poses, "poses")
+    _require_hip(pixel_table, "pixel_table")
+    lib = _lib.load()
+    dev = poses.device
+    image_ids = image_ids.detach().to(dev, torch.int64).contiguous()
+    n = int(num_rays)
+    o = torch.empty((n, 3), dtype=torch.float32, device=dev)
+    d = torch.empty((n, 3), dtype=torch.float32, device=dev)
+    px = torch.empty((n, 3), dtype=torch.float32, device=dev)
+    idx = torch.empty((n,), dtype=torch.int64, device=dev) if return_index else None
+    with _span("select_rays_and_pixels", dev):
+        rc = lib.rf_select_rays_and_pixels(
+            int(height), int(width), float(np.float32(focal)), poses.data_ptr(), image_ids.data_ptr(), int(image_ids.numel()),
+            pixel_table.data_ptr(), int(key) & 0xFFFFFFFFFFFFFFFF, n, o.data_ptr(), d.data_ptr(), px.data_ptr(), _ptr(idx), _stream(dev),
+        )
+    _lib.check(rc, "rf_select_rays_and_pixels")
+    return (o, d, px, idx) if return_index else (o, d, px)
+
+
 def ray_aabb_bounds_hip(origins: Tensor, directions: Tensor, near: float, far: float, aabb) -> Tuple[Tensor, Tensor]:
     """Per-ray [t_enter, t_exit] and hit flags (reference rendering/volumetric/sample.py:71-184)."""
     _require_hip(origins, "ray origins")

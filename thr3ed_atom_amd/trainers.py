@@ -29,7 +29,7 @@ from torch.nn.functional import l1_loss, mse_loss
 from . import distributed as rfdist
 from .camera import CameraBounds, CameraIntrinsics, compute_thre3d_grid_sizes, mse2psnr, scale_camera_intrinsics
 from .constants import CAMERA_BOUNDS, CAMERA_INTRINSICS, HEMISPHERICAL_RADIUS
-from .ops import cast_selected_rays_hip
+from .ops import cast_selected_rays_hip, select_rays_and_pixels_hip
 from .optim import ExponentialLR, FlatGrid, FusedAdam
 from .render_interface import Rays
 from .renderers import render_sh_voxel_grid
@@ -116,7 +116,15 @@ class TrainStepper:
         learning_rate: float,
         apply_diffuse_render_regularization: bool = True,
         data_parallel: bool = True,
+        ray_selection: str = "keyed",
     ):
+        """``ray_selection``: "randperm" draws torch.randperm over all B*H*W pixels exactly like the reference
+        (utils/misc.py:123) and keeps the first ``ray_batch_size``; "keyed" draws the same kind of sample
+        (distinct, uniformly random pixels) with one fused kernel (rf_select_rays_and_pixels) keyed from torch's
+        CPU generator -- no 5-million-key sort per iteration."""
+        if ray_selection not in ("keyed", "randperm"):
+            raise ValueError("ray_selection must be 'keyed' or 'randperm'")
+        self.ray_selection = ray_selection
         grid = vol_mod.thre3d_repr
         if not isinstance(grid, VoxelGrid):
             raise AssertionError(f"cannot train a {type(grid)}; only a VoxelGrid can be used")
@@ -135,6 +143,11 @@ class TrainStepper:
         intr = dataset.camera_intrinsics
         hw = intr.height * intr.width
         dev = dataset.pixels.device
+        if self.ray_selection == "keyed":
+            key = int(torch.randint(-(2**63), 2**63 - 1, (1,), dtype=torch.int64).item())
+            n = min(self.ray_batch_size, image_ids.numel() * hw)
+            o, d, px = select_rays_and_pixels_hip(intr.height, intr.width, float(intr.focal), dataset.poses, image_ids, dataset.pixels, n, key)
+            return Rays(o, d), px
         image_ids = image_ids.to(dev)
         perm = torch.randperm(image_ids.numel() * hw, dtype=torch.long, device=dev)[: self.ray_batch_size]
         poses = dataset.poses[image_ids]
@@ -188,6 +201,7 @@ def train_sh_vox_grid_vol_mod_with_posed_images(
     log: Callable[[str], None] = print,
     history: Optional[List[dict]] = None,
     storage: Optional[str] = "split",
+    ray_selection: str = "keyed",
 ) -> VolumetricModel:
     """Same arguments (minus the feedback/visualisation ones) and same schedule as the reference's
     trainer.  Returns the trained model; ``history`` (if given) collects the logged scalars.
@@ -233,7 +247,7 @@ def train_sh_vox_grid_vol_mod_with_posed_images(
         data = stage_sets[stage - 1]
         batches = data.image_batches(image_batch_cache_size)
         lr = learning_rate * (stagewise_lr_decay_gamma ** (stage - 1))
-        stepper = TrainStepper(vol_mod, ray_batch_size, lr, apply_diffuse_render_regularization)
+        stepper = TrainStepper(vol_mod, ray_batch_size, lr, apply_diffuse_render_regularization, ray_selection=ray_selection)
         scheduler = ExponentialLR(stepper.optimizer, lr_decay_gamma_per_stage)
         if is_main:
             log(
