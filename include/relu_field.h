@@ -172,10 +172,18 @@ int rf_render_backward(const RFGrid* grid, const RFRayBatch* rays, uint32_t flag
  * ReLU the skip is bit-exact.  occupancy_dev holds ceil((X+1)(Y+1)(Z+1)/32) words. */
 int rf_build_occupancy(const RFGrid* grid, float threshold, uint32_t* occupancy_dev, void* stream);
 
+/* The loss of the training iteration (modules/trainers.py:311-317, 329-336) in one launch:
+ * grad_colour_dev [N,3] = scale * d(mean |colour - target|)/d colour = scale * sign(colour - target) / (3N);
+ * sums_dev[0] += sum |colour - target|, sums_dev[1] += sum (colour - target)^2  (L1 loss and MSE/PSNR for
+ * logging; the caller zeroes sums_dev). */
+int rf_l1_loss_grad(const float* colour_dev, const float* target_dev, int64_t num_rays, float scale,
+                    float* grad_colour_dev, float* sums_dev, void* stream);
+
 /* Fused Adam step on a flat float32 parameter buffer (torch.optim.Adam semantics, betas/eps/lr given;
- * modules/trainers.py:242-250,339-341).  step is the 1-based step count used for bias correction. */
-int rf_adam_step(float* param_dev, const float* grad_dev, float* exp_avg_dev, float* exp_avg_sq_dev,
-                 int64_t numel, float lr, float beta1, float beta2, float eps, int32_t step, void* stream);
+ * modules/trainers.py:242-250,339-341).  step is the 1-based step count used for bias correction.
+ * zero_grad != 0 also clears grad_dev after reading it (optimizer.zero_grad() of the next iteration). */
+int rf_adam_step(float* param_dev, float* grad_dev, float* exp_avg_dev, float* exp_avg_sq_dev, int64_t numel,
+                 float lr, float beta1, float beta2, float eps, int32_t step, int32_t zero_grad, void* stream);
 
 #ifdef __cplusplus
 }

@@ -32,8 +32,9 @@ def relu_grid(dev, dens, feat, G, rho=100.0 / 3.0, tunable=True, storage="refere
     )
 
 
+@pytest.mark.parametrize("fused", [True, False])
 @pytest.mark.parametrize("storage", ["reference", "split"])
-def test_g9_reference_trainer_trajectory(hip_device, storage):
+def test_g9_reference_trainer_trajectory(hip_device, storage, fused):
     """TrainStepper fed the batches the REAL reference trainer selected reproduces its losses and parameters."""
     g = load_golden("g9_trainer_trajectory.npz")
     G, deg, hw, n_img, n_rays, steps, S = (int(v) for v in g["config"])
@@ -41,7 +42,7 @@ def test_g9_reference_trainer_trajectory(hip_device, storage):
     grid = relu_grid(hip_device, T(hash_uniform((G, G, G, 1), 901)), T(hash_uniform((G, G, G, F), 900 + F)), G, storage=storage)
     cfg = rf.SHVoxGridRenderConfig(S, rf.CameraBounds(float(g["near"]), float(g["far"])), perturb_sampled_points=False, white_bkgd=True)
     model = rf.VolumetricModel(grid, rf.render_sh_voxel_grid, cfg, device=hip_device)
-    stepper = TrainStepper(model, n_rays, learning_rate=float(g["lr"]))
+    stepper = TrainStepper(model, n_rays, learning_rate=float(g["lr"]), fused=fused)
     for it in range(steps):
         rays = rf.Rays(T(g["origins"][it]).to(hip_device), T(g["directions"][it]).to(hip_device))
         stats = stepper.step_on(rays, T(g["pixels"][it]).to(hip_device))
@@ -133,7 +134,8 @@ def test_fused_adam_matches_torch_adam(hip_device):
         flat.zero_grad()
         grid.densities.grad.copy_(gd)
         grid.features.grad.copy_(gf)
-        opt.step()
+        opt.step(zero_grad=(step % 2 == 0))
+        assert (float(flat.flat_grad.abs().max()) == 0.0) == (step % 2 == 0)
     np.testing.assert_allclose(grid.densities.detach().cpu().numpy(), ref_d.detach().cpu().numpy(), rtol=0, atol=2e-6)
     np.testing.assert_allclose(grid.features.detach().cpu().numpy(), ref_f.detach().cpu().numpy(), rtol=0, atol=2e-6)
 

@@ -33,6 +33,7 @@ EXPORTED_SYMBOLS = [
     "rf_render_forward",
     "rf_render_backward",
     "rf_build_occupancy",
+    "rf_l1_loss_grad",
     "rf_adam_step",
 ]
 
@@ -140,7 +141,8 @@ def load() -> C.CDLL:
         vp,
     ]
     lib.rf_build_occupancy.argtypes = [C.POINTER(RFGrid), f32, vp, vp]
-    lib.rf_adam_step.argtypes = [vp, vp, vp, vp, i64, f32, f32, f32, f32, i32, vp]
+    lib.rf_l1_loss_grad.argtypes = [vp, vp, i64, f32, vp, vp, vp]
+    lib.rf_adam_step.argtypes = [vp, vp, vp, vp, i64, f32, f32, f32, f32, i32, i32, vp]
     for name in EXPORTED_SYMBOLS:
         if name not in ("rf_error_string",):
             getattr(lib, name).restype = C.c_int

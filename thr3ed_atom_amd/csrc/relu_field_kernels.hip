@@ -109,13 +109,29 @@ __device__ __forceinline__ void wave_lds_fence() {
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
-__device__ __forceinline__ float wave_incl_scan_mul(float x, int lane) {
-#pragma unroll
-  for (int off = 1; off < kWave; off <<= 1) {
-    float y = __shfl_up(x, off, kWave);
-    if (lane >= off) x = x * y;
-  }
+// DPP cross-lane move: lanes without a source (or masked out by ROW_MASK) keep `old`
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ float dpp_move(float old, float src) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, old), __builtin_bit_cast(int, src),
+                                                               CTRL, ROW_MASK, 0xf, false));
+}
+constexpr int kDppRowShr1 = 0x111, kDppRowShr2 = 0x112, kDppRowShr4 = 0x114, kDppRowShr8 = 0x118;
+constexpr int kDppRowBcast15 = 0x142, kDppRowBcast31 = 0x143, kDppWaveShr1 = 0x138, kDppWaveShl1 = 0x130;
+
+// inclusive prefix product over the 64 lanes: 4 row_shr steps inside each row of 16, then row_bcast:15 / :31
+// (gfx9 DPP) to fold the rows -- 12 VALU instructions, no LDS traffic
+__device__ __forceinline__ float wave_incl_scan_mul(float x) {
+  x = x * dpp_move<kDppRowShr1, 0xf>(1.0f, x);
+  x = x * dpp_move<kDppRowShr2, 0xf>(1.0f, x);
+  x = x * dpp_move<kDppRowShr4, 0xf>(1.0f, x);
+  x = x * dpp_move<kDppRowShr8, 0xf>(1.0f, x);
+  x = x * dpp_move<kDppRowBcast15, 0xa>(1.0f, x);
+  x = x * dpp_move<kDppRowBcast31, 0xc>(1.0f, x);
   return x;
+}
+
+__device__ __forceinline__ float read_lane(float x, int lane) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, x), lane));
 }
 
 // inclusive SUFFIX sum: result[lane] = sum_{l >= lane} x[l]
@@ -134,7 +150,10 @@ __device__ __forceinline__ float wave_sum(float x) {
   return x;
 }
 
-__device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + expf(-x)); }
+// exp / sigmoid on the hardware transcendental units (v_exp_f32 is 2^x, v_rcp_f32; ~1 ulp each).  The reference's
+// own CPU (SLEEF) and GPU (libdevice) paths differ from each other by as much; the parity bar is 1e-5.
+__device__ __forceinline__ float exp_fast(float x) { return __builtin_amdgcn_exp2f(x * 1.44269504088896340736f); }
+__device__ __forceinline__ float sigmoidf_(float x) { return __builtin_amdgcn_rcpf(1.0f + exp_fast(-x)); }
 
 // ---------------------------------------------------------------------------------------------
 // sampling (rendering/volumetric/sample.py:39-68)
@@ -218,24 +237,30 @@ __device__ __forceinline__ uint32_t pack_cell(const Cell& c) {
 }
 
 struct Corners {
-  long long lin[8];  // linear voxel index of the (clamped) corner, order dx fastest, then dy, then dz
-  float w[8];        // trilinear weight, forced to 0 for corners outside the grid
+  unsigned int lin[8];  // linear voxel index of the (clamped) corner k = dx + 2 dy + 4 dz
+  float w[8];           // trilinear weight, forced to 0 for corners outside the grid
 };
 
+// grid dims <= 2046, so every product below has 24-bit operands (v_mul_u32_u24 runs at full rate, v_mul_lo_u32 does
+// not); voxel counts are limited to 2^32 / stride by the host-side check.
 __device__ __forceinline__ Corners corners_of(uint32_t packed, const float wts[6], const GridArgs& g) {
   const int ix0 = (int)(packed & 0x7ffu) - 1, iy0 = (int)((packed >> 11) & 0x7ffu) - 1, iz0 = (int)(packed >> 22) - 1;
-  const bool okx[2] = {ix0 >= 0 && ix0 < g.X, ix0 + 1 >= 0 && ix0 + 1 < g.X};
-  const bool oky[2] = {iy0 >= 0 && iy0 < g.Y, iy0 + 1 >= 0 && iy0 + 1 < g.Y};
-  const bool okz[2] = {iz0 >= 0 && iz0 < g.Z, iz0 + 1 >= 0 && iz0 + 1 < g.Z};
-  const int cx[2] = {min(max(ix0, 0), g.X - 1), min(max(ix0 + 1, 0), g.X - 1)};
-  const int cy[2] = {min(max(iy0, 0), g.Y - 1), min(max(iy0 + 1, 0), g.Y - 1)};
-  const int cz[2] = {min(max(iz0, 0), g.Z - 1), min(max(iz0 + 1, 0), g.Z - 1)};
+  const bool okx[2] = {ix0 >= 0, ix0 + 1 < g.X};  // the point is inside the box: ix0 in [-1, X-1]
+  const bool oky[2] = {iy0 >= 0, iy0 + 1 < g.Y};
+  const bool okz[2] = {iz0 >= 0, iz0 + 1 < g.Z};
+  const int cx0 = max(ix0, 0), cy0 = max(iy0, 0), cz0 = max(iz0, 0);
+  const unsigned int lin0 = __umul24(__umul24((unsigned)cx0, (unsigned)g.Y) + (unsigned)cy0, (unsigned)g.Z) + (unsigned)cz0;
+  // step to the upper node: a whole voxel, or 0 when the clamped upper node coincides with the lower one
+  const unsigned int sx = (okx[0] && okx[1]) ? __umul24((unsigned)g.Y, (unsigned)g.Z) : 0u;
+  const unsigned int sy = (oky[0] && oky[1]) ? (unsigned)g.Z : 0u;
+  const unsigned int sz = (okz[0] && okz[1]) ? 1u : 0u;
+  const float wxy[4] = {wts[0] * wts[2], wts[1] * wts[2], wts[0] * wts[3], wts[1] * wts[3]};  // [dx + 2 dy]
   Corners c;
 #pragma unroll
   for (int k = 0; k < 8; ++k) {
     const int dx = k & 1, dy = (k >> 1) & 1, dz = k >> 2;
-    c.lin[k] = ((long long)cx[dx] * g.Y + cy[dy]) * g.Z + cz[dz];
-    const float w = (wts[0 + dx] * wts[2 + dy]) * wts[4 + dz];
+    c.lin[k] = lin0 + (dx ? sx : 0u) + (dy ? sy : 0u) + (dz ? sz : 0u);
+    const float w = wxy[dx + 2 * dy] * wts[4 + dz];
     c.w[k] = (okx[dx] && oky[dy] && okz[dz]) ? w : 0.0f;
   }
   return c;
@@ -319,19 +344,13 @@ struct Sample {
   Cell cell;
 };
 
-__device__ __forceinline__ Sample make_sample(const RayState& st, const RayArgs& r, const GridArgs& g, long long ray,
-                                              int s) {
+// the sample of lane-index s given its ray parameter z and the next sample's parameter z_next
+__device__ __forceinline__ Sample sample_at(const RayState& st, const RayArgs& r, const GridArgs& g, int s, float z,
+                                            float z_next) {
   Sample sm;
   sm.valid = s < r.S;
-  const int sc = sm.valid ? s : r.S - 1;
-  const float* tr = r.trand ? r.trand + ray * (long long)r.S : nullptr;
-  sm.z = z_sample(r.tvals, tr, sc, r.S, st.near, st.far);
-  if (sc < r.S - 1) {
-    const float zn = z_sample(r.tvals, tr, sc + 1, r.S, st.near, st.far);
-    sm.delta = (zn - sm.z) * st.dnorm;
-  } else {
-    sm.delta = kInfinity * st.dnorm;  // accumulate.py:50-55
-  }
+  sm.z = z;
+  sm.delta = (s < r.S - 1) ? (z_next - z) * st.dnorm : kInfinity * st.dnorm;  // accumulate.py:50-55
   float p[3];
 #pragma unroll
   for (int a = 0; a < 3; ++a) p[a] = st.o[a] + st.d[a] * sm.z;
@@ -339,6 +358,17 @@ __device__ __forceinline__ Sample make_sample(const RayState& st, const RayArgs&
               p[2] > g.amin[2] && p[2] < g.amax[2];  // strict, voxels.py:252-274
   sm.cell = locate(p, g);
   return sm;
+}
+
+__device__ __forceinline__ float z_of(const RayState& st, const RayArgs& r, long long ray, int s) {
+  const int sc = min(s, r.S - 1);
+  const float* tr = r.trand ? r.trand + ray * (long long)r.S : nullptr;
+  return z_sample(r.tvals, tr, sc, r.S, st.near, st.far);
+}
+
+__device__ __forceinline__ Sample make_sample(const RayState& st, const RayArgs& r, const GridArgs& g, long long ray,
+                                              int s) {
+  return sample_at(st, r, g, s, z_of(st, r, ray, s), z_of(st, r, ray, s + 1));
 }
 
 __device__ __forceinline__ bool cell_occupied(const Cell& c, const GridArgs& g) {
@@ -360,10 +390,14 @@ struct Layout {
   static constexpr int kGroups = kWave / kLPS;
 };
 
+// sum over each aligned group of LPS lanes (LPS <= 16, inside one DPP row); the total lands in the LAST lane of the
+// group -- row_shr adds fuse into v_add_f32_dpp, one instruction per step
 template <int LPS>
-__device__ __forceinline__ float group_sum(float x) {
-#pragma unroll
-  for (int off = 1; off < LPS; off <<= 1) x += __shfl_xor(x, off, kWave);
+__device__ __forceinline__ float group_sum_to_last(float x) {
+  if (LPS >= 16) x += dpp_move<kDppRowShr8, 0xf>(0.0f, x);
+  if (LPS >= 8) x += dpp_move<kDppRowShr4, 0xf>(0.0f, x);
+  if (LPS >= 4) x += dpp_move<kDppRowShr2, 0xf>(0.0f, x);
+  x += dpp_move<kDppRowShr1, 0xf>(0.0f, x);
   return x;
 }
 
@@ -482,9 +516,22 @@ __global__ __launch_bounds__(kBlock) void render_forward_kernel(GridArgs g, RayA
   // Parameter interval of the ray inside the box (same slab test as the AABB sampler).  A chunk whose samples all
   // lie outside it by a safe margin contributes exactly nothing (sigma = 0 -> alpha = 0 -> T unchanged) and is
   // skipped without evaluating a single sample.
-  float t_in, t_out;
-  const bool hits_box = ray_box(st.o, st.d, g.amin, g.amax, 0.0f, -1.0f, t_in, t_out);
+  float t_in = -kInfinity, t_out = kInfinity;
+  bool hits_box = true;
+#pragma unroll
+  for (int a = 0; a < 3; ++a) {  // reciprocal-based: only used with a generous margin, never for sample positions
+    const float inv = __builtin_amdgcn_rcpf(st.d[a] + kZeroPlus);
+    const float ta = (g.amin[a] - st.o[a]) * inv, tb = (g.amax[a] - st.o[a]) * inv;
+    t_in = fmaxf(t_in, fminf(ta, tb));
+    t_out = fminf(t_out, fmaxf(ta, tb));
+  }
+  hits_box = t_out >= t_in - 1e-3f * (1.0f + fabsf(t_in) + fabsf(t_out));
   const float zpad = fabsf(st.far - st.near) / (float)(r.S > 1 ? r.S - 1 : 1);  // jitter stays within one stratum
+
+  // z of the current chunk is computed one iteration ahead, so that the last lane can take its "next sample" from
+  // lane 0 of the following chunk: one z evaluation per sample instead of two
+  float z_cur = 0.0f;
+  bool z_ready = false;
 
   const int nchunks = (r.S + kWave - 1) / kWave;
   for (int chunk = 0; chunk < nchunks; ++chunk) {
@@ -504,11 +551,18 @@ __global__ __launch_bounds__(kBlock) void render_forward_kernel(GridArgs g, RayA
             out.tcache[idx] = T_carry;
           }
         }
+        z_ready = false;
         continue;
       }
     }
     // ---------------- P0: lanes = samples ----------------
-    Sample sm = make_sample(st, r, g, ray, s);
+    if (!z_ready) z_cur = z_of(st, r, ray, s);
+    const float z_nxt = z_of(st, r, ray, s + kWave);  // the following chunk (clamped to the last sample)
+    const float z_up = dpp_move<kDppWaveShl1, 0xf>(0.0f, z_cur);  // lane i <- lane i+1
+    const float z_next = (lane == kWave - 1) ? read_lane(z_nxt, 0) : z_up;
+    Sample sm = sample_at(st, r, g, s, z_cur, z_next);
+    z_cur = z_nxt;
+    z_ready = true;
     bool live = sm.inside;
     if (use_occ && live) live = cell_occupied(sm.cell, g);
     float sigma = 0.0f;
@@ -520,14 +574,13 @@ __global__ __launch_bounds__(kBlock) void render_forward_kernel(GridArgs g, RayA
       float pre;
       sigma = interp_density(cn, g, pre);
     }
-    const float alpha = 1.0f - expf(-(sigma * sm.delta));  // density2occupancy_pb, accumulate.py:24-28
+    const float alpha = 1.0f - exp_fast(-(sigma * sm.delta));  // density2occupancy_pb, accumulate.py:24-28
     const float one_minus = 1.0f - alpha;
-    const float incl = wave_incl_scan_mul(sm.valid ? one_minus : 1.0f, lane);
-    float excl = __shfl_up(incl, 1, kWave);
-    if (lane == 0) excl = 1.0f;
+    const float incl = wave_incl_scan_mul(sm.valid ? one_minus : 1.0f);
+    const float excl = dpp_move<kDppWaveShr1, 0xf>(1.0f, incl);  // lane i <- lane i-1, lane 0 <- 1
     const float T = T_carry * excl;
     const float w = alpha * T;
-    T_carry = T_carry * __shfl(incl, kWave - 1, kWave);
+    T_carry = T_carry * read_lane(incl, kWave - 1);
     processed = min(r.S, (chunk + 1) * kWave);
 
     // a sample needs its colour only if it can contribute: inside, T != 0 and (under ReLU) sigma != 0
@@ -540,8 +593,7 @@ __global__ __launch_bounds__(kBlock) void render_forward_kernel(GridArgs g, RayA
       // corner k = dx + 2 dy + 4 dz (corners_of): lin[1] / lin[2] / lin[4] are the x / y / z upper neighbours
       const uint32_t steps = (cn.lin[1] != cn.lin[0] ? 1u : 0u) | (cn.lin[2] != cn.lin[0] ? 2u : 0u) |
                              (cn.lin[4] != cn.lin[0] ? 4u : 0u);
-      e[0] = (uint32_t)(unsigned long long)cn.lin[0];
-      e[1] = (uint32_t)((unsigned long long)cn.lin[0] >> 32);
+      e[0] = cn.lin[0];
       e[2] = (uint32_t)lane | (steps << 8);
 #pragma unroll
       for (int k = 0; k < 8; ++k) e[4 + k] = __float_as_uint(cn.w[k]);
@@ -559,23 +611,23 @@ __global__ __launch_bounds__(kBlock) void render_forward_kernel(GridArgs g, RayA
       int dst_lane = 0;
       if (has) {
         const uint32_t* e = my_entry + slot * kEntryFwd;
-        const long long lin0 = (long long)(((unsigned long long)e[1] << 32) | e[0]);
+        const unsigned int lin0 = e[0];
         const uint32_t meta = e[2];
         dst_lane = (int)(meta & 0xffu);
         // corner k = dx + 2 dy + 4 dz; the steps to the upper nodes are whole voxels or 0 (clamped at the border)
-        const long long sx = (meta & (1u << 8)) ? (long long)g.Y * g.Z : 0;
-        const long long sy = (meta & (2u << 8)) ? (long long)g.Z : 0;
-        const long long sz = (meta & (4u << 8)) ? 1 : 0;
+        const unsigned int sx = (meta & (1u << 8)) ? __umul24((unsigned)g.Y, (unsigned)g.Z) : 0u;
+        const unsigned int sy = (meta & (2u << 8)) ? (unsigned)g.Z : 0u;
+        const unsigned int sz = (meta & (4u << 8)) ? 1u : 0u;
         Corners c;
 #pragma unroll
         for (int k = 0; k < 8; ++k) {
-          c.lin[k] = lin0 + ((k & 1) ? sx : 0) + ((k & 2) ? sy : 0) + ((k & 4) ? sz : 0);
+          c.lin[k] = lin0 + ((k & 1) ? sx : 0u) + ((k & 2) ? sy : 0u) + ((k & 4) ? sz : 0u);
           c.w[k] = __uint_as_float(e[4 + k]);
         }
         if constexpr (L::kCorner) {
           // lane = corner `sub`; channels 0, K_full, 2*K_full of that corner
           const int kfull = g.F / 3;
-          long long lin = c.lin[0];
+          unsigned int lin = c.lin[0];
           float wk = c.w[0];
 #pragma unroll
           for (int k = 1; k < 8; ++k) {
@@ -625,8 +677,8 @@ __global__ __launch_bounds__(kBlock) void render_forward_kernel(GridArgs g, RayA
         }
       }
 #pragma unroll
-      for (int ch = 0; ch < 3; ++ch) rgb[ch] = group_sum<LPS>(rgb[ch]);
-      if (has && sub == 0) {
+      for (int ch = 0; ch < 3; ++ch) rgb[ch] = group_sum_to_last<LPS>(rgb[ch]);
+      if (has && sub == LPS - 1) {
         if constexpr (L::kCorner) {
 #pragma unroll
           for (int ch = 0; ch < 3; ++ch) rgb[ch] = kC0 * rgb[ch];
@@ -811,7 +863,7 @@ __global__ __launch_bounds__(kBlock) void render_backward_kernel(GridArgs g, Ray
       sigma = cv.w;
       T = fwd.tcache[idx];
     }
-    const float alpha = 1.0f - expf(-(sigma * sm.delta));
+    const float alpha = 1.0f - exp_fast(-(sigma * sm.delta));
     const float w = alpha * T;
     const float Tn = T * (1.0f - alpha);
     float c[3], e = gD * sm.z + gA;
@@ -830,7 +882,7 @@ __global__ __launch_bounds__(kBlock) void render_backward_kernel(GridArgs g, Ray
     if (g.mode == RF_DENSITY_RELU)
       g_pre = (sigma > 0.0f) ? g_sigma : 0.0f;
     else if (g.mode == RF_DENSITY_SOFTPLUS)
-      g_pre = g_sigma * (1.0f - expf(-sigma));  // softplus'(x) = sigmoid(x) = 1 - exp(-softplus(x))
+      g_pre = g_sigma * (1.0f - exp_fast(-sigma));  // softplus'(x) = sigmoid(x) = 1 - exp(-softplus(x))
     else
       g_pre = g_sigma;
     float g_raw[3];
@@ -1057,7 +1109,8 @@ __global__ void build_occupancy_kernel(GridArgs g, float threshold, uint32_t* oc
 // =============================================================================================
 // fused Adam (torch.optim.Adam, no weight decay, no amsgrad)
 // =============================================================================================
-__global__ void adam_kernel(float* __restrict__ p, const float* __restrict__ gradp, float* __restrict__ m,
+template <bool ZERO_GRAD>
+__global__ void adam_kernel(float* __restrict__ p, float* __restrict__ gradp, float* __restrict__ m,
                             float* __restrict__ v, long long n, float lr, float b1, float b2, float eps, float bc1,
                             float bc2_sqrt) {
   const long long n4 = n / 4;
@@ -1077,6 +1130,11 @@ __global__ void adam_kernel(float* __restrict__ p, const float* __restrict__ gra
     reinterpret_cast<f4u*>(p)[i] = pp;
     reinterpret_cast<f4u*>(m)[i] = mm;
     reinterpret_cast<f4u*>(v)[i] = vv;
+    if (ZERO_GRAD) {
+      f4u zz;
+      zz.v[0] = zz.v[1] = zz.v[2] = zz.v[3] = 0.0f;
+      reinterpret_cast<f4u*>(gradp)[i] = zz;
+    }
   }
   // tail
   const long long i = n4 * 4 + (long long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -1087,6 +1145,41 @@ __global__ void adam_kernel(float* __restrict__ p, const float* __restrict__ gra
     p[i] = p[i] - (lr / bc1) * (mm / (sqrtf(vv) / bc2_sqrt + eps));
     m[i] = mm;
     v[i] = vv;
+    if (ZERO_GRAD) gradp[i] = 0.0f;
+  }
+}
+
+// =============================================================================================
+// mean-L1 loss of a rendered batch + its gradient (modules/trainers.py:311-317, 329-336), one launch instead of
+// the ~10 elementwise/reduction kernels autograd runs for l1_loss + mse_loss + their backward
+// =============================================================================================
+__global__ void l1_loss_grad_kernel(const float* __restrict__ colour, const float* __restrict__ target, long long n3,
+                                    float gscale, float* __restrict__ grad, float* __restrict__ sums) {
+  float abs_sum = 0.0f, sq_sum = 0.0f;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n3; i += (long long)gridDim.x * blockDim.x) {
+    const float d = colour[i] - target[i];
+    abs_sum += fabsf(d);
+    sq_sum += d * d;
+    grad[i] = (d > 0.0f) ? gscale : ((d < 0.0f) ? -gscale : 0.0f);  // sign(d) * scale / numel
+  }
+  // wave reduce -> block reduce through LDS -> ONE pair of atomics per block (same-address atomics serialise)
+  __shared__ float s_part[2][kBlock / kWave];
+  abs_sum = wave_sum(abs_sum);
+  sq_sum = wave_sum(sq_sum);
+  const int wave = threadIdx.x >> 6;
+  if ((threadIdx.x & (kWave - 1)) == 0) {
+    s_part[0][wave] = abs_sum;
+    s_part[1][wave] = sq_sum;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    float a = 0.0f, b = 0.0f;
+    for (int w = 0; w < (int)(blockDim.x >> 6); ++w) {
+      a += s_part[0][w];
+      b += s_part[1][w];
+    }
+    unsafeAtomicAdd(sums + 0, a);
+    unsafeAtomicAdd(sums + 1, b);
   }
 }
 
@@ -1352,16 +1445,31 @@ int rf_build_occupancy(const RFGrid* grid, float threshold, uint32_t* occupancy_
   return launch_status();
 }
 
-int rf_adam_step(float* param_dev, const float* grad_dev, float* exp_avg_dev, float* exp_avg_sq_dev, int64_t numel,
-                 float lr, float beta1, float beta2, float eps, int32_t step, void* stream) {
+int rf_l1_loss_grad(const float* colour_dev, const float* target_dev, int64_t num_rays, float scale,
+                    float* grad_colour_dev, float* sums_dev, void* stream) {
+  if (num_rays == 0) return RF_OK;
+  if (!colour_dev || !target_dev || !grad_colour_dev || !sums_dev) return RF_ERR_NULL_POINTER;
+  if (num_rays < 0) return RF_ERR_BAD_SHAPE;
+  const long long n3 = (long long)num_rays * 3;
+  hipLaunchKernelGGL(l1_loss_grad_kernel, dim3(grid_1d(n3, kBlock * 8, 32)), dim3(kBlock), 0, (hipStream_t)stream, colour_dev,
+                     target_dev, n3, scale / (float)n3, grad_colour_dev, sums_dev);
+  return launch_status();
+}
+
+int rf_adam_step(float* param_dev, float* grad_dev, float* exp_avg_dev, float* exp_avg_sq_dev, int64_t numel,
+                 float lr, float beta1, float beta2, float eps, int32_t step, int32_t zero_grad, void* stream) {
   if (numel == 0) return RF_OK;
   if (!param_dev || !grad_dev || !exp_avg_dev || !exp_avg_sq_dev) return RF_ERR_NULL_POINTER;
   if (numel < 0 || step < 1) return RF_ERR_BAD_SHAPE;
   const double bc1 = 1.0 - pow((double)beta1, (double)step);
   const double bc2 = 1.0 - pow((double)beta2, (double)step);
-  hipLaunchKernelGGL(adam_kernel, dim3(grid_1d(numel / 4 + 1, 256, 256LL * 32)), dim3(256), 0, (hipStream_t)stream,
-                     param_dev, grad_dev, exp_avg_dev, exp_avg_sq_dev, (long long)numel, lr, beta1, beta2, eps,
-                     (float)bc1, (float)sqrt(bc2));
+  const dim3 grid(grid_1d(numel / 4 + 1, 256, 256LL * 32)), block(256);
+  if (zero_grad)
+    hipLaunchKernelGGL(adam_kernel<true>, grid, block, 0, (hipStream_t)stream, param_dev, grad_dev, exp_avg_dev,
+                       exp_avg_sq_dev, (long long)numel, lr, beta1, beta2, eps, (float)bc1, (float)sqrt(bc2));
+  else
+    hipLaunchKernelGGL(adam_kernel<false>, grid, block, 0, (hipStream_t)stream, param_dev, grad_dev, exp_avg_dev,
+                       exp_avg_sq_dev, (long long)numel, lr, beta1, beta2, eps, (float)bc1, (float)sqrt(bc2));
   return launch_status();
 }
 

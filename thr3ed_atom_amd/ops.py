@@ -115,13 +115,63 @@ def _ray_batch(origins: Tensor, directions: Tensor, num_samples: int, near: floa
     return rb, tv
 
 
+def render_forward_raw(grid: VoxelGrid, origins: Tensor, directions: Tensor, t_rand: Optional[Tensor], num_samples: int,
+                       near: float, far: float, flags: int, save: bool):
+    """Enqueue rf_render_forward.  Returns (colour [N,3], depth [N,1], acc [N,1], disparity [N,1], caches) where
+    ``caches`` = (sample_cache [N,S,4], trans_cache [N,S], stop [N]) when ``save`` else None.  No autograd."""
+    lib = _lib.load()
+    for name, t in (("ray origins", origins), ("ray directions", directions)):
+        _require_hip(t, name)
+    n = origins.shape[0]
+    dev = origins.device
+    rf_grid = grid.to_rf_grid(use_occupancy=bool(flags & _lib.FLAG_OCCUPANCY_SKIP))
+    rb, tv = _ray_batch(origins, directions, num_samples, near, far, t_rand)
+    colour = torch.empty((n, 3), dtype=torch.float32, device=dev)
+    depth = torch.empty((n, 1), dtype=torch.float32, device=dev)
+    acc = torch.empty((n, 1), dtype=torch.float32, device=dev)
+    disparity = torch.empty((n, 1), dtype=torch.float32, device=dev)
+    out = _lib.RFRenderOut()
+    out.colour_dev, out.depth_dev, out.acc_dev, out.disparity_dev = colour.data_ptr(), depth.data_ptr(), acc.data_ptr(), disparity.data_ptr()
+    caches = None
+    if save:
+        cache = torch.empty((n, num_samples, 4), dtype=torch.float32, device=dev)
+        tcache = torch.empty((n, num_samples), dtype=torch.float32, device=dev)
+        stop = torch.empty((n,), dtype=torch.int32, device=dev)
+        out.sample_cache_dev, out.trans_cache_dev, out.stop_cache_dev = cache.data_ptr(), tcache.data_ptr(), stop.data_ptr()
+        caches = (cache, tcache, stop)
+    with _span(f"render_forward[{_variant(grid, flags)}{',save' if save else ''}]", dev):
+        rc = lib.rf_render_forward(C.byref(rf_grid), C.byref(rb), int(flags), C.byref(out), _stream(dev))
+    _lib.check(rc, "rf_render_forward")
+    return colour, depth, acc, disparity, caches
+
+
+def render_backward_raw(grid: VoxelGrid, origins: Tensor, directions: Tensor, t_rand: Optional[Tensor], num_samples: int,
+                        near: float, far: float, flags: int, caches, g_colour: Optional[Tensor], g_depth: Optional[Tensor],
+                        g_acc: Optional[Tensor], grad_first: Tensor, grad_second: Optional[Tensor]) -> None:
+    """Enqueue rf_render_backward: ACCUMULATES dL/d(grid tensors) into ``grad_first`` / ``grad_second`` (storage
+    order of grid.kernel_tensors())."""
+    lib = _lib.load()
+    dev = origins.device
+    rf_grid = grid.to_rf_grid(use_occupancy=bool(flags & _lib.FLAG_OCCUPANCY_SKIP))
+    rb, tv = _ray_batch(origins, directions, num_samples, near, far, t_rand)
+    grads = _lib.RFRenderGrads()
+    grads.grad_colour_dev, grads.grad_depth_dev, grads.grad_acc_dev = _ptr(g_colour), _ptr(g_depth), _ptr(g_acc)
+    cache, tcache, stop = caches
+    fwd = _lib.RFRenderOut()
+    fwd.sample_cache_dev, fwd.trans_cache_dev, fwd.stop_cache_dev = cache.data_ptr(), tcache.data_ptr(), stop.data_ptr()
+    with _span(f"render_backward[{_variant(grid, flags)}]", dev):
+        rc = lib.rf_render_backward(
+            C.byref(rf_grid), C.byref(rb), int(flags), C.byref(fwd), C.byref(grads), grad_first.data_ptr(), _ptr(grad_second), _stream(dev)
+        )
+    _lib.check(rc, "rf_render_backward")
+
+
 class _ReluFieldRender(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, densities, features, origins, directions, t_rand, grid: VoxelGrid, num_samples, near, far, flags, need_grad):
-        lib = _lib.load()
-        for name, t in (("grid tensor", densities), ("grid tensor", features), ("ray origins", origins), ("ray directions", directions)):
+    def forward(ctx, first, second, origins, directions, t_rand, grid: VoxelGrid, num_samples, near, far, flags, need_grad):
+        for t in (first, second):
             if t is not None:
-                _require_hip(t, name)
+                _require_hip(t, "grid tensor")
         origins = origins.detach().to(torch.float32).contiguous()
         directions = directions.detach().to(torch.float32).contiguous()
         n = origins.shape[0]
@@ -130,41 +180,19 @@ class _ReluFieldRender(torch.autograd.Function):
             t_rand = t_rand.detach().to(torch.float32).contiguous()
             if tuple(t_rand.shape) != (n, num_samples):
                 raise ValueError(f"t_rand must be [{n}, {num_samples}], got {tuple(t_rand.shape)}")
-        dev = origins.device
-        rf_grid = grid.to_rf_grid(use_occupancy=bool(flags & _lib.FLAG_OCCUPANCY_SKIP))
-        rb, tv = _ray_batch(origins, directions, num_samples, near, far, t_rand)
-
-        colour = torch.empty((n, 3), dtype=torch.float32, device=dev)
-        depth = torch.empty((n, 1), dtype=torch.float32, device=dev)
-        acc = torch.empty((n, 1), dtype=torch.float32, device=dev)
-        disparity = torch.empty((n, 1), dtype=torch.float32, device=dev)
-        out = _lib.RFRenderOut()
-        out.colour_dev, out.depth_dev, out.acc_dev, out.disparity_dev = (
-            colour.data_ptr(),
-            depth.data_ptr(),
-            acc.data_ptr(),
-            disparity.data_ptr(),
+        colour, depth, acc, disparity, caches = render_forward_raw(
+            grid, origins, directions, t_rand, int(num_samples), float(near), float(far), int(flags), bool(need_grad)
         )
-        cache = tcache = stop = None
-        if need_grad:
-            cache = torch.empty((n, num_samples, 4), dtype=torch.float32, device=dev)
-            tcache = torch.empty((n, num_samples), dtype=torch.float32, device=dev)
-            stop = torch.empty((n,), dtype=torch.int32, device=dev)
-            out.sample_cache_dev, out.trans_cache_dev, out.stop_cache_dev = cache.data_ptr(), tcache.data_ptr(), stop.data_ptr()
-        with _span(f"render_forward[{_variant(grid, flags)}{',save' if need_grad else ''}]", dev):
-            rc = lib.rf_render_forward(C.byref(rf_grid), C.byref(rb), int(flags), C.byref(out), _stream(dev))
-        _lib.check(rc, "rf_render_forward")
-
         ctx.grid, ctx.flags = grid, int(flags)
         ctx.num_samples, ctx.near, ctx.far = int(num_samples), float(near), float(far)
         ctx.has_rand = t_rand is not None
-        ctx.has_second = features is not None
-        saved = [densities] + ([features] if features is not None else []) + [origins, directions, depth, acc]
+        ctx.has_second = second is not None
+        ctx.need_grad = bool(need_grad)
+        saved = [first] + ([second] if second is not None else []) + [origins, directions]
         if need_grad:
-            saved += [cache, tcache, stop]
+            saved += list(caches)
         if t_rand is not None:
             saved.append(t_rand)
-        ctx.need_grad = need_grad
         ctx.save_for_backward(*saved)
         ctx.mark_non_differentiable(disparity)
         return colour, depth, acc, disparity
@@ -173,44 +201,54 @@ class _ReluFieldRender(torch.autograd.Function):
     def backward(ctx, g_colour, g_depth, g_acc, _g_disparity):
         if not ctx.need_grad:
             return (None,) * 11
-        lib = _lib.load()
         saved = list(ctx.saved_tensors)
-        densities = saved.pop(0)
-        features = saved.pop(0) if ctx.has_second else None
-        origins, directions, depth, acc, cache, tcache, stop = saved[:7]
-        t_rand = saved[7] if ctx.has_rand else None
-        dev = origins.device
+        first = saved.pop(0)
+        second = saved.pop(0) if ctx.has_second else None
+        origins, directions, cache, tcache, stop = saved[:5]
+        t_rand = saved[5] if ctx.has_rand else None
         grid: VoxelGrid = ctx.grid
-        # the kernels read the grid through the module's own tensors; make sure those are the ones saved
-        rf_grid = grid.to_rf_grid(use_occupancy=bool(ctx.flags & _lib.FLAG_OCCUPANCY_SKIP))
-        rf_grid.densities_dev, rf_grid.features_dev = densities.data_ptr(), _ptr(features)
-        rb, tv = _ray_batch(origins, directions, ctx.num_samples, ctx.near, ctx.far, t_rand)
+        cur_first, cur_second = grid.kernel_tensors()
+        if cur_first.data_ptr() != first.data_ptr() or (second is not None and cur_second.data_ptr() != second.data_ptr()):
+            raise RuntimeError("the VoxelGrid's tensors were replaced between forward and backward")
 
         def prep(g):
             return None if g is None else g.detach().to(torch.float32).contiguous()
 
-        g_colour, g_depth, g_acc = prep(g_colour), prep(g_depth), prep(g_acc)
-        grads = _lib.RFRenderGrads()
-        grads.grad_colour_dev, grads.grad_depth_dev, grads.grad_acc_dev = _ptr(g_colour), _ptr(g_depth), _ptr(g_acc)
-        fwd = _lib.RFRenderOut()
-        fwd.sample_cache_dev, fwd.trans_cache_dev, fwd.stop_cache_dev = cache.data_ptr(), tcache.data_ptr(), stop.data_ptr()
-
-        # gradient buffers: reuse a caller-provided flat bucket when there is one (see GradBucket), else
-        # fresh zero-filled tensors.  The kernel accumulates with atomics.
+        # gradient buffers: a caller-provided flat bucket when there is one (optim.FlatGrid), else fresh zero-filled
+        # tensors.  The kernel accumulates with atomics.
         bucket = getattr(grid, "_grad_bucket", None)
-        if bucket is not None and bucket.matches(densities, features):
+        if bucket is not None and bucket.matches(first, second):
             gd, gf = bucket.views_for_accumulation()
             ret_d, ret_f = bucket.autograd_return()
         else:
-            gd = torch.zeros_like(densities)
-            gf = None if features is None else torch.zeros_like(features)
+            gd = torch.zeros_like(first)
+            gf = None if second is None else torch.zeros_like(second)
             ret_d, ret_f = gd, gf
-        with _span(f"render_backward[{_variant(grid, ctx.flags)}]", dev):
-            rc = lib.rf_render_backward(
-                C.byref(rf_grid), C.byref(rb), ctx.flags, C.byref(fwd), C.byref(grads), gd.data_ptr(), _ptr(gf), _stream(dev)
-            )
-        _lib.check(rc, "rf_render_backward")
+        render_backward_raw(
+            grid, origins, directions, t_rand, ctx.num_samples, ctx.near, ctx.far, ctx.flags, (cache, tcache, stop),
+            prep(g_colour), prep(g_depth), prep(g_acc), gd, gf,
+        )
         return ret_d, ret_f, None, None, None, None, None, None, None, None, None
+
+
+def render_flags(white_bkgd: bool, render_diffuse: bool, optimized_sampling: bool, use_occupancy: bool) -> int:
+    flags = 0
+    flags |= _lib.FLAG_WHITE_BKGD if white_bkgd else 0
+    flags |= _lib.FLAG_RENDER_DIFFUSE if render_diffuse else 0
+    flags |= _lib.FLAG_AABB_SAMPLING if optimized_sampling else 0
+    flags |= _lib.FLAG_OCCUPANCY_SKIP if use_occupancy else 0
+    return flags
+
+
+def l1_loss_grad_hip(colour: Tensor, target: Tensor, sums: Tensor, scale: float = 1.0) -> Tensor:
+    """d(scale * mean|colour - target|)/d colour as one kernel; ``sums`` [2] (+= sum |d|, += sum d^2) for logging."""
+    _require_hip(colour, "colour")
+    lib = _lib.load()
+    grad = torch.empty_like(colour)
+    with _span("l1_loss_grad", colour.device):
+        rc = lib.rf_l1_loss_grad(colour.data_ptr(), target.data_ptr(), colour.shape[0], float(scale), grad.data_ptr(), sums.data_ptr(), _stream(colour.device))
+    _lib.check(rc, "rf_l1_loss_grad")
+    return grad
 
 
 def relu_field_render(
@@ -232,14 +270,9 @@ def relu_field_render(
         raise AssertionError("the render op works with FLAT rays [N, 3] only")
     if int(num_samples) < 1:
         raise ValueError("num_samples must be >= 1")
-    flags = 0
-    flags |= _lib.FLAG_WHITE_BKGD if white_bkgd else 0
-    flags |= _lib.FLAG_RENDER_DIFFUSE if render_diffuse else 0
-    flags |= _lib.FLAG_AABB_SAMPLING if optimized_sampling else 0
-    if use_occupancy:
-        if grid.occupancy is None:
-            grid.build_occupancy()
-        flags |= _lib.FLAG_OCCUPANCY_SKIP
+    if use_occupancy and grid.occupancy is None:
+        grid.build_occupancy()
+    flags = render_flags(white_bkgd, render_diffuse, optimized_sampling, use_occupancy)
     # the per-sample cache for the backward pass is only written when a gradient can be asked for
     # grid tensors in storage order: (densities, features) or, for split storage, (base, rest)
     ta, tb = grid.kernel_tensors()
@@ -339,8 +372,9 @@ def ray_aabb_bounds_hip(origins: Tensor, directions: Tensor, near: float, far: f
     return bounds, hit
 
 
-def adam_step_hip(param: Tensor, grad: Tensor, exp_avg: Tensor, exp_avg_sq: Tensor, lr: float, beta1: float, beta2: float, eps: float, step: int) -> None:
-    """In-place fused Adam update of a flat float32 buffer (torch.optim.Adam arithmetic)."""
+def adam_step_hip(param: Tensor, grad: Tensor, exp_avg: Tensor, exp_avg_sq: Tensor, lr: float, beta1: float, beta2: float, eps: float, step: int, zero_grad: bool = False) -> None:
+    """In-place fused Adam update of a flat float32 buffer (torch.optim.Adam arithmetic); ``zero_grad`` also clears
+    ``grad`` in the same pass (the next iteration's optimizer.zero_grad())."""
     for name, t in (("param", param), ("grad", grad), ("exp_avg", exp_avg), ("exp_avg_sq", exp_avg_sq)):
         _require_hip(t, name)
         if not (t.is_contiguous() and t.dtype == torch.float32 and t.numel() == param.numel()):
@@ -348,6 +382,6 @@ def adam_step_hip(param: Tensor, grad: Tensor, exp_avg: Tensor, exp_avg_sq: Tens
     lib = _lib.load()
     with _span("adam_step", param.device):
         rc = lib.rf_adam_step(
-            param.data_ptr(), grad.data_ptr(), exp_avg.data_ptr(), exp_avg_sq.data_ptr(), param.numel(), float(lr), float(beta1), float(beta2), float(eps), int(step), _stream(param.device)
+            param.data_ptr(), grad.data_ptr(), exp_avg.data_ptr(), exp_avg_sq.data_ptr(), param.numel(), float(lr), float(beta1), float(beta2), float(eps), int(step), int(bool(zero_grad)), _stream(param.device)
         )
     _lib.check(rc, "rf_adam_step")

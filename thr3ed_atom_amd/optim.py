@@ -93,11 +93,12 @@ class FusedAdam:
         self.flat.zero_grad()
 
     @torch.no_grad()
-    def step(self) -> None:
+    def step(self, zero_grad: bool = False) -> None:
+        """``zero_grad=True`` clears the gradient bucket in the same pass (saves the separate 235 MB memset)."""
         self.step_count += 1
         adam_step_hip(
             self.flat.flat_param, self.flat.flat_grad, self.exp_avg, self.exp_avg_sq,
-            self.lr, self.betas[0], self.betas[1], self.eps, self.step_count,
+            self.lr, self.betas[0], self.betas[1], self.eps, self.step_count, zero_grad,
         )
 
 

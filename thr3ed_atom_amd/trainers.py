@@ -29,10 +29,17 @@ from torch.nn.functional import l1_loss, mse_loss
 from . import distributed as rfdist
 from .camera import CameraBounds, CameraIntrinsics, compute_thre3d_grid_sizes, mse2psnr, scale_camera_intrinsics
 from .constants import CAMERA_BOUNDS, CAMERA_INTRINSICS, HEMISPHERICAL_RADIUS
-from .ops import cast_selected_rays_hip, select_rays_and_pixels_hip
+from .ops import (
+    cast_selected_rays_hip,
+    l1_loss_grad_hip,
+    render_backward_raw,
+    render_flags,
+    render_forward_raw,
+    select_rays_and_pixels_hip,
+)
 from .optim import ExponentialLR, FlatGrid, FusedAdam
 from .render_interface import Rays
-from .renderers import render_sh_voxel_grid
+from .renderers import _check_supported, render_sh_voxel_grid
 from .volumetric_model import VolumetricModel
 from .voxels import VoxelGrid, scale_voxel_grid_with_required_output_size
 
@@ -117,6 +124,7 @@ class TrainStepper:
         apply_diffuse_render_regularization: bool = True,
         data_parallel: bool = True,
         ray_selection: str = "keyed",
+        fused: bool = True,
     ):
         """``ray_selection``: "randperm" draws torch.randperm over all B*H*W pixels exactly like the reference
         (utils/misc.py:123) and keeps the first ``ray_batch_size``; "keyed" draws the same kind of sample
@@ -125,6 +133,11 @@ class TrainStepper:
         if ray_selection not in ("keyed", "randperm"):
             raise ValueError("ray_selection must be 'keyed' or 'randperm'")
         self.ray_selection = ray_selection
+        # fused=True runs the iteration as a fixed sequence of launches (forward, loss+gradient, backward per
+        # render, then Adam which also clears the gradient bucket) without building an autograd graph;
+        # fused=False goes through torch.autograd like a user of render_rays would.  Same arithmetic either way.
+        self.fused = bool(fused)
+        self._grad_clean = True  # FlatGrid starts zero-filled
         grid = vol_mod.thre3d_repr
         if not isinstance(grid, VoxelGrid):
             raise AssertionError(f"cannot train a {type(grid)}; only a VoxelGrid can be used")
@@ -158,6 +171,11 @@ class TrainStepper:
 
     def step_on(self, rays: Rays, pixels: Tensor) -> StepStats:
         vol_mod = self.vol_mod
+        cfg = vol_mod.render_config
+        if cfg.use_occupancy_mask:
+            vol_mod.thre3d_repr.build_occupancy()  # densities changed in the last Adam step
+        if self.fused:
+            return self._fused_step_on(rays, pixels)
         self.optimizer.zero_grad()
         spec = vol_mod.render_rays(rays).colour
         total = l1_loss(spec, pixels)
@@ -172,7 +190,38 @@ class TrainStepper:
         if self.data_parallel:
             rfdist.all_reduce_mean_(self.flat.flat_grad)
         self.optimizer.step()
+        self._grad_clean = False
         return StepStats(spec_loss, diff_loss, spec_mse, diff_mse)
+
+    def _fused_step_on(self, rays: Rays, pixels: Tensor) -> StepStats:
+        vol_mod, grid = self.vol_mod, self.vol_mod.thre3d_repr
+        cfg = vol_mod.render_config
+        _check_supported(cfg)
+        origins = rays.origins.detach().to(torch.float32).contiguous()
+        directions = rays.directions.detach().to(torch.float32).contiguous()
+        pixels = pixels.detach().to(torch.float32).contiguous()
+        n, S = origins.shape[0], int(cfg.num_samples_per_ray)
+        near, far = float(np.float32(cfg.camera_bounds.near)), float(np.float32(cfg.camera_bounds.far))
+        if not self._grad_clean:
+            self.flat.zero_grad()
+        gd, gf = self.flat.views_for_accumulation()
+        sums = torch.zeros(4, dtype=torch.float32, device=origins.device)
+        for i, diffuse in enumerate((False, True) if self.diffuse else (False,)):
+            t_rand = torch.rand(n, S, dtype=torch.float32, device=origins.device) if cfg.perturb_sampled_points else None
+            if cfg.consume_reference_rng:
+                torch.randn(n, S, dtype=torch.float32, device=origins.device)
+            flags = render_flags(cfg.white_bkgd, diffuse, cfg.optimized_sampling, cfg.use_occupancy_mask)
+            colour, _, _, _, caches = render_forward_raw(grid, origins, directions, t_rand, S, near, far, flags, save=True)
+            g_colour = l1_loss_grad_hip(colour, pixels, sums[2 * i : 2 * i + 2])
+            render_backward_raw(grid, origins, directions, t_rand, S, near, far, flags, caches, g_colour, None, None, gd, gf)
+        self._grad_clean = False
+        if self.data_parallel:
+            rfdist.all_reduce_mean_(self.flat.flat_grad)
+        # (clearing the bucket inside the Adam kernel measured slower than a separate memset: 0.37 vs 0.28 + 0.05 ms)
+        self.optimizer.step()
+        self._grad_clean = False
+        means = sums / float(3 * n)
+        return StepStats(means[0], means[2] if self.diffuse else None, means[1], means[3] if self.diffuse else None)
 
     def step(self, dataset: PosedImagesInMemory, image_ids: Tensor) -> StepStats:
         rays, pixels = self.select(dataset, image_ids)
