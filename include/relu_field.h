@@ -165,6 +165,16 @@ int rf_render_backward(const RFGrid* grid, const RFRayBatch* rays, uint32_t flag
                        const RFRenderGrads* grads, float* grad_densities_dev, float* grad_features_dev,
                        void* stream);
 
+/* VoxelGrid.forward (thre3d_reprs/voxels.py:276-331) as a standalone point query: points_dev [M,3] (any
+ * points: zeros padding outside the grid, no AABB mask) -> out_dev [M, F+1] = (F interpolated features in the
+ * reference order colour*K + k, activated density).  Bit-for-bit the ATen grid_sample recipe. */
+int rf_grid_query(const RFGrid* grid, const float* points_dev, int64_t num_points, float* out_dev, void* stream);
+
+/* Its adjoint into the grid tensors (accumulates, storage layout of `grid`); grad_out_dev is [M, F+1]. */
+int rf_grid_query_backward(const RFGrid* grid, const float* points_dev, int64_t num_points,
+                           const float* grad_out_dev, float* grad_densities_dev, float* grad_features_dev,
+                           void* stream);
+
 /* Exact empty-cell mask for RF_FLAG_OCCUPANCY_SKIP (BASELINE.json configs[4]):
  * bit (cx, cy, cz), cx in [0, X] etc., is set iff any of the (up to 8) grid nodes
  * (cx-1..cx, cy-1..cy, cz-1..cz) that exist has a raw density that can yield sigma != 0 under

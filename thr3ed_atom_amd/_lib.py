@@ -32,6 +32,8 @@ EXPORTED_SYMBOLS = [
     "rf_ray_aabb_bounds",
     "rf_render_forward",
     "rf_render_backward",
+    "rf_grid_query",
+    "rf_grid_query_backward",
     "rf_build_occupancy",
     "rf_l1_loss_grad",
     "rf_adam_step",
@@ -140,6 +142,8 @@ def load() -> C.CDLL:
         vp,
         vp,
     ]
+    lib.rf_grid_query.argtypes = [C.POINTER(RFGrid), vp, i64, vp, vp]
+    lib.rf_grid_query_backward.argtypes = [C.POINTER(RFGrid), vp, i64, vp, vp, vp, vp]
     lib.rf_build_occupancy.argtypes = [C.POINTER(RFGrid), f32, vp, vp]
     lib.rf_l1_loss_grad.argtypes = [vp, vp, i64, f32, vp, vp, vp]
     lib.rf_adam_step.argtypes = [vp, vp, vp, vp, i64, f32, f32, f32, f32, i32, i32, vp]

@@ -949,6 +949,148 @@ __global__ __launch_bounds__(kBlock) void render_backward_kernel(GridArgs g, Ray
 }
 
 // =============================================================================================
+// standalone point query: VoxelGrid.forward (thre3d_reprs/voxels.py:276-331) and its adjoint.
+// One thread per (point, output channel); channel c < F is feature c in the reference order (colour*K + k),
+// channel F is the activated density.  Any point is allowed (zeros padding outside the grid, no AABB mask --
+// the mask belongs to process_points).  Not a hot path: the renderer uses the fused kernels above.
+// =============================================================================================
+struct QueryCorner {
+  long long lin;
+  float w;
+  bool ok;
+};
+
+__device__ __forceinline__ void query_cell(const float p[3], const GridArgs& g, int i0[3], float w0[3], float w1[3]) {
+  const int dims[3] = {g.X, g.Y, g.Z};
+#pragma unroll
+  for (int a = 0; a < 3; ++a) {
+    const float q = p[a] * g.nscale[a] + g.nbias[a];
+    const float idx = ((q + 1.0f) * (float)dims[a] - 1.0f) / 2.0f;
+    const float fl = floorf(idx);
+    w1[a] = idx - fl;
+    w0[a] = (fl + 1.0f) - idx;
+    // far-away points: every corner is outside anyway; clamp so that the integer conversion is defined
+    i0[a] = (int)fminf(fmaxf(fl, -2.0f), (float)dims[a]);
+  }
+}
+
+__device__ __forceinline__ QueryCorner query_corner(int k, const int i0[3], const float w0[3], const float w1[3],
+                                                    const GridArgs& g) {
+  const int dx = k & 1, dy = (k >> 1) & 1, dz = k >> 2;
+  const int ix = i0[0] + dx, iy = i0[1] + dy, iz = i0[2] + dz;
+  QueryCorner c;
+  c.ok = ix >= 0 && ix < g.X && iy >= 0 && iy < g.Y && iz >= 0 && iz < g.Z;
+  c.lin = ((long long)min(max(ix, 0), g.X - 1) * g.Y + min(max(iy, 0), g.Y - 1)) * g.Z + min(max(iz, 0), g.Z - 1);
+  c.w = ((dx ? w1[0] : w0[0]) * (dy ? w1[1] : w0[1])) * (dz ? w1[2] : w0[2]);
+  return c;
+}
+
+// element offset of output channel c of voxel `lin` inside the tensor that holds it; *in_first = it is the
+// densities/base tensor rather than the features/rest tensor
+__device__ __forceinline__ long long query_offset(int c, long long lin, const GridArgs& g, bool* in_first) {
+  const int F = g.F, K = F / 3;
+  if (c == F) {
+    *in_first = true;
+    return lin * g.dstride;
+  }
+  if (g.layout == RF_LAYOUT_SPLIT) {
+    const int ch = c / K, k = c % K;
+    if (k == 0) {
+      *in_first = true;
+      return lin * g.dstride + 1 + ch;
+    }
+    *in_first = false;
+    return lin * g.fstride + ch * (K - 1) + (k - 1);
+  }
+  *in_first = false;
+  return lin * g.fstride + c;
+}
+
+__device__ __forceinline__ float density_post(float pre, int mode) {
+  if (mode == RF_DENSITY_RELU) return fmaxf(pre, 0.0f);
+  if (mode == RF_DENSITY_SOFTPLUS) return (pre > 20.0f) ? pre : log1pf(expf(pre));
+  return pre;
+}
+
+__global__ void grid_query_kernel(GridArgs g, const float* __restrict__ points, long long n, float* __restrict__ out) {
+  const int C = g.F + 1;
+  const long long total = n * C;
+  for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
+       idx += (long long)gridDim.x * blockDim.x) {
+    const long long pt = idx / C;
+    const int c = (int)(idx % C);
+    const float p[3] = {points[pt * 3], points[pt * 3 + 1], points[pt * 3 + 2]};
+    int i0[3];
+    float w0[3], w1[3];
+    query_cell(p, g, i0, w0, w1);
+    const bool dens = (c == g.F);
+    float acc = 0.0f;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      const QueryCorner qc = query_corner(k, i0, w0, w1, g);
+      if (qc.ok) {
+        bool first;
+        const long long off = query_offset(c, qc.lin, g, &first);
+        float v = first ? g.dens[off] : g.feat[off];
+        if (dens) {
+          v = v * g.rho;
+          if (g.mode == RF_DENSITY_ABS) v = fabsf(v);
+        }
+        acc = acc + v * qc.w;
+      }
+    }
+    out[idx] = dens ? density_post(acc, g.mode) : acc;
+  }
+}
+
+__global__ void grid_query_backward_kernel(GridArgs g, const float* __restrict__ points, long long n,
+                                           const float* __restrict__ gout, float* gfirst, float* gsecond) {
+  const int C = g.F + 1;
+  const long long total = n * C;
+  for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
+       idx += (long long)gridDim.x * blockDim.x) {
+    const long long pt = idx / C;
+    const int c = (int)(idx % C);
+    float go = gout[idx];
+    if (go == 0.0f) continue;
+    const float p[3] = {points[pt * 3], points[pt * 3 + 1], points[pt * 3 + 2]};
+    int i0[3];
+    float w0[3], w1[3];
+    query_cell(p, g, i0, w0, w1);
+    const bool dens = (c == g.F);
+    if (dens && (g.mode == RF_DENSITY_RELU || g.mode == RF_DENSITY_SOFTPLUS)) {
+      float pre = 0.0f;  // the activation derivative needs the interpolated pre-activation
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        const QueryCorner qc = query_corner(k, i0, w0, w1, g);
+        if (qc.ok) pre = pre + (g.dens[qc.lin * g.dstride] * g.rho) * qc.w;
+      }
+      if (g.mode == RF_DENSITY_RELU)
+        go = (pre > 0.0f) ? go : 0.0f;
+      else
+        go = go * ((pre > 20.0f) ? 1.0f : 1.0f / (1.0f + expf(-pre)));
+      if (go == 0.0f) continue;
+    }
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      const QueryCorner qc = query_corner(k, i0, w0, w1, g);
+      if (!qc.ok) continue;
+      bool first;
+      const long long off = query_offset(c, qc.lin, g, &first);
+      float gv = qc.w * go;
+      if (dens) {
+        gv = gv * g.rho;
+        if (g.mode == RF_DENSITY_ABS) {
+          const float dv = g.dens[off] * g.rho;
+          gv = (dv > 0.f) ? gv : ((dv < 0.f) ? -gv : 0.0f);
+        }
+      }
+      if (gv != 0.0f) unsafeAtomicAdd((first ? gfirst : gsecond) + off, gv);
+    }
+  }
+}
+
+// =============================================================================================
 // ray generation (rendering/volumetric/utils/misc.py:12-50)
 // =============================================================================================
 struct Pose {
@@ -1430,6 +1572,34 @@ int rf_render_backward(const RFGrid* grid, const RFRayBatch* rays, uint32_t flag
     launch_backward<9, false>(blocks, st, g, r, o, gr, flags);
   else
     launch_backward<16, false>(blocks, st, g, r, o, gr, flags);
+  return launch_status();
+}
+
+int rf_grid_query(const RFGrid* grid, const float* points_dev, int64_t num_points, float* out_dev, void* stream) {
+  const int rc = check_grid(grid);
+  if (rc != RF_OK) return rc;
+  if (num_points == 0) return RF_OK;
+  if (!points_dev || !out_dev) return RF_ERR_NULL_POINTER;
+  if (num_points < 0) return RF_ERR_BAD_SHAPE;
+  const GridArgs g = to_args(grid);
+  const long long total = (long long)num_points * (g.F + 1);
+  hipLaunchKernelGGL(grid_query_kernel, dim3(grid_1d(total, 256)), dim3(256), 0, (hipStream_t)stream, g, points_dev,
+                     (long long)num_points, out_dev);
+  return launch_status();
+}
+
+int rf_grid_query_backward(const RFGrid* grid, const float* points_dev, int64_t num_points, const float* grad_out_dev,
+                           float* grad_densities_dev, float* grad_features_dev, void* stream) {
+  const int rc = check_grid(grid);
+  if (rc != RF_OK) return rc;
+  if (num_points == 0) return RF_OK;
+  if (!points_dev || !grad_out_dev || !grad_densities_dev) return RF_ERR_NULL_POINTER;
+  if (!grad_features_dev && !(grid->layout == RF_LAYOUT_SPLIT && grid->num_features == 3)) return RF_ERR_NULL_POINTER;
+  if (num_points < 0) return RF_ERR_BAD_SHAPE;
+  const GridArgs g = to_args(grid);
+  const long long total = (long long)num_points * (g.F + 1);
+  hipLaunchKernelGGL(grid_query_backward_kernel, dim3(grid_1d(total, 256)), dim3(256), 0, (hipStream_t)stream, g,
+                     points_dev, (long long)num_points, grad_out_dev, grad_densities_dev, grad_features_dev);
   return launch_status();
 }
 

@@ -231,6 +231,47 @@ class _ReluFieldRender(torch.autograd.Function):
         return ret_d, ret_f, None, None, None, None, None, None, None, None, None
 
 
+class _GridQuery(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, first, second, points, grid: VoxelGrid):
+        lib = _lib.load()
+        _require_hip(points, "points")
+        points = points.detach().to(torch.float32).contiguous()
+        m = points.shape[0]
+        out = torch.empty((m, grid.num_features + 1), dtype=torch.float32, device=points.device)
+        rf_grid = grid.to_rf_grid()
+        _lib.check(lib.rf_grid_query(C.byref(rf_grid), points.data_ptr(), m, out.data_ptr(), _stream(points.device)), "rf_grid_query")
+        ctx.grid, ctx.has_second = grid, second is not None
+        ctx.save_for_backward(*([first] + ([second] if second is not None else []) + [points]))
+        return out
+
+    @staticmethod
+    def backward(ctx, g_out):
+        lib = _lib.load()
+        saved = list(ctx.saved_tensors)
+        first = saved.pop(0)
+        second = saved.pop(0) if ctx.has_second else None
+        points = saved[0]
+        g_out = g_out.detach().to(torch.float32).contiguous()
+        gd = torch.zeros_like(first)
+        gf = None if second is None else torch.zeros_like(second)
+        rf_grid = ctx.grid.to_rf_grid()
+        _lib.check(
+            lib.rf_grid_query_backward(C.byref(rf_grid), points.data_ptr(), points.shape[0], g_out.data_ptr(), gd.data_ptr(), _ptr(gf), _stream(points.device)),
+            "rf_grid_query_backward",
+        )
+        return gd, gf, None, None
+
+
+def grid_query(grid: VoxelGrid, points: Tensor) -> Tensor:
+    """[M, 3] points -> [M, F+1] = (interpolated features in the reference order, activated density); differentiable
+    w.r.t. the grid (reference VoxelGrid.forward, thre3d_reprs/voxels.py:276-331)."""
+    if points.dim() != 2 or points.shape[-1] != 3:
+        raise AssertionError("points must be [M, 3]")
+    first, second = grid.kernel_tensors()
+    return _GridQuery.apply(first, second, points, grid)
+
+
 def render_flags(white_bkgd: bool, render_diffuse: bool, optimized_sampling: bool, use_occupancy: bool) -> int:
     flags = 0
     flags |= _lib.FLAG_WHITE_BKGD if white_bkgd else 0

@@ -20,6 +20,7 @@ from .constants import (
     STATE_DICT,
     THRE3D_REPR,
 )
+from . import distributed as rfdist
 from .ops import cast_rays_hip
 from .render_interface import Rays, RenderOut, collate_rendered_output, flatten_rays, reshape_rendered_output
 from .renderers import RenderConfig, RenderProcedure
@@ -104,13 +105,22 @@ class VolumetricModel:
         parallel_points_chunk_size: Optional[int] = None,
         gpu_render: bool = True,
         verbose: bool = False,
+        data_parallel: bool = False,
         **kwargs,
     ) -> RenderOut:
         """Full-image render under no_grad: cast rays, render them in chunks of
         ``parallel_rays_chunk_size`` (None = one chunk), concatenate and reshape to [H, W, .]
         (reference :116-174).  The fused kernel does not need chunking for memory; the argument is
-        honoured so that outputs and RNG consumption follow the reference chunk by chunk."""
+        honoured so that outputs and RNG consumption follow the reference chunk by chunk.
+        ``data_parallel=True`` (extension): under torch.distributed the frame's rays are split over the ranks and
+        the results gathered; every rank returns the full image."""
         flat = flatten_rays(cast_rays(camera_intrinsics, camera_pose, self._device))
+        total_rays = len(flat)
+        if data_parallel and rfdist.world_size() > 1:
+            # rays are independent: every rank renders one contiguous range of the frame against its own replica of
+            # the grid; the only exchange is the gather of the [n, 6] per-ray results at the end
+            lo, hi = rfdist.shard_range(total_rays)
+            flat = flat[lo:hi]
         chunk = len(flat) if parallel_rays_chunk_size is None else int(parallel_rays_chunk_size)
         starts = range(0, len(flat), chunk)
         if verbose:
@@ -124,7 +134,14 @@ class VolumetricModel:
                 if not gpu_render:
                     out = out.to(torch.device("cpu"))
                 chunks.append(out)
-        return reshape_rendered_output(collate_rendered_output(chunks), camera_intrinsics)
+        out = collate_rendered_output(chunks)
+        if data_parallel and rfdist.world_size() > 1:
+            keys = sorted(out.extra.keys())
+            packed = torch.cat([out.colour, out.depth] + [out.extra[k] for k in keys], dim=-1)
+            packed = rfdist.all_gather_rows(packed)
+            assert packed.shape[0] == total_rays
+            out = RenderOut(packed[:, :3], packed[:, 3:4], {k: packed[:, 4 + i : 5 + i] for i, k in enumerate(keys)})
+        return reshape_rendered_output(out, camera_intrinsics)
 
 
 def create_volumetric_model_from_saved_model(

@@ -255,6 +255,17 @@ class VoxelGrid(Module):
         return self._expected_density_scale
 
     @property
+    def num_features(self) -> int:
+        return self._num_features
+
+    def forward(self, points: Tensor, viewdirs: Optional[Tensor] = None) -> Tensor:
+        """[N, 3] -> [N, F+1] = cat(interpolated features, density)  (reference voxels.py:276-331; ``viewdirs`` is
+        only consumed by a radiance transfer function, which this path does not have).  Runs rf_grid_query."""
+        from .ops import grid_query
+
+        return grid_query(self, points)
+
+    @property
     def sh_degree(self) -> int:
         return int(np.sqrt(self._num_features // 3)) - 1
 
