@@ -139,6 +139,7 @@ def main():
     ap.add_argument("--ray-selection", choices=["keyed", "randperm"], default="keyed",
                     help="how a step picks its 16384 random pixels: keyed = fused keyed-permutation kernel (trainer default), "
                     "randperm = torch.randperm over all 5.12 M pixels like the reference")
+    ap.add_argument("--no-kernel-timer", action="store_true", help="do not record per-kernel HIP events in the timed region (no roofline object)")
     ap.add_argument("--cpu-threads", type=int, default=0, help="torch CPU threads for cpu_baseline (0 = all host cores)")
     args = ap.parse_args()
 
@@ -208,14 +209,19 @@ def main():
     batches = dataset.image_batches(args.images)
     for _ in range(args.warmup):
         stepper.step(dataset, next(batches))
-    timer = ops.KernelTimer()
-    ops.KERNEL_TIMER = timer
+    # HIP events are recorded on every `timer_stride`-th timed step only: hundreds of outstanding timing events
+    # make the ROCm runtime stall for tens of ms now and then (measured: 2.0 -> 2.9 ms/step in some runs)
+    timer_stride = max(1, args.steps // 10)
+    n_timed = 0 if args.no_kernel_timer else len(range(0, args.steps, timer_stride))
+    timer = ops.KernelTimer(preallocate=12 * n_timed)
     if world > 1:
         torch.distributed.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
+    for i in range(args.steps):
+        ops.KERNEL_TIMER = timer if (not args.no_kernel_timer and i % timer_stride == 0) else None
         stats = stepper.step(dataset, next(batches))
+    host_issue = time.perf_counter() - t0  # time the host needed to enqueue all steps (GPU runs asynchronously)
     torch.cuda.synchronize()
     if world > 1:
         torch.distributed.barrier()
@@ -251,6 +257,9 @@ def main():
             kernels[name]["algorithmic_GB"] = b / 1e9
             kernels[name]["effective_GBps"] = b / 1e9 / (rec["avg_ms"] / 1e3)
     render_kernels = {k: v for k, v in ksum.items() if k.startswith("render_")}
+    if not render_kernels:
+        print(json.dumps({"ms_per_step": ms_per_step, "value": value, "host_issue_ms_per_step": host_issue / args.steps * 1e3, "note": "kernel timer off"}))
+        return
     dom = max(render_kernels, key=lambda k: render_kernels[k]["total_ms"])
     achieved = alg_bytes[dom] / 1e9 / (ksum[dom]["avg_ms"] / 1e3)
     roofline = {
@@ -287,6 +296,8 @@ def main():
         "steps": args.steps,
         "warmup": args.warmup,
         "ms_per_step": ms_per_step,
+        "host_issue_ms_per_step": host_issue / args.steps * 1e3,
+        "kernel_timer_steps": n_timed,
         "higher_is_better": True,
         "scaling": "weak",
         "vs_baseline": None,

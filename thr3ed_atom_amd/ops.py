@@ -26,8 +26,14 @@ class KernelTimer:
     on the stream the kernels are enqueued on; reading them needs a device synchronise, which the caller
     does once after the timed region."""
 
-    def __init__(self):
+    def __init__(self, preallocate: int = 0):
         self.records: Dict[str, list] = {}
+        # creating HIP events inside a timed loop perturbs it (the runtime grows its signal pool in bursts); a
+        # caller that knows how many spans it will record can have them created up front
+        self._pool = [torch.cuda.Event(enable_timing=True) for _ in range(2 * preallocate)]
+
+    def _event(self):
+        return self._pool.pop() if self._pool else torch.cuda.Event(enable_timing=True)
 
     def span(self, name: str, device):
         return _TimedSpan(self, name, device)
@@ -48,12 +54,12 @@ class _TimedSpan:
         self.timer, self.name, self.device = timer, name, device
 
     def __enter__(self):
-        self.a = torch.cuda.Event(enable_timing=True)
-        self.b = torch.cuda.Event(enable_timing=True)
-        self.a.record(torch.cuda.current_stream(self.device))
+        self.a = self.timer._event()
+        self.b = self.timer._event()
+        self.a.record()
 
     def __exit__(self, *exc):
-        self.b.record(torch.cuda.current_stream(self.device))
+        self.b.record()
         self.timer.records.setdefault(self.name, []).append((self.a, self.b))
         return False
 
@@ -107,8 +113,8 @@ def _ray_batch(origins: Tensor, directions: Tensor, num_samples: int, near: floa
     rb.directions_dev = directions.data_ptr()
     rb.num_rays = origins.shape[0]
     rb.num_samples = int(num_samples)
-    rb.near = float(np.float32(near))
-    rb.far = float(np.float32(far))
+    rb.near = near  # c_float rounds to float32 exactly like np.float32 does
+    rb.far = far
     tv = t_vals_for(num_samples, origins.device)
     rb.t_vals_dev = tv.data_ptr()
     rb.t_rand_dev = _ptr(t_rand)

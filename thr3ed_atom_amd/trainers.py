@@ -94,7 +94,9 @@ class PosedImagesInMemory:
         m = len(self)
         batch_size = min(batch_size, m)
         while True:
-            order = torch.randperm(m, generator=generator)
+            # one host->device copy per EPOCH; the per-iteration batches are device-side slices (a per-step copy
+            # of 8 indices from pageable memory stalls the stream for ~1 ms)
+            order = torch.randperm(m, generator=generator).to(self.images.device)
             for s in range(0, m - batch_size + 1, batch_size):
                 yield order[s : s + batch_size]
 

@@ -321,6 +321,12 @@ class VoxelGrid(Module):
                 )
             if not (t.is_contiguous() and t.dtype == torch.float32):
                 raise RuntimeError("grid tensors must be contiguous float32")
+        # the descriptor is rebuilt only when something it describes changed (it is on the per-launch host path)
+        occ_ptr = self._occupancy.data_ptr() if (use_occupancy and self._occupancy is not None) else None
+        key = (d.data_ptr(), None if f is None else f.data_ptr(), occ_ptr, self._aabb, self._expected_density_scale)
+        cached = self.__dict__.get("_rf_grid_cache")
+        if cached is not None and cached[0] == key:
+            return cached[1]
         g = _lib.RFGrid()
         g.densities_dev = d.data_ptr()
         g.features_dev = None if f is None else f.data_ptr()
@@ -338,7 +344,8 @@ class VoxelGrid(Module):
         g.layout = _lib.LAYOUTS[self.storage]
         g.density_scale = float(self._expected_density_scale)
         g.density_mode = _lib.DENSITY_MODES[self.density_mode]
-        g.occupancy_dev = self._occupancy.data_ptr() if (use_occupancy and self._occupancy is not None) else None
+        g.occupancy_dev = occ_ptr
+        self.__dict__["_rf_grid_cache"] = (key, g)
         return g
 
     def build_occupancy(self, threshold: float = 0.0) -> Tensor:
