@@ -139,6 +139,8 @@ def main():
     ap.add_argument("--ray-selection", choices=["keyed", "randperm"], default="keyed",
                     help="how a step picks its 16384 random pixels: keyed = fused keyed-permutation kernel (trainer default), "
                     "randperm = torch.randperm over all 5.12 M pixels like the reference")
+    ap.add_argument("--backward", choices=["atomic", "binned"], default="atomic",
+                    help="gradient scatter of the train step: float32 atomics, or records sorted by brick + LDS accumulation")
     ap.add_argument("--no-kernel-timer", action="store_true", help="do not record per-kernel HIP events in the timed region (no roofline object)")
     ap.add_argument("--cpu-threads", type=int, default=0, help="torch CPU threads for cpu_baseline (0 = all host cores)")
     args = ap.parse_args()
@@ -204,7 +206,7 @@ def main():
         }
 
     # ---- training steps: the headline ---------------------------------------------------------------
-    stepper = TrainStepper(model, R, learning_rate=0.03, apply_diffuse_render_regularization=True, ray_selection=args.ray_selection)
+    stepper = TrainStepper(model, R, learning_rate=0.03, apply_diffuse_render_regularization=True, ray_selection=args.ray_selection, backward=args.backward)
     torch.manual_seed(1234 + rank)  # every rank draws its own rays
     batches = dataset.image_batches(args.images)
     for _ in range(args.warmup):
@@ -313,6 +315,7 @@ def main():
             "parallelism": f"dp{world}",
             "grid_storage": args.storage,
             "ray_selection": args.ray_selection,
+            "backward": args.backward,
         },
         "rays_per_s": world * 2 * R * args.steps / elapsed,
         "final_specular_psnr": stats.psnr()["specular_psnr"],

@@ -165,6 +165,34 @@ int rf_render_backward(const RFGrid* grid, const RFRayBatch* rays, uint32_t flag
                        const RFRenderGrads* grads, float* grad_densities_dev, float* grad_features_dev,
                        void* stream);
 
+/* ---- binned backward: the same adjoint as rf_render_backward, aggregated in LDS before it reaches memory -------
+ * (1) rf_render_backward_emit: instead of scattering, write per contributing sample a 32-byte record
+ *     records_dev [N*S, 8] = (continuous index x, y, z, dL/d pre-activation density, dL/d raw r, g, b, ray id bits)
+ *     and, for EVERY sample slot, keys_dev [N*S] = id of the brick (brick_size^3 nodes, brick_size in {4, 8}) its
+ *     cell starts in, or 0x7fff for samples without gradient.  ray_basis_dev [N,16] (may be NULL for the diffuse
+ *     pass) receives the signed SH basis of each ray.
+ * (2) the caller sorts keys (torch.sort) -> permutation, and offsets [nbricks+1] (searchsorted);
+ * (3) rf_gather_records: records_sorted[i] = records[perm[i]] for i < *count_dev (= offsets[nbricks]);
+ * (4) rf_brick_accumulate: one workgroup per brick sums every contribution of its cells to the (brick_size+1)^3
+ *     nodes they touch in LDS, then adds that footprint to the gradient tensors with float32 atomics laid out in
+ *     long contiguous runs -- one atomic per (node, channel) of a brick instead of one per sample.  Gradients are
+ *     ACCUMULATED like everywhere else (`accumulate` must be 1).  Up to two record lists (the specular and the
+ *     diffuse render of a training iteration) are folded in one pass. */
+typedef struct RFBrickList {
+  const float* records_sorted_dev; /* [count, 8]                                    */
+  const int64_t* offsets_dev;      /* [nbricks + 1] start of each brick in the list */
+  int32_t render_diffuse;          /* records come from a render_diffuse pass       */
+} RFBrickList;
+
+int rf_render_backward_emit(const RFGrid* grid, const RFRayBatch* rays, uint32_t flags, const RFRenderOut* fwd,
+                            const RFRenderGrads* grads, int32_t brick_size, int16_t* keys_dev, float* records_dev,
+                            float* ray_basis_dev, void* stream);
+int rf_gather_records(const float* records_dev, const int64_t* perm_dev, const int64_t* count_dev, int64_t capacity,
+                      float* records_sorted_dev, void* stream);
+int rf_brick_accumulate(const RFGrid* grid, int32_t brick_size, const RFBrickList* lists, int32_t num_lists,
+                        const float* ray_basis_dev, float* grad_densities_dev, float* grad_features_dev,
+                        int32_t accumulate, void* stream);
+
 /* VoxelGrid.forward (thre3d_reprs/voxels.py:276-331) as a standalone point query: points_dev [M,3] (any
  * points: zeros padding outside the grid, no AABB mask) -> out_dev [M, F+1] = (F interpolated features in the
  * reference order colour*K + k, activated density).  Bit-for-bit the ATen grid_sample recipe. */

@@ -372,3 +372,89 @@ def test_keyed_ray_selection(hip_device):
     torch.manual_seed(3)
     r2, p2 = stepper.select(data, ids)
     assert torch.equal(r1.origins, r2.origins) and torch.equal(p1, p2) and len(r1) == 512
+
+
+def _binned_gradients(grid, rays, cfg, target, device, diffuse_too=True):
+    """(dL/d first, dL/d second) of L1(spec) [+ L1(diffuse)] through the emit -> sort -> brick-accumulate path"""
+    from thr3ed_atom_amd import ops as O
+
+    o, d = rays.origins.contiguous(), rays.directions.contiguous()
+    n, S = o.shape[0], cfg.num_samples_per_ray
+    near, far = float(np.float32(cfg.camera_bounds.near)), float(np.float32(cfg.camera_bounds.far))
+    nb = O.brick_counts(grid, 8)
+    num_bricks = nb[0] * nb[1] * nb[2]
+    boundaries = torch.arange(num_bricks + 1, dtype=torch.int16, device=device)
+    ray_basis = torch.zeros((n, 16), device=device)
+    first, second = grid.kernel_tensors()
+    gd = torch.zeros_like(first)
+    gf = None if second is None else torch.zeros_like(second)
+    sums = torch.zeros(4, device=device)
+    lists, keep = [], []
+    for i, diffuse in enumerate((False, True) if diffuse_too else (False,)):
+        flags = O.render_flags(cfg.white_bkgd, diffuse or cfg.render_diffuse, cfg.optimized_sampling, False)
+        colour, _, _, _, caches = O.render_forward_raw(grid, o, d, None, S, near, far, flags, save=True)
+        g_colour = O.l1_loss_grad_hip(colour, target, sums[2 * i : 2 * i + 2])
+        keys = torch.empty(n * S, dtype=torch.int16, device=device)
+        rec = torch.empty((n * S, 8), device=device)
+        srt = torch.empty((n * S, 8), device=device)
+        O.render_backward_emit_raw(grid, o, d, None, S, near, far, flags, caches, g_colour, None, None, 8, keys, rec, None if diffuse else ray_basis)
+        offsets = O.sort_records_by_brick(keys, rec, srt, num_bricks, boundaries)
+        lists.append((srt, offsets, diffuse or cfg.render_diffuse))
+        keep.append((keys, rec, caches))
+    O.brick_accumulate_raw(grid, 8, lists, ray_basis, gd, gf, accumulate=True)
+    return gd, gf
+
+
+@pytest.mark.parametrize("storage", ["reference", "split"])
+@pytest.mark.parametrize("case", ["grid16_sh2", "aniso_sh2_abs", "aniso_sh1_softplus", "cube20_sh0"])
+def test_binned_backward_equals_atomic_backward(hip_device, storage, case):
+    """The LDS-aggregated backward (emit -> 16-bit sort by brick -> one workgroup per 8^3-cell brick -> coalesced
+    flush; experimental, off by default) gives the gradient of the atomic scatter (and therefore of the reference)
+    for specular + diffuse renders, including partial bricks, the grid border, SH degree 0-2 and the abs / softplus
+    density modes."""
+    from thr3ed_atom_amd.voxels import unpack_split
+
+    cam = hotdog_like_camera()
+    g7 = load_golden("g7_grid16_render.npz")
+    rays = rf.Rays(T(g7["origins"]).to(hip_device), T(g7["directions"]).to(hip_device))
+    target = T(g7["target"]).to(hip_device)
+    dims, F, mode, voxel, loc, rho = {
+        "grid16_sh2": ((16, 16, 16), 27, "relu", (3.0 / 16,) * 3, (0.0, 0.0, 0.0), 100.0 / 3.0),
+        "aniso_sh2_abs": ((13, 9, 18), 27, "abs", (0.22, 0.3, 0.16), (0.1, -0.05, 0.1), 1.0),
+        "aniso_sh1_softplus": ((9, 17, 8), 12, "softplus", (0.3, 0.17, 0.35), (0.0, 0.0, 0.0), 5.0),
+        "cube20_sh0": ((20, 20, 20), 3, "relu", (0.15,) * 3, (0.0, 0.0, 0.0), 100.0 / 3.0),
+    }[case]
+    acts = {"relu": (torch.nn.Identity(), torch.nn.ReLU()), "softplus": (torch.nn.Identity(), torch.nn.Softplus()), "abs": (torch.abs, torch.nn.Identity())}[mode]
+    dens, feat = procedural_grid(dims, F, 303)
+    grid = rf.VoxelGrid(dens.to(hip_device), feat.to(hip_device), rf.VoxelSize(*voxel), rf.VoxelGridLocation(*loc), density_preactivation=acts[0],
+                        density_postactivation=acts[1], expected_density_scale=rho, tunable=True, storage=storage)
+    cfg = rf.SHVoxGridRenderConfig(40, rf.CameraBounds(cam["near"], cam["far"]), perturb_sampled_points=False, white_bkgd=True)
+    model = rf.VolumetricModel(grid, rf.render_sh_voxel_grid, cfg, device=hip_device)
+    loss = torch.nn.functional.l1_loss(model.render_rays(rays).colour, target)
+    loss = loss + torch.nn.functional.l1_loss(model.render_rays(rays, render_diffuse=True).colour, target)
+    loss.backward()
+    ref_d, ref_f = grid.reference_gradients()
+    gd, gf = _binned_gradients(grid, rays, cfg, target, hip_device)
+    if storage == "split":
+        gd, gf = unpack_split(gd, gf)
+    assert float(ref_d.abs().max()) > 0 and float(ref_f.abs().max()) > 0
+    np.testing.assert_allclose(gd.cpu().numpy(), ref_d.cpu().numpy(), rtol=2e-4, atol=2e-6 * float(ref_d.abs().max()))
+    np.testing.assert_allclose(gf.cpu().numpy(), ref_f.cpu().numpy(), rtol=2e-4, atol=2e-6 * float(ref_f.abs().max()))
+
+
+def test_binned_train_step_follows_reference_trajectory(hip_device):
+    g = load_golden("g9_trainer_trajectory.npz")
+    G, deg, hw, n_img, n_rays, steps, S = (int(v) for v in g["config"])
+    F = 3 * (deg + 1) ** 2
+    grid = relu_grid(hip_device, T(hash_uniform((G, G, G, 1), 901)), T(hash_uniform((G, G, G, F), 900 + F)), G, storage="split")
+    cfg = rf.SHVoxGridRenderConfig(S, rf.CameraBounds(float(g["near"]), float(g["far"])), perturb_sampled_points=False, white_bkgd=True)
+    model = rf.VolumetricModel(grid, rf.render_sh_voxel_grid, cfg, device=hip_device)
+    stepper = TrainStepper(model, n_rays, learning_rate=float(g["lr"]), backward="binned")
+    for it in range(steps):
+        rays = rf.Rays(T(g["origins"][it]).to(hip_device), T(g["directions"][it]).to(hip_device))
+        stats = stepper.step_on(rays, T(g["pixels"][it]).to(hip_device))
+        np.testing.assert_allclose(stats.specular_loss.item(), g["specular_loss"][it], rtol=1e-5)
+        np.testing.assert_allclose(stats.diffuse_loss.item(), g["diffuse_loss"][it], rtol=1e-5)
+    dd = np.abs(grid.densities.detach().cpu().numpy() - g["dens_final"])
+    df = np.abs(grid.features.detach().cpu().numpy() - g["feat_final"])
+    assert np.mean(dd < 1e-4) > 0.99 and np.mean(df < 1e-4) > 0.99

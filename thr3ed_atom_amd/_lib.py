@@ -32,6 +32,9 @@ EXPORTED_SYMBOLS = [
     "rf_ray_aabb_bounds",
     "rf_render_forward",
     "rf_render_backward",
+    "rf_render_backward_emit",
+    "rf_gather_records",
+    "rf_brick_accumulate",
     "rf_grid_query",
     "rf_grid_query_backward",
     "rf_build_occupancy",
@@ -92,6 +95,14 @@ class RFRenderGrads(C.Structure):
     ]
 
 
+class RFBrickList(C.Structure):
+    _fields_ = [
+        ("records_sorted_dev", C.c_void_p),
+        ("offsets_dev", C.c_void_p),
+        ("render_diffuse", C.c_int32),
+    ]
+
+
 def build(force: bool = False, verbose: bool = False) -> str:
     """Cross-compile the HIP sources for gfx950 into csrc/librelu_field_hip.so (hipcc needs no GPU)."""
     srcs = [os.path.join(CSRC_DIR, s) for s in SOURCES]
@@ -142,6 +153,11 @@ def load() -> C.CDLL:
         vp,
         vp,
     ]
+    lib.rf_render_backward_emit.argtypes = [
+        C.POINTER(RFGrid), C.POINTER(RFRayBatch), u32, C.POINTER(RFRenderOut), C.POINTER(RFRenderGrads), i32, vp, vp, vp, vp,
+    ]
+    lib.rf_gather_records.argtypes = [vp, vp, vp, i64, vp, vp]
+    lib.rf_brick_accumulate.argtypes = [C.POINTER(RFGrid), i32, C.POINTER(RFBrickList), i32, vp, vp, vp, i32, vp]
     lib.rf_grid_query.argtypes = [C.POINTER(RFGrid), vp, i64, vp, vp]
     lib.rf_grid_query_backward.argtypes = [C.POINTER(RFGrid), vp, i64, vp, vp, vp, vp]
     lib.rf_build_occupancy.argtypes = [C.POINTER(RFGrid), f32, vp, vp]

@@ -172,6 +172,62 @@ def render_backward_raw(grid: VoxelGrid, origins: Tensor, directions: Tensor, t_
     _lib.check(rc, "rf_render_backward")
 
 
+NO_BRICK = 0x7FFF
+
+
+def brick_counts(grid: VoxelGrid, brick_size: int) -> Tuple[int, int, int]:
+    return tuple((d + brick_size - 1) // brick_size for d in grid.grid_dims)
+
+
+def render_backward_emit_raw(grid: VoxelGrid, origins: Tensor, directions: Tensor, t_rand: Optional[Tensor], num_samples: int,
+                             near: float, far: float, flags: int, caches, g_colour: Optional[Tensor], g_depth: Optional[Tensor],
+                             g_acc: Optional[Tensor], brick_size: int, keys: Tensor, records: Tensor, ray_basis: Optional[Tensor]) -> None:
+    """Enqueue rf_render_backward_emit: per-sample gradient records + brick keys instead of a scatter."""
+    lib = _lib.load()
+    dev = origins.device
+    rf_grid = grid.to_rf_grid(use_occupancy=bool(flags & _lib.FLAG_OCCUPANCY_SKIP))
+    rb, tv = _ray_batch(origins, directions, num_samples, near, far, t_rand)
+    grads = _lib.RFRenderGrads()
+    grads.grad_colour_dev, grads.grad_depth_dev, grads.grad_acc_dev = _ptr(g_colour), _ptr(g_depth), _ptr(g_acc)
+    cache, tcache, stop = caches
+    fwd = _lib.RFRenderOut()
+    fwd.sample_cache_dev, fwd.trans_cache_dev, fwd.stop_cache_dev = cache.data_ptr(), tcache.data_ptr(), stop.data_ptr()
+    with _span(f"render_backward_emit[{_variant(grid, flags)}]", dev):
+        rc = lib.rf_render_backward_emit(
+            C.byref(rf_grid), C.byref(rb), int(flags), C.byref(fwd), C.byref(grads), int(brick_size), keys.data_ptr(), records.data_ptr(),
+            _ptr(ray_basis), _stream(dev),
+        )
+    _lib.check(rc, "rf_render_backward_emit")
+
+
+def sort_records_by_brick(keys: Tensor, records: Tensor, records_sorted: Tensor, num_bricks: int, boundaries: Tensor) -> Tensor:
+    """Sort the dense key array (16-bit radix sort), gather the records of keyed samples into brick order and
+    return offsets [num_bricks + 1] (int64) of each brick inside ``records_sorted``."""
+    lib = _lib.load()
+    dev = keys.device
+    with _span("sort_keys", dev):
+        sorted_keys, perm = torch.sort(keys)
+        offsets = torch.searchsorted(sorted_keys, boundaries)
+    with _span("gather_records", dev):
+        rc = lib.rf_gather_records(records.data_ptr(), perm.data_ptr(), offsets[num_bricks:].data_ptr(), keys.numel(), records_sorted.data_ptr(), _stream(dev))
+    _lib.check(rc, "rf_gather_records")
+    return offsets
+
+
+def brick_accumulate_raw(grid: VoxelGrid, brick_size: int, lists, ray_basis: Optional[Tensor], grad_first: Tensor,
+                         grad_second: Optional[Tensor], accumulate: bool) -> None:
+    """``lists`` = [(records_sorted, offsets, render_diffuse), ...] (1 or 2 entries).  Enqueue rf_brick_accumulate."""
+    lib = _lib.load()
+    dev = grad_first.device
+    arr = (_lib.RFBrickList * len(lists))()
+    for i, (rec, off, diffuse) in enumerate(lists):
+        arr[i].records_sorted_dev, arr[i].offsets_dev, arr[i].render_diffuse = rec.data_ptr(), off.data_ptr(), int(bool(diffuse))
+    rf_grid = grid.to_rf_grid()
+    with _span("brick_accumulate", dev):
+        rc = lib.rf_brick_accumulate(C.byref(rf_grid), int(brick_size), arr, len(lists), _ptr(ray_basis), grad_first.data_ptr(), _ptr(grad_second), int(bool(accumulate)), _stream(dev))
+    _lib.check(rc, "rf_brick_accumulate")
+
+
 class _ReluFieldRender(torch.autograd.Function):
     @staticmethod
     def forward(ctx, first, second, origins, directions, t_rand, grid: VoxelGrid, num_samples, near, far, flags, need_grad):

@@ -30,7 +30,11 @@ from . import distributed as rfdist
 from .camera import CameraBounds, CameraIntrinsics, compute_thre3d_grid_sizes, mse2psnr, scale_camera_intrinsics
 from .constants import CAMERA_BOUNDS, CAMERA_INTRINSICS, HEMISPHERICAL_RADIUS
 from .ops import (
+    brick_accumulate_raw,
+    brick_counts,
     cast_selected_rays_hip,
+    render_backward_emit_raw,
+    sort_records_by_brick,
     l1_loss_grad_hip,
     render_backward_raw,
     render_flags,
@@ -127,6 +131,7 @@ class TrainStepper:
         data_parallel: bool = True,
         ray_selection: str = "keyed",
         fused: bool = True,
+        backward: str = "atomic",
     ):
         """``ray_selection``: "randperm" draws torch.randperm over all B*H*W pixels exactly like the reference
         (utils/misc.py:123) and keeps the first ``ray_batch_size``; "keyed" draws the same kind of sample
@@ -140,6 +145,14 @@ class TrainStepper:
         # fused=False goes through torch.autograd like a user of render_rays would.  Same arithmetic either way.
         self.fused = bool(fused)
         self._grad_clean = True  # FlatGrid starts zero-filled
+        # backward="binned" (fused steps only, SH degree <= 2, EXPERIMENTAL): per-sample gradient records are sorted by
+        # 8^3-cell brick and summed in LDS before they reach memory.  Exact, but measured 1.8x slower than the direct
+        # atomic scatter on MI355X because LDS float atomics are no faster than global ones
+        if backward not in ("atomic", "binned"):
+            raise ValueError("backward must be 'atomic' or 'binned'")
+        self.backward = backward
+        self.brick_size = 8
+        self._bins = None
         grid = vol_mod.thre3d_repr
         if not isinstance(grid, VoxelGrid):
             raise AssertionError(f"cannot train a {type(grid)}; only a VoxelGrid can be used")
@@ -204,10 +217,14 @@ class TrainStepper:
         pixels = pixels.detach().to(torch.float32).contiguous()
         n, S = origins.shape[0], int(cfg.num_samples_per_ray)
         near, far = float(np.float32(cfg.camera_bounds.near)), float(np.float32(cfg.camera_bounds.far))
+        binned = self.backward == "binned"
+        if binned:
+            bins = self._bin_buffers(n, S, origins.device)
         if not self._grad_clean:
             self.flat.zero_grad()
         gd, gf = self.flat.views_for_accumulation()
         sums = torch.zeros(4, dtype=torch.float32, device=origins.device)
+        lists = []
         for i, diffuse in enumerate((False, True) if self.diffuse else (False,)):
             t_rand = torch.rand(n, S, dtype=torch.float32, device=origins.device) if cfg.perturb_sampled_points else None
             if cfg.consume_reference_rng:
@@ -215,7 +232,18 @@ class TrainStepper:
             flags = render_flags(cfg.white_bkgd, diffuse, cfg.optimized_sampling, cfg.use_occupancy_mask)
             colour, _, _, _, caches = render_forward_raw(grid, origins, directions, t_rand, S, near, far, flags, save=True)
             g_colour = l1_loss_grad_hip(colour, pixels, sums[2 * i : 2 * i + 2])
-            render_backward_raw(grid, origins, directions, t_rand, S, near, far, flags, caches, g_colour, None, None, gd, gf)
+            if binned:
+                render_backward_emit_raw(
+                    grid, origins, directions, t_rand, S, near, far, flags, caches, g_colour, None, None, self.brick_size,
+                    bins["keys"][i], bins["records"][i], None if diffuse else bins["ray_basis"],
+                )
+                offsets = sort_records_by_brick(bins["keys"][i], bins["records"][i], bins["sorted"][i], bins["num_bricks"], bins["boundaries"])
+                lists.append((bins["sorted"][i], offsets, diffuse))
+            else:
+                render_backward_raw(grid, origins, directions, t_rand, S, near, far, flags, caches, g_colour, None, None, gd, gf)
+        if binned:
+            # one pass over the bricks folds both renders into the gradient bucket
+            brick_accumulate_raw(grid, self.brick_size, lists, bins["ray_basis"], gd, gf, accumulate=True)
         self._grad_clean = False
         if self.data_parallel:
             rfdist.all_reduce_mean_(self.flat.flat_grad)
@@ -224,6 +252,29 @@ class TrainStepper:
         self._grad_clean = False
         means = sums / float(3 * n)
         return StepStats(means[0], means[2] if self.diffuse else None, means[1], means[3] if self.diffuse else None)
+
+    def _bin_buffers(self, n: int, S: int, device):
+        b = self._bins
+        if b is None or b["shape"] != (n, S):
+            grid = self.vol_mod.thre3d_repr
+            nb = brick_counts(grid, self.brick_size)
+            num_bricks = nb[0] * nb[1] * nb[2]
+            if num_bricks >= 0x7FFF:
+                raise ValueError("backward='binned' needs fewer than 32767 bricks (grid too large for 16-bit brick keys)")
+            if grid.sh_degree > 2:
+                raise ValueError("backward='binned' supports SH degree <= 2 (the brick footprint must fit the 160 KB LDS)")
+            passes = 2 if self.diffuse else 1
+            b = {
+                "shape": (n, S),
+                "num_bricks": num_bricks,
+                "keys": [torch.empty(n * S, dtype=torch.int16, device=device) for _ in range(passes)],
+                "records": [torch.empty((n * S, 8), dtype=torch.float32, device=device) for _ in range(passes)],
+                "sorted": [torch.empty((n * S, 8), dtype=torch.float32, device=device) for _ in range(passes)],
+                "ray_basis": torch.zeros((n, 16), dtype=torch.float32, device=device),
+                "boundaries": torch.arange(num_bricks + 1, dtype=torch.int16, device=device),
+            }
+            self._bins = b
+        return b
 
     def step(self, dataset: PosedImagesInMemory, image_ids: Tensor) -> StepStats:
         rays, pixels = self.select(dataset, image_ids)
