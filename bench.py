@@ -133,6 +133,7 @@ def main():
     ap.add_argument("--image-size", type=int, default=800)
     ap.add_argument("--images", type=int, default=8)
     ap.add_argument("--render-frames", type=int, default=3, help="full-frame forward renders timed for fwd_render (0 = skip)")
+    ap.add_argument("--highres-frames", type=int, default=2, help="frames timed for the 256^3 / 512-sample configs[4] render (0 = skip)")
     ap.add_argument("--cpu-rays", type=int, default=2048, help="rays of the cpu_baseline sample (0 = skip)")
     ap.add_argument("--storage", choices=["split", "reference"], default="split",
                     help="HBM layout of the grid: split = MI355X-native (what the trainer uses), reference = the reference's two tensors")
@@ -204,6 +205,41 @@ def main():
             "effective_GBps_kernel": alg / 1e9 / (kms / 1e3),
             "frac_of_hbm_peak": alg / 1e9 / (kms / 1e3) / HBM_PEAK_GBS,
         }
+
+    # ---- configs[4]: 256^3 grid, 512 samples/ray, sparse scene, exact empty-space skipping (rank 0) ------------
+    highres = None
+    if args.highres_frames > 0 and rank == 0:
+        hg = make_grid(dev, 256, args.sh_degree, seed=11, sparse=True, storage=args.storage)
+        hcfg = rf.SHVoxGridRenderConfig(512, bounds, perturb_sampled_points=True, white_bkgd=True)
+        hmodel = rf.VolumetricModel(hg, rf.render_sh_voxel_grid, hcfg, device=dev)
+        pose = rf.pose_spherical(30.0, -30.0, RADIUS)
+        t_build0 = time.perf_counter()
+        hg.build_occupancy()
+        torch.cuda.synchronize()
+        t_build = time.perf_counter() - t_build0
+        times = {}
+        for use in (False, True):
+            hmodel.render(pose, intr, use_occupancy_mask=use)  # warm-up
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(args.highres_frames):
+                hmodel.render(pose, intr, use_occupancy_mask=use)
+            torch.cuda.synchronize()
+            times[use] = (time.perf_counter() - t0) / args.highres_frames
+        a = hmodel.render(pose, intr, use_occupancy_mask=False, perturb_sampled_points=False)
+        b = hmodel.render(pose, intr, use_occupancy_mask=True, perturb_sampled_points=False)
+        occ_bits = int(sum(bin(w & 0xFFFFFFFF).count("1") for w in hg.occupancy.cpu().tolist()))
+        highres = {
+            "workload": f"configs[4]: 256^3 SH-{args.sh_degree} sparse ReLU field, {H}x{W}, 512 jittered samples/ray, VolumetricModel.render",
+            "ms_per_frame_no_mask": times[False] * 1e3,
+            "ms_per_frame_occupancy_mask": times[True] * 1e3,
+            "ray_samples_per_s_occupancy_mask": H * W * 512 / times[True],
+            "occupied_cell_fraction": occ_bits / float(257**3),
+            "mask_build_ms": t_build * 1e3,
+            "mask_is_exact": bool(torch.equal(a.colour, b.colour) and torch.equal(a.depth, b.depth)),
+        }
+        del hmodel, hg, a, b
+        torch.cuda.empty_cache()
 
     # ---- training steps: the headline ---------------------------------------------------------------
     stepper = TrainStepper(model, R, learning_rate=0.03, apply_diffuse_render_regularization=True, ray_selection=args.ray_selection, backward=args.backward)
@@ -324,6 +360,7 @@ def main():
         "roofline": roofline,
         "cpu_baseline": baseline,
         "fwd_render": fwd_render,
+        "highres_render": highres,
     }
     print(json.dumps(line))
 

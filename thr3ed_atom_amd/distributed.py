@@ -48,8 +48,12 @@ def all_reduce_mean_(bucket: Tensor) -> Tensor:
     training step; RCCL picks ring / direct over the xGMI mesh."""
     n = world_size()
     if n > 1:
-        dist.all_reduce(bucket, op=dist.ReduceOp.SUM)
-        bucket.mul_(1.0 / n)
+        if dist.get_backend() == "nccl":
+            # RCCL averages inside the collective: no extra 235 MB read+write pass for the 1/n scaling
+            dist.all_reduce(bucket, op=dist.ReduceOp.AVG)
+        else:
+            dist.all_reduce(bucket, op=dist.ReduceOp.SUM)
+            bucket.mul_(1.0 / n)
     return bucket
 
 
