@@ -54,6 +54,17 @@ def _worker(rank, world, port, result_dir):
     dist.all_gather(gathered, q)
     assert all(torch.equal(gathered[0], t) for t in gathered)
 
+    # 2b. asynchronous mean all-reduce of the two parts of a bucket == one mean all-reduce of the whole bucket
+    whole = torch.arange(100, dtype=torch.float32) * (rank + 1)
+    parts = whole.clone()
+    first = rfdist.all_reduce_mean_async(parts[60:])
+    parts[:60].add_(0.0)  # work on the other part while the first collective is in flight
+    second = rfdist.all_reduce_mean_async(parts[:60])
+    first.wait()
+    second.wait()
+    rfdist.all_reduce_mean_(whole)
+    assert torch.equal(parts, whole) and torch.allclose(whole, torch.arange(100.0) * (sum(range(1, world + 1)) / world))
+
     # 3. ragged row gather (rays of a frame split over ranks) and broadcast
     rows = torch.arange(10 * 3, dtype=torch.float32).reshape(10, 3)
     lo, hi = rfdist.shard_range(10)

@@ -458,3 +458,45 @@ def test_binned_train_step_follows_reference_trajectory(hip_device):
     dd = np.abs(grid.densities.detach().cpu().numpy() - g["dens_final"])
     df = np.abs(grid.features.detach().cpu().numpy() - g["feat_final"])
     assert np.mean(dd < 1e-4) > 0.99 and np.mean(df < 1e-4) > 0.99
+
+
+def test_data_parallel_overlap_wiring(hip_device, monkeypatch):
+    """The data-parallel train step reduces the `rest` gradients right after the specular backward (so that the
+    collective overlaps the diffuse pass, which only touches `base`) and `base` after the diffuse backward.  With a
+    stand-in collective that is the identity (what averaging identical replicas does) the step must equal the
+    single-process step; the recorded calls show order and sizes.  (Real RCCL runs are the driver's 2/4/8-GPU bench.)"""
+    from thr3ed_atom_amd import distributed as rfdist
+
+    g = load_golden("g9_trainer_trajectory.npz")
+    G, deg, hw, n_img, n_rays, steps, S = (int(v) for v in g["config"])
+    F = 3 * (deg + 1) ** 2
+    calls = []
+
+    class Handle:
+        def wait(self):
+            calls.append("wait")
+
+    def fake_async(bucket):
+        calls.append(("async", bucket.numel(), bucket.data_ptr()))
+        return Handle()
+
+    results = []
+    for dp in (False, True):
+        grid = relu_grid(hip_device, T(hash_uniform((G, G, G, 1), 901)), T(hash_uniform((G, G, G, F), 900 + F)), G, storage="split")
+        cfg = rf.SHVoxGridRenderConfig(S, rf.CameraBounds(float(g["near"]), float(g["far"])), perturb_sampled_points=False, white_bkgd=True)
+        model = rf.VolumetricModel(grid, rf.render_sh_voxel_grid, cfg, device=hip_device)
+        stepper = TrainStepper(model, n_rays, learning_rate=float(g["lr"]))
+        if dp:
+            monkeypatch.setattr(rfdist, "world_size", lambda: 2)
+            monkeypatch.setattr(rfdist, "all_reduce_mean_async", fake_async)
+        for it in range(2):
+            rays = rf.Rays(T(g["origins"][it]).to(hip_device), T(g["directions"][it]).to(hip_device))
+            stepper.step_on(rays, T(g["pixels"][it]).to(hip_device))
+        results.append((grid.densities.detach().clone(), grid.features.detach().clone(), stepper))
+    monkeypatch.undo()
+    assert torch.allclose(results[0][0], results[1][0], atol=1e-6) and torch.allclose(results[0][1], results[1][1], atol=1e-6)
+    flat = results[1][2].flat
+    first, second = flat.flat_gradient_parts()
+    per_step = [("async", second.numel(), second.data_ptr()), ("async", first.numel(), first.data_ptr()), "wait", "wait"]
+    assert calls == per_step * 2
+    assert first.numel() == G**3 * 4 and second.numel() == G**3 * (F - 3)

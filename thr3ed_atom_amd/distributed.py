@@ -57,6 +57,32 @@ def all_reduce_mean_(bucket: Tensor) -> Tensor:
     return bucket
 
 
+class _MeanHandle:
+    """Completion handle of an asynchronous mean all-reduce (``wait()`` makes the current stream wait for it)."""
+
+    def __init__(self, work, bucket: Tensor, scale: Optional[float]):
+        self._work, self._bucket, self._scale = work, bucket, scale
+
+    def wait(self) -> None:
+        if self._work is not None:
+            self._work.wait()
+            if self._scale is not None:
+                self._bucket.mul_(self._scale)
+            self._work = None
+
+
+def all_reduce_mean_async(bucket: Tensor) -> _MeanHandle:
+    """Start averaging ``bucket`` over all ranks and return immediately.  The collective runs on the backend's own
+    stream after everything already enqueued on the current stream, i.e. concurrently with kernels launched
+    afterwards -- used to reduce the ``rest`` gradients while the diffuse pass (which only touches ``base``) runs."""
+    n = world_size()
+    if n == 1:
+        return _MeanHandle(None, bucket, None)
+    if dist.get_backend() == "nccl":
+        return _MeanHandle(dist.all_reduce(bucket, op=dist.ReduceOp.AVG, async_op=True), bucket, None)
+    return _MeanHandle(dist.all_reduce(bucket, op=dist.ReduceOp.SUM, async_op=True), bucket, 1.0 / n)
+
+
 def broadcast_(tensor: Tensor, src: int = 0) -> Tensor:
     if world_size() > 1:
         dist.broadcast(tensor, src=src)

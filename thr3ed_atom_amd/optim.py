@@ -55,6 +55,11 @@ class FlatGrid:
     def views_for_accumulation(self) -> Tuple[Tensor, Tensor]:
         return self._gd, self._gf
 
+    def flat_gradient_parts(self) -> Tuple[Tensor, Optional[Tensor]]:
+        """The gradient bucket as its two contiguous 1-D parts (first tensor | second tensor)."""
+        nd = self._d.numel()
+        return self.flat_grad[:nd], (self.flat_grad[nd:] if self._f is not None else None)
+
     @staticmethod
     def autograd_return() -> Tuple[None, None]:
         # the kernel has already added into .grad; returning None keeps autograd from adding again

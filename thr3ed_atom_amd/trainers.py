@@ -225,6 +225,13 @@ class TrainStepper:
         gd, gf = self.flat.views_for_accumulation()
         sums = torch.zeros(4, dtype=torch.float32, device=origins.device)
         lists = []
+        # data parallel: with split storage the diffuse pass only touches `base`, so the all-reduce of the `rest`
+        # gradients (201 of the 235 MB at degree 2) starts right after the specular backward and overlaps it
+        overlap = (
+            self.data_parallel and rfdist.world_size() > 1 and self.diffuse and not binned
+            and grid.storage == "split" and gf is not None
+        )
+        pending = []
         for i, diffuse in enumerate((False, True) if self.diffuse else (False,)):
             t_rand = torch.rand(n, S, dtype=torch.float32, device=origins.device) if cfg.perturb_sampled_points else None
             if cfg.consume_reference_rng:
@@ -241,11 +248,17 @@ class TrainStepper:
                 lists.append((bins["sorted"][i], offsets, diffuse))
             else:
                 render_backward_raw(grid, origins, directions, t_rand, S, near, far, flags, caches, g_colour, None, None, gd, gf)
+                if overlap and i == 0:
+                    pending.append(rfdist.all_reduce_mean_async(self.flat.flat_gradient_parts()[1]))
         if binned:
             # one pass over the bricks folds both renders into the gradient bucket
             brick_accumulate_raw(grid, self.brick_size, lists, bins["ray_basis"], gd, gf, accumulate=True)
         self._grad_clean = False
-        if self.data_parallel:
+        if overlap:
+            pending.append(rfdist.all_reduce_mean_async(self.flat.flat_gradient_parts()[0]))
+            for handle in pending:
+                handle.wait()
+        elif self.data_parallel:
             rfdist.all_reduce_mean_(self.flat.flat_grad)
         # (clearing the bucket inside the Adam kernel measured slower than a separate memset: 0.37 vs 0.28 + 0.05 ms)
         self.optimizer.step()
