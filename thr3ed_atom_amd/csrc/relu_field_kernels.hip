@@ -1520,26 +1520,33 @@ __global__ void ray_aabb_bounds_kernel(const float* origins, const float* dirs, 
 // occupancy mask (exact empty-space skipping for the ReLU field)
 // =============================================================================================
 __global__ void build_occupancy_kernel(GridArgs g, float threshold, uint32_t* occ, long long nwords) {
+  // one lane per cell, 64 consecutive cells (z fastest) per wave -> two mask words per __ballot; the 8 nodes of
+  // neighbouring cells overlap, so the loads hit L1
   const long long ncell = (long long)(g.X + 1) * (g.Y + 1) * (g.Z + 1);
-  for (long long wd = (long long)blockIdx.x * blockDim.x + threadIdx.x; wd < nwords;
-       wd += (long long)gridDim.x * blockDim.x) {
-    uint32_t bits = 0;
-    for (int b = 0; b < 32; ++b) {
-      const long long cell = wd * 32 + b;
-      if (cell >= ncell) break;
-      const int cz = (int)(cell % (g.Z + 1));
-      const int cy = (int)((cell / (g.Z + 1)) % (g.Y + 1));
-      const int cx = (int)(cell / ((long long)(g.Z + 1) * (g.Y + 1)));
-      bool occ_cell = (g.mode != RF_DENSITY_RELU);
-      for (int k = 0; k < 8 && !occ_cell; ++k) {
-        const int x = cx - 1 + (k & 1), y = cy - 1 + ((k >> 1) & 1), z = cz - 1 + (k >> 2);
-        if (x < 0 || x >= g.X || y < 0 || y >= g.Y || z < 0 || z >= g.Z) continue;
-        const float v = g.dens[(((long long)x * g.Y + y) * g.Z + z) * g.dstride] * g.rho;
-        occ_cell = v > threshold;
+  const long long nwave_items = (ncell + 63) / 64;
+  const int lane = threadIdx.x & 63;
+  const long long wave0 = ((long long)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  const long long wave_stride = ((long long)gridDim.x * blockDim.x) >> 6;
+  for (long long item = wave0; item < nwave_items; item += wave_stride) {
+    const long long cell = item * 64 + lane;
+    bool occ_cell = false;
+    if (cell < ncell) {
+      occ_cell = (g.mode != RF_DENSITY_RELU);
+      if (!occ_cell) {
+        const int cz = (int)(cell % (g.Z + 1));
+        const long long t = cell / (g.Z + 1);
+        const int cy = (int)(t % (g.Y + 1)), cx = (int)(t / (g.Y + 1));
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+          const int x = cx - 1 + (k & 1), y = cy - 1 + ((k >> 1) & 1), z = cz - 1 + (k >> 2);
+          if (x >= 0 && x < g.X && y >= 0 && y < g.Y && z >= 0 && z < g.Z)
+            occ_cell = occ_cell || (g.dens[(((long long)x * g.Y + y) * g.Z + z) * g.dstride] * g.rho > threshold);
+        }
       }
-      bits |= (occ_cell ? 1u : 0u) << b;
     }
-    occ[wd] = bits;
+    const unsigned long long bits = __ballot(occ_cell);
+    if (lane == 0 && item * 2 < nwords) occ[item * 2] = (uint32_t)bits;
+    if (lane == 32 && item * 2 + 1 < nwords) occ[item * 2 + 1] = (uint32_t)(bits >> 32);
   }
 }
 
@@ -2013,7 +2020,7 @@ int rf_build_occupancy(const RFGrid* grid, float threshold, uint32_t* occupancy_
   const GridArgs g = to_args(grid);
   const long long ncell = (long long)(g.X + 1) * (g.Y + 1) * (g.Z + 1);
   const long long nwords = (ncell + 31) / 32;
-  hipLaunchKernelGGL(build_occupancy_kernel, dim3(grid_1d(nwords, 256)), dim3(256), 0, (hipStream_t)stream, g,
+  hipLaunchKernelGGL(build_occupancy_kernel, dim3(grid_1d(ncell, 256, 256LL * 32)), dim3(256), 0, (hipStream_t)stream, g,
                      threshold, occupancy_dev, nwords);
   return launch_status();
 }
