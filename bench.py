@@ -269,6 +269,9 @@ def main():
         te = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         torch.distributed.all_reduce(te, op=torch.distributed.ReduceOp.MAX)
         elapsed = float(te.item())
+        # every rank leaves the group together, BEFORE rank 0 starts its single-process reporting legs
+        torch.distributed.barrier()
+        torch.distributed.destroy_process_group()
 
     if rank != 0:
         return
