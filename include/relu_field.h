@@ -165,29 +165,32 @@ int rf_render_backward(const RFGrid* grid, const RFRayBatch* rays, uint32_t flag
                        const RFRenderGrads* grads, float* grad_densities_dev, float* grad_features_dev,
                        void* stream);
 
-/* ---- binned backward: the same adjoint as rf_render_backward, aggregated in LDS before it reaches memory -------
+/* ---- binned backward: the same adjoint as rf_render_backward without a single atomic -----------------------------
  * (1) rf_render_backward_emit: instead of scattering, write per contributing sample a 32-byte record
  *     records_dev [N*S, 8] = (continuous index x, y, z, dL/d pre-activation density, dL/d raw r, g, b, ray id bits)
- *     and, for EVERY sample slot, keys_dev [N*S] = id of the brick (brick_size^3 nodes, brick_size in {4, 8}) its
- *     cell starts in, or 0x7fff for samples without gradient.  ray_basis_dev [N,16] (may be NULL for the diffuse
- *     pass) receives the signed SH basis of each ray.
- * (2) the caller sorts keys (torch.sort) -> permutation, and offsets [nbricks+1] (searchsorted);
- * (3) rf_gather_records: records_sorted[i] = records[perm[i]] for i < *count_dev (= offsets[nbricks]);
- * (4) rf_brick_accumulate: one workgroup per brick sums every contribution of its cells to the (brick_size+1)^3
- *     nodes they touch in LDS, then adds that footprint to the gradient tensors with float32 atomics laid out in
- *     long contiguous runs -- one atomic per (node, channel) of a brick instead of one per sample.  Gradients are
- *     ACCUMULATED like everywhere else (`accumulate` must be 1).  Up to two record lists (the specular and the
- *     diffuse render of a training iteration) are folded in one pass. */
+ *     and, for EVERY sample slot, keys_dev [N*S] = brick * 8 + flags, where brick = id of the brick (brick_size^3
+ *     nodes, brick_size in {4, 8}) holding the LOWER node of the sample's cell and flag bit a says that the cell's
+ *     upper node on axis a belongs to the next brick; -1 for samples without gradient.  ray_basis_dev [N,16] (may
+ *     be NULL for the diffuse pass) receives the signed SH basis of each ray.  At most 4096 bricks (16-bit keys).
+ * (2) the caller sorts keys (torch.sort) -> permutation, and offsets [8*nbricks+1] (searchsorted; last = N*S);
+ * (3) rf_gather_records: records_sorted[i] = records[perm[i]] for *begin_dev (= offsets[0]) <= i < capacity;
+ * (4) rf_brick_accumulate: one workgroup per brick OWNS the brick's nodes: it reads exactly the record classes
+ *     that touch them (its own brick's and, per flags, up to 7 lower neighbours'), sums them in LDS with plain
+ *     read-add-writes (each wavefront owns a disjoint channel group, so nothing races and no LDS atomics are
+ *     needed) and writes the brick with plain coalesced stores: accumulate = 0 overwrites EVERY element of the
+ *     gradient tensors (no zero-fill needed), accumulate = 1 adds.  Up to two record lists (the specular and the
+ *     diffuse render of a training iteration) are folded in one pass.  SH degree <= 2.  The sum order is fixed by
+ *     the (stable) sort: results are run-to-run deterministic, unlike the atomic scatter. */
 typedef struct RFBrickList {
   const float* records_sorted_dev; /* [count, 8]                                    */
-  const int64_t* offsets_dev;      /* [nbricks + 1] start of each brick in the list */
+  const int64_t* offsets_dev;      /* [8 * nbricks + 1] start of each (brick, flags) class */
   int32_t render_diffuse;          /* records come from a render_diffuse pass       */
 } RFBrickList;
 
 int rf_render_backward_emit(const RFGrid* grid, const RFRayBatch* rays, uint32_t flags, const RFRenderOut* fwd,
                             const RFRenderGrads* grads, int32_t brick_size, int16_t* keys_dev, float* records_dev,
                             float* ray_basis_dev, void* stream);
-int rf_gather_records(const float* records_dev, const int64_t* perm_dev, const int64_t* count_dev, int64_t capacity,
+int rf_gather_records(const float* records_dev, const int64_t* perm_dev, const int64_t* begin_dev, int64_t capacity,
                       float* records_sorted_dev, void* stream);
 int rf_brick_accumulate(const RFGrid* grid, int32_t brick_size, const RFBrickList* lists, int32_t num_lists,
                         const float* ray_basis_dev, float* grad_densities_dev, float* grad_features_dev,

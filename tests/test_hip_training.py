@@ -374,7 +374,7 @@ def test_keyed_ray_selection(hip_device):
     assert torch.equal(r1.origins, r2.origins) and torch.equal(p1, p2) and len(r1) == 512
 
 
-def _binned_gradients(grid, rays, cfg, target, device, diffuse_too=True):
+def _binned_gradients(grid, rays, cfg, target, device, diffuse_too=True, accumulate=False):
     """(dL/d first, dL/d second) of L1(spec) [+ L1(diffuse)] through the emit -> sort -> brick-accumulate path"""
     from thr3ed_atom_amd import ops as O
 
@@ -383,11 +383,12 @@ def _binned_gradients(grid, rays, cfg, target, device, diffuse_too=True):
     near, far = float(np.float32(cfg.camera_bounds.near)), float(np.float32(cfg.camera_bounds.far))
     nb = O.brick_counts(grid, 8)
     num_bricks = nb[0] * nb[1] * nb[2]
-    boundaries = torch.arange(num_bricks + 1, dtype=torch.int16, device=device)
+    boundaries = torch.arange(num_bricks * 8, dtype=torch.int16, device=device)
     ray_basis = torch.zeros((n, 16), device=device)
     first, second = grid.kernel_tensors()
-    gd = torch.zeros_like(first)
-    gf = None if second is None else torch.zeros_like(second)
+    # accumulate=False overwrites every element (no zero-fill needed): start from garbage to prove it
+    gd = torch.full_like(first, 7.0) if not accumulate else torch.zeros_like(first)
+    gf = None if second is None else (torch.full_like(second, -3.0) if not accumulate else torch.zeros_like(second))
     sums = torch.zeros(4, device=device)
     lists, keep = [], []
     for i, diffuse in enumerate((False, True) if diffuse_too else (False,)):
@@ -398,18 +399,25 @@ def _binned_gradients(grid, rays, cfg, target, device, diffuse_too=True):
         rec = torch.empty((n * S, 8), device=device)
         srt = torch.empty((n * S, 8), device=device)
         O.render_backward_emit_raw(grid, o, d, None, S, near, far, flags, caches, g_colour, None, None, 8, keys, rec, None if diffuse else ray_basis)
-        offsets = O.sort_records_by_brick(keys, rec, srt, num_bricks, boundaries)
+        offsets = torch.full((num_bricks * 8 + 1,), n * S, dtype=torch.int64, device=device)
+        O.sort_records_by_brick(keys, rec, srt, offsets, boundaries)
         lists.append((srt, offsets, diffuse or cfg.render_diffuse))
         keep.append((keys, rec, caches))
-    O.brick_accumulate_raw(grid, 8, lists, ray_basis, gd, gf, accumulate=True)
+    O.brick_accumulate_raw(grid, 8, lists, ray_basis, gd, gf, accumulate=accumulate)
+    if accumulate:  # adding the same lists once more doubles the result
+        O.brick_accumulate_raw(grid, 8, lists, ray_basis, gd, gf, accumulate=True)
+        gd.mul_(0.5)
+        if gf is not None:
+            gf.mul_(0.5)
     return gd, gf
 
 
+@pytest.mark.parametrize("accumulate", [False, True])
 @pytest.mark.parametrize("storage", ["reference", "split"])
 @pytest.mark.parametrize("case", ["grid16_sh2", "aniso_sh2_abs", "aniso_sh1_softplus", "cube20_sh0"])
-def test_binned_backward_equals_atomic_backward(hip_device, storage, case):
-    """The LDS-aggregated backward (emit -> 16-bit sort by brick -> one workgroup per 8^3-cell brick -> coalesced
-    flush; experimental, off by default) gives the gradient of the atomic scatter (and therefore of the reference)
+def test_binned_backward_equals_atomic_backward(hip_device, storage, case, accumulate):
+    """The LDS-aggregated backward (emit -> 16-bit sort by (brick, flags) -> one workgroup per 8^3-node brick that owns
+    its nodes exclusively -> plain coalesced stores) gives the gradient of the atomic scatter (and therefore of the reference)
     for specular + diffuse renders, including partial bricks, the grid border, SH degree 0-2 and the abs / softplus
     density modes."""
     from thr3ed_atom_amd.voxels import unpack_split
@@ -434,7 +442,7 @@ def test_binned_backward_equals_atomic_backward(hip_device, storage, case):
     loss = loss + torch.nn.functional.l1_loss(model.render_rays(rays, render_diffuse=True).colour, target)
     loss.backward()
     ref_d, ref_f = grid.reference_gradients()
-    gd, gf = _binned_gradients(grid, rays, cfg, target, hip_device)
+    gd, gf = _binned_gradients(grid, rays, cfg, target, hip_device, accumulate=accumulate)
     if storage == "split":
         gd, gf = unpack_split(gd, gf)
     assert float(ref_d.abs().max()) > 0 and float(ref_f.abs().max()) > 0

@@ -96,7 +96,7 @@ struct GradArgs {
   int nby, nbz;     // bricks along y and z
 };
 
-constexpr short kNoBrick = 0x7fff;
+constexpr short kNoBrick = -1;  // sorts in front of every (brick, flags) key
 
 // 16-byte load/store at 4-byte alignment (a corner's 27 features start at a multiple of 108 B)
 struct __attribute__((packed, aligned(4))) f4u {
@@ -924,9 +924,17 @@ __global__ __launch_bounds__(kBlock) void render_backward_kernel(GridArgs g, Ray
         const long long slot = ray * (long long)r.S + s;
         short key = kNoBrick;
         if (need) {
-          const int bx = max(sm.cell.i0[0], 0) >> gr.brick_shift, by = max(sm.cell.i0[1], 0) >> gr.brick_shift,
-                    bz = max(sm.cell.i0[2], 0) >> gr.brick_shift;
-          key = (short)((bx * gr.nby + by) * gr.nbz + bz);
+          // key = brick of the cell's lower node * 8 + flags; flag bit a = the cell's UPPER node on axis a belongs to
+          // the next brick (and exists), i.e. the record also touches nodes of that neighbour
+          const int dims3[3] = {g.X, g.Y, g.Z};
+          int b3[3], flags3 = 0;
+#pragma unroll
+          for (int a = 0; a < 3; ++a) {
+            const int lo = max(sm.cell.i0[a], 0), up = sm.cell.i0[a] + 1;
+            b3[a] = lo >> gr.brick_shift;
+            if (up < dims3[a] && (up >> gr.brick_shift) != b3[a]) flags3 |= 1 << a;
+          }
+          key = (short)((((b3[0] * gr.nby + b3[1]) * gr.nbz + b3[2]) << 3) | flags3);
           float4* rec = reinterpret_cast<float4*>(gr.records) + slot * 2;
           rec[0] = make_float4(sm.cell.idx[0], sm.cell.idx[1], sm.cell.idx[2], g_pre);
           rec[1] = make_float4(g_raw[0], g_raw[1], g_raw[2], __int_as_float((int)ray));
@@ -1012,10 +1020,12 @@ __global__ __launch_bounds__(kBlock) void render_backward_kernel(GridArgs g, Ray
 // point for a non-atomic (channel-owned read-modify-write) variant.
 // =============================================================================================
 __global__ void gather_records_kernel(const float4* __restrict__ rec, const long long* __restrict__ perm,
-                                      const long long* __restrict__ count_ptr, long long capacity,
+                                      const long long* __restrict__ begin_ptr, long long capacity,
                                       float4* __restrict__ out) {
-  const long long count = min(*count_ptr, capacity);
-  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < count; i += (long long)gridDim.x * blockDim.x) {
+  // sorted position p holds a real record for p >= *begin (the slots without gradient sort in front)
+  const long long begin = *begin_ptr;
+  for (long long i = begin + (long long)blockIdx.x * blockDim.x + threadIdx.x; i < capacity;
+       i += (long long)gridDim.x * blockDim.x) {
     const long long src = perm[i];
     out[2 * i] = rec[2 * src];
     out[2 * i + 1] = rec[2 * src + 1];
@@ -1034,7 +1044,8 @@ struct BrickArgs {
   const float* ray_basis;  // [N, 16]
   int shift;               // log2(B)
   int nbx, nby, nbz;
-  int accumulate;          // must be 1: footprints of neighbouring bricks overlap, results are added
+  int accumulate;          // 0: grad = brick sum (no zero-fill needed), 1: grad += brick sum
+  int debug;
 };
 
 // LDS channel order of a node ("split order"): 0 = density, 1..3 = degree-0 R,G,B, 4 + r = rest channel r
@@ -1053,193 +1064,306 @@ __device__ __forceinline__ void lds_channel_meaning(int c, int& colour, int& bas
   }
 }
 
-constexpr int kBrickThreads = 512;  // 8 waves: one workgroup per CU (its LDS footprint is ~125 KB at degree 2)
+// One workgroup (4 waves) per NODE brick: it owns B^3 nodes exclusively, so the result is written with plain stores.
+// Race-free accumulation without LDS atomics (tools/lds_microbench*.hip: ds_add_f32 retires 0.33 lane/clk/CU, plain
+// read-add-write is issue-bound): each wave owns a disjoint CHANNEL group and walks ALL records that touch the brick --
+//   wave 0: the base channels (density, degree-0 r, g, b): 8 corners x 4 channels = 32 lanes, two records per step;
+//           it is also the only wave with work on diffuse records;
+//   wave w>0: rest channels [8(w-1), 8w): 8 corners x 8 channels = 64 lanes (degree 2: three such waves).
+// Records are sorted by key = cell-brick * 8 + flags, so the records of a source brick that reach into this brick
+// (flags superset of the offset) are a handful of contiguous ranges: no record is read that does not contribute.
+// The kernel is instruction-issue bound, so everything per record that does not depend on the lane's channel is
+// computed ONCE, by 8 threads per record, into a small LDS table (corner address + corner weight, per-channel
+// dL/draw * basis); the accumulation loop is then 2 table reads, 1 multiply and the read-add-write.  Tables are
+// double buffered and the global loads of the next batch are in flight during the accumulation of the current one.
+constexpr int kBrickThreads = 256;
+constexpr int kBrickBatch = 32;   // records per table (8 staging threads per record)
+constexpr int kMaxRanges = 28;    // 14 (source brick, flag run) ranges per list, two lists
+
+__host__ __device__ inline int brick_row_stride(int B, int C) { return B * C + ((8 - (B * C) % 32) + 32) % 32; }
+__host__ __device__ inline int brick_slab_stride(int B, int C) {
+  const int sy = brick_row_stride(B, C);
+  return B * sy + ((16 - (B * sy) % 32) + 32) % 32;
+}
+__host__ __device__ inline int brick_acc_words(int B, int C) { return B * brick_slab_stride(B, C) + 64; }  // + trash row
+
+// (offset to the source brick, first flag class, last flag class): classes f with (f & o) == o, merged into runs
+__constant__ unsigned char kBrickRuns[14][3] = {{0, 0, 7}, {1, 1, 1}, {1, 3, 3}, {1, 5, 5}, {1, 7, 7}, {2, 2, 3}, {2, 6, 7},
+                                                {3, 3, 3}, {3, 7, 7}, {4, 4, 7}, {5, 5, 5}, {5, 7, 7}, {6, 6, 7}, {7, 7, 7}};
+
+// packed lower nodes (one byte per axis): do the two cells have a node in common?
+__device__ __forceinline__ bool cells_share_nodes(uint32_t ca, uint32_t cb) {
+  const int dx = (int)(ca & 0xffu) - (int)(cb & 0xffu), dy = (int)((ca >> 8) & 0xffu) - (int)((cb >> 8) & 0xffu),
+            dz = (int)((ca >> 16) & 0xffu) - (int)((cb >> 16) & 0xffu);
+  return (unsigned)(dx + 1) <= 2u && (unsigned)(dy + 1) <= 2u && (unsigned)(dz + 1) <= 2u;
+}
 
 template <int K>
 __global__ __launch_bounds__(kBrickThreads) void brick_accumulate_kernel(GridArgs g, BrickArgs a, float* gdens,
                                                                          float* gfeat) {
   constexpr int C = 3 * K + 1;
-  constexpr int LPC = (C <= 16) ? 16 : (C <= 32 ? 32 : 64);
-  constexpr int UPI = kWave / LPC, NPASS = 8 / UPI;
-  constexpr int WAVES = kBrickThreads / kWave;
-  // work-list entry: [0] packed local lower node (+1)  [1..6] w0x w1x w0y w1y w0z w1z  [7] dL/dpre  [8..10] dL/draw rgb
-  //                  [11] unused  [12..12+K) signed SH basis of the record's ray (specular records only)
-  constexpr int ES = 12 + K;
-  extern __shared__ __attribute__((aligned(16))) float smem[];
+  constexpr int NREST = C - 4;                 // channels beyond the base record
+  constexpr int REST_WAVES = (NREST + 7) / 8;  // waves needed for them (3 at degree 2)
+  constexpr int CP = (C + 7) / 8;              // channels each of the 8 staging threads of a record prepares
+  constexpr int ROW = 16 + 8 * CP + 2;         // table row: 8 x (corner address, corner weight), 8 * CP channel values, packed cell (+ pad: rows stay 8-byte aligned)
+  extern __shared__ __attribute__((aligned(16))) float acc[];  // node (x, y, z), channel c at x * SX + y * SY + z * C + c
+  __shared__ __attribute__((aligned(16))) uint32_t table[2][(kBrickBatch + 1) * ROW];  // separate object: never aliases acc; + 1 spare row (prefetch)
+  __shared__ long long s_rstart[kMaxRanges];
+  __shared__ int s_rcount[kMaxRanges];
+  __shared__ int s_rcum[kMaxRanges + 1];  // cumulative record counts of the non-empty ranges
+  __shared__ int s_nranges, s_nspec;
   const int B = 1 << a.shift;
-  const int E = B + 1;  // nodes per edge of the brick's footprint: its B^3 cells touch (B+1)^3 nodes
-  const int nodes = E * E * E;
-  float* acc = smem;                                                    // [nodes][C], node = (x * E + y) * E + z
-  uint32_t* lists_lds = reinterpret_cast<uint32_t*>(smem + nodes * C);  // [waves][64][ES]
+  // row pads chosen so that the 8 corners of a cell start 4 banks apart: a 64-lane (8 corners x 8 channels) access
+  // then hits every LDS bank exactly twice
+  const int SY = brick_row_stride(B, C), SX = brick_slab_stride(B, C);
+  const int TRASH = B * SX;  // contributions to nodes this brick does not own land here and are never written out
+  const int acc_words = TRASH + 64;
 
-  const int lane = threadIdx.x & (kWave - 1);
-  const int wave = threadIdx.x >> 6;
-  uint32_t* my_entry = lists_lds + wave * (kWave * ES);
-
+  const int tid = threadIdx.x;
+  const int lane = tid & (kWave - 1);
+  const int wave = tid >> 6;
   const int brick = blockIdx.x;
-  long long total = 0;
-  for (int li = 0; li < a.nlists; ++li) total += a.lists[li].offsets[brick + 1] - a.lists[li].offsets[brick];
-  if (total == 0) return;  // nothing landed in this brick (wave-uniform)
-
   const int bz = brick % a.nbz, by = (brick / a.nbz) % a.nby, bx = brick / (a.nbz * a.nby);
-  // node 0 of the footprint: the brick's first cell has lower node B*b, except that the border brick also holds the
-  // cells whose lower node is -1
-  const int ox0 = (bx << a.shift) - (bx == 0), oy0 = (by << a.shift) - (by == 0), oz0 = (bz << a.shift) - (bz == 0);
-  const int ex = E + (bx == 0), ey = E + (by == 0), ez = E + (bz == 0);  // footprint extent incl. the virtual -1 layer
-  (void)ex;
+  const int X0 = bx << a.shift, Y0 = by << a.shift, Z0 = bz << a.shift;
 
-  for (int i = threadIdx.x; i < nodes * C; i += kBrickThreads) acc[i] = 0.0f;
+  // ---- which sorted ranges reach into this brick: 14 per list, fetched in parallel, compacted by one thread
+  if (tid < 14 * a.nlists) {
+    const int li = tid / 14, e = tid - li * 14;
+    const int o = kBrickRuns[e][0];
+    const int sx = bx - (o & 1), sy = by - ((o >> 1) & 1), sz = bz - (o >> 2);
+    long long rs = 0, re = 0;
+    if (sx >= 0 && sy >= 0 && sz >= 0) {
+      const long long key0 = (long long)((sx * a.nby + sy) * a.nbz + sz) << 3;
+      rs = a.lists[li].offsets[key0 + kBrickRuns[e][1]];
+      re = a.lists[li].offsets[key0 + kBrickRuns[e][2] + 1];
+    }
+    s_rstart[tid] = rs;
+    s_rcount[tid] = (int)(re - rs);
+  }
   __syncthreads();
+  if (tid == 0) {
+    int n = 0, cum = 0, nspec = 0;
+    s_rcum[0] = 0;
+    for (int i = 0; i < 14 * a.nlists; ++i) {
+      const int cnt = s_rcount[i];
+      if (cnt > 0) {
+        s_rstart[n] = s_rstart[i];  // n <= i: compaction in place
+        s_rcount[n] = i / 14;       // from now on: the list the range belongs to
+        cum += cnt;
+        s_rcum[++n] = cum;
+        if (!a.lists[i / 14].diffuse) nspec = cum;  // specular lists come first
+      }
+    }
+    s_nranges = n;
+    s_nspec = nspec;
+  }
+  __syncthreads();
+  const int nranges = s_nranges;
+  const int total = s_rcum[nranges];
+  const int nspec_total = s_nspec;
+  if (total == 0 && a.accumulate) return;  // nothing reaches this brick
+  if (total > 0)
+    for (int i = tid; i < acc_words; i += kBrickThreads) acc[i] = 0.0f;
 
-  const int c_spec = lane % LPC, unit_spec = lane / LPC;
-  int colour_spec, k_spec;
-  lds_channel_meaning<K>(c_spec, colour_spec, k_spec);
-  const bool lane_spec_active = c_spec < C;
-  const int c_diff = lane & 3, unit_diff = lane >> 2;  // corner mode: (density, r, g, b) x 8 corners x 2 records
+  // ---- staging role: 8 threads per record; thread `part` prepares corner `part` and channels [part * CP, part * CP + CP)
+  const int sj = tid >> 3, part = tid & 7;
+  const int pdx = (part >> 2) & 1, pdy = (part >> 1) & 1, pdz = part & 1;
+  int sri = 0;  // running range index of this thread's records (they advance monotonically)
+  // ---- accumulation role
+  // wave 0: lane = half(record A/B) x corner(8) x channel(4);  waves 1..: lane = corner(8) x channel(8)
+  // each group of 32 lanes = 8 corners x 4 channels: with the row pads above the 8 corner bases are distinct multiples
+  // of 4 banks, i.e. the ds_read/ds_write of a group is conflict free
+  const int q = (lane >> 2) & 7;
+  const int c = (wave == 0) ? (lane & 3) : 4 + (wave - 1) * 8 + (lane & 3) + ((lane >> 5) << 2);
+  const bool rest_active = wave >= 1 && wave - 1 < REST_WAVES && c < C;
 
-  for (int li = 0; li < a.nlists; ++li) {
-    const BrickList L = a.lists[li];
-    const long long start = L.offsets[brick], end = L.offsets[brick + 1];
-    for (long long base = start + (long long)wave * kWave; base < end; base += (long long)WAVES * kWave) {
-      // ---- lanes = records: stage them (with their ray's basis) in LDS
-      const long long rdx = base + lane;
-      const bool have = rdx < end;
+  float4 r0 = make_float4(0.f, 0.f, 0.f, 0.f), r1 = r0;  // this thread's record of the batch being staged
+  int rinfo = -1;                                          // its list (or -1: no record)
+  auto fetch = [&](int base) {
+    const int v = base + sj;
+    rinfo = -1;
+    if (v < total) {
+      while (s_rcum[sri + 1] <= v) ++sri;
+      const long long pos = s_rstart[sri] + (v - s_rcum[sri]);
+      rinfo = s_rcount[sri];
+      const float4* rec = a.lists[rinfo].rec + 2 * pos;
+      r0 = rec[0];
+      r1 = rec[1];
+    }
+  };
+
+  const int nbatches = (total + kBrickBatch - 1) / kBrickBatch;
+  if (nbatches > 0) fetch(0);
+  for (int b = 0; b <= nbatches; ++b) {
+    // -- (1) the SH basis values this thread needs for batch b (dependent on the record fetched one round earlier)
+    float yb[CP];
+    const bool have = b < nbatches && rinfo >= 0;
+    const bool diffuse = have && a.lists[rinfo].diffuse;
+    const float4 c0 = r0, c1 = r1;
+#pragma unroll
+    for (int i = 0; i < CP; ++i) {
+      int colour, basis_k;
+      const int ch = part * CP + i;
+      lds_channel_meaning<K>(ch < C ? ch : 0, colour, basis_k);
+      yb[i] = kC0;
+      if (have && !diffuse && basis_k > 0) yb[i] = a.ray_basis[(long long)__float_as_int(c1.w) * 16 + basis_k];
+    }
+    // -- (2) start fetching the records of batch b + 1
+    if (b + 1 < nbatches) fetch((b + 1) * kBrickBatch);
+    // -- (3) accumulate batch b - 1 from its table
+    if (b > 0 && !(a.debug & 1)) {
+      // records j and j + 16 of a batch (usually samples of different rays) are handled together: when their cells
+      // share no node (lower nodes >= 2 apart on some axis) the two read-add-writes are independent and overlap,
+      // otherwise they are issued one after the other.  The table entries of step j + 1 are fetched before the
+      // read-add-write of step j, so that only the accumulator latency is on the critical path.
+      const uint32_t* tb = table[(b - 1) & 1];
+      const int base = (b - 1) * kBrickBatch;
+      const int nb = min(kBrickBatch, total - base);
+      constexpr int H = kBrickBatch / 2;
+      uint32_t shared_mask;  // bit j: the cells of records j and j + H have a node in common
+      {
+        const int l = lane & (H - 1);
+        shared_mask = (uint32_t)__ballot(cells_share_nodes(tb[l * ROW + ROW - 2], tb[(l + H) * ROW + ROW - 2]));
+        if (a.debug & 8) shared_mask = 0;
+        if (a.debug & 16) shared_mask = 0xffffffffu;
+      }
+      if (wave == 0 && !(a.debug & 32)) {
+        const int half = lane >> 5;
+        const int steps = min(nb, H);  // rows >= nb are padded (zero weight, trash address, far-away cell)
+        const uint32_t* row = tb + half * (H * ROW);
+        uint2 aw = *reinterpret_cast<const uint2*>(row + 2 * q);
+        float gv = __uint_as_float(row[16 + c]);
+        for (int j = 0; j < steps; ++j) {
+          row += ROW;  // step j + 1 (the table has a spare row behind the last one)
+          const uint2 aw_n = *reinterpret_cast<const uint2*>(row + 2 * q);
+          const float gv_n = __uint_as_float(row[16 + c]);
+          const float add = __uint_as_float(aw.y) * gv;
+          float* dst = &acc[aw.x + c];
+          if ((shared_mask >> j) & 1u) {
+            if (half == 0) *dst = *dst + add;
+            if (half == 1) *dst = *dst + add;
+          } else {
+            *dst = *dst + add;
+          }
+          aw = aw_n;
+          gv = gv_n;
+        }
+      } else if (rest_active && wave > 0 && !(a.debug & 64)) {
+        const int ns = min(max(nspec_total - base, 0), nb);  // diffuse records carry nothing for the rest channels
+        const int steps = min(ns, H);
+        const uint32_t* rowA = tb;
+        uint2 awA = *reinterpret_cast<const uint2*>(rowA + 2 * q);
+        uint2 awB = *reinterpret_cast<const uint2*>(rowA + H * ROW + 2 * q);  // beyond ns: a diffuse or padded row (rest values 0)
+        float gA = __uint_as_float(rowA[16 + c]), gB = __uint_as_float(rowA[H * ROW + 16 + c]);
+        for (int j = 0; j < steps; ++j) {
+          rowA += ROW;
+          const uint2 awA_n = *reinterpret_cast<const uint2*>(rowA + 2 * q);
+          const uint2 awB_n = *reinterpret_cast<const uint2*>(rowA + H * ROW + 2 * q);
+          const float gA_n = __uint_as_float(rowA[16 + c]), gB_n = __uint_as_float(rowA[H * ROW + 16 + c]);
+          const float addA = __uint_as_float(awA.y) * gA;
+          const float addB = __uint_as_float(awB.y) * gB;
+          float* dA = &acc[awA.x + c];
+          float* dB = &acc[awB.x + c];
+          if ((shared_mask >> j) & 1u) {
+            *dA = *dA + addA;
+            *dB = *dB + addB;
+          } else {
+            const float vA = *dA, vB = *dB;
+            *dA = vA + addA;
+            *dB = vB + addB;
+          }
+          awA = awA_n;
+          awB = awB_n;
+          gA = gA_n;
+          gB = gB_n;
+        }
+      }
+    }
+    // -- (4) build the table of batch b
+    if (b < nbatches && !(a.debug & 2)) {
+      uint32_t* row = table[b & 1] + sj * ROW;
+      uint32_t addr = (uint32_t)TRASH;
+      uint32_t cell = 0x00f0f0f0u + (uint32_t)(sj & 7) * 0x00040404u;  // padded rows: far from every real cell
+      float wc = 0.0f;
+      float gval[CP];
+#pragma unroll
+      for (int i = 0; i < CP; ++i) gval[i] = 0.0f;
       if (have) {
-        const float4 r0 = L.rec[2 * rdx], r1 = L.rec[2 * rdx + 1];
-        const float idx[3] = {r0.x, r0.y, r0.z};
-        const int org[3] = {ox0, oy0, oz0};
-        uint32_t pk = 0;
-        uint32_t* en = my_entry + lane * ES;
+        const float idx[3] = {c0.x, c0.y, c0.z};
+        const int org[3] = {X0, Y0, Z0};
+        const int dim[3] = {g.X, g.Y, g.Z};
+        const int dd[3] = {pdx, pdy, pdz};
+        int n3[3];
+        bool owned = true;
+        float w3[3];
+        cell = 0;
 #pragma unroll
         for (int ax = 0; ax < 3; ++ax) {
           const float fl = floorf(idx[ax]);
-          en[1 + 2 * ax] = __float_as_uint((fl + 1.0f) - idx[ax]);  // w0: same arithmetic as locate()
-          en[2 + 2 * ax] = __float_as_uint(idx[ax] - fl);           // w1
-          pk |= (uint32_t)((int)fl - org[ax]) << (8 * ax);          // lower node relative to the footprint, >= 0
+          cell |= (uint32_t)((int)fl - org[ax] + 1) << (8 * ax);  // lower node relative to the brick: 0..B
+          w3[ax] = dd[ax] ? (idx[ax] - fl) : ((fl + 1.0f) - idx[ax]);  // same arithmetic as locate()
+          n3[ax] = (int)fl - org[ax] + dd[ax];
+          owned = owned && n3[ax] >= 0 && n3[ax] < B && org[ax] + n3[ax] < dim[ax];
         }
-        en[0] = pk;
-        en[7] = __float_as_uint(r0.w);
-        en[8] = __float_as_uint(r1.x);
-        en[9] = __float_as_uint(r1.y);
-        en[10] = __float_as_uint(r1.z);
-        if (!L.diffuse) {
-          const float* yb = a.ray_basis + (long long)__float_as_int(r1.w) * 16;
+        if (owned) {
+          addr = (uint32_t)(n3[0] * SX + n3[1] * SY + n3[2] * C);
+          wc = (w3[0] * w3[1]) * w3[2];
+        }
+        const float graw[4] = {c1.x, c1.y, c1.z, c0.w * g.rho};  // colour 3 = density: dL/dpre * rho
 #pragma unroll
-          for (int k = 0; k < K; ++k) en[12 + k] = __float_as_uint(yb[k]);
+        for (int i = 0; i < CP; ++i) {
+          int colour, basis_k;
+          const int ch = part * CP + i;
+          lds_channel_meaning<K>(ch < C ? ch : 0, colour, basis_k);
+          float gv = graw[colour];
+          if (ch > 0) gv = gv * yb[i];
+          if (diffuse && ch >= 4) gv = 0.0f;
+          gval[i] = (ch < C) ? gv : 0.0f;
         }
       }
-      const int count = (int)min((long long)kWave, end - base);
-      wave_lds_fence();
-
-      // ---- lanes = channels: add the 8 corners of every staged record into the footprint accumulator
-      // (a node of the virtual -1 layer or beyond the grid is outside the footprint array bounds check below)
-      if (L.diffuse) {
-        for (int b0 = 0; b0 < count; b0 += 2) {
-          const int slot = b0 + (unit_diff >> 3);
-          if (slot < count) {
-            const uint32_t* en = my_entry + slot * ES;
-            const uint32_t pk = en[0];
-            const int q = unit_diff & 7;
-            const int dx = (q >> 2) & 1, dy = (q >> 1) & 1, dz = q & 1;
-            const int nx = (int)(pk & 0xffu) + dx, ny = (int)((pk >> 8) & 0xffu) + dy, nz = (int)((pk >> 16) & 0xffu) + dz;
-            const int X = ox0 + nx, Y = oy0 + ny, Z = oz0 + nz;
-            if (X >= 0 && X < g.X && Y >= 0 && Y < g.Y && Z >= 0 && Z < g.Z) {
-              const float wc = (__uint_as_float(en[1 + dx]) * __uint_as_float(en[3 + dy])) * __uint_as_float(en[5 + dz]);
-              float gv;
-              if (c_diff == 0) {
-                gv = (wc * __uint_as_float(en[7])) * g.rho;
-                if (g.mode == RF_DENSITY_ABS) {
-                  const float dv = g.dens[(((long long)X * g.Y + Y) * g.Z + Z) * g.dstride] * g.rho;
-                  gv = (dv > 0.f) ? gv : ((dv < 0.f) ? -gv : 0.0f);
-                }
-              } else {
-                gv = wc * (__uint_as_float(en[7 + c_diff]) * kC0);
-              }
-              // footprint index: the virtual -1 layer of a border brick was excluded by the X >= 0 test
-              const int fx = X - (bx << a.shift), fy = Y - (by << a.shift), fz = Z - (bz << a.shift);
-              if (gv != 0.0f) atomicAdd(&acc[((fx * E + fy) * E + fz) * C + c_diff], gv);
-            }
-          }
-        }
-      } else if (lane_spec_active) {
-        for (int slot = 0; slot < count; ++slot) {
-          const uint32_t* en = my_entry + slot * ES;
-          const uint32_t pk = en[0];
-          const int l0x = (int)(pk & 0xffu), l0y = (int)((pk >> 8) & 0xffu), l0z = (int)((pk >> 16) & 0xffu);
-          // this lane's share of the record's gradient, before the corner weight
-          const float gsel = __uint_as_float(en[(colour_spec == 3) ? 7 : 8 + colour_spec]);
-          const float gbase = (colour_spec == 3) ? gsel : gsel * __uint_as_float(en[12 + k_spec]);
-          if (gbase == 0.0f) continue;
+      row[2 * part] = addr;
+      row[2 * part + 1] = __float_as_uint(wc);
+      if (part == 0) row[ROW - 2] = cell;
 #pragma unroll
-          for (int pass_i = 0; pass_i < NPASS; ++pass_i) {
-            const int q = (pass_i * UPI + unit_spec) & 7;
-            const int dx = (q >> 2) & 1, dy = (q >> 1) & 1, dz = q & 1;
-            const int X = ox0 + l0x + dx, Y = oy0 + l0y + dy, Z = oz0 + l0z + dz;
-            if (X >= 0 && X < g.X && Y >= 0 && Y < g.Y && Z >= 0 && Z < g.Z) {
-              const float wc = (__uint_as_float(en[1 + dx]) * __uint_as_float(en[3 + dy])) * __uint_as_float(en[5 + dz]);
-              float gv;
-              if (colour_spec == 3) {
-                gv = (wc * gbase) * g.rho;
-                if (g.mode == RF_DENSITY_ABS) {
-                  const float dv = g.dens[(((long long)X * g.Y + Y) * g.Z + Z) * g.dstride] * g.rho;
-                  gv = (dv > 0.f) ? gv : ((dv < 0.f) ? -gv : 0.0f);
-                }
-              } else {
-                gv = wc * gbase;
-              }
-              const int fx = X - (bx << a.shift), fy = Y - (by << a.shift), fz = Z - (bz << a.shift);
-              if (gv != 0.0f) atomicAdd(&acc[((fx * E + fy) * E + fz) * C + c_spec], gv);
-            }
-          }
-        }
-      }
-      wave_lds_fence();
+      for (int i = 0; i < CP; ++i) row[16 + part * CP + i] = __float_as_uint(gval[i]);
     }
+    __syncthreads();
   }
-  __syncthreads();
 
-  // ---- flush the footprint: float32 atomics, but ONE per (node, channel) of the brick instead of one per sample, and
-  // laid out so that a wave covers long contiguous runs (a z-column of E nodes is contiguous in both tensors)
-  (void)ey;
-  (void)ez;
+  // ---- write the brick out: plain stores (exclusive owner), contiguous runs along z
   const bool split = g.layout == RF_LAYOUT_SPLIT;
-  const int X0 = bx << a.shift, Y0 = by << a.shift, Z0 = bz << a.shift;
-  for (int i = threadIdx.x; i < nodes * C; i += kBrickThreads) {
-    // enumerate (column, tensor part, z, channel-in-part) so that consecutive threads hit consecutive addresses
-    int col, fz, c;
-    const int n_first = split ? 4 : 1;  // channels of a node that live in the densities/base tensor
-    const int per_col_first = E * n_first, per_col = E * C;
-    col = i / per_col;
-    const int rem = i - col * per_col;
-    if (rem < per_col_first) {
-      fz = rem / n_first;
-      c = rem - fz * n_first;
-    } else {
-      const int r2 = rem - per_col_first;
-      fz = r2 / (C - n_first);
-      c = n_first + (r2 - fz * (C - n_first));
-    }
-    const int fx = col / E, fy = col - fx * E;
-    const int X = X0 + fx, Y = Y0 + fy, Z = Z0 + fz;
-    if (X >= g.X || Y >= g.Y || Z >= g.Z) continue;
-    // LDS channel order is the split order; map it to the tensor
-    int lds_c = c;
-    float* dst;
-    const long long lin = ((long long)X * g.Y + Y) * g.Z + Z;
-    if (split) {
-      dst = (c < 4) ? gdens + lin * g.dstride + c : gfeat + lin * g.fstride + (c - 4);
-    } else {
-      // reference layout: part 0 = density (lds channel 0); part 1 = features in tensor order f = colour*K + k
-      if (c == 0) {
-        dst = gdens + lin * g.dstride;
+  const int n_first = split ? 4 : 1;  // channels of a node that live in the densities/base tensor
+  const int n_second = C - n_first;
+  for (int pass = 0; pass < 2 && !(a.debug & 4); ++pass) {
+    const int nch = pass == 0 ? n_first : n_second;
+    if (nch == 0) continue;
+    const int run = B * nch;  // floats of one z column in this tensor
+    float* out = pass == 0 ? gdens : gfeat;
+    const long long ostride = pass == 0 ? g.dstride : g.fstride;
+    for (int i = tid; i < B * B * run; i += kBrickThreads) {
+      const int col = i / run, r = i - col * run;
+      const int fz = r / nch, c2 = r - fz * nch;
+      const int fx = col >> a.shift, fy = col & (B - 1);
+      const int X = X0 + fx, Y = Y0 + fy, Z = Z0 + fz;
+      if (X >= g.X || Y >= g.Y || Z >= g.Z) continue;
+      int lds_c;
+      if (split) {
+        lds_c = pass * 4 + c2;
+      } else if (pass == 0) {
+        lds_c = 0;
       } else {
-        const int f = c - 1, colour = f / K, kk = f - colour * K;
-        lds_c = (kk == 0) ? 1 + colour : 4 + colour * (K - 1) + (kk - 1);
-        dst = gfeat + lin * g.fstride + f;
+        const int col3 = c2 / K, kk = c2 - col3 * K;  // reference order colour * K + k
+        lds_c = (kk == 0) ? 1 + col3 : 4 + col3 * (K - 1) + (kk - 1);
       }
+      const long long lin = ((long long)X * g.Y + Y) * g.Z + Z;
+      float v = total > 0 ? acc[fx * SX + fy * SY + fz * C + lds_c] : 0.0f;
+      if (lds_c == 0 && g.mode == RF_DENSITY_ABS) {  // d|x|/dx of the raw density, applied once per node
+        const float dv = g.dens[lin * g.dstride] * g.rho;
+        v = (dv > 0.f) ? v : ((dv < 0.f) ? -v : 0.0f);
+      }
+      float* dst = out + lin * ostride + c2;
+      *dst = a.accumulate ? (*dst + v) : v;
     }
-    const float v = acc[((fx * E + fy) * E + fz) * C + lds_c];
-    if (v != 0.0f) unsafeAtomicAdd(dst, v);
   }
 }
 
@@ -1892,7 +2016,7 @@ static int brick_geometry(const RFGrid* grid, int brick_size, int* shift, int nb
     nb[a] = (grid->dims[a] + brick_size - 1) / brick_size;
     total *= nb[a];
   }
-  return (total < 0x7fff) ? RF_OK : RF_ERR_UNSUPPORTED;  // brick ids are 16-bit sort keys
+  return (total * 8 - 1 <= 0x7fff) ? RF_OK : RF_ERR_UNSUPPORTED;  // (brick, flags) must fit a positive 16-bit sort key
 }
 
 int rf_render_backward_emit(const RFGrid* grid, const RFRayBatch* rays, uint32_t flags, const RFRenderOut* fwd,
@@ -1913,14 +2037,14 @@ int rf_render_backward_emit(const RFGrid* grid, const RFRayBatch* rays, uint32_t
   return backward_impl(grid, rays, flags, fwd, grads, gr, stream);
 }
 
-int rf_gather_records(const float* records_dev, const int64_t* perm_dev, const int64_t* count_dev, int64_t capacity,
+int rf_gather_records(const float* records_dev, const int64_t* perm_dev, const int64_t* begin_dev, int64_t capacity,
                       float* records_sorted_dev, void* stream) {
   if (capacity == 0) return RF_OK;
-  if (!records_dev || !perm_dev || !count_dev || !records_sorted_dev) return RF_ERR_NULL_POINTER;
+  if (!records_dev || !perm_dev || !begin_dev || !records_sorted_dev) return RF_ERR_NULL_POINTER;
   if (capacity < 0) return RF_ERR_BAD_SHAPE;
   hipLaunchKernelGGL(gather_records_kernel, dim3(grid_1d(capacity, 256, 256LL * 8)), dim3(256), 0, (hipStream_t)stream,
                      reinterpret_cast<const float4*>(records_dev), reinterpret_cast<const long long*>(perm_dev),
-                     reinterpret_cast<const long long*>(count_dev), (long long)capacity,
+                     reinterpret_cast<const long long*>(begin_dev), (long long)capacity,
                      reinterpret_cast<float4*>(records_sorted_dev));
   return launch_status();
 }
@@ -1929,15 +2053,15 @@ extern "C++" {
 template <int K>
 static int launch_brick(const GridArgs& g, const BrickArgs& a, int nbricks, float* gd, float* gf, hipStream_t st) {
   const int B = 1 << a.shift;
-  const size_t lds = (size_t)(B + 1) * (B + 1) * (B + 1) * (3 * K + 1) * sizeof(float) + (size_t)(kBrickThreads / kWave) * kWave * (12 + K) * sizeof(uint32_t);
-  static bool configured = false;  // raise the dynamic-LDS limit of this instantiation once
-  if (!configured) {
+  const size_t lds = (size_t)brick_acc_words(B, 3 * K + 1) * sizeof(float);
+  if (lds > 150 * 1024) return RF_ERR_UNSUPPORTED;  // 160 KB per CU minus the kernel's static staging buffers
+  static size_t configured = 0;  // raise the dynamic-LDS limit of this instantiation when a larger one is needed
+  if (lds > configured) {
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(&brick_accumulate_kernel<K>),
-                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
+                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
       return RF_ERR_LAUNCH;
-    configured = true;
+    configured = lds;
   }
-  if (lds > 160 * 1024) return RF_ERR_UNSUPPORTED;
   hipLaunchKernelGGL((brick_accumulate_kernel<K>), dim3(nbricks), dim3(kBrickThreads), lds, st, g, a, gd, gf);
   return launch_status();
 }
@@ -1951,7 +2075,7 @@ int rf_brick_accumulate(const RFGrid* grid, int32_t brick_size, const RFBrickLis
   if (!lists || !grad_densities_dev) return RF_ERR_NULL_POINTER;
   if (!grad_features_dev && !(grid->layout == RF_LAYOUT_SPLIT && grid->num_features == 3)) return RF_ERR_NULL_POINTER;
   if (num_lists < 1 || num_lists > 2) return RF_ERR_BAD_SHAPE;
-  if (!accumulate) return RF_ERR_UNSUPPORTED;  // the footprints of neighbouring bricks overlap: results are added
+  if (grid->num_features > 27) return RF_ERR_UNSUPPORTED;  // 3 rest waves cover 24 channels (SH degree <= 2)
   int shift, nb[3];
   rc = brick_geometry(grid, brick_size, &shift, nb);
   if (rc != RF_OK) return rc;
@@ -1965,6 +2089,7 @@ int rf_brick_accumulate(const RFGrid* grid, int32_t brick_size, const RFBrickLis
     a.lists[i].diffuse = lists[i].render_diffuse || grid->num_features == 3;
   }
   a.ray_basis = ray_basis_dev;
+  { const char* e = getenv("RF_BRICK_DEBUG"); a.debug = e ? atoi(e) : 0; }
   a.shift = shift;
   a.nbx = nb[0];
   a.nby = nb[1];

@@ -200,16 +200,18 @@ def render_backward_emit_raw(grid: VoxelGrid, origins: Tensor, directions: Tenso
     _lib.check(rc, "rf_render_backward_emit")
 
 
-def sort_records_by_brick(keys: Tensor, records: Tensor, records_sorted: Tensor, num_bricks: int, boundaries: Tensor) -> Tensor:
-    """Sort the dense key array (16-bit radix sort), gather the records of keyed samples into brick order and
-    return offsets [num_bricks + 1] (int64) of each brick inside ``records_sorted``."""
+def sort_records_by_brick(keys: Tensor, records: Tensor, records_sorted: Tensor, offsets: Tensor, boundaries: Tensor) -> Tensor:
+    """Sort the dense key array (16-bit radix sort; key = brick * 8 + boundary flags, -1 = slot without gradient) and
+    gather the records of keyed samples into that order.  ``offsets`` [8 * num_bricks + 1] (int64, last element
+    preset to keys.numel()) receives the start of every (brick, flags) class inside ``records_sorted``; positions are
+    absolute, the unkeyed slots occupy [0, offsets[0])."""
     lib = _lib.load()
     dev = keys.device
     with _span("sort_keys", dev):
         sorted_keys, perm = torch.sort(keys)
-        offsets = torch.searchsorted(sorted_keys, boundaries)
+        torch.searchsorted(sorted_keys, boundaries, out=offsets[:-1])
     with _span("gather_records", dev):
-        rc = lib.rf_gather_records(records.data_ptr(), perm.data_ptr(), offsets[num_bricks:].data_ptr(), keys.numel(), records_sorted.data_ptr(), _stream(dev))
+        rc = lib.rf_gather_records(records.data_ptr(), perm.data_ptr(), offsets.data_ptr(), keys.numel(), records_sorted.data_ptr(), _stream(dev))
     _lib.check(rc, "rf_gather_records")
     return offsets
 

@@ -220,15 +220,14 @@ class TrainStepper:
         binned = self.backward == "binned"
         if binned:
             bins = self._bin_buffers(n, S, origins.device)
-        if not self._grad_clean:
+        if not self._grad_clean and not binned:  # the binned pass overwrites the whole bucket
             self.flat.zero_grad()
         gd, gf = self.flat.views_for_accumulation()
         sums = torch.zeros(4, dtype=torch.float32, device=origins.device)
-        lists = []
         # data parallel: with split storage the diffuse pass only touches `base`, so the all-reduce of the `rest`
         # gradients (201 of the 235 MB at degree 2) starts right after the specular backward and overlaps it
         overlap = (
-            self.data_parallel and rfdist.world_size() > 1 and self.diffuse and not binned
+            self.data_parallel and rfdist.world_size() > 1 and self.diffuse
             and grid.storage == "split" and gf is not None
         )
         pending = []
@@ -239,20 +238,20 @@ class TrainStepper:
             flags = render_flags(cfg.white_bkgd, diffuse, cfg.optimized_sampling, cfg.use_occupancy_mask)
             colour, _, _, _, caches = render_forward_raw(grid, origins, directions, t_rand, S, near, far, flags, save=True)
             g_colour = l1_loss_grad_hip(colour, pixels, sums[2 * i : 2 * i + 2])
-            if binned:
+            if binned and not diffuse:
+                # specular pass (28 channels per node): records -> 16-bit sort -> exclusive node bricks, plain stores that
+                # overwrite the whole bucket (no zero-fill).  The diffuse pass (4 channels = one 16-byte sector per
+                # corner) is cheaper through the atomic scatter than through the sort, and adds on top.
                 render_backward_emit_raw(
                     grid, origins, directions, t_rand, S, near, far, flags, caches, g_colour, None, None, self.brick_size,
-                    bins["keys"][i], bins["records"][i], None if diffuse else bins["ray_basis"],
+                    bins["keys"], bins["records"], bins["ray_basis"],
                 )
-                offsets = sort_records_by_brick(bins["keys"][i], bins["records"][i], bins["sorted"][i], bins["num_bricks"], bins["boundaries"])
-                lists.append((bins["sorted"][i], offsets, diffuse))
+                offsets = sort_records_by_brick(bins["keys"], bins["records"], bins["sorted"], bins["offsets"], bins["boundaries"])
+                brick_accumulate_raw(grid, self.brick_size, [(bins["sorted"], offsets, False)], bins["ray_basis"], gd, gf, accumulate=False)
             else:
                 render_backward_raw(grid, origins, directions, t_rand, S, near, far, flags, caches, g_colour, None, None, gd, gf)
-                if overlap and i == 0:
-                    pending.append(rfdist.all_reduce_mean_async(self.flat.flat_gradient_parts()[1]))
-        if binned:
-            # one pass over the bricks folds both renders into the gradient bucket
-            brick_accumulate_raw(grid, self.brick_size, lists, bins["ray_basis"], gd, gf, accumulate=True)
+            if overlap and i == 0:
+                pending.append(rfdist.all_reduce_mean_async(self.flat.flat_gradient_parts()[1]))
         self._grad_clean = False
         if overlap:
             pending.append(rfdist.all_reduce_mean_async(self.flat.flat_gradient_parts()[0]))
@@ -272,19 +271,19 @@ class TrainStepper:
             grid = self.vol_mod.thre3d_repr
             nb = brick_counts(grid, self.brick_size)
             num_bricks = nb[0] * nb[1] * nb[2]
-            if num_bricks >= 0x7FFF:
-                raise ValueError("backward='binned' needs fewer than 32767 bricks (grid too large for 16-bit brick keys)")
+            if num_bricks > 4096:
+                raise ValueError("backward='binned' needs at most 4096 bricks ((brick, flags) keys are 16-bit sort keys)")
             if grid.sh_degree > 2:
-                raise ValueError("backward='binned' supports SH degree <= 2 (the brick footprint must fit the 160 KB LDS)")
-            passes = 2 if self.diffuse else 1
+                raise ValueError("backward='binned' supports SH degree <= 2 (the brick accumulators must fit the 160 KB LDS)")
             b = {
                 "shape": (n, S),
                 "num_bricks": num_bricks,
-                "keys": [torch.empty(n * S, dtype=torch.int16, device=device) for _ in range(passes)],
-                "records": [torch.empty((n * S, 8), dtype=torch.float32, device=device) for _ in range(passes)],
-                "sorted": [torch.empty((n * S, 8), dtype=torch.float32, device=device) for _ in range(passes)],
+                "keys": torch.empty(n * S, dtype=torch.int16, device=device),
+                "records": torch.empty((n * S, 8), dtype=torch.float32, device=device),
+                "sorted": torch.empty((n * S, 8), dtype=torch.float32, device=device),
                 "ray_basis": torch.zeros((n, 16), dtype=torch.float32, device=device),
-                "boundaries": torch.arange(num_bricks + 1, dtype=torch.int16, device=device),
+                "boundaries": torch.arange(num_bricks * 8, dtype=torch.int16, device=device),
+                "offsets": torch.full((num_bricks * 8 + 1,), n * S, dtype=torch.int64, device=device),
             }
             self._bins = b
         return b
