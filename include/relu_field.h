@@ -173,16 +173,19 @@ int rf_render_backward(const RFGrid* grid, const RFRayBatch* rays, uint32_t flag
  *     upper node on axis a belongs to the next brick; -1 for samples without gradient.  ray_basis_dev [N,16] (may
  *     be NULL for the diffuse pass) receives the signed SH basis of each ray.  At most 4096 bricks (16-bit keys).
  * (2) the caller sorts keys (torch.sort) -> permutation, and offsets [8*nbricks+1] (searchsorted; last = N*S);
- * (3) rf_gather_records: records_sorted[i] = records[perm[i]] for *begin_dev (= offsets[0]) <= i < capacity;
+ * (3) rf_expand_records: for *begin_dev (= offsets[0]) <= i < capacity, records_sorted[i] = the EXPANDED record of slot
+ *     perm[i]: rf_expanded_record_floats(F) floats = (index x, y, z, 0) followed by dL/d(interpolated channel) for
+ *     every channel of a node (density first, then degree-0 r, g, b, then colour-major higher degrees), i.e. the SH
+ *     basis of the record's ray already multiplied in;
  * (4) rf_brick_accumulate: one workgroup per brick OWNS the brick's nodes: it reads exactly the record classes
  *     that touch them (its own brick's and, per flags, up to 7 lower neighbours'), sums them in LDS with plain
  *     read-add-writes (each wavefront owns a disjoint channel group, so nothing races and no LDS atomics are
  *     needed) and writes the brick with plain coalesced stores: accumulate = 0 overwrites EVERY element of the
- *     gradient tensors (no zero-fill needed), accumulate = 1 adds.  Up to two record lists (the specular and the
- *     diffuse render of a training iteration) are folded in one pass.  SH degree <= 2.  The sum order is fixed by
- *     the (stable) sort: results are run-to-run deterministic, unlike the atomic scatter. */
+ *     gradient tensors (no zero-fill needed), accumulate = 1 adds.  Up to two record lists (specular lists first)
+ *     are folded in one pass.  SH degree <= 2.  The sum order is fixed by the (stable) sort: results are run-to-run
+ *     deterministic, unlike the atomic scatter. */
 typedef struct RFBrickList {
-  const float* records_sorted_dev; /* [count, 8]                                    */
+  const float* records_sorted_dev; /* [capacity, rf_expanded_record_floats(F)]      */
   const int64_t* offsets_dev;      /* [8 * nbricks + 1] start of each (brick, flags) class */
   int32_t render_diffuse;          /* records come from a render_diffuse pass       */
 } RFBrickList;
@@ -190,11 +193,12 @@ typedef struct RFBrickList {
 int rf_render_backward_emit(const RFGrid* grid, const RFRayBatch* rays, uint32_t flags, const RFRenderOut* fwd,
                             const RFRenderGrads* grads, int32_t brick_size, int16_t* keys_dev, float* records_dev,
                             float* ray_basis_dev, void* stream);
-int rf_gather_records(const float* records_dev, const int64_t* perm_dev, const int64_t* begin_dev, int64_t capacity,
-                      float* records_sorted_dev, void* stream);
+int rf_expand_records(const RFGrid* grid, const float* records_dev, const int64_t* perm_dev, const int64_t* begin_dev,
+                      int64_t capacity, const float* ray_basis_dev, int32_t render_diffuse, float* records_sorted_dev,
+                      void* stream);
+int32_t rf_expanded_record_floats(int32_t num_features);
 int rf_brick_accumulate(const RFGrid* grid, int32_t brick_size, const RFBrickList* lists, int32_t num_lists,
-                        const float* ray_basis_dev, float* grad_densities_dev, float* grad_features_dev,
-                        int32_t accumulate, void* stream);
+                        float* grad_densities_dev, float* grad_features_dev, int32_t accumulate, void* stream);
 
 /* VoxelGrid.forward (thre3d_reprs/voxels.py:276-331) as a standalone point query: points_dev [M,3] (any
  * points: zeros padding outside the grid, no AABB mask) -> out_dev [M, F+1] = (F interpolated features in the

@@ -397,15 +397,16 @@ def _binned_gradients(grid, rays, cfg, target, device, diffuse_too=True, accumul
         g_colour = O.l1_loss_grad_hip(colour, target, sums[2 * i : 2 * i + 2])
         keys = torch.empty(n * S, dtype=torch.int16, device=device)
         rec = torch.empty((n * S, 8), device=device)
-        srt = torch.empty((n * S, 8), device=device)
+        srt = torch.empty((n * S, O.expanded_record_floats(grid)), device=device)
         O.render_backward_emit_raw(grid, o, d, None, S, near, far, flags, caches, g_colour, None, None, 8, keys, rec, None if diffuse else ray_basis)
         offsets = torch.full((num_bricks * 8 + 1,), n * S, dtype=torch.int64, device=device)
-        O.sort_records_by_brick(keys, rec, srt, offsets, boundaries)
+        is_diffuse = diffuse or cfg.render_diffuse
+        O.sort_records_by_brick(grid, keys, rec, None if is_diffuse else ray_basis, is_diffuse, srt, offsets, boundaries)
         lists.append((srt, offsets, diffuse or cfg.render_diffuse))
         keep.append((keys, rec, caches))
-    O.brick_accumulate_raw(grid, 8, lists, ray_basis, gd, gf, accumulate=accumulate)
+    O.brick_accumulate_raw(grid, 8, lists, gd, gf, accumulate=accumulate)
     if accumulate:  # adding the same lists once more doubles the result
-        O.brick_accumulate_raw(grid, 8, lists, ray_basis, gd, gf, accumulate=True)
+        O.brick_accumulate_raw(grid, 8, lists, gd, gf, accumulate=True)
         gd.mul_(0.5)
         if gf is not None:
             gf.mul_(0.5)

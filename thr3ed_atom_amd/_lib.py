@@ -33,7 +33,8 @@ EXPORTED_SYMBOLS = [
     "rf_render_forward",
     "rf_render_backward",
     "rf_render_backward_emit",
-    "rf_gather_records",
+    "rf_expand_records",
+    "rf_expanded_record_floats",
     "rf_brick_accumulate",
     "rf_grid_query",
     "rf_grid_query_backward",
@@ -156,8 +157,10 @@ def load() -> C.CDLL:
     lib.rf_render_backward_emit.argtypes = [
         C.POINTER(RFGrid), C.POINTER(RFRayBatch), u32, C.POINTER(RFRenderOut), C.POINTER(RFRenderGrads), i32, vp, vp, vp, vp,
     ]
-    lib.rf_gather_records.argtypes = [vp, vp, vp, i64, vp, vp]
-    lib.rf_brick_accumulate.argtypes = [C.POINTER(RFGrid), i32, C.POINTER(RFBrickList), i32, vp, vp, vp, i32, vp]
+    lib.rf_expand_records.argtypes = [C.POINTER(RFGrid), vp, vp, vp, i64, vp, i32, vp, vp]
+    lib.rf_expanded_record_floats.argtypes = [i32]
+    lib.rf_expanded_record_floats.restype = i32
+    lib.rf_brick_accumulate.argtypes = [C.POINTER(RFGrid), i32, C.POINTER(RFBrickList), i32, vp, vp, i32, vp]
     lib.rf_grid_query.argtypes = [C.POINTER(RFGrid), vp, i64, vp, vp]
     lib.rf_grid_query_backward.argtypes = [C.POINTER(RFGrid), vp, i64, vp, vp, vp, vp]
     lib.rf_build_occupancy.argtypes = [C.POINTER(RFGrid), f32, vp, vp]

@@ -1019,33 +1019,18 @@ __global__ __launch_bounds__(kBlock) void render_backward_kernel(GridArgs g, Ray
 // (tests) but 1.8x SLOWER than the direct atomic scatter, which therefore stays the default; kept as the starting
 // point for a non-atomic (channel-owned read-modify-write) variant.
 // =============================================================================================
-__global__ void gather_records_kernel(const float4* __restrict__ rec, const long long* __restrict__ perm,
-                                      const long long* __restrict__ begin_ptr, long long capacity,
-                                      float4* __restrict__ out) {
-  // sorted position p holds a real record for p >= *begin (the slots without gradient sort in front)
-  const long long begin = *begin_ptr;
-  for (long long i = begin + (long long)blockIdx.x * blockDim.x + threadIdx.x; i < capacity;
-       i += (long long)gridDim.x * blockDim.x) {
-    const long long src = perm[i];
-    out[2 * i] = rec[2 * src];
-    out[2 * i + 1] = rec[2 * src + 1];
-  }
-}
-
 struct BrickList {
-  const float4* rec;         // sorted records
-  const long long* offsets;  // [nbricks + 1]
+  const float4* rec;         // sorted, expanded records: record_quads(K) float4 each
+  const long long* offsets;  // [8 * nbricks + 1]
   int diffuse;
 };
 
 struct BrickArgs {
   BrickList lists[2];
   int nlists;
-  const float* ray_basis;  // [N, 16]
   int shift;               // log2(B)
   int nbx, nby, nbz;
   int accumulate;          // 0: grad = brick sum (no zero-fill needed), 1: grad += brick sum
-  int debug;
 };
 
 // LDS channel order of a node ("split order"): 0 = density, 1..3 = degree-0 R,G,B, 4 + r = rest channel r
@@ -1059,23 +1044,69 @@ __device__ __forceinline__ void lds_channel_meaning(int c, int& colour, int& bas
     basis_k = 0;
   } else {
     const int rr = c - 4;
-    colour = (K > 1) ? rr / (K - 1) : 0;
-    basis_k = (K > 1) ? rr % (K - 1) + 1 : 0;
+    constexpr int KR = K > 1 ? K - 1 : 1;
+    colour = (K > 1) ? rr / KR : 0;
+    basis_k = (K > 1) ? rr % KR + 1 : 0;
+  }
+}
+
+// float4s of an expanded record: (index x, y, z, -) followed by the per-channel values in LDS channel order
+__host__ __device__ constexpr int record_quads(int K) { return 1 + (3 * K + 1 + 3) / 4; }
+
+// Sorted position p (>= *begin: the slots without gradient sort in front) receives the EXPANDED record of slot
+// perm[p]: its continuous index and, for every channel of a node, dL/d(interpolated channel) = dL/draw colour * SH basis
+// of the record's ray (channel 0: dL/dpre * rho).  Everything the brick pass needs per record that does not depend on
+// the corner, computed once here (4 lanes per float4 of output; coalesced 16-byte stores).
+template <int K>
+__global__ void expand_records_kernel(const float4* __restrict__ rec, const long long* __restrict__ perm,
+                                      const long long* __restrict__ begin_ptr, long long capacity,
+                                      const float* __restrict__ ray_basis, int diffuse, float rho,
+                                      float4* __restrict__ out) {
+  constexpr int C = 3 * K + 1;
+  constexpr int Q = record_quads(K);
+  const long long begin = *begin_ptr;
+  const long long items = (capacity - begin) * Q;
+  for (long long it = (long long)blockIdx.x * blockDim.x + threadIdx.x; it < items; it += (long long)gridDim.x * blockDim.x) {
+    const long long i = begin + it / Q;
+    const int part = (int)(it % Q);
+    const long long src = perm[i];
+    const float4 r0 = rec[2 * src];
+    float4 o;
+    if (part == 0) {
+      o = make_float4(r0.x, r0.y, r0.z, 0.0f);
+    } else {
+      const float4 r1 = rec[2 * src + 1];
+      const float graw[4] = {r1.x, r1.y, r1.z, r0.w * rho};  // colour 3 = density
+      const float* yb = ray_basis + (long long)__float_as_int(r1.w) * 16;
+      float v[4];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int ch = 4 * (part - 1) + e;
+        int colour, basis_k;
+        lds_channel_meaning<K>(ch < C ? ch : 0, colour, basis_k);
+        float gv = graw[colour];
+        if (ch > 0) gv = gv * ((diffuse || basis_k == 0) ? kC0 : yb[basis_k]);
+        if (ch >= C || (diffuse && ch >= 4)) gv = 0.0f;
+        v[e] = gv;
+      }
+      o = make_float4(v[0], v[1], v[2], v[3]);
+    }
+    out[i * Q + part] = o;
   }
 }
 
 // One workgroup (4 waves) per NODE brick: it owns B^3 nodes exclusively, so the result is written with plain stores.
-// Race-free accumulation without LDS atomics (tools/lds_microbench*.hip: ds_add_f32 retires 0.33 lane/clk/CU, plain
-// read-add-write is issue-bound): each wave owns a disjoint CHANNEL group and walks ALL records that touch the brick --
+// Race-free accumulation without LDS atomics (tools/lds_microbench*.hip: ds_add_f32 retires 0.33 lane/clk/CU, a plain
+// read-add-write chain is bound by the 65-cycle LDS latency): each wave owns a disjoint CHANNEL group and walks ALL
+// records that touch the brick --
 //   wave 0: the base channels (density, degree-0 r, g, b): 8 corners x 4 channels = 32 lanes, two records per step;
-//           it is also the only wave with work on diffuse records;
-//   wave w>0: rest channels [8(w-1), 8w): 8 corners x 8 channels = 64 lanes (degree 2: three such waves).
+//   wave w>0: rest channels [8(w-1), 8w): 2 x (8 corners x 4 channels) = 64 lanes (degree 2: three such waves).
 // Records are sorted by key = cell-brick * 8 + flags, so the records of a source brick that reach into this brick
 // (flags superset of the offset) are a handful of contiguous ranges: no record is read that does not contribute.
-// The kernel is instruction-issue bound, so everything per record that does not depend on the lane's channel is
-// computed ONCE, by 8 threads per record, into a small LDS table (corner address + corner weight, per-channel
-// dL/draw * basis); the accumulation loop is then 2 table reads, 1 multiply and the read-add-write.  Tables are
-// double buffered and the global loads of the next batch are in flight during the accumulation of the current one.
+// Per batch of 32 records, 8 threads per record build a table row (corner address + weight per corner, the record's
+// per-channel values, its packed cell); the accumulation loop is then 2 table reads, 1 multiply and the
+// read-add-write.  Tables are double buffered; the global loads of batch b + 1 are issued before the accumulation of
+// batch b and consumed after it.
 constexpr int kBrickThreads = 256;
 constexpr int kBrickBatch = 32;   // records per table (8 staging threads per record)
 constexpr int kMaxRanges = 28;    // 14 (source brick, flag run) ranges per list, two lists
@@ -1086,10 +1117,6 @@ __host__ __device__ inline int brick_slab_stride(int B, int C) {
   return B * sy + ((16 - (B * sy) % 32) + 32) % 32;
 }
 __host__ __device__ inline int brick_acc_words(int B, int C) { return B * brick_slab_stride(B, C) + 64; }  // + trash row
-
-// (offset to the source brick, first flag class, last flag class): classes f with (f & o) == o, merged into runs
-__constant__ unsigned char kBrickRuns[14][3] = {{0, 0, 7}, {1, 1, 1}, {1, 3, 3}, {1, 5, 5}, {1, 7, 7}, {2, 2, 3}, {2, 6, 7},
-                                                {3, 3, 3}, {3, 7, 7}, {4, 4, 7}, {5, 5, 5}, {5, 7, 7}, {6, 6, 7}, {7, 7, 7}};
 
 // packed lower nodes (one byte per axis): do the two cells have a node in common?
 __device__ __forceinline__ bool cells_share_nodes(uint32_t ca, uint32_t cb) {
@@ -1102,19 +1129,22 @@ template <int K>
 __global__ __launch_bounds__(kBrickThreads) void brick_accumulate_kernel(GridArgs g, BrickArgs a, float* gdens,
                                                                          float* gfeat) {
   constexpr int C = 3 * K + 1;
+  constexpr int C4 = (C + 3) / 4 * 4;
+  constexpr int Q = record_quads(K);
+  static_assert(Q <= 8 || K == 16, "8 staging threads per record");
   constexpr int NREST = C - 4;                 // channels beyond the base record
   constexpr int REST_WAVES = (NREST + 7) / 8;  // waves needed for them (3 at degree 2)
-  constexpr int CP = (C + 7) / 8;              // channels each of the 8 staging threads of a record prepares
-  constexpr int ROW = 16 + 8 * CP + 2;         // table row: 8 x (corner address, corner weight), 8 * CP channel values, packed cell (+ pad: rows stay 8-byte aligned)
+  constexpr int CELL = 16 + C4;                // table row: 8 x (corner address, corner weight), C4 channel values, cell
+  constexpr int ROW = (CELL + 1 + 3) / 4 * 4;  // rows stay 16-byte aligned
   extern __shared__ __attribute__((aligned(16))) float acc[];  // node (x, y, z), channel c at x * SX + y * SY + z * C + c
   __shared__ __attribute__((aligned(16))) uint32_t table[2][(kBrickBatch + 1) * ROW];  // separate object: never aliases acc; + 1 spare row (prefetch)
   __shared__ long long s_rstart[kMaxRanges];
-  __shared__ int s_rcount[kMaxRanges];
+  __shared__ int s_rlist[kMaxRanges];
   __shared__ int s_rcum[kMaxRanges + 1];  // cumulative record counts of the non-empty ranges
-  __shared__ int s_nranges, s_nspec;
+  __shared__ int s_nspec;
   const int B = 1 << a.shift;
-  // row pads chosen so that the 8 corners of a cell start 4 banks apart: a 64-lane (8 corners x 8 channels) access
-  // then hits every LDS bank exactly twice
+  // row pads chosen so that the 8 corners of a cell start 4 banks apart: the ds_read/ds_write of a 32-lane group
+  // (8 corners x 4 channels) is conflict free
   const int SY = brick_row_stride(B, C), SX = brick_slab_stride(B, C);
   const int TRASH = B * SX;  // contributions to nodes this brick does not own land here and are never written out
   const int acc_words = TRASH + 64;
@@ -1126,108 +1156,91 @@ __global__ __launch_bounds__(kBrickThreads) void brick_accumulate_kernel(GridArg
   const int bz = brick % a.nbz, by = (brick / a.nbz) % a.nby, bx = brick / (a.nbz * a.nby);
   const int X0 = bx << a.shift, Y0 = by << a.shift, Z0 = bz << a.shift;
 
-  // ---- which sorted ranges reach into this brick: 14 per list, fetched in parallel, compacted by one thread
-  if (tid < 14 * a.nlists) {
-    const int li = tid / 14, e = tid - li * 14;
-    const int o = kBrickRuns[e][0];
+  // ---- which sorted ranges reach into this brick: 14 (offset to the source brick o, run of flag classes f with
+  // (f & o) == o) per list, fetched by 14 lanes each and compacted with a wave scan
+  if (wave == 0) {
+    const int li = lane / 14, e = lane - li * 14;
+    const bool in_use = lane < 14 * a.nlists;
+    // nibble tables over e: source offset, first and last flag class of the run
+    const int o = (int)((0x76554332211110ull >> (4 * e)) & 7), f0 = (int)((0x76754736275310ull >> (4 * e)) & 7),
+              f1 = (int)((0x77757737375317ull >> (4 * e)) & 7);
     const int sx = bx - (o & 1), sy = by - ((o >> 1) & 1), sz = bz - (o >> 2);
-    long long rs = 0, re = 0;
-    if (sx >= 0 && sy >= 0 && sz >= 0) {
-      const long long key0 = (long long)((sx * a.nby + sy) * a.nbz + sz) << 3;
-      rs = a.lists[li].offsets[key0 + kBrickRuns[e][1]];
-      re = a.lists[li].offsets[key0 + kBrickRuns[e][2] + 1];
+    long long rs = 0;
+    int cnt = 0;
+    if (in_use && sx >= 0 && sy >= 0 && sz >= 0) {
+      const long long* off = (li ? a.lists[1].offsets : a.lists[0].offsets) + ((long long)((sx * a.nby + sy) * a.nbz + sz) << 3);
+      rs = off[f0];
+      cnt = (int)(off[f1 + 1] - rs);
     }
-    s_rstart[tid] = rs;
-    s_rcount[tid] = (int)(re - rs);
+    const unsigned long long nonempty = __ballot(cnt > 0);
+    int cum = cnt;  // inclusive prefix sum over the lanes
+#pragma unroll
+    for (int d = 1; d < 32; d <<= 1) {
+      const int up = __shfl_up(cum, d);
+      if (lane >= d) cum += up;
+    }
+    const int slot = __popcll(nonempty & ((1ull << lane) - 1ull));
+    if (cnt > 0) {
+      s_rstart[slot] = rs;
+      s_rlist[slot] = li;
+      s_rcum[slot + 1] = cum;
+    }
+    if (lane == 0) s_rcum[0] = 0;
+    // records of specular lists (they come first) are the only ones with rest channels
+    const int spec = (in_use && !(li ? a.lists[1].diffuse : a.lists[0].diffuse)) ? cnt : 0;
+    int spec_sum = spec;
+#pragma unroll
+    for (int d = 1; d < 32; d <<= 1) spec_sum += __shfl_xor(spec_sum, d);
+    if (lane == 0) s_nspec = spec_sum;
+    if (lane == 31) s_rcum[kMaxRanges] = cum;  // total (lanes >= 28 carry cnt = 0)
   }
   __syncthreads();
-  if (tid == 0) {
-    int n = 0, cum = 0, nspec = 0;
-    s_rcum[0] = 0;
-    for (int i = 0; i < 14 * a.nlists; ++i) {
-      const int cnt = s_rcount[i];
-      if (cnt > 0) {
-        s_rstart[n] = s_rstart[i];  // n <= i: compaction in place
-        s_rcount[n] = i / 14;       // from now on: the list the range belongs to
-        cum += cnt;
-        s_rcum[++n] = cum;
-        if (!a.lists[i / 14].diffuse) nspec = cum;  // specular lists come first
-      }
-    }
-    s_nranges = n;
-    s_nspec = nspec;
-  }
-  __syncthreads();
-  const int nranges = s_nranges;
-  const int total = s_rcum[nranges];
+  const int total = s_rcum[kMaxRanges];
   const int nspec_total = s_nspec;
   if (total == 0 && a.accumulate) return;  // nothing reaches this brick
-  if (total > 0)
-    for (int i = tid; i < acc_words; i += kBrickThreads) acc[i] = 0.0f;
+  if (total > 0) {
+    float4* acc4 = reinterpret_cast<float4*>(acc);
+    for (int i = tid; i < acc_words / 4; i += kBrickThreads) acc4[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+  }
 
-  // ---- staging role: 8 threads per record; thread `part` prepares corner `part` and channels [part * CP, part * CP + CP)
+  // ---- staging role: 8 threads per record; thread `part` prepares corner `part` and copies float4 `part` of the record
   const int sj = tid >> 3, part = tid & 7;
   const int pdx = (part >> 2) & 1, pdy = (part >> 1) & 1, pdz = part & 1;
   int sri = 0;  // running range index of this thread's records (they advance monotonically)
-  // ---- accumulation role
-  // wave 0: lane = half(record A/B) x corner(8) x channel(4);  waves 1..: lane = corner(8) x channel(8)
-  // each group of 32 lanes = 8 corners x 4 channels: with the row pads above the 8 corner bases are distinct multiples
-  // of 4 banks, i.e. the ds_read/ds_write of a group is conflict free
+  // ---- accumulation role: each group of 32 lanes = 8 corners x 4 channels
   const int q = (lane >> 2) & 7;
   const int c = (wave == 0) ? (lane & 3) : 4 + (wave - 1) * 8 + (lane & 3) + ((lane >> 5) << 2);
   const bool rest_active = wave >= 1 && wave - 1 < REST_WAVES && c < C;
 
-  float4 r0 = make_float4(0.f, 0.f, 0.f, 0.f), r1 = r0;  // this thread's record of the batch being staged
-  int rinfo = -1;                                          // its list (or -1: no record)
-  auto fetch = [&](int base) {
-    const int v = base + sj;
-    rinfo = -1;
-    if (v < total) {
+  const int nbatches = (total + kBrickBatch - 1) / kBrickBatch;
+  for (int b = -1; b < nbatches; ++b) {
+    // -- (1) issue the loads of batch b + 1: the record's index quad and this thread's quad of channel values
+    float4 ridx = make_float4(0.f, 0.f, 0.f, 0.f), rval = ridx;
+    const int v = (b + 1) * kBrickBatch + sj;
+    const bool have = b + 1 < nbatches && v < total;
+    if (have) {
       while (s_rcum[sri + 1] <= v) ++sri;
       const long long pos = s_rstart[sri] + (v - s_rcum[sri]);
-      rinfo = s_rcount[sri];
-      const float4* rec = a.lists[rinfo].rec + 2 * pos;
-      r0 = rec[0];
-      r1 = rec[1];
+      const float4* rec = (s_rlist[sri] ? a.lists[1].rec : a.lists[0].rec) + pos * Q;
+      ridx = rec[0];
+      if (part >= 1 && part < Q) rval = rec[part];
     }
-  };
-
-  const int nbatches = (total + kBrickBatch - 1) / kBrickBatch;
-  if (nbatches > 0) fetch(0);
-  for (int b = 0; b <= nbatches; ++b) {
-    // -- (1) the SH basis values this thread needs for batch b (dependent on the record fetched one round earlier)
-    float yb[CP];
-    const bool have = b < nbatches && rinfo >= 0;
-    const bool diffuse = have && a.lists[rinfo].diffuse;
-    const float4 c0 = r0, c1 = r1;
-#pragma unroll
-    for (int i = 0; i < CP; ++i) {
-      int colour, basis_k;
-      const int ch = part * CP + i;
-      lds_channel_meaning<K>(ch < C ? ch : 0, colour, basis_k);
-      yb[i] = kC0;
-      if (have && !diffuse && basis_k > 0) yb[i] = a.ray_basis[(long long)__float_as_int(c1.w) * 16 + basis_k];
-    }
-    // -- (2) start fetching the records of batch b + 1
-    if (b + 1 < nbatches) fetch((b + 1) * kBrickBatch);
-    // -- (3) accumulate batch b - 1 from its table
-    if (b > 0 && !(a.debug & 1)) {
+    // -- (2) accumulate batch b from its table
+    if (b >= 0) {
       // records j and j + 16 of a batch (usually samples of different rays) are handled together: when their cells
       // share no node (lower nodes >= 2 apart on some axis) the two read-add-writes are independent and overlap,
       // otherwise they are issued one after the other.  The table entries of step j + 1 are fetched before the
       // read-add-write of step j, so that only the accumulator latency is on the critical path.
-      const uint32_t* tb = table[(b - 1) & 1];
-      const int base = (b - 1) * kBrickBatch;
+      const uint32_t* tb = table[b & 1];
+      const int base = b * kBrickBatch;
       const int nb = min(kBrickBatch, total - base);
       constexpr int H = kBrickBatch / 2;
       uint32_t shared_mask;  // bit j: the cells of records j and j + H have a node in common
       {
         const int l = lane & (H - 1);
-        shared_mask = (uint32_t)__ballot(cells_share_nodes(tb[l * ROW + ROW - 2], tb[(l + H) * ROW + ROW - 2]));
-        if (a.debug & 8) shared_mask = 0;
-        if (a.debug & 16) shared_mask = 0xffffffffu;
+        shared_mask = (uint32_t)__ballot(cells_share_nodes(tb[l * ROW + CELL], tb[(l + H) * ROW + CELL]));
       }
-      if (wave == 0 && !(a.debug & 32)) {
+      if (wave == 0) {
         const int half = lane >> 5;
         const int steps = min(nb, H);  // rows >= nb are padded (zero weight, trash address, far-away cell)
         const uint32_t* row = tb + half * (H * ROW);
@@ -1248,7 +1261,7 @@ __global__ __launch_bounds__(kBrickThreads) void brick_accumulate_kernel(GridArg
           aw = aw_n;
           gv = gv_n;
         }
-      } else if (rest_active && wave > 0 && !(a.debug & 64)) {
+      } else if (rest_active) {
         const int ns = min(max(nspec_total - base, 0), nb);  // diffuse records carry nothing for the rest channels
         const int steps = min(ns, H);
         const uint32_t* rowA = tb;
@@ -1279,17 +1292,14 @@ __global__ __launch_bounds__(kBrickThreads) void brick_accumulate_kernel(GridArg
         }
       }
     }
-    // -- (4) build the table of batch b
-    if (b < nbatches && !(a.debug & 2)) {
-      uint32_t* row = table[b & 1] + sj * ROW;
+    // -- (3) build the table of batch b + 1 from the loads issued in (1)
+    if (b + 1 < nbatches) {
+      uint32_t* row = table[(b + 1) & 1] + sj * ROW;
       uint32_t addr = (uint32_t)TRASH;
       uint32_t cell = 0x00f0f0f0u + (uint32_t)(sj & 7) * 0x00040404u;  // padded rows: far from every real cell
       float wc = 0.0f;
-      float gval[CP];
-#pragma unroll
-      for (int i = 0; i < CP; ++i) gval[i] = 0.0f;
       if (have) {
-        const float idx[3] = {c0.x, c0.y, c0.z};
+        const float idx[3] = {ridx.x, ridx.y, ridx.z};
         const int org[3] = {X0, Y0, Z0};
         const int dim[3] = {g.X, g.Y, g.Z};
         const int dd[3] = {pdx, pdy, pdz};
@@ -1300,7 +1310,7 @@ __global__ __launch_bounds__(kBrickThreads) void brick_accumulate_kernel(GridArg
 #pragma unroll
         for (int ax = 0; ax < 3; ++ax) {
           const float fl = floorf(idx[ax]);
-          cell |= (uint32_t)((int)fl - org[ax] + 1) << (8 * ax);  // lower node relative to the brick: 0..B
+          cell |= (uint32_t)((int)fl - org[ax] + 1) << (8 * ax);       // lower node relative to the brick: 0..B
           w3[ax] = dd[ax] ? (idx[ax] - fl) : ((fl + 1.0f) - idx[ax]);  // same arithmetic as locate()
           n3[ax] = (int)fl - org[ax] + dd[ax];
           owned = owned && n3[ax] >= 0 && n3[ax] < B && org[ax] + n3[ax] < dim[ax];
@@ -1309,32 +1319,47 @@ __global__ __launch_bounds__(kBrickThreads) void brick_accumulate_kernel(GridArg
           addr = (uint32_t)(n3[0] * SX + n3[1] * SY + n3[2] * C);
           wc = (w3[0] * w3[1]) * w3[2];
         }
-        const float graw[4] = {c1.x, c1.y, c1.z, c0.w * g.rho};  // colour 3 = density: dL/dpre * rho
-#pragma unroll
-        for (int i = 0; i < CP; ++i) {
-          int colour, basis_k;
-          const int ch = part * CP + i;
-          lds_channel_meaning<K>(ch < C ? ch : 0, colour, basis_k);
-          float gv = graw[colour];
-          if (ch > 0) gv = gv * yb[i];
-          if (diffuse && ch >= 4) gv = 0.0f;
-          gval[i] = (ch < C) ? gv : 0.0f;
-        }
       }
-      row[2 * part] = addr;
-      row[2 * part + 1] = __float_as_uint(wc);
-      if (part == 0) row[ROW - 2] = cell;
-#pragma unroll
-      for (int i = 0; i < CP; ++i) row[16 + part * CP + i] = __float_as_uint(gval[i]);
+      *reinterpret_cast<uint2*>(row + 2 * part) = make_uint2(addr, __float_as_uint(wc));
+      if (part >= 1 && part < Q) *reinterpret_cast<float4*>(row + 16 + 4 * (part - 1)) = rval;
+      if (part == 0) row[CELL] = cell;
     }
     __syncthreads();
   }
 
   // ---- write the brick out: plain stores (exclusive owner), contiguous runs along z
   const bool split = g.layout == RF_LAYOUT_SPLIT;
+  if (split && (C & 3) == 0 && (g.dstride & 3) == 0 && (g.fstride & 3) == 0 && !a.accumulate) {
+    // split layout, whole float4s: base [X,Y,Z,4] = channels 0..3 of a node, rest [X,Y,Z,C-4] = channels 4..C-1
+    constexpr int QN = C / 4;  // float4s per node
+    constexpr int QR = QN > 1 ? QN - 1 : 1;
+    const int nq = B * B * B * QN;
+    for (int i = tid; i < nq; i += kBrickThreads) {
+      // i -> (column (x, y), quad group, z, quad) with the quads of one tensor contiguous along z
+      const int col = i / (B * QN), r = i - col * (B * QN);
+      const bool first = r < B;  // the B base quads of the column come first
+      const int fz = first ? r : (r - B) / QR;
+      const int qd = first ? 0 : 1 + (r - B) - fz * QR;
+      const int fx = col >> a.shift, fy = col & (B - 1);
+      const int X = X0 + fx, Y = Y0 + fy, Z = Z0 + fz;
+      if (X >= g.X || Y >= g.Y || Z >= g.Z) continue;
+      const long long lin = ((long long)X * g.Y + Y) * g.Z + Z;
+      float4 v = total > 0 ? *reinterpret_cast<const float4*>(&acc[fx * SX + fy * SY + fz * C + 4 * qd]) : make_float4(0.f, 0.f, 0.f, 0.f);
+      if (qd == 0) {
+        if (g.mode == RF_DENSITY_ABS) {  // d|x|/dx of the raw density, applied once per node
+          const float dv = g.dens[lin * g.dstride] * g.rho;
+          v.x = (dv > 0.f) ? v.x : ((dv < 0.f) ? -v.x : 0.0f);
+        }
+        *reinterpret_cast<float4*>(gdens + lin * g.dstride) = v;
+      } else {
+        *reinterpret_cast<float4*>(gfeat + lin * g.fstride + 4 * (qd - 1)) = v;
+      }
+    }
+    return;
+  }
   const int n_first = split ? 4 : 1;  // channels of a node that live in the densities/base tensor
   const int n_second = C - n_first;
-  for (int pass = 0; pass < 2 && !(a.debug & 4); ++pass) {
+  for (int pass = 0; pass < 2; ++pass) {
     const int nch = pass == 0 ? n_first : n_second;
     if (nch == 0) continue;
     const int run = B * nch;  // floats of one z column in this tensor
@@ -2037,17 +2062,41 @@ int rf_render_backward_emit(const RFGrid* grid, const RFRayBatch* rays, uint32_t
   return backward_impl(grid, rays, flags, fwd, grads, gr, stream);
 }
 
-int rf_gather_records(const float* records_dev, const int64_t* perm_dev, const int64_t* begin_dev, int64_t capacity,
-                      float* records_sorted_dev, void* stream) {
+extern "C++" {
+template <int K>
+static int launch_expand(const float* records_dev, const int64_t* perm_dev, const int64_t* begin_dev, int64_t capacity,
+                         const float* ray_basis_dev, int diffuse, float rho, float* out, hipStream_t st) {
+  hipLaunchKernelGGL((expand_records_kernel<K>), dim3(grid_1d(capacity * record_quads(K), 256, 256LL * 16)), dim3(256), 0, st,
+                     reinterpret_cast<const float4*>(records_dev), reinterpret_cast<const long long*>(perm_dev),
+                     reinterpret_cast<const long long*>(begin_dev), (long long)capacity, ray_basis_dev, diffuse, rho,
+                     reinterpret_cast<float4*>(out));
+  return launch_status();
+}
+}  // extern "C++"
+
+int rf_expand_records(const RFGrid* grid, const float* records_dev, const int64_t* perm_dev, const int64_t* begin_dev,
+                      int64_t capacity, const float* ray_basis_dev, int32_t render_diffuse, float* records_sorted_dev,
+                      void* stream) {
+  const int rc = check_grid(grid);
+  if (rc != RF_OK) return rc;
   if (capacity == 0) return RF_OK;
   if (!records_dev || !perm_dev || !begin_dev || !records_sorted_dev) return RF_ERR_NULL_POINTER;
   if (capacity < 0) return RF_ERR_BAD_SHAPE;
-  hipLaunchKernelGGL(gather_records_kernel, dim3(grid_1d(capacity, 256, 256LL * 8)), dim3(256), 0, (hipStream_t)stream,
-                     reinterpret_cast<const float4*>(records_dev), reinterpret_cast<const long long*>(perm_dev),
-                     reinterpret_cast<const long long*>(begin_dev), (long long)capacity,
-                     reinterpret_cast<float4*>(records_sorted_dev));
-  return launch_status();
+  if (grid->num_features > 27) return RF_ERR_UNSUPPORTED;
+  const int diffuse = render_diffuse || grid->num_features == 3;
+  if (!diffuse && !ray_basis_dev) return RF_ERR_NULL_POINTER;
+  hipStream_t st = (hipStream_t)stream;
+  switch (grid->num_features / 3) {
+    case 1:
+      return launch_expand<1>(records_dev, perm_dev, begin_dev, capacity, ray_basis_dev, diffuse, grid->density_scale, records_sorted_dev, st);
+    case 4:
+      return launch_expand<4>(records_dev, perm_dev, begin_dev, capacity, ray_basis_dev, diffuse, grid->density_scale, records_sorted_dev, st);
+    default:
+      return launch_expand<9>(records_dev, perm_dev, begin_dev, capacity, ray_basis_dev, diffuse, grid->density_scale, records_sorted_dev, st);
+  }
 }
+
+int32_t rf_expanded_record_floats(int32_t num_features) { return 4 * record_quads(num_features / 3); }
 
 extern "C++" {
 template <int K>
@@ -2068,8 +2117,7 @@ static int launch_brick(const GridArgs& g, const BrickArgs& a, int nbricks, floa
 }  // extern "C++"
 
 int rf_brick_accumulate(const RFGrid* grid, int32_t brick_size, const RFBrickList* lists, int32_t num_lists,
-                        const float* ray_basis_dev, float* grad_densities_dev, float* grad_features_dev,
-                        int32_t accumulate, void* stream) {
+                        float* grad_densities_dev, float* grad_features_dev, int32_t accumulate, void* stream) {
   int rc = check_grid(grid);
   if (rc != RF_OK) return rc;
   if (!lists || !grad_densities_dev) return RF_ERR_NULL_POINTER;
@@ -2083,13 +2131,11 @@ int rf_brick_accumulate(const RFGrid* grid, int32_t brick_size, const RFBrickLis
   a.nlists = num_lists;
   for (int i = 0; i < num_lists; ++i) {
     if (!lists[i].records_sorted_dev || !lists[i].offsets_dev) return RF_ERR_NULL_POINTER;
-    if (!lists[i].render_diffuse && !ray_basis_dev && grid->num_features > 3) return RF_ERR_NULL_POINTER;
     a.lists[i].rec = reinterpret_cast<const float4*>(lists[i].records_sorted_dev);
     a.lists[i].offsets = reinterpret_cast<const long long*>(lists[i].offsets_dev);
     a.lists[i].diffuse = lists[i].render_diffuse || grid->num_features == 3;
   }
-  a.ray_basis = ray_basis_dev;
-  { const char* e = getenv("RF_BRICK_DEBUG"); a.debug = e ? atoi(e) : 0; }
+  if (num_lists == 2 && a.lists[0].diffuse && !a.lists[1].diffuse) return RF_ERR_BAD_SHAPE;  // specular lists first
   a.shift = shift;
   a.nbx = nb[0];
   a.nby = nb[1];
@@ -2103,10 +2149,8 @@ int rf_brick_accumulate(const RFGrid* grid, int32_t brick_size, const RFBrickLis
       return launch_brick<1>(g, a, nbricks, grad_densities_dev, grad_features_dev, st);
     case 4:
       return launch_brick<4>(g, a, nbricks, grad_densities_dev, grad_features_dev, st);
-    case 9:
-      return launch_brick<9>(g, a, nbricks, grad_densities_dev, grad_features_dev, st);
     default:
-      return launch_brick<16>(g, a, nbricks, grad_densities_dev, grad_features_dev, st);
+      return launch_brick<9>(g, a, nbricks, grad_densities_dev, grad_features_dev, st);
   }
 }
 

@@ -200,25 +200,35 @@ def render_backward_emit_raw(grid: VoxelGrid, origins: Tensor, directions: Tenso
     _lib.check(rc, "rf_render_backward_emit")
 
 
-def sort_records_by_brick(keys: Tensor, records: Tensor, records_sorted: Tensor, offsets: Tensor, boundaries: Tensor) -> Tensor:
+def expanded_record_floats(grid: VoxelGrid) -> int:
+    """floats per record in the sorted, expanded list consumed by rf_brick_accumulate"""
+    return int(_lib.load().rf_expanded_record_floats(int(grid.num_features)))
+
+
+def sort_records_by_brick(grid: VoxelGrid, keys: Tensor, records: Tensor, ray_basis: Optional[Tensor], render_diffuse: bool,
+                          records_sorted: Tensor, offsets: Tensor, boundaries: Tensor) -> Tensor:
     """Sort the dense key array (16-bit radix sort; key = brick * 8 + boundary flags, -1 = slot without gradient) and
-    gather the records of keyed samples into that order.  ``offsets`` [8 * num_bricks + 1] (int64, last element
-    preset to keys.numel()) receives the start of every (brick, flags) class inside ``records_sorted``; positions are
-    absolute, the unkeyed slots occupy [0, offsets[0])."""
+    write the records of keyed samples, expanded to per-channel values, in that order.  ``offsets``
+    [8 * num_bricks + 1] (int64, last element preset to keys.numel()) receives the start of every (brick, flags)
+    class inside ``records_sorted`` [keys.numel(), expanded_record_floats]; positions are absolute, the unkeyed slots
+    occupy [0, offsets[0])."""
     lib = _lib.load()
     dev = keys.device
     with _span("sort_keys", dev):
         sorted_keys, perm = torch.sort(keys)
         torch.searchsorted(sorted_keys, boundaries, out=offsets[:-1])
-    with _span("gather_records", dev):
-        rc = lib.rf_gather_records(records.data_ptr(), perm.data_ptr(), offsets.data_ptr(), keys.numel(), records_sorted.data_ptr(), _stream(dev))
-    _lib.check(rc, "rf_gather_records")
+    rf_grid = grid.to_rf_grid()
+    with _span("expand_records", dev):
+        rc = lib.rf_expand_records(C.byref(rf_grid), records.data_ptr(), perm.data_ptr(), offsets.data_ptr(), keys.numel(),
+                                   _ptr(ray_basis), int(bool(render_diffuse)), records_sorted.data_ptr(), _stream(dev))
+    _lib.check(rc, "rf_expand_records")
     return offsets
 
 
-def brick_accumulate_raw(grid: VoxelGrid, brick_size: int, lists, ray_basis: Optional[Tensor], grad_first: Tensor,
-                         grad_second: Optional[Tensor], accumulate: bool) -> None:
-    """``lists`` = [(records_sorted, offsets, render_diffuse), ...] (1 or 2 entries).  Enqueue rf_brick_accumulate."""
+def brick_accumulate_raw(grid: VoxelGrid, brick_size: int, lists, grad_first: Tensor, grad_second: Optional[Tensor],
+                         accumulate: bool) -> None:
+    """``lists`` = [(records_sorted, offsets, render_diffuse), ...] (1 or 2 entries, specular first).  Enqueue
+    rf_brick_accumulate."""
     lib = _lib.load()
     dev = grad_first.device
     arr = (_lib.RFBrickList * len(lists))()
@@ -226,7 +236,7 @@ def brick_accumulate_raw(grid: VoxelGrid, brick_size: int, lists, ray_basis: Opt
         arr[i].records_sorted_dev, arr[i].offsets_dev, arr[i].render_diffuse = rec.data_ptr(), off.data_ptr(), int(bool(diffuse))
     rf_grid = grid.to_rf_grid()
     with _span("brick_accumulate", dev):
-        rc = lib.rf_brick_accumulate(C.byref(rf_grid), int(brick_size), arr, len(lists), _ptr(ray_basis), grad_first.data_ptr(), _ptr(grad_second), int(bool(accumulate)), _stream(dev))
+        rc = lib.rf_brick_accumulate(C.byref(rf_grid), int(brick_size), arr, len(lists), grad_first.data_ptr(), _ptr(grad_second), int(bool(accumulate)), _stream(dev))
     _lib.check(rc, "rf_brick_accumulate")
 
 

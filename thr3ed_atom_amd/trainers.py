@@ -35,6 +35,7 @@ from .ops import (
     cast_selected_rays_hip,
     render_backward_emit_raw,
     sort_records_by_brick,
+    expanded_record_floats,
     l1_loss_grad_hip,
     render_backward_raw,
     render_flags,
@@ -246,8 +247,8 @@ class TrainStepper:
                     grid, origins, directions, t_rand, S, near, far, flags, caches, g_colour, None, None, self.brick_size,
                     bins["keys"], bins["records"], bins["ray_basis"],
                 )
-                offsets = sort_records_by_brick(bins["keys"], bins["records"], bins["sorted"], bins["offsets"], bins["boundaries"])
-                brick_accumulate_raw(grid, self.brick_size, [(bins["sorted"], offsets, False)], bins["ray_basis"], gd, gf, accumulate=False)
+                offsets = sort_records_by_brick(grid, bins["keys"], bins["records"], bins["ray_basis"], False, bins["sorted"], bins["offsets"], bins["boundaries"])
+                brick_accumulate_raw(grid, self.brick_size, [(bins["sorted"], offsets, False)], gd, gf, accumulate=False)
             else:
                 render_backward_raw(grid, origins, directions, t_rand, S, near, far, flags, caches, g_colour, None, None, gd, gf)
             if overlap and i == 0:
@@ -280,7 +281,7 @@ class TrainStepper:
                 "num_bricks": num_bricks,
                 "keys": torch.empty(n * S, dtype=torch.int16, device=device),
                 "records": torch.empty((n * S, 8), dtype=torch.float32, device=device),
-                "sorted": torch.empty((n * S, 8), dtype=torch.float32, device=device),
+                "sorted": torch.empty((n * S, expanded_record_floats(grid)), dtype=torch.float32, device=device),
                 "ray_basis": torch.zeros((n, 16), dtype=torch.float32, device=device),
                 "boundaries": torch.arange(num_bricks * 8, dtype=torch.int16, device=device),
                 "offsets": torch.full((num_bricks * 8 + 1,), n * S, dtype=torch.int64, device=device),
