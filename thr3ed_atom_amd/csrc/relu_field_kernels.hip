@@ -1097,25 +1097,29 @@ __global__ void expand_records_kernel(const float4* __restrict__ rec, const long
 
 // One workgroup (4 waves) per NODE brick: it owns B^3 nodes exclusively, so the result is written with plain stores.
 // Race-free accumulation without LDS atomics (tools/lds_microbench*.hip: ds_add_f32 retires 0.33 lane/clk/CU, a plain
-// read-add-write chain is bound by the 65-cycle LDS latency): each wave owns a disjoint CHANNEL group and walks ALL
-// records that touch the brick --
-//   wave 0: the base channels (density, degree-0 r, g, b): 8 corners x 4 channels = 32 lanes, two records per step;
-//   wave w>0: rest channels [8(w-1), 8w): 2 x (8 corners x 4 channels) = 64 lanes (degree 2: three such waves).
+// read-add-write chain is bound by the 65-cycle LDS latency): waves 0 and 1 each own HALF the channels of every node
+// and walk ALL records that touch the brick; a lane owns (corner, channel pair) and adds with one 8-byte
+// read-add-write (8 corners x 7 pairs = 56 lanes at degree 2) -- the LDS pipe, not the VALU, bounds this kernel, and
+// 8-byte accesses halve the LDS instructions per record.
 // Records are sorted by key = cell-brick * 8 + flags, so the records of a source brick that reach into this brick
 // (flags superset of the offset) are a handful of contiguous ranges: no record is read that does not contribute.
-// Per batch of 32 records, 8 threads per record build a table row (corner address + weight per corner, the record's
-// per-channel values, its packed cell); the accumulation loop is then 2 table reads, 1 multiply and the
-// read-add-write.  Tables are double buffered; the global loads of batch b + 1 are issued before the accumulation of
-// batch b and consumed after it.
+// Waves 2 and 3 are producers: per batch of 32 records, 8 threads per record build a table row (corner address +
+// weight per corner, the record's per-channel values, its packed cell) one batch ahead of the consumers, with the
+// global loads of the batch after that in flight; the consumers' loop is then 2 table reads, 2 multiplies and the
+// read-add-write.
 constexpr int kBrickThreads = 256;
 constexpr int kBrickBatch = 32;   // records per table (8 staging threads per record)
 constexpr int kMaxRanges = 28;    // 14 (source brick, flag run) ranges per list, two lists
 
-__host__ __device__ inline int brick_row_stride(int B, int C) { return B * C + ((8 - (B * C) % 32) + 32) % 32; }
-__host__ __device__ inline int brick_slab_stride(int B, int C) {
-  const int sy = brick_row_stride(B, C);
-  return B * sy + ((16 - (B * sy) % 32) + 32) % 32;
+// accumulator geometry: node stride CS = channels rounded up to a multiple of 4 (8-byte read-add-writes, float4 flush);
+// rows (z runs) are padded so that the row stride is 48 mod 64 words: the four corners (dy, dz) of a 32-lane group then
+// start at banks 0 / 28 / 48 / 12 of the 64 banks an 8-byte access sees -- 14-word spans that overlap in 2 banks only
+__host__ __device__ inline int brick_node_stride(int C) { return (C + 3) / 4 * 4; }
+__host__ __device__ inline int brick_row_stride(int B, int C) {
+  const int row = B * brick_node_stride(C);
+  return row + ((48 - row % 64) + 64) % 64;
 }
+__host__ __device__ inline int brick_slab_stride(int B, int C) { return B * brick_row_stride(B, C); }
 __host__ __device__ inline int brick_acc_words(int B, int C) { return B * brick_slab_stride(B, C) + 64; }  // + trash row
 
 // packed lower nodes (one byte per axis): do the two cells have a node in common?
@@ -1132,19 +1136,17 @@ __global__ __launch_bounds__(kBrickThreads) void brick_accumulate_kernel(GridArg
   constexpr int C4 = (C + 3) / 4 * 4;
   constexpr int Q = record_quads(K);
   static_assert(Q <= 8 || K == 16, "8 staging threads per record");
-  constexpr int NREST = C - 4;                 // channels beyond the base record
-  constexpr int REST_WAVES = (NREST + 7) / 8;  // waves needed for them (3 at degree 2)
+  constexpr int CS = C4;                       // node stride in the accumulator
+  constexpr int PW = (CS / 2 + 1) / 2;         // channel pairs owned by each of the two accumulating waves (7 at degree 2)
+  static_assert(PW <= 8 || K == 16, "a lane owns (corner, pair): 8 corners x up to 8 pairs");
   constexpr int CELL = 16 + C4;                // table row: 8 x (corner address, corner weight), C4 channel values, cell
   constexpr int ROW = (CELL + 1 + 3) / 4 * 4;  // rows stay 16-byte aligned
-  extern __shared__ __attribute__((aligned(16))) float acc[];  // node (x, y, z), channel c at x * SX + y * SY + z * C + c
+  extern __shared__ __attribute__((aligned(16))) float acc[];  // node (x, y, z), channel c at x * SX + y * SY + z * CS + c
   __shared__ __attribute__((aligned(16))) uint32_t table[2][(kBrickBatch + 1) * ROW];  // separate object: never aliases acc; + 1 spare row (prefetch)
   __shared__ long long s_rstart[kMaxRanges];
   __shared__ int s_rlist[kMaxRanges];
   __shared__ int s_rcum[kMaxRanges + 1];  // cumulative record counts of the non-empty ranges
-  __shared__ int s_nspec;
   const int B = 1 << a.shift;
-  // row pads chosen so that the 8 corners of a cell start 4 banks apart: the ds_read/ds_write of a 32-lane group
-  // (8 corners x 4 channels) is conflict free
   const int SY = brick_row_stride(B, C), SX = brick_slab_stride(B, C);
   const int TRASH = B * SX;  // contributions to nodes this brick does not own land here and are never written out
   const int acc_words = TRASH + 64;
@@ -1186,127 +1188,62 @@ __global__ __launch_bounds__(kBrickThreads) void brick_accumulate_kernel(GridArg
       s_rcum[slot + 1] = cum;
     }
     if (lane == 0) s_rcum[0] = 0;
-    // records of specular lists (they come first) are the only ones with rest channels
-    const int spec = (in_use && !(li ? a.lists[1].diffuse : a.lists[0].diffuse)) ? cnt : 0;
-    int spec_sum = spec;
-#pragma unroll
-    for (int d = 1; d < 32; d <<= 1) spec_sum += __shfl_xor(spec_sum, d);
-    if (lane == 0) s_nspec = spec_sum;
     if (lane == 31) s_rcum[kMaxRanges] = cum;  // total (lanes >= 28 carry cnt = 0)
   }
   __syncthreads();
   const int total = s_rcum[kMaxRanges];
-  const int nspec_total = s_nspec;
   if (total == 0 && a.accumulate) return;  // nothing reaches this brick
   if (total > 0) {
     float4* acc4 = reinterpret_cast<float4*>(acc);
     for (int i = tid; i < acc_words / 4; i += kBrickThreads) acc4[i] = make_float4(0.f, 0.f, 0.f, 0.f);
   }
 
-  // ---- staging role: 8 threads per record; thread `part` prepares corner `part` and copies float4 `part` of the record
-  const int sj = tid >> 3, part = tid & 7;
-  const int pdx = (part >> 2) & 1, pdy = (part >> 1) & 1, pdz = part & 1;
-  int sri = 0;  // running range index of this thread's records (they advance monotonically)
-  // ---- accumulation role: each group of 32 lanes = 8 corners x 4 channels
-  const int q = (lane >> 2) & 7;
-  const int c = (wave == 0) ? (lane & 3) : 4 + (wave - 1) * 8 + (lane & 3) + ((lane >> 5) << 2);
-  const bool rest_active = wave >= 1 && wave - 1 < REST_WAVES && c < C;
-
   const int nbatches = (total + kBrickBatch - 1) / kBrickBatch;
-  for (int b = -1; b < nbatches; ++b) {
-    // -- (1) issue the loads of batch b + 1: the record's index quad and this thread's quad of channel values
-    float4 ridx = make_float4(0.f, 0.f, 0.f, 0.f), rval = ridx;
-    const int v = (b + 1) * kBrickBatch + sj;
-    const bool have = b + 1 < nbatches && v < total;
-    if (have) {
-      while (s_rcum[sri + 1] <= v) ++sri;
-      const long long pos = s_rstart[sri] + (v - s_rcum[sri]);
-      const float4* rec = (s_rlist[sri] ? a.lists[1].rec : a.lists[0].rec) + pos * Q;
-      ridx = rec[0];
-      if (part >= 1 && part < Q) rval = rec[part];
+  constexpr int H = kBrickBatch / 2;
+
+  // ---- producer role (waves 2 and 3): 8 threads per record, two records (sj, sj + H) per thread; thread `part`
+  // prepares corner `part` and copies float4 `part` of the record
+  const bool producer = wave >= 2;
+  const int sj = ((tid - 2 * kWave) >> 3) & (H - 1), part = tid & 7;
+  const int pdx = (part >> 2) & 1, pdy = (part >> 1) & 1, pdz = part & 1;
+  const int vpart = (part >= 1 && part < Q) ? part : 0;
+  int sri[2] = {0, 0};  // running range index of this thread's two record streams (they advance monotonically)
+  float4 ridx[2], rval[2];
+  ridx[0] = ridx[1] = rval[0] = rval[1] = make_float4(0.f, 0.f, 0.f, 0.f);
+
+  // -- issue the loads of batch bb (unconditional, clamped to the last record: no divergent register merges)
+  auto issue = [&](int bb) {
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+      const int v = min(bb * kBrickBatch + sj + t * H, total - 1);
+      while (s_rcum[sri[t] + 1] <= v) ++sri[t];
+      const long long pos = s_rstart[sri[t]] + (v - s_rcum[sri[t]]);
+      const float4* rec = (s_rlist[sri[t]] ? a.lists[1].rec : a.lists[0].rec) + pos * Q;
+      ridx[t] = rec[0];
+      rval[t] = rec[vpart];
     }
-    // -- (2) accumulate batch b from its table
-    if (b >= 0) {
-      // records j and j + 16 of a batch (usually samples of different rays) are handled together: when their cells
-      // share no node (lower nodes >= 2 apart on some axis) the two read-add-writes are independent and overlap,
-      // otherwise they are issued one after the other.  The table entries of step j + 1 are fetched before the
-      // read-add-write of step j, so that only the accumulator latency is on the critical path.
-      const uint32_t* tb = table[b & 1];
-      const int base = b * kBrickBatch;
-      const int nb = min(kBrickBatch, total - base);
-      constexpr int H = kBrickBatch / 2;
-      uint32_t shared_mask;  // bit j: the cells of records j and j + H have a node in common
-      {
-        const int l = lane & (H - 1);
-        shared_mask = (uint32_t)__ballot(cells_share_nodes(tb[l * ROW + CELL], tb[(l + H) * ROW + CELL]));
-      }
-      if (wave == 0) {
-        const int half = lane >> 5;
-        const int steps = min(nb, H);  // rows >= nb are padded (zero weight, trash address, far-away cell)
-        const uint32_t* row = tb + half * (H * ROW);
-        uint2 aw = *reinterpret_cast<const uint2*>(row + 2 * q);
-        float gv = __uint_as_float(row[16 + c]);
-        for (int j = 0; j < steps; ++j) {
-          row += ROW;  // step j + 1 (the table has a spare row behind the last one)
-          const uint2 aw_n = *reinterpret_cast<const uint2*>(row + 2 * q);
-          const float gv_n = __uint_as_float(row[16 + c]);
-          const float add = __uint_as_float(aw.y) * gv;
-          float* dst = &acc[aw.x + c];
-          if ((shared_mask >> j) & 1u) {
-            if (half == 0) *dst = *dst + add;
-            if (half == 1) *dst = *dst + add;
-          } else {
-            *dst = *dst + add;
-          }
-          aw = aw_n;
-          gv = gv_n;
-        }
-      } else if (rest_active) {
-        const int ns = min(max(nspec_total - base, 0), nb);  // diffuse records carry nothing for the rest channels
-        const int steps = min(ns, H);
-        const uint32_t* rowA = tb;
-        uint2 awA = *reinterpret_cast<const uint2*>(rowA + 2 * q);
-        uint2 awB = *reinterpret_cast<const uint2*>(rowA + H * ROW + 2 * q);  // beyond ns: a diffuse or padded row (rest values 0)
-        float gA = __uint_as_float(rowA[16 + c]), gB = __uint_as_float(rowA[H * ROW + 16 + c]);
-        for (int j = 0; j < steps; ++j) {
-          rowA += ROW;
-          const uint2 awA_n = *reinterpret_cast<const uint2*>(rowA + 2 * q);
-          const uint2 awB_n = *reinterpret_cast<const uint2*>(rowA + H * ROW + 2 * q);
-          const float gA_n = __uint_as_float(rowA[16 + c]), gB_n = __uint_as_float(rowA[H * ROW + 16 + c]);
-          const float addA = __uint_as_float(awA.y) * gA;
-          const float addB = __uint_as_float(awB.y) * gB;
-          float* dA = &acc[awA.x + c];
-          float* dB = &acc[awB.x + c];
-          if ((shared_mask >> j) & 1u) {
-            *dA = *dA + addA;
-            *dB = *dB + addB;
-          } else {
-            const float vA = *dA, vB = *dB;
-            *dA = vA + addA;
-            *dB = vB + addB;
-          }
-          awA = awA_n;
-          awB = awB_n;
-          gA = gA_n;
-          gB = gB_n;
-        }
-      }
-    }
-    // -- (3) build the table of batch b + 1 from the loads issued in (1)
-    if (b + 1 < nbatches) {
-      uint32_t* row = table[(b + 1) & 1] + sj * ROW;
+  };
+
+  // -- build the table of batch bb from the loads issued for it
+  auto build = [&](int bb) {
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+      const int rj = sj + t * H;
+      uint32_t* row = table[bb & 1] + rj * ROW;
       uint32_t addr = (uint32_t)TRASH;
-      uint32_t cell = 0x00f0f0f0u + (uint32_t)(sj & 7) * 0x00040404u;  // padded rows: far from every real cell
+      uint32_t cell = 0x00f0f0f0u + (uint32_t)(rj & 7) * 0x00040404u;  // padded rows: far from every real cell
       float wc = 0.0f;
-      if (have) {
-        const float idx[3] = {ridx.x, ridx.y, ridx.z};
+      float4 val = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (bb * kBrickBatch + rj < total) {
+        const float idx[3] = {ridx[t].x, ridx[t].y, ridx[t].z};
         const int org[3] = {X0, Y0, Z0};
         const int dim[3] = {g.X, g.Y, g.Z};
         const int dd[3] = {pdx, pdy, pdz};
         int n3[3];
         bool owned = true;
         float w3[3];
-        cell = 0;
+        // (the 4th word of the index quad is 0; reading it keeps all four load registers reserved until here)
+        cell = __float_as_uint(ridx[t].w);
 #pragma unroll
         for (int ax = 0; ax < 3; ++ax) {
           const float fl = floorf(idx[ax]);
@@ -1316,13 +1253,91 @@ __global__ __launch_bounds__(kBrickThreads) void brick_accumulate_kernel(GridArg
           owned = owned && n3[ax] >= 0 && n3[ax] < B && org[ax] + n3[ax] < dim[ax];
         }
         if (owned) {
-          addr = (uint32_t)(n3[0] * SX + n3[1] * SY + n3[2] * C);
+          addr = (uint32_t)(n3[0] * SX + n3[1] * SY + n3[2] * CS);
           wc = (w3[0] * w3[1]) * w3[2];
         }
+        val = rval[t];
       }
       *reinterpret_cast<uint2*>(row + 2 * part) = make_uint2(addr, __float_as_uint(wc));
-      if (part >= 1 && part < Q) *reinterpret_cast<float4*>(row + 16 + 4 * (part - 1)) = rval;
+      if (part >= 1 && part < Q) *reinterpret_cast<float4*>(row + 16 + 4 * (part - 1)) = val;
       if (part == 0) row[CELL] = cell;
+    }
+  };
+
+  // ---- consumer role (waves 0 and 1): lane = corner q x channel pair; this lane's two channels start at `ch`
+  const int q = lane >> 3;
+  const int ch = 2 * (wave * PW + (lane & 7));
+  const bool acc_active = wave < 2 && (lane & 7) < PW && ch < CS;
+
+  // -- accumulate batch b from its table
+  // records j and j + 16 of a batch (usually samples of different rays) are handled together: when their cells share
+  // no node (lower nodes >= 2 apart on some axis) the two read-add-writes are independent and overlap, otherwise
+  // they are issued one after the other.  The table entries of step j + 1 are fetched before the read-add-write of
+  // step j, so that only the accumulator latency is on the critical path.
+  auto accumulate = [&](int b) {
+    const uint32_t* tb = table[b & 1];
+    const int base = b * kBrickBatch;
+    const int nb = min(kBrickBatch, total - base);
+    uint32_t shared_mask;  // bit j: the cells of records j and j + H have a node in common
+    {
+      const int l = lane & (H - 1);
+      shared_mask = (uint32_t)__ballot(cells_share_nodes(tb[l * ROW + CELL], tb[(l + H) * ROW + CELL]));
+    }
+    if (!acc_active) return;
+    const int steps = min(nb, H);  // rows >= nb are padded (zero weight, trash address, far-away cell)
+    const uint32_t* rowA = tb;
+    uint2 awA = *reinterpret_cast<const uint2*>(rowA + 2 * q);
+    uint2 awB = *reinterpret_cast<const uint2*>(rowA + H * ROW + 2 * q);
+    float2 gA = *reinterpret_cast<const float2*>(rowA + 16 + ch), gB = *reinterpret_cast<const float2*>(rowA + H * ROW + 16 + ch);
+    for (int j = 0; j < steps; ++j) {
+      rowA += ROW;  // step j + 1 (the table has a spare row behind the last one)
+      const uint2 awA_n = *reinterpret_cast<const uint2*>(rowA + 2 * q);
+      const uint2 awB_n = *reinterpret_cast<const uint2*>(rowA + H * ROW + 2 * q);
+      const float2 gA_n = *reinterpret_cast<const float2*>(rowA + 16 + ch), gB_n = *reinterpret_cast<const float2*>(rowA + H * ROW + 16 + ch);
+      const float wA = __uint_as_float(awA.y), wB = __uint_as_float(awB.y);
+      float2* dA = reinterpret_cast<float2*>(&acc[awA.x + ch]);
+      float2* dB = reinterpret_cast<float2*>(&acc[awB.x + ch]);
+      if ((shared_mask >> j) & 1u) {
+        float2 vA = *dA;
+        vA.x = vA.x + wA * gA.x;
+        vA.y = vA.y + wA * gA.y;
+        *dA = vA;
+        float2 vB = *dB;
+        vB.x = vB.x + wB * gB.x;
+        vB.y = vB.y + wB * gB.y;
+        *dB = vB;
+      } else {
+        float2 vA = *dA, vB = *dB;
+        vA.x = vA.x + wA * gA.x;
+        vA.y = vA.y + wA * gA.y;
+        vB.x = vB.x + wB * gB.x;
+        vB.y = vB.y + wB * gB.y;
+        *dA = vA;
+        *dB = vB;
+      }
+      awA = awA_n;
+      awB = awB_n;
+      gA = gA_n;
+      gB = gB_n;
+    }
+  };
+
+  // producers run one batch ahead of the consumers (tables are double buffered) and keep the record loads of the batch
+  // after that in flight: those take several microseconds under load, a whole accumulation round hides them
+  if (total > 0 && producer) {
+    issue(0);
+    build(0);
+    if (nbatches > 1) issue(1);
+  }
+  __syncthreads();
+  for (int b = 0; b < nbatches; ++b) {
+    if (producer) {
+      if (b + 1 < nbatches) {
+        build(b + 1);
+        if (b + 2 < nbatches) issue(b + 2);
+      }
+    } else {
+      accumulate(b);
     }
     __syncthreads();
   }
@@ -1344,7 +1359,7 @@ __global__ __launch_bounds__(kBrickThreads) void brick_accumulate_kernel(GridArg
       const int X = X0 + fx, Y = Y0 + fy, Z = Z0 + fz;
       if (X >= g.X || Y >= g.Y || Z >= g.Z) continue;
       const long long lin = ((long long)X * g.Y + Y) * g.Z + Z;
-      float4 v = total > 0 ? *reinterpret_cast<const float4*>(&acc[fx * SX + fy * SY + fz * C + 4 * qd]) : make_float4(0.f, 0.f, 0.f, 0.f);
+      float4 v = total > 0 ? *reinterpret_cast<const float4*>(&acc[fx * SX + fy * SY + fz * CS + 4 * qd]) : make_float4(0.f, 0.f, 0.f, 0.f);
       if (qd == 0) {
         if (g.mode == RF_DENSITY_ABS) {  // d|x|/dx of the raw density, applied once per node
           const float dv = g.dens[lin * g.dstride] * g.rho;
@@ -1381,7 +1396,7 @@ __global__ __launch_bounds__(kBrickThreads) void brick_accumulate_kernel(GridArg
         lds_c = (kk == 0) ? 1 + col3 : 4 + col3 * (K - 1) + (kk - 1);
       }
       const long long lin = ((long long)X * g.Y + Y) * g.Z + Z;
-      float v = total > 0 ? acc[fx * SX + fy * SY + fz * C + lds_c] : 0.0f;
+      float v = total > 0 ? acc[fx * SX + fy * SY + fz * CS + lds_c] : 0.0f;
       if (lds_c == 0 && g.mode == RF_DENSITY_ABS) {  // d|x|/dx of the raw density, applied once per node
         const float dv = g.dens[lin * g.dstride] * g.rho;
         v = (dv > 0.f) ? v : ((dv < 0.f) ? -v : 0.0f);
