@@ -140,8 +140,10 @@ def main():
     ap.add_argument("--ray-selection", choices=["keyed", "randperm"], default="keyed",
                     help="how a step picks its 16384 random pixels: keyed = fused keyed-permutation kernel (trainer default), "
                     "randperm = torch.randperm over all 5.12 M pixels like the reference")
-    ap.add_argument("--backward", choices=["atomic", "binned"], default="atomic",
-                    help="gradient scatter of the train step: float32 atomics, or records sorted by brick + LDS accumulation")
+    ap.add_argument("--backward", choices=["auto", "atomic", "binned"], default="auto",
+                    help="specular gradient scatter of the train step: float32 atomics, or records binned by brick + atomic-free "
+                    "LDS accumulation (auto = binned where supported and measured faster)")
+    ap.add_argument("--deterministic", action="store_true", help="binned backward: stable radix sort instead of the counting sort")
     ap.add_argument("--no-kernel-timer", action="store_true", help="do not record per-kernel HIP events in the timed region (no roofline object)")
     ap.add_argument("--cpu-threads", type=int, default=0, help="torch CPU threads for cpu_baseline (0 = all host cores)")
     args = ap.parse_args()
@@ -242,7 +244,7 @@ def main():
         torch.cuda.empty_cache()
 
     # ---- training steps: the headline ---------------------------------------------------------------
-    stepper = TrainStepper(model, R, learning_rate=0.03, apply_diffuse_render_regularization=True, ray_selection=args.ray_selection, backward=args.backward)
+    stepper = TrainStepper(model, R, learning_rate=0.03, apply_diffuse_render_regularization=True, ray_selection=args.ray_selection, backward=args.backward, deterministic=args.deterministic)
     torch.manual_seed(1234 + rank)  # every rank draws its own rays
     batches = dataset.image_batches(args.images)
     for _ in range(args.warmup):
@@ -289,6 +291,9 @@ def main():
         f"render_backward[sh{args.sh_degree}]": n_in * 8 * C * 4 + R * 48,
         "render_backward[diffuse]": n_in * 8 * 4 * 4 + R * 48,
         "adam_step": G**3 * C * 4 * 7,
+        # binned specular backward: the brick pass is the kernel that moves the scatter payload (8 corners x C
+        # x 4 B per in-AABB sample) into the gradient tensor; emit / bin / scatter-expand are its front end
+        "brick_accumulate": n_in * 8 * C * 4,
     }
     kernels = {}
     for name, rec in ksum.items():
@@ -297,7 +302,7 @@ def main():
         if b:
             kernels[name]["algorithmic_GB"] = b / 1e9
             kernels[name]["effective_GBps"] = b / 1e9 / (rec["avg_ms"] / 1e3)
-    render_kernels = {k: v for k, v in ksum.items() if k.startswith("render_")}
+    render_kernels = {k: v for k, v in ksum.items() if k.startswith("render_") and k in alg_bytes or k == "brick_accumulate"}
     if not render_kernels:
         print(json.dumps({"ms_per_step": ms_per_step, "value": value, "host_issue_ms_per_step": host_issue / args.steps * 1e3, "note": "kernel timer off"}))
         return
@@ -316,6 +321,19 @@ def main():
         "note": "effective bandwidth: algorithmic gather/scatter bytes (8 corners x C x 4 B per in-AABB sample, SURVEY 8d), "
         "not credited for cache reuse or skipped zero-weight samples, so it can exceed DRAM traffic",
     }
+    pipeline = [k for k in ksum if k.startswith("render_backward_emit") or k in ("sort_keys", "expand_records", "bin_offsets", "scatter_records", "brick_accumulate")]
+    if "brick_accumulate" in ksum:
+        # the whole specular backward (emit -> bin -> scatter-expand -> brick pass) against the same scatter payload
+        total_ms = sum(ksum[k]["avg_ms"] for k in pipeline)
+        pbytes = alg_bytes["brick_accumulate"] + R * 48
+        roofline["pipeline"] = {
+            "kernels": pipeline,
+            "total_ms": total_ms,
+            "algorithmic_bytes": pbytes,
+            "achieved": pbytes / 1e9 / (total_ms / 1e3),
+            "frac": pbytes / 1e9 / (total_ms / 1e3) / HBM_PEAK_GBS,
+        }
+        roofline["note"] += "; brick_accumulate is the last of the kernels of the specular backward -- `pipeline` prices all of them against the same bytes"
     prof = os.path.join(ROOT, "profiles", "pmc_traffic.json")
     if os.path.exists(prof):
         try:
@@ -354,7 +372,7 @@ def main():
             "parallelism": f"dp{world}",
             "grid_storage": args.storage,
             "ray_selection": args.ray_selection,
-            "backward": args.backward,
+            "backward": stepper.backward + ("+atomic diffuse pass" if stepper.backward == "binned" else ""),
         },
         "rays_per_s": world * 2 * R * args.steps / elapsed,
         "final_specular_psnr": stats.psnr()["specular_psnr"],

@@ -172,6 +172,7 @@ int rf_render_backward(const RFGrid* grid, const RFRayBatch* rays, uint32_t flag
  *     nodes, brick_size in {4, 8}) holding the LOWER node of the sample's cell and flag bit a says that the cell's
  *     upper node on axis a belongs to the next brick; -1 for samples without gradient.  ray_basis_dev [N,16] (may
  *     be NULL for the diffuse pass) receives the signed SH basis of each ray.  At most 4096 bricks (16-bit keys).
+ *     hist_dev (may be NULL): see rf_bin_offsets below.
  * (2) the caller sorts keys (torch.sort) -> permutation, and offsets [8*nbricks+1] (searchsorted; last = N*S);
  * (3) rf_expand_records: for *begin_dev (= offsets[0]) <= i < capacity, records_sorted[i] = the EXPANDED record of slot
  *     perm[i]: rf_expanded_record_floats(F) floats = (index x, y, z, 0) followed by dL/d(interpolated channel) for
@@ -192,11 +193,21 @@ typedef struct RFBrickList {
 
 int rf_render_backward_emit(const RFGrid* grid, const RFRayBatch* rays, uint32_t flags, const RFRenderOut* fwd,
                             const RFRenderGrads* grads, int32_t brick_size, int16_t* keys_dev, float* records_dev,
-                            float* ray_basis_dev, void* stream);
+                            float* ray_basis_dev, int32_t* hist_dev, void* stream);
 int rf_expand_records(const RFGrid* grid, const float* records_dev, const int64_t* perm_dev, const int64_t* begin_dev,
                       int64_t capacity, const float* ray_basis_dev, int32_t render_diffuse, float* records_sorted_dev,
                       void* stream);
 int32_t rf_expanded_record_floats(int32_t num_features);
+/* Counting-sort alternative to steps (2)+(3) (no torch.sort): pass hist_dev [8*nbricks] (int32, zero before the first
+ * use) to rf_render_backward_emit, which adds the number of records per key; rf_bin_offsets turns it into offsets_dev
+ * [8*nbricks+1] (positions start at 0: unkeyed slots take no room) and a copy cursor_dev [8*nbricks] (int32);
+ * rf_scatter_records then writes every keyed slot's expanded record at the next free position of its key (atomic
+ * cursor: the order inside a class, hence the float32 summation order, is not run-to-run reproducible) and, when
+ * hist_dev is given, clears its num_keys counters for the next iteration. */
+int rf_bin_offsets(const int32_t* hist_dev, int32_t num_keys, int64_t* offsets_dev, int32_t* cursor_dev, void* stream);
+int rf_scatter_records(const RFGrid* grid, const int16_t* keys_dev, const float* records_dev, int64_t capacity,
+                       int32_t* cursor_dev, const float* ray_basis_dev, int32_t render_diffuse, float* records_sorted_dev,
+                       int32_t* hist_dev, int32_t num_keys, void* stream);
 int rf_brick_accumulate(const RFGrid* grid, int32_t brick_size, const RFBrickList* lists, int32_t num_lists,
                         float* grad_densities_dev, float* grad_features_dev, int32_t accumulate, void* stream);
 

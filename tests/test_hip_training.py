@@ -374,7 +374,7 @@ def test_keyed_ray_selection(hip_device):
     assert torch.equal(r1.origins, r2.origins) and torch.equal(p1, p2) and len(r1) == 512
 
 
-def _binned_gradients(grid, rays, cfg, target, device, diffuse_too=True, accumulate=False):
+def _binned_gradients(grid, rays, cfg, target, device, diffuse_too=True, accumulate=False, binning="sort"):
     """(dL/d first, dL/d second) of L1(spec) [+ L1(diffuse)] through the emit -> sort -> brick-accumulate path"""
     from thr3ed_atom_amd import ops as O
 
@@ -398,10 +398,16 @@ def _binned_gradients(grid, rays, cfg, target, device, diffuse_too=True, accumul
         keys = torch.empty(n * S, dtype=torch.int16, device=device)
         rec = torch.empty((n * S, 8), device=device)
         srt = torch.empty((n * S, O.expanded_record_floats(grid)), device=device)
-        O.render_backward_emit_raw(grid, o, d, None, S, near, far, flags, caches, g_colour, None, None, 8, keys, rec, None if diffuse else ray_basis)
+        hist = torch.zeros(num_bricks * 8, dtype=torch.int32, device=device) if binning == "count" else None
+        O.render_backward_emit_raw(grid, o, d, None, S, near, far, flags, caches, g_colour, None, None, 8, keys, rec, None if diffuse else ray_basis, hist)
         offsets = torch.full((num_bricks * 8 + 1,), n * S, dtype=torch.int64, device=device)
         is_diffuse = diffuse or cfg.render_diffuse
-        O.sort_records_by_brick(grid, keys, rec, None if is_diffuse else ray_basis, is_diffuse, srt, offsets, boundaries)
+        if binning == "count":
+            cursor = torch.empty(num_bricks * 8, dtype=torch.int32, device=device)
+            O.bin_records_by_brick(grid, keys, rec, None if is_diffuse else ray_basis, is_diffuse, hist, cursor, srt, offsets)
+            assert int(hist.abs().sum()) == 0 and int(offsets[-1]) == int((keys >= 0).sum())
+        else:
+            O.sort_records_by_brick(grid, keys, rec, None if is_diffuse else ray_basis, is_diffuse, srt, offsets, boundaries)
         lists.append((srt, offsets, diffuse or cfg.render_diffuse))
         keep.append((keys, rec, caches))
     O.brick_accumulate_raw(grid, 8, lists, gd, gf, accumulate=accumulate)
@@ -413,10 +419,10 @@ def _binned_gradients(grid, rays, cfg, target, device, diffuse_too=True, accumul
     return gd, gf
 
 
-@pytest.mark.parametrize("accumulate", [False, True])
+@pytest.mark.parametrize("accumulate,binning", [(False, "sort"), (True, "sort"), (False, "count")])
 @pytest.mark.parametrize("storage", ["reference", "split"])
 @pytest.mark.parametrize("case", ["grid16_sh2", "aniso_sh2_abs", "aniso_sh1_softplus", "cube20_sh0"])
-def test_binned_backward_equals_atomic_backward(hip_device, storage, case, accumulate):
+def test_binned_backward_equals_atomic_backward(hip_device, storage, case, accumulate, binning):
     """The LDS-aggregated backward (emit -> 16-bit sort by (brick, flags) -> one workgroup per 8^3-node brick that owns
     its nodes exclusively -> plain coalesced stores) gives the gradient of the atomic scatter (and therefore of the reference)
     for specular + diffuse renders, including partial bricks, the grid border, SH degree 0-2 and the abs / softplus
@@ -443,7 +449,7 @@ def test_binned_backward_equals_atomic_backward(hip_device, storage, case, accum
     loss = loss + torch.nn.functional.l1_loss(model.render_rays(rays, render_diffuse=True).colour, target)
     loss.backward()
     ref_d, ref_f = grid.reference_gradients()
-    gd, gf = _binned_gradients(grid, rays, cfg, target, hip_device, accumulate=accumulate)
+    gd, gf = _binned_gradients(grid, rays, cfg, target, hip_device, accumulate=accumulate, binning=binning)
     if storage == "split":
         gd, gf = unpack_split(gd, gf)
     assert float(ref_d.abs().max()) > 0 and float(ref_f.abs().max()) > 0

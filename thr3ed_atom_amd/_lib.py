@@ -35,6 +35,8 @@ EXPORTED_SYMBOLS = [
     "rf_render_backward_emit",
     "rf_expand_records",
     "rf_expanded_record_floats",
+    "rf_bin_offsets",
+    "rf_scatter_records",
     "rf_brick_accumulate",
     "rf_grid_query",
     "rf_grid_query_backward",
@@ -155,11 +157,13 @@ def load() -> C.CDLL:
         vp,
     ]
     lib.rf_render_backward_emit.argtypes = [
-        C.POINTER(RFGrid), C.POINTER(RFRayBatch), u32, C.POINTER(RFRenderOut), C.POINTER(RFRenderGrads), i32, vp, vp, vp, vp,
+        C.POINTER(RFGrid), C.POINTER(RFRayBatch), u32, C.POINTER(RFRenderOut), C.POINTER(RFRenderGrads), i32, vp, vp, vp, vp, vp,
     ]
     lib.rf_expand_records.argtypes = [C.POINTER(RFGrid), vp, vp, vp, i64, vp, i32, vp, vp]
     lib.rf_expanded_record_floats.argtypes = [i32]
     lib.rf_expanded_record_floats.restype = i32
+    lib.rf_bin_offsets.argtypes = [vp, i32, vp, vp, vp]
+    lib.rf_scatter_records.argtypes = [C.POINTER(RFGrid), vp, vp, i64, vp, vp, i32, vp, vp, i32, vp]
     lib.rf_brick_accumulate.argtypes = [C.POINTER(RFGrid), i32, C.POINTER(RFBrickList), i32, vp, vp, i32, vp]
     lib.rf_grid_query.argtypes = [C.POINTER(RFGrid), vp, i64, vp, vp]
     lib.rf_grid_query_backward.argtypes = [C.POINTER(RFGrid), vp, i64, vp, vp, vp, vp]

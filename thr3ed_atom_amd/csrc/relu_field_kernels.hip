@@ -94,9 +94,36 @@ struct GradArgs {
   float* ray_basis; // [N, 16] signed SH basis of the ray (may be NULL)
   int brick_shift;  // log2 of the brick edge (nodes)
   int nby, nbz;     // bricks along y and z
+  int* hist;        // [8 * nbricks] records per key, added to (may be NULL)
 };
 
 constexpr short kNoBrick = -1;  // sorts in front of every (brick, flags) key
+
+// Lanes hold the keys of 64 consecutive sample slots (-1 = none).  Consecutive samples of a ray mostly share their
+// key, so one atomic per RUN of equal keys is issued (by the run's first lane) instead of one per lane.  Returns this
+// lane's rank = counter value before the run + position inside the run (only meaningful for key >= 0); with
+// WANT_RANK = false the atomic is fire-and-forget.
+template <bool WANT_RANK>
+__device__ __forceinline__ int add_key_runs(int* counters, int key, int lane) {
+  const bool active = key >= 0;
+  const int prev = __shfl_up(key, 1);
+  const bool head = active && (lane == 0 || prev != key);
+  const unsigned long long heads = __ballot(head);
+  const unsigned long long ends = __ballot(head || !active);  // a run stops at the next head or inactive lane
+  const unsigned long long above = (lane == 63) ? 0ull : (ends & ~((2ull << lane) - 1ull));
+  const int run = (above ? __builtin_ctzll(above) : 64) - lane;
+  int base = 0;
+  if (head) {
+    if (WANT_RANK)
+      base = atomicAdd(&counters[key], run);
+    else
+      atomicAdd(&counters[key], run);
+  }
+  if (!WANT_RANK) return 0;
+  const unsigned long long below = heads & ((lane == 63) ? ~0ull : ((2ull << lane) - 1ull));
+  const int hl = below ? 63 - __builtin_clzll(below) : 0;
+  return __shfl(base, hl) + (lane - hl);
+}
 
 // 16-byte load/store at 4-byte alignment (a corner's 27 features start at a multiple of 108 B)
 struct __attribute__((packed, aligned(4))) f4u {
@@ -920,6 +947,7 @@ __global__ __launch_bounds__(kBlock) void render_backward_kernel(GridArgs g, Ray
     const bool live = have && sm.inside;
     const bool need = live && (g_pre != 0.f || g_raw[0] != 0.f || g_raw[1] != 0.f || g_raw[2] != 0.f);
     if constexpr (EMIT) {
+      short key_of_lane = kNoBrick;
       if (sm.valid) {
         const long long slot = ray * (long long)r.S + s;
         short key = kNoBrick;
@@ -940,7 +968,9 @@ __global__ __launch_bounds__(kBlock) void render_backward_kernel(GridArgs g, Ray
           rec[1] = make_float4(g_raw[0], g_raw[1], g_raw[2], __int_as_float((int)ray));
         }
         gr.keys[slot] = key;
+        key_of_lane = key;
       }
+      if (gr.hist) add_key_runs<false>(gr.hist, (int)key_of_lane, lane);
       continue;
     }
     const unsigned long long mask = __ballot(need);
@@ -1092,6 +1122,132 @@ __global__ void expand_records_kernel(const float4* __restrict__ rec, const long
       o = make_float4(v[0], v[1], v[2], v[3]);
     }
     out[i * Q + part] = o;
+  }
+}
+
+// Counting-sort alternative to torch.sort + expand: hist[k] = records per key (filled by the emit pass) ->
+// offsets[k] = exclusive prefix sum (int64, what rf_brick_accumulate reads), cursor[k] = the same as int32 for the
+// scatter pass; hist is cleared for the next iteration.  One workgroup (at most 32768 keys).
+__global__ __launch_bounds__(1024) void bin_offsets_kernel(const int* __restrict__ hist, int nkeys, long long* __restrict__ offsets,
+                                                           int* __restrict__ cursor) {
+  // workgroup i owns keys [1024 i, 1024 i + 1024): it sums everything in front of its segment (coalesced, L2-resident)
+  // and scans its own segment with wave shuffles -- no dependency between workgroups
+  __shared__ int s_front[16], s_own[16];
+  const int t = threadIdx.x, lane = t & (kWave - 1), wave = t >> 6;
+  const int seg0 = blockIdx.x * 1024;
+  int front = 0;
+  for (int k = t; k < seg0; k += 1024) front += hist[k];
+#pragma unroll
+  for (int d = 1; d < kWave; d <<= 1) front += __shfl_xor(front, d);
+  const int k = seg0 + t;
+  const int c = k < nkeys ? hist[k] : 0;
+  int incl = c;
+#pragma unroll
+  for (int d = 1; d < kWave; d <<= 1) {
+    const int up = __shfl_up(incl, d);
+    if (lane >= d) incl += up;
+  }
+  if (lane == kWave - 1) {
+    s_front[wave] = front;
+    s_own[wave] = incl;
+  }
+  __syncthreads();
+  int base = 0, before = 0, own = 0;
+#pragma unroll
+  for (int w = 0; w < 16; ++w) {
+    base += s_front[w];
+    if (w < wave) before += s_own[w];
+    own += s_own[w];
+  }
+  if (k < nkeys) {
+    const int excl = base + before + incl - c;
+    offsets[k] = excl;
+    cursor[k] = excl;
+  }
+  if (t == 0 && seg0 + 1024 >= nkeys) offsets[nkeys] = base + own;
+}
+
+// Every keyed slot takes the next free position of its key class (run-aggregated atomic cursor) and its expanded record
+// is written there.  One wave per 256 consecutive slots (4 chunks of 64 whose atomics are in flight together): active
+// slots are compacted into LDS, then groups of Q lanes write the Q quads of a record (coalesced 16-byte stores).  The
+// order inside a class depends on the atomics' timing (unlike the sort path, results are not run-to-run bit-identical).
+// Also clears `hist` for the next iteration.
+template <int K>
+__global__ __launch_bounds__(256) void scatter_records_kernel(const short* __restrict__ keys, const float4* __restrict__ rec,
+                                                              long long capacity, int* __restrict__ cursor,
+                                                              const float* __restrict__ ray_basis, int diffuse, float rho,
+                                                              float4* __restrict__ out, int* __restrict__ hist, int nkeys) {
+  constexpr int C = 3 * K + 1;
+  constexpr int Q = record_quads(K);
+  constexpr int NCH = 4;  // chunks per wave
+  __shared__ long long s_slot[4][NCH * kWave];
+  __shared__ int s_pos[4][NCH * kWave];
+  const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x >> 6;
+  if (hist)
+    for (long long k = (long long)blockIdx.x * blockDim.x + threadIdx.x; k < nkeys; k += (long long)gridDim.x * blockDim.x) hist[k] = 0;
+  const long long slot0 = ((long long)blockIdx.x * 4 + wave) * (NCH * kWave);
+  if (slot0 >= capacity) return;
+  int key[NCH], run[NCH], hl[NCH], base[NCH];
+  bool head[NCH];
+  unsigned long long act[NCH];
+#pragma unroll
+  for (int i = 0; i < NCH; ++i) {
+    const long long slot = slot0 + i * kWave + lane;
+    key[i] = slot < capacity ? (int)keys[slot] : -1;
+  }
+#pragma unroll
+  for (int i = 0; i < NCH; ++i) {
+    const bool active = key[i] >= 0;
+    act[i] = __ballot(active);
+    const int prev = __shfl_up(key[i], 1);
+    head[i] = active && (lane == 0 || prev != key[i]);
+    const unsigned long long heads = __ballot(head[i]);
+    const unsigned long long ends = __ballot(head[i] || !active);
+    const unsigned long long above = (lane == 63) ? 0ull : (ends & ~((2ull << lane) - 1ull));
+    run[i] = (above ? __builtin_ctzll(above) : 64) - lane;
+    const unsigned long long below = heads & ((lane == 63) ? ~0ull : ((2ull << lane) - 1ull));
+    hl[i] = below ? 63 - __builtin_clzll(below) : 0;
+  }
+#pragma unroll
+  for (int i = 0; i < NCH; ++i) base[i] = head[i] ? atomicAdd(&cursor[key[i]], run[i]) : 0;  // 4 atomics in flight
+  int n_act = 0;
+#pragma unroll
+  for (int i = 0; i < NCH; ++i) {
+    const int pos = __shfl(base[i], hl[i]) + (lane - hl[i]);
+    if (key[i] >= 0) {
+      const int e = n_act + __popcll(act[i] & ((1ull << lane) - 1ull));
+      s_slot[wave][e] = slot0 + i * kWave + lane;
+      s_pos[wave][e] = pos;
+    }
+    n_act += __popcll(act[i]);
+  }
+  wave_lds_fence();
+  const int items = n_act * Q;
+  for (int it = lane; it < items; it += kWave) {
+    const int e = it / Q, part = it - e * Q;
+    const long long src = s_slot[wave][e];
+    const float4 r0 = rec[2 * src];
+    float4 o;
+    if (part == 0) {
+      o = make_float4(r0.x, r0.y, r0.z, 0.0f);
+    } else {
+      const float4 r1 = rec[2 * src + 1];
+      const float graw[4] = {r1.x, r1.y, r1.z, r0.w * rho};  // colour 3 = density
+      const float* yb = ray_basis + (long long)__float_as_int(r1.w) * 16;
+      float v[4];
+#pragma unroll
+      for (int x = 0; x < 4; ++x) {
+        const int ch = 4 * (part - 1) + x;
+        int colour, basis_k;
+        lds_channel_meaning<K>(ch < C ? ch : 0, colour, basis_k);
+        float gv = graw[colour];
+        if (ch > 0) gv = gv * ((diffuse || basis_k == 0) ? kC0 : yb[basis_k]);
+        if (ch >= C || (diffuse && ch >= 4)) gv = 0.0f;
+        v[x] = gv;
+      }
+      o = make_float4(v[0], v[1], v[2], v[3]);
+    }
+    out[(long long)s_pos[wave][e] * Q + part] = o;
   }
 }
 
@@ -2061,7 +2217,7 @@ static int brick_geometry(const RFGrid* grid, int brick_size, int* shift, int nb
 
 int rf_render_backward_emit(const RFGrid* grid, const RFRayBatch* rays, uint32_t flags, const RFRenderOut* fwd,
                             const RFRenderGrads* grads, int32_t brick_size, int16_t* keys_dev, float* records_dev,
-                            float* ray_basis_dev, void* stream) {
+                            float* ray_basis_dev, int32_t* hist_dev, void* stream) {
   if (!grid) return RF_ERR_NULL_POINTER;
   if (!keys_dev || !records_dev) return RF_ERR_NULL_POINTER;
   int shift, nb[3];
@@ -2074,6 +2230,7 @@ int rf_render_backward_emit(const RFGrid* grid, const RFRayBatch* rays, uint32_t
   gr.brick_shift = shift;
   gr.nby = nb[1];
   gr.nbz = nb[2];
+  gr.hist = hist_dev;
   return backward_impl(grid, rays, flags, fwd, grads, gr, stream);
 }
 
@@ -2108,6 +2265,48 @@ int rf_expand_records(const RFGrid* grid, const float* records_dev, const int64_
       return launch_expand<4>(records_dev, perm_dev, begin_dev, capacity, ray_basis_dev, diffuse, grid->density_scale, records_sorted_dev, st);
     default:
       return launch_expand<9>(records_dev, perm_dev, begin_dev, capacity, ray_basis_dev, diffuse, grid->density_scale, records_sorted_dev, st);
+  }
+}
+
+int rf_bin_offsets(const int32_t* hist_dev, int32_t num_keys, int64_t* offsets_dev, int32_t* cursor_dev, void* stream) {
+  if (!hist_dev || !offsets_dev || !cursor_dev) return RF_ERR_NULL_POINTER;
+  if (num_keys < 1 || num_keys > 32768) return RF_ERR_BAD_SHAPE;
+  hipLaunchKernelGGL(bin_offsets_kernel, dim3((num_keys + 1023) / 1024), dim3(1024), 0, (hipStream_t)stream, hist_dev, num_keys,
+                     reinterpret_cast<long long*>(offsets_dev), cursor_dev);
+  return launch_status();
+}
+
+extern "C++" {
+template <int K>
+static int launch_scatter(const int16_t* keys_dev, const float* records_dev, int64_t capacity, int32_t* cursor_dev,
+                          const float* ray_basis_dev, int diffuse, float rho, float* out, int32_t* hist_dev, int nkeys,
+                          hipStream_t st) {
+  hipLaunchKernelGGL((scatter_records_kernel<K>), dim3((unsigned)((capacity + 1023) / 1024)), dim3(256), 0, st, keys_dev,
+                     reinterpret_cast<const float4*>(records_dev), (long long)capacity, cursor_dev, ray_basis_dev, diffuse, rho,
+                     reinterpret_cast<float4*>(out), hist_dev, nkeys);
+  return launch_status();
+}
+}  // extern "C++"
+
+int rf_scatter_records(const RFGrid* grid, const int16_t* keys_dev, const float* records_dev, int64_t capacity,
+                       int32_t* cursor_dev, const float* ray_basis_dev, int32_t render_diffuse, float* records_sorted_dev,
+                       int32_t* hist_dev, int32_t num_keys, void* stream) {
+  const int rc = check_grid(grid);
+  if (rc != RF_OK) return rc;
+  if (capacity == 0) return RF_OK;
+  if (!keys_dev || !records_dev || !cursor_dev || !records_sorted_dev) return RF_ERR_NULL_POINTER;
+  if (capacity < 0) return RF_ERR_BAD_SHAPE;
+  if (grid->num_features > 27) return RF_ERR_UNSUPPORTED;
+  const int diffuse = render_diffuse || grid->num_features == 3;
+  if (!diffuse && !ray_basis_dev) return RF_ERR_NULL_POINTER;
+  hipStream_t st = (hipStream_t)stream;
+  switch (grid->num_features / 3) {
+    case 1:
+      return launch_scatter<1>(keys_dev, records_dev, capacity, cursor_dev, ray_basis_dev, diffuse, grid->density_scale, records_sorted_dev, hist_dev, num_keys, st);
+    case 4:
+      return launch_scatter<4>(keys_dev, records_dev, capacity, cursor_dev, ray_basis_dev, diffuse, grid->density_scale, records_sorted_dev, hist_dev, num_keys, st);
+    default:
+      return launch_scatter<9>(keys_dev, records_dev, capacity, cursor_dev, ray_basis_dev, diffuse, grid->density_scale, records_sorted_dev, hist_dev, num_keys, st);
   }
 }
 

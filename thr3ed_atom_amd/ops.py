@@ -181,8 +181,10 @@ def brick_counts(grid: VoxelGrid, brick_size: int) -> Tuple[int, int, int]:
 
 def render_backward_emit_raw(grid: VoxelGrid, origins: Tensor, directions: Tensor, t_rand: Optional[Tensor], num_samples: int,
                              near: float, far: float, flags: int, caches, g_colour: Optional[Tensor], g_depth: Optional[Tensor],
-                             g_acc: Optional[Tensor], brick_size: int, keys: Tensor, records: Tensor, ray_basis: Optional[Tensor]) -> None:
-    """Enqueue rf_render_backward_emit: per-sample gradient records + brick keys instead of a scatter."""
+                             g_acc: Optional[Tensor], brick_size: int, keys: Tensor, records: Tensor, ray_basis: Optional[Tensor],
+                             hist: Optional[Tensor] = None) -> None:
+    """Enqueue rf_render_backward_emit: per-sample gradient records + brick keys instead of a scatter; ``hist`` (int32
+    [8 * num_bricks], optional) is incremented by the number of records per key (for ``bin_records_by_brick``)."""
     lib = _lib.load()
     dev = origins.device
     rf_grid = grid.to_rf_grid(use_occupancy=bool(flags & _lib.FLAG_OCCUPANCY_SKIP))
@@ -195,7 +197,7 @@ def render_backward_emit_raw(grid: VoxelGrid, origins: Tensor, directions: Tenso
     with _span(f"render_backward_emit[{_variant(grid, flags)}]", dev):
         rc = lib.rf_render_backward_emit(
             C.byref(rf_grid), C.byref(rb), int(flags), C.byref(fwd), C.byref(grads), int(brick_size), keys.data_ptr(), records.data_ptr(),
-            _ptr(ray_basis), _stream(dev),
+            _ptr(ray_basis), _ptr(hist), _stream(dev),
         )
     _lib.check(rc, "rf_render_backward_emit")
 
@@ -222,6 +224,24 @@ def sort_records_by_brick(grid: VoxelGrid, keys: Tensor, records: Tensor, ray_ba
         rc = lib.rf_expand_records(C.byref(rf_grid), records.data_ptr(), perm.data_ptr(), offsets.data_ptr(), keys.numel(),
                                    _ptr(ray_basis), int(bool(render_diffuse)), records_sorted.data_ptr(), _stream(dev))
     _lib.check(rc, "rf_expand_records")
+    return offsets
+
+
+def bin_records_by_brick(grid: VoxelGrid, keys: Tensor, records: Tensor, ray_basis: Optional[Tensor], render_diffuse: bool,
+                         hist: Tensor, cursor: Tensor, records_sorted: Tensor, offsets: Tensor) -> Tensor:
+    """Counting sort instead of torch.sort: ``hist`` (filled by render_backward_emit_raw) -> ``offsets``
+    [8 * num_bricks + 1] (int64; positions start at 0) and ``cursor`` (int32 scratch); every keyed slot then takes the
+    next free position of its key class (atomic cursor) and its expanded record is written there.  ``hist`` is cleared."""
+    lib = _lib.load()
+    dev = keys.device
+    with _span("bin_offsets", dev):
+        rc = lib.rf_bin_offsets(hist.data_ptr(), int(hist.numel()), offsets.data_ptr(), cursor.data_ptr(), _stream(dev))
+    _lib.check(rc, "rf_bin_offsets")
+    rf_grid = grid.to_rf_grid()
+    with _span("scatter_records", dev):
+        rc = lib.rf_scatter_records(C.byref(rf_grid), keys.data_ptr(), records.data_ptr(), keys.numel(), cursor.data_ptr(),
+                                    _ptr(ray_basis), int(bool(render_diffuse)), records_sorted.data_ptr(), hist.data_ptr(), int(hist.numel()), _stream(dev))
+    _lib.check(rc, "rf_scatter_records")
     return offsets
 
 

@@ -35,6 +35,7 @@ from .ops import (
     cast_selected_rays_hip,
     render_backward_emit_raw,
     sort_records_by_brick,
+    bin_records_by_brick,
     expanded_record_floats,
     l1_loss_grad_hip,
     render_backward_raw,
@@ -132,7 +133,8 @@ class TrainStepper:
         data_parallel: bool = True,
         ray_selection: str = "keyed",
         fused: bool = True,
-        backward: str = "atomic",
+        backward: str = "auto",
+        deterministic: bool = False,
     ):
         """``ray_selection``: "randperm" draws torch.randperm over all B*H*W pixels exactly like the reference
         (utils/misc.py:123) and keeps the first ``ray_batch_size``; "keyed" draws the same kind of sample
@@ -146,12 +148,14 @@ class TrainStepper:
         # fused=False goes through torch.autograd like a user of render_rays would.  Same arithmetic either way.
         self.fused = bool(fused)
         self._grad_clean = True  # FlatGrid starts zero-filled
-        # backward="binned" (fused steps only, SH degree <= 2, EXPERIMENTAL): per-sample gradient records are sorted by
-        # 8^3-cell brick and summed in LDS before they reach memory.  Exact, but measured 1.8x slower than the direct
-        # atomic scatter on MI355X because LDS float atomics are no faster than global ones
-        if backward not in ("atomic", "binned"):
-            raise ValueError("backward must be 'atomic' or 'binned'")
-        self.backward = backward
+        # backward="binned" (fused steps only, SH degree <= 2, at most 4096 bricks): the specular pass writes per-sample
+        # gradient records, bins them by (8^3-node brick, boundary flags) and sums each brick in LDS without atomics
+        # (DESIGN.md section 4); the diffuse pass stays on the atomic scatter.  deterministic=True bins with a stable
+        # radix sort (fixed float32 summation order in the specular pass) instead of the faster counting sort.
+        # "auto" = binned where it was measured faster (fused step, SH degree 2, grid of at most 4096 bricks), else atomic.
+        if backward not in ("auto", "atomic", "binned"):
+            raise ValueError("backward must be 'auto', 'atomic' or 'binned'")
+        self.deterministic = bool(deterministic)
         self.brick_size = 8
         self._bins = None
         grid = vol_mod.thre3d_repr
@@ -165,6 +169,10 @@ class TrainStepper:
         self.data_parallel = data_parallel
         self.flat = FlatGrid(grid)
         self.optimizer = FusedAdam(self.flat, lr=learning_rate, betas=(0.9, 0.999))
+        if backward == "auto":
+            nb = brick_counts(grid, self.brick_size)
+            backward = "binned" if (self.fused and grid.sh_degree == 2 and nb[0] * nb[1] * nb[2] <= 4096) else "atomic"
+        self.backward = backward
 
     def select(self, dataset: PosedImagesInMemory, image_ids: Tensor):
         """Synchronous random subset of rays and pixels of the given images
@@ -245,9 +253,12 @@ class TrainStepper:
                 # corner) is cheaper through the atomic scatter than through the sort, and adds on top.
                 render_backward_emit_raw(
                     grid, origins, directions, t_rand, S, near, far, flags, caches, g_colour, None, None, self.brick_size,
-                    bins["keys"], bins["records"], bins["ray_basis"],
+                    bins["keys"], bins["records"], bins["ray_basis"], None if self.deterministic else bins["hist"],
                 )
-                offsets = sort_records_by_brick(grid, bins["keys"], bins["records"], bins["ray_basis"], False, bins["sorted"], bins["offsets"], bins["boundaries"])
+                if self.deterministic:  # stable 16-bit radix sort: fixed summation order
+                    offsets = sort_records_by_brick(grid, bins["keys"], bins["records"], bins["ray_basis"], False, bins["sorted"], bins["offsets"], bins["boundaries"])
+                else:  # counting sort with atomic cursors
+                    offsets = bin_records_by_brick(grid, bins["keys"], bins["records"], bins["ray_basis"], False, bins["hist"], bins["cursor"], bins["sorted"], bins["offsets"])
                 brick_accumulate_raw(grid, self.brick_size, [(bins["sorted"], offsets, False)], gd, gf, accumulate=False)
             else:
                 render_backward_raw(grid, origins, directions, t_rand, S, near, far, flags, caches, g_colour, None, None, gd, gf)
@@ -285,6 +296,8 @@ class TrainStepper:
                 "ray_basis": torch.zeros((n, 16), dtype=torch.float32, device=device),
                 "boundaries": torch.arange(num_bricks * 8, dtype=torch.int16, device=device),
                 "offsets": torch.full((num_bricks * 8 + 1,), n * S, dtype=torch.int64, device=device),
+                "hist": torch.zeros(num_bricks * 8, dtype=torch.int32, device=device),
+                "cursor": torch.empty(num_bricks * 8, dtype=torch.int32, device=device),
             }
             self._bins = b
         return b
