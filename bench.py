@@ -124,8 +124,8 @@ def cpu_baseline(grid, rays_cpu, pixels_cpu, num_samples, n_rays, threads=0):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=50)
-    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=50, help="untimed steps first (clocks and caches take ~50 steps to settle)")
     ap.add_argument("--grid", type=int, default=128)
     ap.add_argument("--sh-degree", type=int, default=2)
     ap.add_argument("--rays", type=int, default=16384, help="ray batch per GPU (reference CLI default)")
@@ -144,6 +144,7 @@ def main():
                     help="specular gradient scatter of the train step: float32 atomics, or records binned by brick + atomic-free "
                     "LDS accumulation (auto = binned where supported and measured faster)")
     ap.add_argument("--deterministic", action="store_true", help="binned backward: stable radix sort instead of the counting sort")
+    ap.add_argument("--timed-steps", type=int, default=10, help="how many of the --steps record per-kernel HIP events")
     ap.add_argument("--no-kernel-timer", action="store_true", help="do not record per-kernel HIP events in the timed region (no roofline object)")
     ap.add_argument("--cpu-threads", type=int, default=0, help="torch CPU threads for cpu_baseline (0 = all host cores)")
     args = ap.parse_args()
@@ -251,7 +252,7 @@ def main():
         stepper.step(dataset, next(batches))
     # HIP events are recorded on every `timer_stride`-th timed step only: hundreds of outstanding timing events
     # make the ROCm runtime stall for tens of ms now and then (measured: 2.0 -> 2.9 ms/step in some runs)
-    timer_stride = max(1, args.steps // 10)
+    timer_stride = max(1, args.steps // max(1, args.timed_steps))
     n_timed = 0 if args.no_kernel_timer else len(range(0, args.steps, timer_stride))
     timer = ops.KernelTimer(preallocate=12 * n_timed)
     if world > 1:

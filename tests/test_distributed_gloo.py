@@ -73,6 +73,17 @@ def _worker(rank, world, port, result_dir):
     b = torch.full((4,), float(rank))
     rfdist.broadcast_(b, src=0)
     assert torch.equal(b, torch.zeros(4))
+    # 4. sharded optimizer exchange (ZeRO stage 1): reduce-scatter(mean) -> every rank updates its own chunk only ->
+    #    all-gather of the chunks  ==  all-reduce(mean) followed by the full update on every rank
+    grad = torch.arange(96.0) * (rank + 1)
+    param = torch.zeros(96)
+    assert rfdist.can_shard(96) and not rfdist.can_shard(97) or world == 1
+    h = rfdist.reduce_scatter_mean_async(grad)
+    h.wait()
+    assert (h.hi - h.lo) * world == 96 and h.lo == rank * (96 // world)
+    param[h.lo : h.hi] -= 0.1 * h.shard
+    rfdist.all_gather_chunks_(param)
+    assert torch.allclose(param, -0.1 * torch.arange(96.0) * (sum(range(1, world + 1)) / world))
     open(os.path.join(result_dir, f"ok{rank}"), "w").write("ok")
     dist.destroy_process_group()
 
@@ -98,3 +109,7 @@ def test_single_process_helpers_are_noops():
     assert rfdist.world_size() == 1 and rfdist.rank() == 0
     assert torch.equal(rfdist.all_reduce_mean_(t.clone()), t)
     assert torch.equal(rfdist.all_gather_rows(t), t)
+    h = rfdist.reduce_scatter_mean_async(t)
+    h.wait()
+    assert (h.lo, h.hi) == (0, 5) and rfdist.can_shard(5)
+    assert torch.equal(rfdist.all_gather_chunks_(t.clone()), t)

@@ -1,6 +1,8 @@
 """Training-side parity on the GPU: the trainer core, the flat gradient bucket, fused Adam,
 PSNR after equal steps, exact empty-space skipping, checkpoints, and size-independent properties at the full
 BASELINE.json size.  All through the C ABI; the oracle / torch references are the checkers only."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -500,9 +502,10 @@ def test_data_parallel_overlap_wiring(hip_device, monkeypatch):
         grid = relu_grid(hip_device, T(hash_uniform((G, G, G, 1), 901)), T(hash_uniform((G, G, G, F), 900 + F)), G, storage="split")
         cfg = rf.SHVoxGridRenderConfig(S, rf.CameraBounds(float(g["near"]), float(g["far"])), perturb_sampled_points=False, white_bkgd=True)
         model = rf.VolumetricModel(grid, rf.render_sh_voxel_grid, cfg, device=hip_device)
-        stepper = TrainStepper(model, n_rays, learning_rate=float(g["lr"]))
+        stepper = TrainStepper(model, n_rays, learning_rate=float(g["lr"]), shard_optimizer=False)
         if dp:
             monkeypatch.setattr(rfdist, "world_size", lambda: 2)
+            monkeypatch.setattr(rfdist, "_collectives_on", lambda: True)
             monkeypatch.setattr(rfdist, "all_reduce_mean_async", fake_async)
         for it in range(2):
             rays = rf.Rays(T(g["origins"][it]).to(hip_device), T(g["directions"][it]).to(hip_device))
@@ -515,3 +518,93 @@ def test_data_parallel_overlap_wiring(hip_device, monkeypatch):
     per_step = [("async", second.numel(), second.data_ptr()), ("async", first.numel(), first.data_ptr()), "wait", "wait"]
     assert calls == per_step * 2
     assert first.numel() == G**3 * 4 and second.numel() == G**3 * (F - 3)
+
+
+def test_data_parallel_sharded_optimizer_wiring(hip_device, monkeypatch):
+    """Default data-parallel step (ZeRO stage 1): `rest` is reduce-scattered right after the specular backward, `base`
+    after the diffuse backward, Adam runs on this rank's chunk of each only, and the updated chunks are all-gathered.
+    With stand-in collectives for rank 0 of 2 (identity reduce = averaging identical replicas; all-gather delivers
+    nothing) the own chunks must equal the single-process step and the other chunks must still hold their old values."""
+    from thr3ed_atom_amd import distributed as rfdist
+
+    g = load_golden("g9_trainer_trajectory.npz")
+    G, deg, hw, n_img, n_rays, steps, S = (int(v) for v in g["config"])
+    F = 3 * (deg + 1) ** 2
+    calls = []
+
+    class Handle:
+        def __init__(self, bucket):
+            self.lo, self.hi = 0, bucket.numel() // 2
+            self.shard = bucket[: self.hi]
+
+        def wait(self):
+            calls.append("wait")
+
+    def fake_reduce_scatter(bucket):
+        calls.append(("reduce_scatter", bucket.numel()))
+        return Handle(bucket)
+
+    def fake_all_gather(bucket):
+        calls.append(("all_gather", bucket.numel()))
+        return bucket
+
+    out = []
+    for dp in (False, True):
+        grid = relu_grid(hip_device, T(hash_uniform((G, G, G, 1), 901)), T(hash_uniform((G, G, G, F), 900 + F)), G, storage="split")
+        cfg = rf.SHVoxGridRenderConfig(S, rf.CameraBounds(float(g["near"]), float(g["far"])), perturb_sampled_points=False, white_bkgd=True)
+        model = rf.VolumetricModel(grid, rf.render_sh_voxel_grid, cfg, device=hip_device)
+        stepper = TrainStepper(model, n_rays, learning_rate=float(g["lr"]))
+        before = stepper.flat.flat_param.clone()
+        if dp:
+            monkeypatch.setattr(rfdist, "world_size", lambda: 2)
+            monkeypatch.setattr(rfdist, "_collectives_on", lambda: True)
+            monkeypatch.setattr(rfdist, "reduce_scatter_mean_async", fake_reduce_scatter)
+            monkeypatch.setattr(rfdist, "all_gather_chunks_", fake_all_gather)
+        rays = rf.Rays(T(g["origins"][0]).to(hip_device), T(g["directions"][0]).to(hip_device))
+        stepper.step_on(rays, T(g["pixels"][0]).to(hip_device))
+        out.append((before, stepper.flat.flat_param.clone()))
+    monkeypatch.undo()
+    (before, full), (_, mine) = out
+    nd, nr = G**3 * 4, G**3 * (F - 3)
+    own = torch.zeros(nd + nr, dtype=torch.bool, device=full.device)
+    own[: nd // 2] = True
+    own[nd : nd + nr // 2] = True
+    assert float((full - before).abs().max()) > 0
+    assert torch.allclose(mine[own], full[own], atol=1e-6) and torch.equal(mine[~own], before[~own])
+    assert calls == [("reduce_scatter", nr), ("reduce_scatter", nd), "wait", "wait", ("all_gather", nr), ("all_gather", nd)]
+
+
+@pytest.mark.parametrize("shard_optimizer", [True, False])
+def test_data_parallel_step_through_rccl_single_rank(hip_device, shard_optimizer):
+    """The data-parallel train step with its collectives really going through RCCL (a process group of ONE rank on this
+    GPU: reduce_scatter_tensor / all_gather_into_tensor / asynchronous all_reduce with ReduceOp.AVG) must equal the
+    plain step.  (Multi-rank semantics are covered by the gloo tests; 2/4/8-GPU runs are the driver's.)"""
+    import torch.distributed as dist
+    from thr3ed_atom_amd import distributed as rfdist
+
+    g = load_golden("g9_trainer_trajectory.npz")
+    G, deg, hw, n_img, n_rays, steps, S = (int(v) for v in g["config"])
+    F = 3 * (deg + 1) ** 2
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29541")
+    created = not dist.is_initialized()
+    if created:
+        dist.init_process_group(backend="nccl", rank=0, world_size=1)
+    try:
+        out = []
+        for dp in (False, True):
+            rfdist.FORCE_COLLECTIVES = dp
+            grid = relu_grid(hip_device, T(hash_uniform((G, G, G, 1), 901)), T(hash_uniform((G, G, G, F), 900 + F)), G, storage="split")
+            cfg = rf.SHVoxGridRenderConfig(S, rf.CameraBounds(float(g["near"]), float(g["far"])), perturb_sampled_points=False, white_bkgd=True)
+            model = rf.VolumetricModel(grid, rf.render_sh_voxel_grid, cfg, device=hip_device)
+            stepper = TrainStepper(model, n_rays, learning_rate=float(g["lr"]), shard_optimizer=shard_optimizer)
+            for it in range(2):
+                rays = rf.Rays(T(g["origins"][it]).to(hip_device), T(g["directions"][it]).to(hip_device))
+                stepper.step_on(rays, T(g["pixels"][it]).to(hip_device))
+            out.append(stepper.flat.flat_param.clone())
+        torch.cuda.synchronize()
+        assert torch.allclose(out[0], out[1], atol=1e-6)
+    finally:
+        rfdist.FORCE_COLLECTIVES = False
+        if created:
+            dist.destroy_process_group()

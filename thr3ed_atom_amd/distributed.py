@@ -2,9 +2,11 @@
 
 The reference has no distributed code at all (single process, single device).  Rays are independent, so
 the path shards naturally: every rank renders its own ray batch against a replicated grid; training adds
-exactly ONE exchange step per iteration -- an all-reduce (average) of the flat gradient bucket
-(``FlatGrid.flat_grad``: 234.9 MB at 128^3 / SH degree 2), after which every rank applies the identical
-Adam update, so parameters stay bit-identical replicas without ever being broadcast again.
+exactly ONE exchange per iteration over the flat gradient bucket (``FlatGrid.flat_grad``: 234.9 MB at 128^3 /
+SH degree 2): either an all-reduce (average) after which every rank applies the identical Adam update, or --
+the trainer's default -- its two halves around a SHARDED Adam (ZeRO stage 1): reduce-scatter of the gradients,
+every rank updates only its 1/N of the parameters, all-gather of the updated parameters.  Same bytes on the
+links, 1/N of the optimizer's 1.6 GB of HBM traffic per rank, and the replicas stay bit-identical either way.
 
 Backend "nccl" is RCCL on ROCm; "gloo" is used by the CPU tests of the collective wiring.
 """
@@ -47,7 +49,7 @@ def all_reduce_mean_(bucket: Tensor) -> Tensor:
     """In-place average of one flat bucket over all ranks (no-op for a world of 1).  One collective per
     training step; RCCL picks ring / direct over the xGMI mesh."""
     n = world_size()
-    if n > 1:
+    if _collectives_on():
         if dist.get_backend() == "nccl":
             # RCCL averages inside the collective: no extra 235 MB read+write pass for the 1/n scaling
             dist.all_reduce(bucket, op=dist.ReduceOp.AVG)
@@ -76,11 +78,80 @@ def all_reduce_mean_async(bucket: Tensor) -> _MeanHandle:
     stream after everything already enqueued on the current stream, i.e. concurrently with kernels launched
     afterwards -- used to reduce the ``rest`` gradients while the diffuse pass (which only touches ``base``) runs."""
     n = world_size()
-    if n == 1:
+    if not _collectives_on():
         return _MeanHandle(None, bucket, None)
     if dist.get_backend() == "nccl":
         return _MeanHandle(dist.all_reduce(bucket, op=dist.ReduceOp.AVG, async_op=True), bucket, None)
     return _MeanHandle(dist.all_reduce(bucket, op=dist.ReduceOp.SUM, async_op=True), bucket, 1.0 / n)
+
+
+class _ShardHandle:
+    """Completion handle of an asynchronous mean reduce-scatter; after ``wait()``, ``shard`` holds the averaged
+    elements [lo, hi) of the bucket -- the ones this rank is responsible for."""
+
+    def __init__(self, work, shard: Tensor, lo: int, hi: int, scale: Optional[float]):
+        self._work, self.shard, self.lo, self.hi, self._scale = work, shard, lo, hi, scale
+
+    def wait(self) -> None:
+        if self._work is not None:
+            self._work.wait()
+            if self._scale is not None:
+                self.shard.mul_(self._scale)
+            self._work = None
+
+
+# tests on a single GPU set this to push world-size-1 calls through RCCL as well (API / shape / aliasing checks)
+FORCE_COLLECTIVES = False
+
+
+def _collectives_on() -> bool:
+    return world_size() > 1 or (FORCE_COLLECTIVES and dist.is_available() and dist.is_initialized())
+
+
+def can_shard(numel: int) -> bool:
+    """Equal shards only (reduce_scatter_tensor / all_gather_into_tensor operate on equal chunks)."""
+    return numel % world_size() == 0
+
+
+def reduce_scatter_mean_async(bucket: Tensor, out: Optional[Tensor] = None) -> _ShardHandle:
+    """Start averaging ``bucket`` over all ranks such that rank r receives chunk r, into ``out`` (a separate buffer of
+    numel/N elements; allocated when not given).  Half the traffic of an all-reduce; the other half is the all-gather
+    of the updated parameters (``all_gather_chunks_``) after every rank has applied the optimizer to its own chunk
+    only (ZeRO stage 1)."""
+    n = world_size()
+    if not _collectives_on():
+        return _ShardHandle(None, bucket, 0, bucket.numel(), None)
+    assert bucket.numel() % n == 0
+    chunk = bucket.numel() // n
+    lo = rank() * chunk
+    if out is None:
+        out = torch.empty(chunk, dtype=bucket.dtype, device=bucket.device)
+    assert out.numel() == chunk
+    if dist.get_backend() == "nccl":
+        work = dist.reduce_scatter_tensor(out, bucket, op=dist.ReduceOp.AVG, async_op=True)
+        return _ShardHandle(work, out, lo, lo + chunk, None)
+    # gloo has no reduce-scatter: reduce everything, keep the own chunk (CPU tests of the wiring)
+    dist.all_reduce(bucket, op=dist.ReduceOp.SUM)
+    out.copy_(bucket[lo : lo + chunk])
+    return _ShardHandle(None, out.mul_(1.0 / n), lo, lo + chunk, None)
+
+
+def all_gather_chunks_(bucket: Tensor) -> Tensor:
+    """Every rank contributes chunk r of ``bucket`` and receives all the others (in ``bucket``)."""
+    n = world_size()
+    if _collectives_on():
+        assert bucket.numel() % n == 0
+        chunk = bucket.numel() // n
+        lo = rank() * chunk
+        mine = bucket[lo : lo + chunk].clone()  # separate send buffer: no aliasing with the receive buffer
+        if dist.get_backend() == "nccl":
+            dist.all_gather_into_tensor(bucket, mine)
+        else:
+            parts = [torch.empty(chunk, dtype=bucket.dtype, device=bucket.device) for _ in range(n)]
+            dist.all_gather(parts, mine)
+            for r, part in enumerate(parts):
+                bucket[r * chunk : (r + 1) * chunk].copy_(part)
+    return bucket
 
 
 def broadcast_(tensor: Tensor, src: int = 0) -> Tensor:

@@ -98,13 +98,21 @@ class FusedAdam:
         self.flat.zero_grad()
 
     @torch.no_grad()
-    def step(self, zero_grad: bool = False) -> None:
-        """``zero_grad=True`` clears the gradient bucket in the same pass (saves the separate 235 MB memset)."""
+    def step(self, zero_grad: bool = False, ranges=None) -> None:
+        """``zero_grad=True`` clears the gradient bucket in the same pass.  ``ranges`` = [(lo, hi, grad), ...] restricts
+        the update to those slices of the flat buffer, with the (averaged) gradients of each slice given separately
+        (sharded data-parallel optimizer: the moments of the other slices stay untouched on this rank, their
+        parameters arrive by all-gather)."""
         self.step_count += 1
-        adam_step_hip(
-            self.flat.flat_param, self.flat.flat_grad, self.exp_avg, self.exp_avg_sq,
-            self.lr, self.betas[0], self.betas[1], self.eps, self.step_count, zero_grad,
-        )
+        if ranges is None:
+            ranges = [(0, self.flat.flat_param.numel(), self.flat.flat_grad)]
+        for lo, hi, grad in ranges:
+            if hi > lo:
+                assert grad.numel() == hi - lo
+                adam_step_hip(
+                    self.flat.flat_param[lo:hi], grad, self.exp_avg[lo:hi], self.exp_avg_sq[lo:hi],
+                    self.lr, self.betas[0], self.betas[1], self.eps, self.step_count, zero_grad,
+                )
 
 
 class ExponentialLR:

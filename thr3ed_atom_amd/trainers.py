@@ -135,6 +135,7 @@ class TrainStepper:
         fused: bool = True,
         backward: str = "auto",
         deterministic: bool = False,
+        shard_optimizer: bool = True,
     ):
         """``ray_selection``: "randperm" draws torch.randperm over all B*H*W pixels exactly like the reference
         (utils/misc.py:123) and keeps the first ``ray_batch_size``; "keyed" draws the same kind of sample
@@ -156,6 +157,8 @@ class TrainStepper:
         if backward not in ("auto", "atomic", "binned"):
             raise ValueError("backward must be 'auto', 'atomic' or 'binned'")
         self.deterministic = bool(deterministic)
+        # data parallel: every rank runs Adam on 1/N of the grid only (ZeRO stage 1) -- see _fused_step_on
+        self.shard_optimizer = bool(shard_optimizer)
         self.brick_size = 8
         self._bins = None
         grid = vol_mod.thre3d_repr
@@ -235,10 +238,11 @@ class TrainStepper:
         sums = torch.zeros(4, dtype=torch.float32, device=origins.device)
         # data parallel: with split storage the diffuse pass only touches `base`, so the all-reduce of the `rest`
         # gradients (201 of the 235 MB at degree 2) starts right after the specular backward and overlaps it
-        overlap = (
-            self.data_parallel and rfdist.world_size() > 1 and self.diffuse
-            and grid.storage == "split" and gf is not None
-        )
+        dp = self.data_parallel and rfdist._collectives_on()
+        overlap = dp and self.diffuse and grid.storage == "split" and gf is not None
+        # ... and with equal chunks the exchange is split around a sharded Adam (reduce-scatter | update 1/N | all-gather)
+        sharded = overlap and self.shard_optimizer and rfdist.can_shard(gd.numel()) and rfdist.can_shard(gf.numel())
+        reduce_async = rfdist.reduce_scatter_mean_async if sharded else rfdist.all_reduce_mean_async
         pending = []
         for i, diffuse in enumerate((False, True) if self.diffuse else (False,)):
             t_rand = torch.rand(n, S, dtype=torch.float32, device=origins.device) if cfg.perturb_sampled_points else None
@@ -263,16 +267,25 @@ class TrainStepper:
             else:
                 render_backward_raw(grid, origins, directions, t_rand, S, near, far, flags, caches, g_colour, None, None, gd, gf)
             if overlap and i == 0:
-                pending.append(rfdist.all_reduce_mean_async(self.flat.flat_gradient_parts()[1]))
+                pending.append(reduce_async(self.flat.flat_gradient_parts()[1]))
         self._grad_clean = False
         if overlap:
-            pending.append(rfdist.all_reduce_mean_async(self.flat.flat_gradient_parts()[0]))
+            pending.append(reduce_async(self.flat.flat_gradient_parts()[0]))
             for handle in pending:
                 handle.wait()
-        elif self.data_parallel:
+        elif dp:
             rfdist.all_reduce_mean_(self.flat.flat_grad)
         # (clearing the bucket inside the Adam kernel measured slower than a separate memset: 0.37 vs 0.28 + 0.05 ms)
-        self.optimizer.step()
+        if sharded:
+            # ZeRO stage 1: this rank holds the averaged gradients of one chunk of `rest` and one of `base`; it updates
+            # only those parameters, then the chunks are exchanged
+            nd = self.flat.flat_gradient_parts()[0].numel()
+            rest_h, base_h = pending
+            self.optimizer.step(ranges=[(base_h.lo, base_h.hi, base_h.shard), (nd + rest_h.lo, nd + rest_h.hi, rest_h.shard)])
+            rfdist.all_gather_chunks_(self.flat.flat_param[nd:])
+            rfdist.all_gather_chunks_(self.flat.flat_param[:nd])
+        else:
+            self.optimizer.step()
         self._grad_clean = False
         means = sums / float(3 * n)
         return StepStats(means[0], means[2] if self.diffuse else None, means[1], means[3] if self.diffuse else None)
