@@ -27,7 +27,7 @@ def main():
     counters = sorted({c for k in agg.values() for c in k})
     print("| kernel | launches | " + " | ".join(f"{c} avg/launch" for c in counters) + " |")
     print("|---|---:|" + "---:|" * len(counters))
-    keep = [k for k in agg if k.startswith("render_") or k.startswith("brick_") or k in ("adam_kernel",)]
+    keep = [k for k in agg if k.startswith(("render_", "brick_", "scatter_", "expand_", "bin_")) or k in ("adam_kernel",)]
     for k in sorted(keep):
         n = max(len(v) for v in agg[k].values())
         cells = []
