@@ -373,7 +373,7 @@ def main():
             "parallelism": f"dp{world}",
             "grid_storage": args.storage,
             "ray_selection": args.ray_selection,
-            "backward": stepper.backward + ("+atomic diffuse pass" if stepper.backward == "binned" else ""),
+            "backward": stepper.backward,
         },
         "rays_per_s": world * 2 * R * args.steps / elapsed,
         "final_specular_psnr": stats.psnr()["specular_psnr"],

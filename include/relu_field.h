@@ -182,11 +182,13 @@ int rf_render_backward(const RFGrid* grid, const RFRayBatch* rays, uint32_t flag
  *     that touch them (its own brick's and, per flags, up to 7 lower neighbours'), sums them in LDS with plain
  *     read-add-writes (each wavefront owns a disjoint channel group, so nothing races and no LDS atomics are
  *     needed) and writes the brick with plain coalesced stores: accumulate = 0 overwrites EVERY element of the
- *     gradient tensors (no zero-fill needed), accumulate = 1 adds.  Up to two record lists (specular lists first)
- *     are folded in one pass.  SH degree <= 2.  The sum order is fixed by the (stable) sort: results are run-to-run
- *     deterministic, unlike the atomic scatter. */
+ *     gradient tensors (no zero-fill needed), accumulate = 1 adds.  Up to two record lists of the same kind are
+ *     folded in one pass.  SH degree <= 2.  Lists of a render_diffuse pass carry the 4 base channels only (records of
+ *     rf_expanded_record_floats(3) = 8 floats, whatever the grid's degree): their bricks need 8 KB of LDS instead of
+ *     60 and only density + degree-0 gradients are written (with accumulate = 0: only THOSE are overwritten).  With
+ *     the sort of step (2) the sum order is fixed: results are run-to-run deterministic, unlike the atomic scatter. */
 typedef struct RFBrickList {
-  const float* records_sorted_dev; /* [capacity, rf_expanded_record_floats(F)]      */
+  const float* records_sorted_dev; /* [capacity, rf_expanded_record_floats(F)] (diffuse: F = 3) */
   const int64_t* offsets_dev;      /* [8 * nbricks + 1] start of each (brick, flags) class */
   int32_t render_diffuse;          /* records come from a render_diffuse pass       */
 } RFBrickList;

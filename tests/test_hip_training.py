@@ -399,11 +399,11 @@ def _binned_gradients(grid, rays, cfg, target, device, diffuse_too=True, accumul
         g_colour = O.l1_loss_grad_hip(colour, target, sums[2 * i : 2 * i + 2])
         keys = torch.empty(n * S, dtype=torch.int16, device=device)
         rec = torch.empty((n * S, 8), device=device)
-        srt = torch.empty((n * S, O.expanded_record_floats(grid)), device=device)
+        is_diffuse = diffuse or cfg.render_diffuse
+        srt = torch.empty((n * S, O.expanded_record_floats(grid, is_diffuse)), device=device)
         hist = torch.zeros(num_bricks * 8, dtype=torch.int32, device=device) if binning == "count" else None
         O.render_backward_emit_raw(grid, o, d, None, S, near, far, flags, caches, g_colour, None, None, 8, keys, rec, None if diffuse else ray_basis, hist)
         offsets = torch.full((num_bricks * 8 + 1,), n * S, dtype=torch.int64, device=device)
-        is_diffuse = diffuse or cfg.render_diffuse
         if binning == "count":
             cursor = torch.empty(num_bricks * 8, dtype=torch.int32, device=device)
             O.bin_records_by_brick(grid, keys, rec, None if is_diffuse else ray_basis, is_diffuse, hist, cursor, srt, offsets)
@@ -412,9 +412,12 @@ def _binned_gradients(grid, rays, cfg, target, device, diffuse_too=True, accumul
             O.sort_records_by_brick(grid, keys, rec, None if is_diffuse else ray_basis, is_diffuse, srt, offsets, boundaries)
         lists.append((srt, offsets, diffuse or cfg.render_diffuse))
         keep.append((keys, rec, caches))
-    O.brick_accumulate_raw(grid, 8, lists, gd, gf, accumulate=accumulate)
+    # the specular list first (it writes every channel), the diffuse list (base channels only) on top
+    for k, one in enumerate(lists):
+        O.brick_accumulate_raw(grid, 8, [one], gd, gf, accumulate=accumulate or k > 0)
     if accumulate:  # adding the same lists once more doubles the result
-        O.brick_accumulate_raw(grid, 8, lists, gd, gf, accumulate=True)
+        for one in lists:
+            O.brick_accumulate_raw(grid, 8, [one], gd, gf, accumulate=True)
         gd.mul_(0.5)
         if gf is not None:
             gf.mul_(0.5)

@@ -1061,6 +1061,7 @@ struct BrickArgs {
   int shift;               // log2(B)
   int nbx, nby, nbz;
   int accumulate;          // 0: grad = brick sum (no zero-fill needed), 1: grad += brick sum
+  int fmul;                // reference layout: feature index of degree-0 colour c is c * fmul (base-only lists on an SH grid)
 };
 
 // LDS channel order of a node ("split order"): 0 = density, 1..3 = degree-0 R,G,B, 4 + r = rest channel r
@@ -1500,7 +1501,7 @@ __global__ __launch_bounds__(kBrickThreads) void brick_accumulate_kernel(GridArg
 
   // ---- write the brick out: plain stores (exclusive owner), contiguous runs along z
   const bool split = g.layout == RF_LAYOUT_SPLIT;
-  if (split && (C & 3) == 0 && (g.dstride & 3) == 0 && (g.fstride & 3) == 0 && !a.accumulate) {
+  if (split && (C & 3) == 0 && (g.dstride & 3) == 0 && (C == 4 || (g.fstride & 3) == 0)) {
     // split layout, whole float4s: base [X,Y,Z,4] = channels 0..3 of a node, rest [X,Y,Z,C-4] = channels 4..C-1
     constexpr int QN = C / 4;  // float4s per node
     constexpr int QR = QN > 1 ? QN - 1 : 1;
@@ -1521,9 +1522,19 @@ __global__ __launch_bounds__(kBrickThreads) void brick_accumulate_kernel(GridArg
           const float dv = g.dens[lin * g.dstride] * g.rho;
           v.x = (dv > 0.f) ? v.x : ((dv < 0.f) ? -v.x : 0.0f);
         }
-        *reinterpret_cast<float4*>(gdens + lin * g.dstride) = v;
+        float4* dst = reinterpret_cast<float4*>(gdens + lin * g.dstride);
+        if (a.accumulate) {
+          const float4 o = *dst;
+          v = make_float4(o.x + v.x, o.y + v.y, o.z + v.z, o.w + v.w);
+        }
+        *dst = v;
       } else {
-        *reinterpret_cast<float4*>(gfeat + lin * g.fstride + 4 * (qd - 1)) = v;
+        float4* dst = reinterpret_cast<float4*>(gfeat + lin * g.fstride + 4 * (qd - 1));
+        if (a.accumulate) {
+          const float4 o = *dst;
+          v = make_float4(o.x + v.x, o.y + v.y, o.z + v.z, o.w + v.w);
+        }
+        *dst = v;
       }
     }
     return;
@@ -1557,7 +1568,7 @@ __global__ __launch_bounds__(kBrickThreads) void brick_accumulate_kernel(GridArg
         const float dv = g.dens[lin * g.dstride] * g.rho;
         v = (dv > 0.f) ? v : ((dv < 0.f) ? -v : 0.0f);
       }
-      float* dst = out + lin * ostride + c2;
+      float* dst = out + lin * ostride + (long long)c2 * (pass == 1 && !split ? a.fmul : 1);
       *dst = a.accumulate ? (*dst + v) : v;
     }
   }
@@ -2258,7 +2269,7 @@ int rf_expand_records(const RFGrid* grid, const float* records_dev, const int64_
   const int diffuse = render_diffuse || grid->num_features == 3;
   if (!diffuse && !ray_basis_dev) return RF_ERR_NULL_POINTER;
   hipStream_t st = (hipStream_t)stream;
-  switch (grid->num_features / 3) {
+  switch (diffuse ? 1 : grid->num_features / 3) {  // diffuse lists carry the 4 base channels only
     case 1:
       return launch_expand<1>(records_dev, perm_dev, begin_dev, capacity, ray_basis_dev, diffuse, grid->density_scale, records_sorted_dev, st);
     case 4:
@@ -2300,7 +2311,7 @@ int rf_scatter_records(const RFGrid* grid, const int16_t* keys_dev, const float*
   const int diffuse = render_diffuse || grid->num_features == 3;
   if (!diffuse && !ray_basis_dev) return RF_ERR_NULL_POINTER;
   hipStream_t st = (hipStream_t)stream;
-  switch (grid->num_features / 3) {
+  switch (diffuse ? 1 : grid->num_features / 3) {  // diffuse lists carry the 4 base channels only
     case 1:
       return launch_scatter<1>(keys_dev, records_dev, capacity, cursor_dev, ray_basis_dev, diffuse, grid->density_scale, records_sorted_dev, hist_dev, num_keys, st);
     case 4:
@@ -2349,7 +2360,9 @@ int rf_brick_accumulate(const RFGrid* grid, int32_t brick_size, const RFBrickLis
     a.lists[i].offsets = reinterpret_cast<const long long*>(lists[i].offsets_dev);
     a.lists[i].diffuse = lists[i].render_diffuse || grid->num_features == 3;
   }
-  if (num_lists == 2 && a.lists[0].diffuse && !a.lists[1].diffuse) return RF_ERR_BAD_SHAPE;  // specular lists first
+  if (num_lists == 2 && a.lists[0].diffuse != a.lists[1].diffuse) return RF_ERR_BAD_SHAPE;  // record formats differ
+  const int base_only = a.lists[0].diffuse;  // 4 accumulator channels per node, written to the base channels only
+  a.fmul = base_only ? grid->num_features / 3 : 1;
   a.shift = shift;
   a.nbx = nb[0];
   a.nby = nb[1];
@@ -2358,7 +2371,7 @@ int rf_brick_accumulate(const RFGrid* grid, int32_t brick_size, const RFBrickLis
   const GridArgs g = to_args(grid);
   const int nbricks = nb[0] * nb[1] * nb[2];
   hipStream_t st = (hipStream_t)stream;
-  switch (grid->num_features / 3) {
+  switch (base_only ? 1 : grid->num_features / 3) {
     case 1:
       return launch_brick<1>(g, a, nbricks, grad_densities_dev, grad_features_dev, st);
     case 4:

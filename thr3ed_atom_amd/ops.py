@@ -202,9 +202,9 @@ def render_backward_emit_raw(grid: VoxelGrid, origins: Tensor, directions: Tenso
     _lib.check(rc, "rf_render_backward_emit")
 
 
-def expanded_record_floats(grid: VoxelGrid) -> int:
-    """floats per record in the sorted, expanded list consumed by rf_brick_accumulate"""
-    return int(_lib.load().rf_expanded_record_floats(int(grid.num_features)))
+def expanded_record_floats(grid: VoxelGrid, render_diffuse: bool = False) -> int:
+    """floats per record in the sorted, expanded list consumed by rf_brick_accumulate (diffuse passes: base channels only)"""
+    return int(_lib.load().rf_expanded_record_floats(3 if render_diffuse else int(grid.num_features)))
 
 
 def sort_records_by_brick(grid: VoxelGrid, keys: Tensor, records: Tensor, ray_basis: Optional[Tensor], render_diffuse: bool,

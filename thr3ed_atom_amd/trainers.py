@@ -149,10 +149,10 @@ class TrainStepper:
         # fused=False goes through torch.autograd like a user of render_rays would.  Same arithmetic either way.
         self.fused = bool(fused)
         self._grad_clean = True  # FlatGrid starts zero-filled
-        # backward="binned" (fused steps only, SH degree <= 2, at most 4096 bricks): the specular pass writes per-sample
-        # gradient records, bins them by (8^3-node brick, boundary flags) and sums each brick in LDS without atomics
-        # (DESIGN.md section 4); the diffuse pass stays on the atomic scatter.  deterministic=True bins with a stable
-        # radix sort (fixed float32 summation order in the specular pass) instead of the faster counting sort.
+        # backward="binned" (fused steps only, SH degree <= 2, at most 4096 bricks): both passes write per-sample
+        # gradient records, bin them by (8^3-node brick, boundary flags) and sum each brick in LDS without atomics
+        # (DESIGN.md section 4).  deterministic=True bins with a stable radix sort (fixed float32 summation order, run-to-run
+        # bit-identical gradients) instead of the faster counting sort.
         # "auto" = binned where it was measured faster (fused step, SH degree 2, grid of at most 4096 bricks), else atomic.
         if backward not in ("auto", "atomic", "binned"):
             raise ValueError("backward must be 'auto', 'atomic' or 'binned'")
@@ -251,19 +251,21 @@ class TrainStepper:
             flags = render_flags(cfg.white_bkgd, diffuse, cfg.optimized_sampling, cfg.use_occupancy_mask)
             colour, _, _, _, caches = render_forward_raw(grid, origins, directions, t_rand, S, near, far, flags, save=True)
             g_colour = l1_loss_grad_hip(colour, pixels, sums[2 * i : 2 * i + 2])
-            if binned and not diffuse:
-                # specular pass (28 channels per node): records -> 16-bit sort -> exclusive node bricks, plain stores that
-                # overwrite the whole bucket (no zero-fill).  The diffuse pass (4 channels = one 16-byte sector per
-                # corner) is cheaper through the atomic scatter than through the sort, and adds on top.
+            if binned:
+                # per-sample gradient records -> binned by (8^3-node brick, boundary flags) -> every brick summed in LDS
+                # without atomics and written with plain stores.  The specular pass overwrites the whole bucket (no
+                # zero-fill); the diffuse pass carries the 4 base channels only and adds on top.  Both reuse the same
+                # scratch buffers (stream order).
                 render_backward_emit_raw(
                     grid, origins, directions, t_rand, S, near, far, flags, caches, g_colour, None, None, self.brick_size,
-                    bins["keys"], bins["records"], bins["ray_basis"], None if self.deterministic else bins["hist"],
+                    bins["keys"], bins["records"], None if diffuse else bins["ray_basis"], None if self.deterministic else bins["hist"],
                 )
+                basis = None if diffuse else bins["ray_basis"]
                 if self.deterministic:  # stable 16-bit radix sort: fixed summation order
-                    offsets = sort_records_by_brick(grid, bins["keys"], bins["records"], bins["ray_basis"], False, bins["sorted"], bins["offsets"], bins["boundaries"])
+                    offsets = sort_records_by_brick(grid, bins["keys"], bins["records"], basis, diffuse, bins["sorted"], bins["offsets"], bins["boundaries"])
                 else:  # counting sort with atomic cursors
-                    offsets = bin_records_by_brick(grid, bins["keys"], bins["records"], bins["ray_basis"], False, bins["hist"], bins["cursor"], bins["sorted"], bins["offsets"])
-                brick_accumulate_raw(grid, self.brick_size, [(bins["sorted"], offsets, False)], gd, gf, accumulate=False)
+                    offsets = bin_records_by_brick(grid, bins["keys"], bins["records"], basis, diffuse, bins["hist"], bins["cursor"], bins["sorted"], bins["offsets"])
+                brick_accumulate_raw(grid, self.brick_size, [(bins["sorted"], offsets, diffuse)], gd, gf, accumulate=diffuse)
             else:
                 render_backward_raw(grid, origins, directions, t_rand, S, near, far, flags, caches, g_colour, None, None, gd, gf)
             if overlap and i == 0:
