@@ -1260,10 +1260,10 @@ __global__ __launch_bounds__(256) void scatter_records_kernel(const short* __res
 // 8-byte accesses halve the LDS instructions per record.
 // Records are sorted by key = cell-brick * 8 + flags, so the records of a source brick that reach into this brick
 // (flags superset of the offset) are a handful of contiguous ranges: no record is read that does not contribute.
-// Waves 2 and 3 are producers: per batch of 32 records, 8 threads per record build a table row (corner address +
-// weight per corner, the record's per-channel values, its packed cell) one batch ahead of the consumers, with the
-// global loads of the batch after that in flight; the consumers' loop is then 2 table reads, 2 multiplies and the
-// read-add-write.
+// Waves 2 and 3 are producers: per batch of 32 records, 8 lanes per record build a table row (corner address + weight
+// per corner, the record's per-channel values, its packed cell) one batch ahead of the consumers; the two waves
+// alternate batches, so that the global loads of a batch (several microseconds under load) have two accumulation
+// rounds to arrive.  The consumers' loop is then 2 table reads, 2 multiplies and the read-add-write.
 constexpr int kBrickThreads = 256;
 constexpr int kBrickBatch = 32;   // records per table (8 staging threads per record)
 constexpr int kMaxRanges = 28;    // 14 (source brick, flag run) ranges per list, two lists
@@ -1296,10 +1296,14 @@ __global__ __launch_bounds__(kBrickThreads) void brick_accumulate_kernel(GridArg
   constexpr int CS = C4;                       // node stride in the accumulator
   constexpr int PW = (CS / 2 + 1) / 2;         // channel pairs owned by each of the two accumulating waves (7 at degree 2)
   static_assert(PW <= 8 || K == 16, "a lane owns (corner, pair): 8 corners x up to 8 pairs");
-  constexpr int CELL = 16 + C4;                // table row: 8 x (corner address, corner weight), C4 channel values, cell
-  constexpr int ROW = (CELL + 1 + 3) / 4 * 4;  // rows stay 16-byte aligned
+  // table of a batch: one entry per STEP = the pair of records (j, j + 16), interleaved so that a consumer lane fetches
+  // both records' data with one 16-byte read: 8 x (addrA, wA, addrB, wB), then CS/2 x (gA.x, gA.y, gB.x, gB.y), then
+  // the two packed cells
+  constexpr int GOFF = 32;                        // words: start of the channel values of a step
+  constexpr int CELL = GOFF + 2 * C4;             // words: the two packed cells
+  constexpr int ROW = (CELL + 2 + 3) / 4 * 4;     // words per step, 16-byte aligned
   extern __shared__ __attribute__((aligned(16))) float acc[];  // node (x, y, z), channel c at x * SX + y * SY + z * CS + c
-  __shared__ __attribute__((aligned(16))) uint32_t table[2][(kBrickBatch + 1) * ROW];  // separate object: never aliases acc; + 1 spare row (prefetch)
+  __shared__ __attribute__((aligned(16))) uint32_t table[2][(kBrickBatch / 2 + 2) * ROW];  // separate object: never aliases acc; + 2 spare steps (prefetch)
   __shared__ long long s_rstart[kMaxRanges];
   __shared__ int s_rlist[kMaxRanges];
   __shared__ int s_rcum[kMaxRanges + 1];  // cumulative record counts of the non-empty ranges
@@ -1358,21 +1362,28 @@ __global__ __launch_bounds__(kBrickThreads) void brick_accumulate_kernel(GridArg
   const int nbatches = (total + kBrickBatch - 1) / kBrickBatch;
   constexpr int H = kBrickBatch / 2;
 
-  // ---- producer role (waves 2 and 3): 8 threads per record, two records (sj, sj + H) per thread; thread `part`
-  // prepares corner `part` and copies float4 `part` of the record
+  // ---- producer role (waves 2 and 3): wave 2 prepares the even batches, wave 3 the odd ones, so that the record loads
+  // of a batch have two whole accumulation rounds to arrive.  8 lanes per record (lane `part` prepares corner `part`
+  // and copies float4 `part` of the record), four records (sj + 8 t) per lane.
   const bool producer = wave >= 2;
-  const int sj = ((tid - 2 * kWave) >> 3) & (H - 1), part = tid & 7;
+  const int parity = wave & 1;
+  constexpr int TPL = kBrickBatch / 8;  // records per producer lane
+  const int sj = lane >> 3, part = lane & 7;
   const int pdx = (part >> 2) & 1, pdy = (part >> 1) & 1, pdz = part & 1;
   const int vpart = (part >= 1 && part < Q) ? part : 0;
-  int sri[2] = {0, 0};  // running range index of this thread's two record streams (they advance monotonically)
-  float4 ridx[2], rval[2];
-  ridx[0] = ridx[1] = rval[0] = rval[1] = make_float4(0.f, 0.f, 0.f, 0.f);
+  int sri[TPL];  // running range index of this lane's record streams (they advance monotonically)
+  float4 ridx[TPL], rval[TPL];
+#pragma unroll
+  for (int t = 0; t < TPL; ++t) {
+    sri[t] = 0;
+    ridx[t] = rval[t] = make_float4(0.f, 0.f, 0.f, 0.f);
+  }
 
   // -- issue the loads of batch bb (unconditional, clamped to the last record: no divergent register merges)
   auto issue = [&](int bb) {
 #pragma unroll
-    for (int t = 0; t < 2; ++t) {
-      const int v = min(bb * kBrickBatch + sj + t * H, total - 1);
+    for (int t = 0; t < TPL; ++t) {
+      const int v = min(bb * kBrickBatch + sj + 8 * t, total - 1);
       while (s_rcum[sri[t] + 1] <= v) ++sri[t];
       const long long pos = s_rstart[sri[t]] + (v - s_rcum[sri[t]]);
       const float4* rec = (s_rlist[sri[t]] ? a.lists[1].rec : a.lists[0].rec) + pos * Q;
@@ -1384,9 +1395,10 @@ __global__ __launch_bounds__(kBrickThreads) void brick_accumulate_kernel(GridArg
   // -- build the table of batch bb from the loads issued for it
   auto build = [&](int bb) {
 #pragma unroll
-    for (int t = 0; t < 2; ++t) {
-      const int rj = sj + t * H;
-      uint32_t* row = table[bb & 1] + rj * ROW;
+    for (int t = 0; t < TPL; ++t) {
+      const int rj = sj + 8 * t;
+      const int half = rj / H;  // record A or B of step rj % H
+      uint32_t* row = table[bb & 1] + (rj & (H - 1)) * ROW;
       uint32_t addr = (uint32_t)TRASH;
       uint32_t cell = 0x00f0f0f0u + (uint32_t)(rj & 7) * 0x00040404u;  // padded rows: far from every real cell
       float wc = 0.0f;
@@ -1415,9 +1427,13 @@ __global__ __launch_bounds__(kBrickThreads) void brick_accumulate_kernel(GridArg
         }
         val = rval[t];
       }
-      *reinterpret_cast<uint2*>(row + 2 * part) = make_uint2(addr, __float_as_uint(wc));
-      if (part >= 1 && part < Q) *reinterpret_cast<float4*>(row + 16 + 4 * (part - 1)) = val;
-      if (part == 0) row[CELL] = cell;
+      *reinterpret_cast<uint2*>(row + 4 * part + 2 * half) = make_uint2(addr, __float_as_uint(wc));
+      if (part >= 1 && part < Q) {  // channels 4 (part - 1) .. + 3 = channel pairs 2 (part - 1) and 2 (part - 1) + 1
+        float* gp = reinterpret_cast<float*>(row) + GOFF + 8 * (part - 1) + 2 * half;
+        *reinterpret_cast<float2*>(gp) = make_float2(val.x, val.y);
+        *reinterpret_cast<float2*>(gp + 4) = make_float2(val.z, val.w);
+      }
+      if (part == 0) row[CELL + half] = cell;
     }
   };
 
@@ -1438,60 +1454,71 @@ __global__ __launch_bounds__(kBrickThreads) void brick_accumulate_kernel(GridArg
     uint32_t shared_mask;  // bit j: the cells of records j and j + H have a node in common
     {
       const int l = lane & (H - 1);
-      shared_mask = (uint32_t)__ballot(cells_share_nodes(tb[l * ROW + CELL], tb[(l + H) * ROW + CELL]));
+      const uint2 cells = *reinterpret_cast<const uint2*>(tb + l * ROW + CELL);
+      shared_mask = (uint32_t)__ballot(cells_share_nodes(cells.x, cells.y));
     }
     if (!acc_active) return;
-    const int steps = min(nb, H);  // rows >= nb are padded (zero weight, trash address, far-away cell)
-    const uint32_t* rowA = tb;
-    uint2 awA = *reinterpret_cast<const uint2*>(rowA + 2 * q);
-    uint2 awB = *reinterpret_cast<const uint2*>(rowA + H * ROW + 2 * q);
-    float2 gA = *reinterpret_cast<const float2*>(rowA + 16 + ch), gB = *reinterpret_cast<const float2*>(rowA + H * ROW + 16 + ch);
-    for (int j = 0; j < steps; ++j) {
-      rowA += ROW;  // step j + 1 (the table has a spare row behind the last one)
-      const uint2 awA_n = *reinterpret_cast<const uint2*>(rowA + 2 * q);
-      const uint2 awB_n = *reinterpret_cast<const uint2*>(rowA + H * ROW + 2 * q);
-      const float2 gA_n = *reinterpret_cast<const float2*>(rowA + 16 + ch), gB_n = *reinterpret_cast<const float2*>(rowA + H * ROW + 16 + ch);
-      const float wA = __uint_as_float(awA.y), wB = __uint_as_float(awB.y);
-      float2* dA = reinterpret_cast<float2*>(&acc[awA.x + ch]);
-      float2* dB = reinterpret_cast<float2*>(&acc[awB.x + ch]);
-      if ((shared_mask >> j) & 1u) {
+    const int steps = min(nb, H);  // records >= nb are padded (zero weight, trash address, far-away cell)
+    const uint32_t* row = tb;
+    const int aoff = 4 * q, goff = GOFF + 2 * ch;  // this lane's (addrA, wA, addrB, wB) and (gA.x, gA.y, gB.x, gB.y)
+    // one step: read-add-write of both records with the data in (aw, gg)
+    auto rmw = [&](const uint4& aw, const float4& gg, bool shared) {
+      const float wA = __uint_as_float(aw.y), wB = __uint_as_float(aw.w);
+      float2* dA = reinterpret_cast<float2*>(&acc[aw.x + ch]);
+      float2* dB = reinterpret_cast<float2*>(&acc[aw.z + ch]);
+      if (shared) {
         float2 vA = *dA;
-        vA.x = vA.x + wA * gA.x;
-        vA.y = vA.y + wA * gA.y;
+        vA.x = vA.x + wA * gg.x;
+        vA.y = vA.y + wA * gg.y;
         *dA = vA;
         float2 vB = *dB;
-        vB.x = vB.x + wB * gB.x;
-        vB.y = vB.y + wB * gB.y;
+        vB.x = vB.x + wB * gg.z;
+        vB.y = vB.y + wB * gg.w;
         *dB = vB;
       } else {
         float2 vA = *dA, vB = *dB;
-        vA.x = vA.x + wA * gA.x;
-        vA.y = vA.y + wA * gA.y;
-        vB.x = vB.x + wB * gB.x;
-        vB.y = vB.y + wB * gB.y;
+        vA.x = vA.x + wA * gg.x;
+        vA.y = vA.y + wA * gg.y;
+        vB.x = vB.x + wB * gg.z;
+        vB.y = vB.y + wB * gg.w;
         *dA = vA;
         *dB = vB;
       }
-      awA = awA_n;
-      awB = awB_n;
-      gA = gA_n;
-      gB = gB_n;
+    };
+    // two steps per iteration with alternating register sets (no copies); the entries of the next two steps are
+    // fetched before the read-add-writes of the current two
+    uint4 aw0 = *reinterpret_cast<const uint4*>(row + aoff), aw1 = *reinterpret_cast<const uint4*>(row + ROW + aoff);
+    float4 g0 = *reinterpret_cast<const float4*>(row + goff), g1 = *reinterpret_cast<const float4*>(row + ROW + goff);
+    for (int j = 0; j < steps; j += 2) {
+      row += 2 * ROW;
+      const uint4 aw0n = *reinterpret_cast<const uint4*>(row + aoff), aw1n = *reinterpret_cast<const uint4*>(row + ROW + aoff);
+      const float4 g0n = *reinterpret_cast<const float4*>(row + goff), g1n = *reinterpret_cast<const float4*>(row + ROW + goff);
+      rmw(aw0, g0, (shared_mask >> j) & 1u);
+      if (j + 1 < steps) rmw(aw1, g1, (shared_mask >> (j + 1)) & 1u);
+      aw0 = aw0n;
+      aw1 = aw1n;
+      g0 = g0n;
+      g1 = g1n;
     }
   };
 
-  // producers run one batch ahead of the consumers (tables are double buffered) and keep the record loads of the batch
-  // after that in flight: those take several microseconds under load, a whole accumulation round hides them
+  // producers run one batch ahead of the consumers (tables are double buffered); the loads of a producer wave's next
+  // batch (two batches later) are issued as soon as it has built the current one
   if (total > 0 && producer) {
-    issue(0);
-    build(0);
-    if (nbatches > 1) issue(1);
+    if (parity == 0) {
+      issue(0);
+      build(0);
+      if (nbatches > 2) issue(2);
+    } else if (nbatches > 1) {
+      issue(1);
+    }
   }
   __syncthreads();
   for (int b = 0; b < nbatches; ++b) {
     if (producer) {
-      if (b + 1 < nbatches) {
+      if (b + 1 < nbatches && ((b + 1) & 1) == parity) {
         build(b + 1);
-        if (b + 2 < nbatches) issue(b + 2);
+        if (b + 3 < nbatches) issue(b + 3);
       }
     } else {
       accumulate(b);
