@@ -294,7 +294,8 @@ def main():
         "adam_step": G**3 * C * 4 * 7,
         # binned specular backward: the brick pass is the kernel that moves the scatter payload (8 corners x C
         # x 4 B per in-AABB sample) into the gradient tensor; emit / bin / scatter-expand are its front end
-        "brick_accumulate": n_in * 8 * C * 4,
+        f"brick_accumulate[sh{args.sh_degree}]": n_in * 8 * C * 4,
+        "brick_accumulate[diffuse]": n_in * 8 * 4 * 4,
     }
     kernels = {}
     for name, rec in ksum.items():
@@ -303,7 +304,7 @@ def main():
         if b:
             kernels[name]["algorithmic_GB"] = b / 1e9
             kernels[name]["effective_GBps"] = b / 1e9 / (rec["avg_ms"] / 1e3)
-    render_kernels = {k: v for k, v in ksum.items() if k.startswith("render_") and k in alg_bytes or k == "brick_accumulate"}
+    render_kernels = {k: v for k, v in ksum.items() if (k.startswith("render_") or k.startswith("brick_accumulate")) and k in alg_bytes}
     if not render_kernels:
         print(json.dumps({"ms_per_step": ms_per_step, "value": value, "host_issue_ms_per_step": host_issue / args.steps * 1e3, "note": "kernel timer off"}))
         return
@@ -322,11 +323,13 @@ def main():
         "note": "effective bandwidth: algorithmic gather/scatter bytes (8 corners x C x 4 B per in-AABB sample, SURVEY 8d), "
         "not credited for cache reuse or skipped zero-weight samples, so it can exceed DRAM traffic",
     }
-    pipeline = [k for k in ksum if k.startswith("render_backward_emit") or k in ("sort_keys", "expand_records", "bin_offsets", "scatter_records", "brick_accumulate")]
-    if "brick_accumulate" in ksum:
+    spec = f"sh{args.sh_degree}"
+    pipeline = [k for k in ksum if k in (f"render_backward_emit[{spec}]", "sort_keys", "expand_records", f"scatter_records[{spec}]", f"brick_accumulate[{spec}]")]
+    if f"brick_accumulate[{spec}]" in ksum:
         # the whole specular backward (emit -> bin -> scatter-expand -> brick pass) against the same scatter payload
-        total_ms = sum(ksum[k]["avg_ms"] for k in pipeline)
-        pbytes = alg_bytes["brick_accumulate"] + R * 48
+        # (bin_offsets, 10 us, is shared by both passes and counted once)
+        total_ms = sum(ksum[k]["avg_ms"] for k in pipeline) + ksum.get("bin_offsets", {"avg_ms": 0.0})["avg_ms"]
+        pbytes = alg_bytes[f"brick_accumulate[{spec}]"] + R * 48
         roofline["pipeline"] = {
             "kernels": pipeline,
             "total_ms": total_ms,
@@ -334,7 +337,7 @@ def main():
             "achieved": pbytes / 1e9 / (total_ms / 1e3),
             "frac": pbytes / 1e9 / (total_ms / 1e3) / HBM_PEAK_GBS,
         }
-        roofline["note"] += "; brick_accumulate is the last of the kernels of the specular backward -- `pipeline` prices all of them against the same bytes"
+        roofline["note"] += "; brick_accumulate is the last kernel of the binned specular backward -- `pipeline` prices all of its kernels against the same bytes"
     prof = os.path.join(ROOT, "profiles", "pmc_traffic.json")
     if os.path.exists(prof):
         try:

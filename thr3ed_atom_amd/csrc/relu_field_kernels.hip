@@ -1371,22 +1371,25 @@ __global__ __launch_bounds__(kBrickThreads) void brick_accumulate_kernel(GridArg
   const int sj = lane >> 3, part = lane & 7;
   const int pdx = (part >> 2) & 1, pdy = (part >> 1) & 1, pdz = part & 1;
   const int vpart = (part >= 1 && part < Q) ? part : 0;
-  int sri[TPL];  // running range index of this lane's record streams (they advance monotonically)
+  int sri = 0;  // running range index of the record this lane LOCATES (record lane & 31 of a batch; monotonic)
   float4 ridx[TPL], rval[TPL];
 #pragma unroll
-  for (int t = 0; t < TPL; ++t) {
-    sri[t] = 0;
-    ridx[t] = rval[t] = make_float4(0.f, 0.f, 0.f, 0.f);
-  }
+  for (int t = 0; t < TPL; ++t) ridx[t] = rval[t] = make_float4(0.f, 0.f, 0.f, 0.f);
 
-  // -- issue the loads of batch bb (unconditional, clamped to the last record: no divergent register merges)
+  // -- issue the loads of batch bb (unconditional, clamped to the last record: no divergent register merges).  Lane l
+  // locates record l & 31 in the range list once; the 8 lanes that stage a record fetch its address by shuffle.
   auto issue = [&](int bb) {
+    const int v = min(bb * kBrickBatch + (lane & (kBrickBatch - 1)), total - 1);
+    while (s_rcum[sri + 1] <= v) ++sri;
+    const long long pos = s_rstart[sri] + (v - s_rcum[sri]);
+    const float4* mine = (s_rlist[sri] ? a.lists[1].rec : a.lists[0].rec) + pos * Q;
+    const unsigned long long addr = reinterpret_cast<unsigned long long>(mine);
+    const int lo = (int)(uint32_t)addr, hi = (int)(uint32_t)(addr >> 32);
 #pragma unroll
     for (int t = 0; t < TPL; ++t) {
-      const int v = min(bb * kBrickBatch + sj + 8 * t, total - 1);
-      while (s_rcum[sri[t] + 1] <= v) ++sri[t];
-      const long long pos = s_rstart[sri[t]] + (v - s_rcum[sri[t]]);
-      const float4* rec = (s_rlist[sri[t]] ? a.lists[1].rec : a.lists[0].rec) + pos * Q;
+      const int src = sj + 8 * t;
+      const unsigned long long ra = ((unsigned long long)(uint32_t)__shfl(hi, src) << 32) | (uint32_t)__shfl(lo, src);
+      const float4* rec = reinterpret_cast<const float4*>(ra);
       ridx[t] = rec[0];
       rval[t] = rec[vpart];
     }
@@ -1485,20 +1488,23 @@ __global__ __launch_bounds__(kBrickThreads) void brick_accumulate_kernel(GridArg
         *dB = vB;
       }
     };
-    // two steps per iteration with alternating register sets (no copies); the entries of the next two steps are
-    // fetched before the read-add-writes of the current two
-    uint4 aw0 = *reinterpret_cast<const uint4*>(row + aoff), aw1 = *reinterpret_cast<const uint4*>(row + ROW + aoff);
-    float4 g0 = *reinterpret_cast<const float4*>(row + goff), g1 = *reinterpret_cast<const float4*>(row + ROW + goff);
-    for (int j = 0; j < steps; j += 2) {
-      row += 2 * ROW;
-      const uint4 aw0n = *reinterpret_cast<const uint4*>(row + aoff), aw1n = *reinterpret_cast<const uint4*>(row + ROW + aoff);
-      const float4 g0n = *reinterpret_cast<const float4*>(row + goff), g1n = *reinterpret_cast<const float4*>(row + ROW + goff);
-      rmw(aw0, g0, (shared_mask >> j) & 1u);
-      if (j + 1 < steps) rmw(aw1, g1, (shared_mask >> (j + 1)) & 1u);
-      aw0 = aw0n;
-      aw1 = aw1n;
-      g0 = g0n;
-      g1 = g1n;
+    // four steps per iteration on two register sets X / Y that alternate by name (no register copies): while the
+    // read-add-writes of two steps run from one set, the entries of the next two steps are fetched into the other
+    uint4 awX0 = *reinterpret_cast<const uint4*>(row + aoff), awX1 = *reinterpret_cast<const uint4*>(row + ROW + aoff);
+    float4 gX0 = *reinterpret_cast<const float4*>(row + goff), gX1 = *reinterpret_cast<const float4*>(row + ROW + goff);
+    for (int j = 0; j < steps; j += 4) {
+      const uint32_t* rowY = row + 2 * ROW;
+      const uint4 awY0 = *reinterpret_cast<const uint4*>(rowY + aoff), awY1 = *reinterpret_cast<const uint4*>(rowY + ROW + aoff);
+      const float4 gY0 = *reinterpret_cast<const float4*>(rowY + goff), gY1 = *reinterpret_cast<const float4*>(rowY + ROW + goff);
+      rmw(awX0, gX0, (shared_mask >> j) & 1u);
+      if (j + 1 < steps) rmw(awX1, gX1, (shared_mask >> (j + 1)) & 1u);
+      row += 4 * ROW;  // (the table has two spare steps behind the last one)
+      awX0 = *reinterpret_cast<const uint4*>(row + aoff);
+      awX1 = *reinterpret_cast<const uint4*>(row + ROW + aoff);
+      gX0 = *reinterpret_cast<const float4*>(row + goff);
+      gX1 = *reinterpret_cast<const float4*>(row + ROW + goff);
+      if (j + 2 < steps) rmw(awY0, gY0, (shared_mask >> (j + 2)) & 1u);
+      if (j + 3 < steps) rmw(awY1, gY1, (shared_mask >> (j + 3)) & 1u);
     }
   };
 

@@ -238,7 +238,7 @@ def bin_records_by_brick(grid: VoxelGrid, keys: Tensor, records: Tensor, ray_bas
         rc = lib.rf_bin_offsets(hist.data_ptr(), int(hist.numel()), offsets.data_ptr(), cursor.data_ptr(), _stream(dev))
     _lib.check(rc, "rf_bin_offsets")
     rf_grid = grid.to_rf_grid()
-    with _span("scatter_records", dev):
+    with _span(f"scatter_records[{'diffuse' if render_diffuse or grid.sh_degree == 0 else 'sh' + str(grid.sh_degree)}]", dev):
         rc = lib.rf_scatter_records(C.byref(rf_grid), keys.data_ptr(), records.data_ptr(), keys.numel(), cursor.data_ptr(),
                                     _ptr(ray_basis), int(bool(render_diffuse)), records_sorted.data_ptr(), hist.data_ptr(), int(hist.numel()), _stream(dev))
     _lib.check(rc, "rf_scatter_records")
@@ -255,7 +255,7 @@ def brick_accumulate_raw(grid: VoxelGrid, brick_size: int, lists, grad_first: Te
     for i, (rec, off, diffuse) in enumerate(lists):
         arr[i].records_sorted_dev, arr[i].offsets_dev, arr[i].render_diffuse = rec.data_ptr(), off.data_ptr(), int(bool(diffuse))
     rf_grid = grid.to_rf_grid()
-    with _span("brick_accumulate", dev):
+    with _span(f"brick_accumulate[{'diffuse' if lists[0][2] or grid.sh_degree == 0 else 'sh' + str(grid.sh_degree)}]", dev):
         rc = lib.rf_brick_accumulate(C.byref(rf_grid), int(brick_size), arr, len(lists), grad_first.data_ptr(), _ptr(grad_second), int(bool(accumulate)), _stream(dev))
     _lib.check(rc, "rf_brick_accumulate")
 
