@@ -132,8 +132,8 @@ def main():
     ap.add_argument("--samples", type=int, default=256)
     ap.add_argument("--image-size", type=int, default=800)
     ap.add_argument("--images", type=int, default=8)
-    ap.add_argument("--render-frames", type=int, default=3, help="full-frame forward renders timed for fwd_render (0 = skip)")
-    ap.add_argument("--highres-frames", type=int, default=2, help="frames timed for the 256^3 / 512-sample configs[4] render (0 = skip)")
+    ap.add_argument("--render-frames", type=int, default=5, help="full-frame forward renders timed for fwd_render (0 = skip)")
+    ap.add_argument("--highres-frames", type=int, default=5, help="frames timed for the 256^3 / 512-sample configs[4] render (0 = skip)")
     ap.add_argument("--cpu-rays", type=int, default=2048, help="rays of the cpu_baseline sample (0 = skip)")
     ap.add_argument("--storage", choices=["split", "reference"], default="split",
                     help="HBM layout of the grid: split = MI355X-native (what the trainer uses), reference = the reference's two tensors")
@@ -144,7 +144,7 @@ def main():
                     help="specular gradient scatter of the train step: float32 atomics, or records binned by brick + atomic-free "
                     "LDS accumulation (auto = binned where supported and measured faster)")
     ap.add_argument("--deterministic", action="store_true", help="binned backward: stable radix sort instead of the counting sort")
-    ap.add_argument("--timed-steps", type=int, default=10, help="how many of the --steps record per-kernel HIP events")
+    ap.add_argument("--timed-steps", type=int, default=5, help="how many of the --steps record per-kernel HIP events")
     ap.add_argument("--no-kernel-timer", action="store_true", help="do not record per-kernel HIP events in the timed region (no roofline object)")
     ap.add_argument("--cpu-threads", type=int, default=0, help="torch CPU threads for cpu_baseline (0 = all host cores)")
     args = ap.parse_args()
@@ -183,19 +183,24 @@ def main():
         pose = rf.pose_spherical(30.0, -30.0, RADIUS)
         model.render(pose, intr)  # warm-up
         timer = ops.KernelTimer()
-        ops.KERNEL_TIMER = timer
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        for _ in range(args.render_frames):
+        # every frame is timed on its own (sync before and after) and the MEDIAN is reported: the ROCm runtime now and then
+        # stalls for tens of ms (observed with many outstanding timing events), which would swamp a 4 ms frame
+        frame_s = []
+        for i in range(args.render_frames):
+            ops.KERNEL_TIMER = timer if i == 0 else None  # per-kernel events on one frame only
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
             model.render(pose, intr)
-        torch.cuda.synchronize()
-        dt = (time.perf_counter() - t0) / args.render_frames
+            torch.cuda.synchronize()
+            frame_s.append(time.perf_counter() - t0)
+        dt = float(np.median(frame_s))
         ops.KERNEL_TIMER = None
         rays = rf.flatten_rays(rf.cast_rays(intr, pose, dev))
         n_in = count_inside(rays.origins, rays.directions, S, grid.aabb)
         ksum = timer.summary()
         kname = f"render_forward[sh{args.sh_degree}]"
-        kms = ksum[kname]["total_ms"] / args.render_frames
+        kms = ksum[kname]["total_ms"]  # the one frame with events
+        del timer
         alg = n_in * 8 * (3 * (args.sh_degree + 1) ** 2 + 1) * 4 + H * W * 48
         fwd_render = {
             "workload": f"{G}^3 SH-{args.sh_degree} ReLU field, {H}x{W}, {S} samples/ray, jittered, VolumetricModel.render (32768-ray chunks)",
@@ -224,11 +229,14 @@ def main():
         for use in (False, True):
             hmodel.render(pose, intr, use_occupancy_mask=use)  # warm-up
             torch.cuda.synchronize()
-            t0 = time.perf_counter()
+            frame_s = []
             for _ in range(args.highres_frames):
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
                 hmodel.render(pose, intr, use_occupancy_mask=use)
-            torch.cuda.synchronize()
-            times[use] = (time.perf_counter() - t0) / args.highres_frames
+                torch.cuda.synchronize()
+                frame_s.append(time.perf_counter() - t0)
+            times[use] = float(np.median(frame_s))  # median of per-frame times (see fwd_render)
         a = hmodel.render(pose, intr, use_occupancy_mask=False, perturb_sampled_points=False)
         b = hmodel.render(pose, intr, use_occupancy_mask=True, perturb_sampled_points=False)
         occ_bits = int(sum(bin(w & 0xFFFFFFFF).count("1") for w in hg.occupancy.cpu().tolist()))
@@ -304,7 +312,7 @@ def main():
         if b:
             kernels[name]["algorithmic_GB"] = b / 1e9
             kernels[name]["effective_GBps"] = b / 1e9 / (rec["avg_ms"] / 1e3)
-    render_kernels = {k: v for k, v in ksum.items() if (k.startswith("render_") or k.startswith("brick_accumulate")) and k in alg_bytes}
+    render_kernels = {k: v for k, v in ksum.items() if k in alg_bytes}  # every kernel of the step with a byte model
     if not render_kernels:
         print(json.dumps({"ms_per_step": ms_per_step, "value": value, "host_issue_ms_per_step": host_issue / args.steps * 1e3, "note": "kernel timer off"}))
         return
@@ -320,8 +328,16 @@ def main():
         "traffic": None,
         "algorithmic_bytes_per_launch": alg_bytes[dom],
         "avg_launch_ms": ksum[dom]["avg_ms"],
-        "note": "effective bandwidth: algorithmic gather/scatter bytes (8 corners x C x 4 B per in-AABB sample, SURVEY 8d), "
-        "not credited for cache reuse or skipped zero-weight samples, so it can exceed DRAM traffic",
+        "note": (
+            "streaming kernel: 4 reads + 3 writes of 4 B per parameter (param, grad, exp_avg, exp_avg_sq); algorithmic = real traffic"
+            if dom == "adam_step"
+            else "effective bandwidth: algorithmic gather/scatter bytes (8 corners x C x 4 B per in-AABB sample, SURVEY 8d), "
+            "not credited for cache reuse or skipped zero-weight samples, so it can exceed DRAM traffic"
+        ),
+        "by_kernel": {
+            k: {"avg_launch_ms": ksum[k]["avg_ms"], "achieved": alg_bytes[k] / 1e9 / (ksum[k]["avg_ms"] / 1e3), "frac": alg_bytes[k] / 1e9 / (ksum[k]["avg_ms"] / 1e3) / HBM_PEAK_GBS}
+            for k in render_kernels
+        },
     }
     spec = f"sh{args.sh_degree}"
     pipeline = [k for k in ksum if k in (f"render_backward_emit[{spec}]", "sort_keys", "expand_records", f"scatter_records[{spec}]", f"brick_accumulate[{spec}]")]
@@ -337,7 +353,7 @@ def main():
             "achieved": pbytes / 1e9 / (total_ms / 1e3),
             "frac": pbytes / 1e9 / (total_ms / 1e3) / HBM_PEAK_GBS,
         }
-        roofline["note"] += "; brick_accumulate is the last kernel of the binned specular backward -- `pipeline` prices all of its kernels against the same bytes"
+        roofline["pipeline"]["note"] = "the binned specular backward as a whole (emit -> bin -> scatter-expand -> brick pass) against the scatter payload of SURVEY 8d"
     prof = os.path.join(ROOT, "profiles", "pmc_traffic.json")
     if os.path.exists(prof):
         try:
