@@ -8,7 +8,7 @@ float32 buffer (densities | features) with one matching gradient buffer:
 
   * the backward kernel accumulates straight into the gradient buffer (no per-render allocation, no
     AccumulateGrad add);
-  * ``zero_grad`` is one memset, the data-parallel exchange is ONE all-reduce of one bucket over
+  * ``zero_grad`` is one memset, the data-parallel exchange is ONE collective pass over one bucket on
     RCCL/xGMI (distributed.py), and Adam is one fused kernel over the flat buffer (rf_adam_step).
 
 The Parameters stay ordinary ``nn.Parameter`` objects (views of the flat storage), so ``state_dict`` and

@@ -12,9 +12,10 @@ reference's dictionary layout.  TensorBoard, LPIPS and feedback-image writing ar
 What is done the MI355X way instead of translated:
   * rays are generated only for the selected pixels (rf_cast_selected_rays) instead of casting
     8 x H x W rays and discarding all but 16384 of them every iteration;
-  * gradients accumulate in one flat bucket and Adam is one fused kernel (optim.py);
-  * with WORLD_SIZE > 1 every rank draws its own ray batch and the bucket is all-reduced once per
-    iteration over RCCL (distributed.py).
+  * gradients accumulate in one flat bucket and Adam is one fused kernel (optim.py); the specular backward of the
+    fused step bins per-sample gradient records by 8^3-node brick and sums every brick in LDS without atomics;
+  * with WORLD_SIZE > 1 every rank draws its own ray batch and the bucket is exchanged once per iteration over RCCL:
+    reduce-scatter, Adam on 1/N of the grid per rank, all-gather of the parameters (distributed.py).
 """
 import dataclasses
 import time
