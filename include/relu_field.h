@@ -143,8 +143,8 @@ int rf_cast_selected_rays(int32_t height, int32_t width, float focal, const floa
  * b*H*W + i*W + j. */
 int rf_select_rays_and_pixels(int32_t height, int32_t width, float focal, const float* poses_dev,
                               const int64_t* image_ids_dev, int32_t num_batch_images, const float* pixel_table_dev,
-                              uint64_t key, int64_t num_rays, float* origins_dev, float* directions_dev,
-                              float* pixels_dev, int64_t* pixel_index_dev, void* stream);
+                              uint64_t key, int64_t first_index, int64_t num_rays, float* origins_dev,
+                              float* directions_dev, float* pixels_dev, int64_t* pixel_index_dev, void* stream);
 
 /* _ray_aabb_intersection (rendering/volumetric/sample.py:71-184): bounds_dev [N, 2], hit_dev [N] (0/1,
  * may be NULL). */

@@ -65,11 +65,17 @@ def main():
     ap.add_argument("--apply_diffuse_render_regularization", type=lambda s: s.lower() != "false", default=True)
     ap.add_argument("--save_frequency", type=int, default=1000)
     ap.add_argument("--summary_frequency", type=int, default=50)
+    ap.add_argument("--global_batch", action="store_true",
+                    help="data parallel: --ray_batch_size is the GLOBAL batch, split over the ranks (strong scaling: N GPUs "
+                    "reproduce the single-GPU run); default: every rank draws its own --ray_batch_size rays (weak scaling)")
+    ap.add_argument("--seed", type=int, default=42)
     args = ap.parse_args()
 
     rank, local_rank, world = rfdist.init_from_env()
     dev = torch.device("cuda", local_rank)
     torch.cuda.set_device(dev)
+    # ray selection draws from the CPU generator: equal seeds on all ranks for one global batch, distinct ones otherwise
+    torch.manual_seed(args.seed if args.global_batch else args.seed + rank)
     if args.synthetic or args.data_path is None:
         data = synthetic_dataset(dev, args.synthetic_size, 24, args.train_num_samples_per_ray)
     else:
@@ -103,6 +109,7 @@ def main():
         lr_decay_gamma_per_stage=args.lr_decay_gamma_per_stage, lr_decay_steps_per_stage=args.lr_decay_steps_per_stage,
         stagewise_lr_decay_gamma=args.stagewise_lr_decay_gamma, save_freq=args.save_frequency, test_freq=args.num_iterations_per_stage,
         summary_freq=args.summary_frequency, apply_diffuse_render_regularization=args.apply_diffuse_render_regularization,
+        global_batch=args.global_batch,
     )
 
 

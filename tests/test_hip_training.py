@@ -611,3 +611,41 @@ def test_data_parallel_step_through_rccl_single_rank(hip_device, shard_optimizer
         rfdist.FORCE_COLLECTIVES = False
         if created:
             dist.destroy_process_group()
+
+
+def test_global_batch_slices_reproduce_the_single_gpu_step(hip_device, monkeypatch):
+    """Strong scaling: with ``global_batch=True`` the ranks draw the SAME keyed permutation and take disjoint
+    contiguous slices of it; the average of their gradient buckets is the single-GPU gradient.  Two ranks are played
+    one after the other on this GPU (stand-in rank / world size, collectives off)."""
+    from thr3ed_atom_amd import distributed as rfdist
+
+    G, deg, S, R = 16, 2, 32, 512
+    F = 3 * (deg + 1) ** 2
+    cam = hotdog_like_camera()
+    images = T(hash_uniform((4, 3, 24, 24), 77, 0.0, 1.0)).to(hip_device)
+    cams = [rf.pose_spherical(40.0 * k, -30.0, cam["radius"]) for k in range(4)]
+    poses = torch.stack([torch.cat([c.rotation, c.translation.reshape(3, 1)], dim=1) for c in cams]).to(hip_device)
+    data = PosedImagesInMemory(images, poses, rf.CameraIntrinsics(24, 24, 33.0), rf.CameraBounds(cam["near"], cam["far"]))
+
+    def run(rank, world):
+        grid = relu_grid(hip_device, T(hash_uniform((G, G, G, 1), 901)), T(hash_uniform((G, G, G, F), 900 + F)), G, storage="split")
+        cfg = rf.SHVoxGridRenderConfig(S, data.camera_bounds, perturb_sampled_points=False, white_bkgd=True)
+        model = rf.VolumetricModel(grid, rf.render_sh_voxel_grid, cfg, device=hip_device)
+        stepper = TrainStepper(model, R, learning_rate=0.03, global_batch=world > 1)
+        monkeypatch.setattr(rfdist, "world_size", lambda: world)
+        monkeypatch.setattr(rfdist, "rank", lambda: rank)
+        monkeypatch.setattr(rfdist, "_collectives_on", lambda: False)
+        torch.manual_seed(5)  # the same CPU generator state on every "rank"
+        rays, pixels = stepper.select(data, torch.arange(4))
+        stepper.step_on(rays, pixels)
+        monkeypatch.undo()
+        return rays.origins.clone(), rays.directions.clone(), pixels.clone(), stepper.flat.flat_grad.clone()
+
+    o, d, px, g_full = run(0, 1)
+    parts = [run(r, 2) for r in range(2)]
+    assert all(p[0].shape[0] == R // 2 for p in parts)
+    assert torch.equal(torch.cat([p[0] for p in parts]), o) and torch.equal(torch.cat([p[1] for p in parts]), d)
+    assert torch.equal(torch.cat([p[2] for p in parts]), px)
+    g_avg = 0.5 * (parts[0][3] + parts[1][3])
+    assert float(g_full.abs().max()) > 0
+    np.testing.assert_allclose(g_avg.cpu().numpy(), g_full.cpu().numpy(), rtol=2e-4, atol=2e-6 * float(g_full.abs().max()))

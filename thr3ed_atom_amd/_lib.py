@@ -143,7 +143,7 @@ def load() -> C.CDLL:
     fp = C.POINTER(C.c_float)
     lib.rf_cast_rays.argtypes = [i32, i32, f32, fp, fp, vp, vp, vp]
     lib.rf_cast_selected_rays.argtypes = [i32, i32, f32, vp, i32, vp, i64, vp, vp, vp]
-    lib.rf_select_rays_and_pixels.argtypes = [i32, i32, f32, vp, vp, i32, vp, C.c_uint64, i64, vp, vp, vp, vp, vp]
+    lib.rf_select_rays_and_pixels.argtypes = [i32, i32, f32, vp, vp, i32, vp, C.c_uint64, i64, i64, vp, vp, vp, vp, vp]
     lib.rf_ray_aabb_bounds.argtypes = [vp, vp, i64, f32, f32, fp, fp, vp, vp, vp]
     lib.rf_render_forward.argtypes = [C.POINTER(RFGrid), C.POINTER(RFRayBatch), u32, C.POINTER(RFRenderOut), vp]
     lib.rf_render_backward.argtypes = [

@@ -1836,12 +1836,12 @@ __device__ __forceinline__ unsigned long long keyed_permutation(unsigned long lo
 
 __global__ void select_rays_and_pixels_kernel(int H, int W, float focal, const float* poses, const int64_t* image_ids,
                                               int num_batch_images, const float* pixel_table, unsigned long long key,
-                                              int bits, long long n, float* origins, float* dirs, float* pixels,
-                                              int64_t* pixel_index) {
+                                              int bits, long long first, long long n, float* origins, float* dirs,
+                                              float* pixels, int64_t* pixel_index) {
   const long long hw = (long long)H * W;
   const unsigned long long P = (unsigned long long)num_batch_images * hw;
   for (long long q = (long long)blockIdx.x * blockDim.x + threadIdx.x; q < n; q += (long long)gridDim.x * blockDim.x) {
-    const long long p = (long long)keyed_permutation((unsigned long long)q, P, bits, key);
+    const long long p = (long long)keyed_permutation((unsigned long long)(first + q), P, bits, key);
     const int b = (int)(p / hw);
     const long long rem = p - (long long)b * hw;
     const int i = (int)(rem / W), j = (int)(rem % W);
@@ -2144,20 +2144,20 @@ int rf_cast_selected_rays(int32_t height, int32_t width, float focal, const floa
 
 int rf_select_rays_and_pixels(int32_t height, int32_t width, float focal, const float* poses_dev,
                               const int64_t* image_ids_dev, int32_t num_batch_images, const float* pixel_table_dev,
-                              uint64_t key, int64_t num_rays, float* origins_dev, float* directions_dev,
-                              float* pixels_dev, int64_t* pixel_index_dev, void* stream) {
+                              uint64_t key, int64_t first_index, int64_t num_rays, float* origins_dev,
+                              float* directions_dev, float* pixels_dev, int64_t* pixel_index_dev, void* stream) {
   if (num_rays == 0) return RF_OK;
   if (!poses_dev || !pixel_table_dev || !origins_dev || !directions_dev || !pixels_dev) return RF_ERR_NULL_POINTER;
-  if (height < 1 || width < 1 || num_batch_images < 1 || num_rays < 0) return RF_ERR_BAD_SHAPE;
+  if (height < 1 || width < 1 || num_batch_images < 1 || num_rays < 0 || first_index < 0) return RF_ERR_BAD_SHAPE;
   const unsigned long long P = (unsigned long long)num_batch_images * height * width;
-  if ((unsigned long long)num_rays > P) return RF_ERR_BAD_SHAPE;  // cannot draw more distinct pixels than exist
+  if ((unsigned long long)(first_index + num_rays) > P) return RF_ERR_BAD_SHAPE;  // cannot draw more distinct pixels than exist
   int bits = 2;
   while ((1ull << bits) < P) ++bits;
   if (bits > 62) return RF_ERR_BAD_SHAPE;
   hipLaunchKernelGGL(select_rays_and_pixels_kernel, dim3(grid_1d(num_rays, 256)), dim3(256), 0, (hipStream_t)stream,
                      height, width, focal, poses_dev, image_ids_dev, num_batch_images, pixel_table_dev,
-                     (unsigned long long)key, bits, (long long)num_rays, origins_dev, directions_dev, pixels_dev,
-                     pixel_index_dev);
+                     (unsigned long long)key, bits, (long long)first_index, (long long)num_rays, origins_dev, directions_dev,
+                     pixels_dev, pixel_index_dev);
   return launch_status();
 }
 

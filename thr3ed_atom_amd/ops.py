@@ -464,10 +464,11 @@ def cast_selected_rays_hip(height: int, width: int, focal: float, poses: Tensor,
     return o, d
 
 
-def select_rays_and_pixels_hip(height: int, width: int, focal: float, poses: Tensor, image_ids: Tensor, pixel_table: Tensor, num_rays: int, key: int, return_index: bool = False):
+def select_rays_and_pixels_hip(height: int, width: int, focal: float, poses: Tensor, image_ids: Tensor, pixel_table: Tensor, num_rays: int, key: int, return_index: bool = False, first_index: int = 0):
     """Fused random batch selection: ``num_rays`` distinct pixels of the images ``image_ids`` chosen by a keyed
     pseudo-random permutation, with their rays and target colours -> (origins, directions, pixels[, index]).
-    ``poses`` [M,3,4] and ``pixel_table`` [M*H*W,3] cover the whole dataset."""
+    ``poses`` [M,3,4] and ``pixel_table`` [M*H*W,3] cover the whole dataset.  ``first_index`` > 0 draws elements
+    [first_index, first_index + num_rays) of the same permutation (disjoint slices of one global batch)."""
     _require_hip(poses, "poses")
     _require_hip(pixel_table, "pixel_table")
     lib = _lib.load()
@@ -481,7 +482,7 @@ def select_rays_and_pixels_hip(height: int, width: int, focal: float, poses: Ten
     with _span("select_rays_and_pixels", dev):
         rc = lib.rf_select_rays_and_pixels(
             int(height), int(width), float(np.float32(focal)), poses.data_ptr(), image_ids.data_ptr(), int(image_ids.numel()),
-            pixel_table.data_ptr(), int(key) & 0xFFFFFFFFFFFFFFFF, n, o.data_ptr(), d.data_ptr(), px.data_ptr(), _ptr(idx), _stream(dev),
+            pixel_table.data_ptr(), int(key) & 0xFFFFFFFFFFFFFFFF, int(first_index), n, o.data_ptr(), d.data_ptr(), px.data_ptr(), _ptr(idx), _stream(dev),
         )
     _lib.check(rc, "rf_select_rays_and_pixels")
     return (o, d, px, idx) if return_index else (o, d, px)

@@ -137,6 +137,7 @@ class TrainStepper:
         backward: str = "auto",
         deterministic: bool = False,
         shard_optimizer: bool = True,
+        global_batch: bool = False,
     ):
         """``ray_selection``: "randperm" draws torch.randperm over all B*H*W pixels exactly like the reference
         (utils/misc.py:123) and keeps the first ``ray_batch_size``; "keyed" draws the same kind of sample
@@ -161,6 +162,11 @@ class TrainStepper:
         self.deterministic = bool(deterministic)
         # data parallel: every rank runs Adam on 1/N of the grid only (ZeRO stage 1) -- see _fused_step_on
         self.shard_optimizer = bool(shard_optimizer)
+        # data parallel, strong scaling: ``ray_batch_size`` is the GLOBAL batch; every rank draws the SAME random
+        # permutation (identical CPU RNG state on all ranks is the caller's job: seed them equally) and takes its own
+        # contiguous slice of it, so that N ranks reproduce the single-GPU iteration up to float summation order.
+        # Default (False) = weak scaling: every rank draws its own ``ray_batch_size`` rays.
+        self.global_batch = bool(global_batch)
         self.brick_size = 8
         self._bins = None
         grid = vol_mod.thre3d_repr
@@ -185,13 +191,14 @@ class TrainStepper:
         intr = dataset.camera_intrinsics
         hw = intr.height * intr.width
         dev = dataset.pixels.device
+        total = min(self.ray_batch_size, image_ids.numel() * hw)
+        lo, hi = rfdist.shard_range(total) if (self.global_batch and self.data_parallel) else (0, total)
         if self.ray_selection == "keyed":
             key = int(torch.randint(-(2**63), 2**63 - 1, (1,), dtype=torch.int64).item())
-            n = min(self.ray_batch_size, image_ids.numel() * hw)
-            o, d, px = select_rays_and_pixels_hip(intr.height, intr.width, float(intr.focal), dataset.poses, image_ids, dataset.pixels, n, key)
+            o, d, px = select_rays_and_pixels_hip(intr.height, intr.width, float(intr.focal), dataset.poses, image_ids, dataset.pixels, hi - lo, key, first_index=lo)
             return Rays(o, d), px
         image_ids = image_ids.to(dev)
-        perm = torch.randperm(image_ids.numel() * hw, dtype=torch.long, device=dev)[: self.ray_batch_size]
+        perm = torch.randperm(image_ids.numel() * hw, dtype=torch.long)[lo:hi].to(dev) if self.global_batch else torch.randperm(image_ids.numel() * hw, dtype=torch.long, device=dev)[:total]
         poses = dataset.poses[image_ids]
         origins, directions = cast_selected_rays_hip(intr.height, intr.width, float(intr.focal), poses, perm)
         b = torch.div(perm, hw, rounding_mode="floor")
@@ -349,11 +356,14 @@ def train_sh_vox_grid_vol_mod_with_posed_images(
     history: Optional[List[dict]] = None,
     storage: Optional[str] = "split",
     ray_selection: str = "keyed",
+    global_batch: bool = False,
 ) -> VolumetricModel:
     """Same arguments (minus the feedback/visualisation ones) and same schedule as the reference's
     trainer.  Returns the trained model; ``history`` (if given) collects the logged scalars.
     ``storage`` selects the HBM layout the grid is trained in ("split" = MI355X-native, "reference", or
-    None = keep the model's); checkpoints and ``.densities`` / ``.features`` stay in the reference layout."""
+    None = keep the model's); checkpoints and ``.densities`` / ``.features`` stay in the reference layout.
+    ``global_batch`` (data parallel): ``ray_batch_size`` is split over the ranks instead of drawn per rank (seed all
+    ranks equally)."""
     grid = vol_mod.thre3d_repr
     assert isinstance(grid, VoxelGrid), f"cannot use a {type(grid)} with this TrainProcedure"
     assert vol_mod.render_procedure is render_sh_voxel_grid, "non SH-based VoxelGrids cannot be used with this TrainProcedure"
@@ -394,7 +404,7 @@ def train_sh_vox_grid_vol_mod_with_posed_images(
         data = stage_sets[stage - 1]
         batches = data.image_batches(image_batch_cache_size)
         lr = learning_rate * (stagewise_lr_decay_gamma ** (stage - 1))
-        stepper = TrainStepper(vol_mod, ray_batch_size, lr, apply_diffuse_render_regularization, ray_selection=ray_selection)
+        stepper = TrainStepper(vol_mod, ray_batch_size, lr, apply_diffuse_render_regularization, ray_selection=ray_selection, global_batch=global_batch)
         scheduler = ExponentialLR(stepper.optimizer, lr_decay_gamma_per_stage)
         if is_main:
             log(

@@ -10,7 +10,7 @@ def wrapped(self, *a, **k):
     seen["stepper"] = self
     return orig(self, *a, **k)
 trainers.TrainStepper._fused_step_on = wrapped
-sys.argv = ["bench.py", "--steps", "10", "--warmup", "5", "--cpu-rays", "0", "--render-frames", "0", "--highres-frames", "0", "--backward", "binned"]
+sys.argv = ["bench.py", "--steps", os.environ.get("STEPS", "10"), "--warmup", "5", "--cpu-rays", "0", "--render-frames", "0", "--highres-frames", "0", "--backward", "binned"]
 runpy.run_path(os.path.join(sys.path[0], "bench.py"), run_name="__main__")
 st = seen["stepper"]
 b = st._bins
@@ -19,7 +19,7 @@ grid = st.vol_mod.thre3d_repr
 from thr3ed_atom_amd.ops import brick_counts
 nbx, nby, nbz = brick_counts(grid, st.brick_size)
 tot_vis = torch.zeros(nb, dtype=torch.int64, device="cuda")
-for i, off in enumerate(b["offsets"]):
+for i, off in enumerate([b["offsets"]]):
     cnt = (off[1:] - off[:-1]).view(nbx, nby, nbz, 8)
     print(f"list {i}: slots {off[-1].item()}, records {int(off[-1] - off[0])}, per-flag-class", cnt.sum((0, 1, 2)).tolist())
     vis = torch.zeros(nbx, nby, nbz, dtype=torch.int64, device="cuda")
