@@ -1031,23 +1031,19 @@ __global__ __launch_bounds__(kBlock) void render_backward_kernel(GridArgs g, Ray
 }
 
 // =============================================================================================
-// binned backward ("brick accumulate")
+// binned backward: the same adjoint without float atomics
 //
-// The atomic scatter above is pinned on the memory-side atomic unit (~21 G sector requests/s).  This path
-// aggregates before the fabric instead: render_backward_kernel<.., EMIT=true> writes one 32-byte gradient record per
-// contributing sample plus the id of the B^3-node brick its cell starts in; the records are sorted by brick
-// (16-bit radix sort, done by the caller) and gathered into that order; then ONE workgroup per brick accumulates, in
-// LDS (ds_add_f32), every contribution of its B^3 cells to the (B+1)^3 nodes they touch and adds that footprint to
-// memory with float32 atomics in long contiguous runs: one atomic per (node, channel) of a brick instead of one
-// per sample (5.6 M instead of 25 M fabric requests per training step at 128^3 / degree 2).  Specular and diffuse
-// records of a training step go through the same pass.
-//
-// MEASURED (MI355X, 16384 rays x 256 samples, 128^3 degree 2): emit 0.06 + 0.04 ms, sorts 2 x 0.13 ms, gathers
-// 2 x 0.02 ms, brick accumulate 2.5 ms -- of which the ds_add_f32 phase alone is 2.3 ms and the atomic flush 0.3 ms:
-// LDS float atomics retire at ~0.5 lane/clk/CU on gfx950, i.e. no faster than the global atomics they were meant
-// to replace (tools/atomic_microbench.hip: 213 G lane-atomics/s chip-wide = 0.35 lane/clk/CU).  The path is exact
-// (tests) but 1.8x SLOWER than the direct atomic scatter, which therefore stays the default; kept as the starting
-// point for a non-atomic (channel-owned read-modify-write) variant.
+// The atomic scatter above is pinned on the memory-side atomic unit (~21 G sector requests/s).  This path aggregates
+// in LDS first, under EXCLUSIVE ownership so that no atomics are needed at all:
+//   1. render_backward_kernel<.., EMIT=true> writes one 32-byte gradient record per contributing sample and a 16-bit
+//      key per slot: key = brick * 8 + flags, brick = the B^3-NODE brick holding the cell's lower node, flag bit a = the
+//      cell's upper node on axis a lies in the next brick; it also counts the records per key;
+//   2. bin_offsets_kernel + scatter_records_kernel (counting sort, atomic cursors) -- or torch.sort +
+//      expand_records_kernel (stable, fixed summation order) -- put the EXPANDED records (index + per-channel values, SH
+//      basis multiplied in) in key order;
+//   3. brick_accumulate_kernel: one workgroup per brick reads the <= 14 key ranges that touch its nodes, sums them in LDS
+//      with plain read-add-writes (waves own disjoint channels) and writes the brick with plain stores.
+// History and measurements: DESIGN.md section 4.
 // =============================================================================================
 struct BrickList {
   const float4* rec;         // sorted, expanded records: record_quads(K) float4 each
