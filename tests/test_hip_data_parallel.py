@@ -1,0 +1,92 @@
+"""Two REAL processes training data-parallel on one GPU: the full fused HIP step (binned backward, sharded Adam, strong
+and weak scaling modes) with the exchange going through torch.distributed -- gloo with device tensors here, because
+RCCL refuses two ranks on one device; the RCCL calls themselves are exercised by
+test_hip_training.py::test_data_parallel_step_through_rccl_single_rank and multi-GPU runs are the driver's."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+import thr3ed_atom_amd as rf
+from thr3ed_atom_amd import distributed as rfdist
+from thr3ed_atom_amd.trainers import PosedImagesInMemory, TrainStepper
+from tests.helpers import hash_uniform, hotdog_like_camera
+
+pytestmark = pytest.mark.gpu
+
+G, DEG, S, R = 16, 2, 32, 512
+F = 3 * (DEG + 1) ** 2
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _setup(dev):
+    cam = hotdog_like_camera()
+    images = torch.from_numpy(hash_uniform((4, 3, 24, 24), 77, 0.0, 1.0)).to(dev)
+    cams = [rf.pose_spherical(40.0 * k, -30.0, cam["radius"]) for k in range(4)]
+    poses = torch.stack([torch.cat([c.rotation, c.translation.reshape(3, 1)], dim=1) for c in cams]).to(dev)
+    data = PosedImagesInMemory(images, poses, rf.CameraIntrinsics(24, 24, 33.0), rf.CameraBounds(cam["near"], cam["far"]))
+    grid = rf.VoxelGrid(
+        torch.from_numpy(hash_uniform((G, G, G, 1), 901)).to(dev), torch.from_numpy(hash_uniform((G, G, G, F), 900 + F)).to(dev),
+        rf.VoxelSize(3.0 / G, 3.0 / G, 3.0 / G), density_preactivation=torch.nn.Identity(), density_postactivation=torch.nn.ReLU(),
+        expected_density_scale=100.0 / 3.0, tunable=True, storage="split",
+    )
+    cfg = rf.SHVoxGridRenderConfig(S, data.camera_bounds, perturb_sampled_points=False, white_bkgd=True)
+    return data, rf.VolumetricModel(grid, rf.render_sh_voxel_grid, cfg, device=dev)
+
+
+def _train(stepper, data, steps=3):
+    torch.manual_seed(5)  # the CPU generator picks the rays: the same state on every rank
+    for _ in range(steps):
+        stepper.step(data, torch.arange(4))
+    torch.cuda.synchronize()
+    return stepper.flat.flat_param.clone()
+
+
+def _worker(rank, world, port, result_dir, shard_optimizer):
+    os.environ.update(RANK=str(rank), LOCAL_RANK="0", WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dev = torch.device("cuda", 0)
+    torch.cuda.set_device(dev)
+    dist.init_process_group(backend="gloo", rank=rank, world_size=world)
+    try:
+        # strong scaling: the ranks split ONE global batch -> the run must equal the single-process run
+        data, model = _setup(dev)
+        dp = _train(TrainStepper(model, R, learning_rate=0.03, global_batch=True, shard_optimizer=shard_optimizer), data)
+        gathered = [torch.empty_like(dp) for _ in range(world)]
+        dist.all_gather(gathered, dp)
+        assert all(torch.equal(gathered[0], t) for t in gathered), "replicas diverged"
+        data, model = _setup(dev)
+        single = _train(TrainStepper(model, R, learning_rate=0.03, data_parallel=False), data)
+        err = float((dp - single).abs().max())
+        moved = float((single - torch.cat([t.reshape(-1) for t in model.thre3d_repr.kernel_tensors()]).detach()).abs().max())
+        assert err <= 2e-4, f"data-parallel run differs from the single-process run by {err}"
+        # weak scaling: every rank draws its own batch; replicas must still agree
+        data, model = _setup(dev)
+        stepper = TrainStepper(model, R // 2, learning_rate=0.03, shard_optimizer=shard_optimizer)
+        torch.manual_seed(11 + rank)
+        for _ in range(2):
+            stepper.step(data, torch.arange(4))
+        torch.cuda.synchronize()
+        mine = stepper.flat.flat_param.clone()
+        gathered = [torch.empty_like(mine) for _ in range(world)]
+        dist.all_gather(gathered, mine)
+        assert all(torch.equal(gathered[0], t) for t in gathered), "replicas diverged (weak scaling)"
+        open(os.path.join(result_dir, f"ok{rank}"), "w").write(f"{err} {moved}")
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("shard_optimizer", [True, False])
+def test_two_processes_train_data_parallel_on_one_gpu(tmp_path, shard_optimizer):
+    assert torch.cuda.is_available()
+    world = 2
+    mp.spawn(_worker, args=(world, _free_port(), str(tmp_path), shard_optimizer), nprocs=world, join=True)
+    assert sorted(os.listdir(tmp_path)) == [f"ok{r}" for r in range(world)]
