@@ -132,6 +132,7 @@ struct __attribute__((packed, aligned(4))) f4u {
 struct __attribute__((packed, aligned(4))) f3u {
   float v[3];
 };
+typedef float vf4 __attribute__((ext_vector_type(4)));  // naturally aligned 16-byte vector (non-temporal builtins)
 
 // ---------------------------------------------------------------------------------------------
 // wave-level helpers (64 lanes)
@@ -1563,7 +1564,9 @@ __global__ __launch_bounds__(kBrickThreads) void brick_accumulate_kernel(GridArg
           const float4 o = *dst;
           v = make_float4(o.x + v.x, o.y + v.y, o.z + v.z, o.w + v.w);
         }
-        *dst = v;
+        // non-temporal: nothing reads the `rest` gradients again before the optimizer (or the collective) streams them
+        const vf4 v4 = {v.x, v.y, v.z, v.w};
+        __builtin_nontemporal_store(v4, reinterpret_cast<vf4*>(dst));
       }
     }
     return;
@@ -1913,8 +1916,6 @@ __global__ void build_occupancy_kernel(GridArgs g, float threshold, uint32_t* oc
 // =============================================================================================
 // fused Adam (torch.optim.Adam, no weight decay, no amsgrad)
 // =============================================================================================
-typedef float vf4 __attribute__((ext_vector_type(4)));
-
 // STREAM = true (all four pointers 16-byte aligned): one float4 per thread; the gradient and the two moments are
 // streamed with non-temporal loads/stores (nothing reads them again before 700 MB of other traffic has passed), the
 // parameters with ordinary ones (the next forward pass reads them).  Measured on MI355X (tools/adam_microbench.hip):
