@@ -135,7 +135,7 @@ def main():
     ap.add_argument("--render-frames", type=int, default=5, help="full-frame forward renders timed for fwd_render (0 = skip)")
     ap.add_argument("--highres-frames", type=int, default=5, help="frames timed for the 256^3 / 512-sample configs[4] render (0 = skip)")
     ap.add_argument("--cpu-rays", type=int, default=2048, help="rays of the cpu_baseline sample (0 = skip)")
-    ap.add_argument("--storage", choices=["split", "reference"], default="split",
+    ap.add_argument("--storage", choices=["split", "bricked", "reference"], default="split",
                     help="HBM layout of the grid: split = MI355X-native (what the trainer uses), reference = the reference's two tensors")
     ap.add_argument("--ray-selection", choices=["keyed", "randperm"], default="keyed",
                     help="how a step picks its 16384 random pixels: keyed = fused keyed-permutation kernel (trainer default), "

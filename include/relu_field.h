@@ -52,10 +52,15 @@ enum {
 enum {
   RF_LAYOUT_REFERENCE = 0, /* the reference's two tensors: densities [X,Y,Z,1], features [X,Y,Z,F]
                               (feature index = colour*K + k, thre3d_reprs/voxels.py:70-71)                 */
-  RF_LAYOUT_SPLIT = 1      /* MI355X-native: densities_dev -> base [X,Y,Z,4] = (density, sh0 r, sh0 g, sh0 b),
+  RF_LAYOUT_SPLIT = 1,     /* MI355X-native: densities_dev -> base [X,Y,Z,4] = (density, sh0 r, sh0 g, sh0 b),
                               features_dev -> rest [X,Y,Z,F-3] with index = colour*(K-1) + (k-1), k >= 1
                               (NULL when F == 3).  The diffuse pass and the density gather touch only the
                               16-byte base records; gradient buffers use the same layout.                 */
+  RF_LAYOUT_BRICKED = 2    /* the split channel arrangement with BRICK-MAJOR node order: the grid is cut into
+                              8x8x8-node bricks stored contiguously, base [NBX,NBY,NBZ,8,8,8,4] and rest
+                              [NBX,NBY,NBZ,8,8,8,F-3] with NB* = ceil(dim/8) (nodes beyond dims are padding the
+                              kernels never touch).  The 8 corners of a cell lie within ~1 KB (base) instead of
+                              megabytes apart, and a brick of the binned backward is one contiguous write.    */
 };
 
 /* render flags (SHVoxGridRenderConfig fields, thre3d_reprs/renderers.py:28-45) */

@@ -35,7 +35,7 @@ def relu_grid(dev, dens, feat, G, rho=100.0 / 3.0, tunable=True, storage="refere
 
 
 @pytest.mark.parametrize("fused", [True, False])
-@pytest.mark.parametrize("storage", ["reference", "split"])
+@pytest.mark.parametrize("storage", ["reference", "split", "bricked"])
 def test_g9_reference_trainer_trajectory(hip_device, storage, fused):
     """TrainStepper fed the batches the REAL reference trainer selected reproduces its losses and parameters."""
     g = load_golden("g9_trainer_trajectory.npz")
@@ -118,6 +118,44 @@ def test_split_storage_is_the_same_grid(hip_device, tmp_path):
     assert torch.equal(spl.densities, ref.densities * 2.0) and torch.equal(spl.features, ref.features * 3.0)
     up = rf.scale_voxel_grid_with_required_output_size(spl, (12, 12, 12))
     assert up.storage == "split" and up.features.shape == (12, 12, 12, 27)
+
+
+def test_bricked_storage_is_the_same_grid(hip_device, tmp_path):
+    """reference <-> bricked storage (split channels, 8^3-node bricks contiguous, dims padded to multiples of 8): same
+    accessors, same state_dict, bit-identical renders and gradients, checkpoints interchangeable."""
+    dens, feat = procedural_grid((9, 10, 19), 27, 13)
+    ref = relu_grid(hip_device, dens, feat, 9, storage="reference")
+    brk = relu_grid(hip_device, dens, feat, 9, storage="bricked")
+    assert torch.equal(brk.densities, ref.densities) and torch.equal(brk.features, ref.features)
+    assert [tuple(p.shape) for p in brk.parameters()] == [(2, 2, 3, 8, 8, 8, 4), (2, 2, 3, 8, 8, 8, 24)]
+    sd_ref, sd_brk = ref.state_dict(), brk.state_dict()
+    assert sorted(sd_brk.keys()) == ["_densities", "_features"] and all(torch.equal(sd_ref[k], sd_brk[k]) for k in sd_ref)
+    cam = hotdog_like_camera()
+    g7 = load_golden("g7_grid16_render.npz")
+    rays = rf.Rays(T(g7["origins"]).to(hip_device), T(g7["directions"]).to(hip_device))
+    cfg = rf.SHVoxGridRenderConfig(40, rf.CameraBounds(cam["near"], cam["far"]), perturb_sampled_points=False, white_bkgd=True)
+    spl = relu_grid(hip_device, dens, feat, 9, storage="split")
+    a, b = rf.render_sh_voxel_grid(spl, rays, cfg), rf.render_sh_voxel_grid(brk, rays, cfg)
+    assert torch.equal(a.colour, b.colour) and torch.equal(a.depth, b.depth)  # same arithmetic, different addresses
+    target = T(g7["target"]).to(hip_device)
+    torch.nn.functional.l1_loss(a.colour, target).backward()
+    torch.nn.functional.l1_loss(b.colour, target).backward()
+    for x, y in zip(spl.reference_gradients(), brk.reference_gradients()):
+        np.testing.assert_allclose(y.cpu().numpy(), x.cpu().numpy(), rtol=2e-4, atol=2e-6 * float(x.abs().max()))
+    pts = T(hash_uniform((257, 3), 21, -0.9, 0.9)).to(hip_device)
+    assert torch.equal(brk(pts), ref(pts))
+    model = rf.VolumetricModel(brk, rf.render_sh_voxel_grid, cfg, device=hip_device)
+    torch.save(model.get_save_info(extra_info={}), tmp_path / "m.pth")
+    for storage in ("reference", "bricked"):
+        creator = lambda info, st=storage: rf.create_voxel_grid_from_saved_info_dict(info, storage=st)
+        loaded, _ = rf.create_volumetric_model_from_saved_model(tmp_path / "m.pth", creator, device=hip_device)
+        assert loaded.thre3d_repr.storage == storage
+        assert torch.equal(loaded.thre3d_repr.features, ref.features) and torch.equal(loaded.thre3d_repr.densities, ref.densities)
+    brk.densities = ref.densities * 2.0
+    brk.features = ref.features * 3.0
+    assert torch.equal(brk.densities, ref.densities * 2.0) and torch.equal(brk.features, ref.features * 3.0)
+    up = rf.scale_voxel_grid_with_required_output_size(brk, (12, 12, 12))
+    assert up.storage == "bricked" and up.features.shape == (12, 12, 12, 27)
 
 
 def test_fused_adam_matches_torch_adam(hip_device):
@@ -219,7 +257,7 @@ def test_full_trainer_two_stages_and_checkpoint_roundtrip(hip_device, tmp_path):
     assert torch.equal(a, b)
 
 
-@pytest.mark.parametrize("storage", ["reference", "split"])
+@pytest.mark.parametrize("storage", ["reference", "split", "bricked"])
 def test_occupancy_skipping_is_exact(hip_device, storage):
     """BASELINE.json configs[4] at reduced size: density-threshold occupancy mask, ReLU field, threshold 0:
     outputs AND gradients are bit-identical with and without the mask on a sparse scene."""
@@ -425,7 +463,7 @@ def _binned_gradients(grid, rays, cfg, target, device, diffuse_too=True, accumul
 
 
 @pytest.mark.parametrize("accumulate,binning", [(False, "sort"), (True, "sort"), (False, "count")])
-@pytest.mark.parametrize("storage", ["reference", "split"])
+@pytest.mark.parametrize("storage", ["reference", "split", "bricked"])
 @pytest.mark.parametrize("case", ["grid16_sh2", "aniso_sh2_abs", "aniso_sh1_softplus", "cube20_sh0"])
 def test_binned_backward_equals_atomic_backward(hip_device, storage, case, accumulate, binning):
     """The LDS-aggregated backward (emit -> 16-bit sort by (brick, flags) -> one workgroup per 8^3-node brick that owns
@@ -455,8 +493,7 @@ def test_binned_backward_equals_atomic_backward(hip_device, storage, case, accum
     loss.backward()
     ref_d, ref_f = grid.reference_gradients()
     gd, gf = _binned_gradients(grid, rays, cfg, target, hip_device, accumulate=accumulate, binning=binning)
-    if storage == "split":
-        gd, gf = unpack_split(gd, gf)
+    gd, gf = grid.unpack(gd, gf)
     assert float(ref_d.abs().max()) > 0 and float(ref_f.abs().max()) > 0
     np.testing.assert_allclose(gd.cpu().numpy(), ref_d.cpu().numpy(), rtol=2e-4, atol=2e-6 * float(ref_d.abs().max()))
     np.testing.assert_allclose(gf.cpu().numpy(), ref_f.cpu().numpy(), rtol=2e-4, atol=2e-6 * float(ref_f.abs().max()))

@@ -17,7 +17,7 @@ HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off"
 
 # enums of relu_field.h
 DENSITY_MODES = {"relu": 0, "softplus": 1, "abs": 2, "identity": 3}
-LAYOUTS = {"reference": 0, "split": 1}
+LAYOUTS = {"reference": 0, "split": 1, "bricked": 2}
 FLAG_WHITE_BKGD = 1
 FLAG_RENDER_DIFFUSE = 2
 FLAG_AABB_SAMPLING = 4

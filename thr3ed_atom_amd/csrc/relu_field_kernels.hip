@@ -59,8 +59,22 @@ struct GridArgs {
   float amin[3], amax[3], nscale[3], nbias[3];
   float rho;
   int mode;
-  int layout;  // RF_LAYOUT_REFERENCE: dens[.,1] + feat[.,F];  RF_LAYOUT_SPLIT: dens = base[.,4], feat = rest[.,F-3]
+  int layout;  // channel arrangement. RF_LAYOUT_REFERENCE: dens[.,1] + feat[.,F];  RF_LAYOUT_SPLIT: dens = base[.,4], feat = rest[.,F-3]
+  // node order: linear (x, y, z) with z fastest, or (RF_LAYOUT_BRICKED) brick-major: 8^3-node bricks stored contiguously,
+  // brick (bx, by, bz) at ((bx * nby + by) * nbz + bz) * 512, node (x & 7, y & 7, z & 7) inside it with z fastest
+  int bricked;
+  int nby, nbz;
+  unsigned int step[3];  // index step to the next node along x, y, z (inside a brick for the bricked order)
+  unsigned int jump[3];  // bricked: step from the last node of a brick to the first node of the next brick on that axis
 };
+
+// index of node (x, y, z) in the grid tensors (to be multiplied by the tensor's channel stride)
+__device__ __forceinline__ unsigned int node_lin(const GridArgs& g, int x, int y, int z) {
+  if (g.bricked)
+    return (__umul24(__umul24((unsigned)(x >> 3), (unsigned)g.nby) + (unsigned)(y >> 3), (unsigned)g.nbz) + (unsigned)(z >> 3)) * 512u +
+           (unsigned)(((x & 7) << 6) | ((y & 7) << 3) | (z & 7));
+  return __umul24(__umul24((unsigned)x, (unsigned)g.Y) + (unsigned)y, (unsigned)g.Z) + (unsigned)z;
+}
 
 struct RayArgs {
   const float* origins;
@@ -287,11 +301,12 @@ __device__ __forceinline__ Corners corners_of(uint32_t packed, const float wts[6
   const bool oky[2] = {iy0 >= 0, iy0 + 1 < g.Y};
   const bool okz[2] = {iz0 >= 0, iz0 + 1 < g.Z};
   const int cx0 = max(ix0, 0), cy0 = max(iy0, 0), cz0 = max(iz0, 0);
-  const unsigned int lin0 = __umul24(__umul24((unsigned)cx0, (unsigned)g.Y) + (unsigned)cy0, (unsigned)g.Z) + (unsigned)cz0;
-  // step to the upper node: a whole voxel, or 0 when the clamped upper node coincides with the lower one
-  const unsigned int sx = (okx[0] && okx[1]) ? __umul24((unsigned)g.Y, (unsigned)g.Z) : 0u;
-  const unsigned int sy = (oky[0] && oky[1]) ? (unsigned)g.Z : 0u;
-  const unsigned int sz = (okz[0] && okz[1]) ? 1u : 0u;
+  const unsigned int lin0 = node_lin(g, cx0, cy0, cz0);
+  // step to the upper node: a whole voxel (a jump into the next brick when the lower node is a brick's last one), or 0
+  // when the clamped upper node coincides with the lower one
+  const unsigned int sx = (okx[0] && okx[1]) ? ((g.bricked && (cx0 & 7) == 7) ? g.jump[0] : g.step[0]) : 0u;
+  const unsigned int sy = (oky[0] && oky[1]) ? ((g.bricked && (cy0 & 7) == 7) ? g.jump[1] : g.step[1]) : 0u;
+  const unsigned int sz = (okz[0] && okz[1]) ? ((g.bricked && (cz0 & 7) == 7) ? g.jump[2] : g.step[2]) : 0u;
   const float wxy[4] = {wts[0] * wts[2], wts[1] * wts[2], wts[0] * wts[3], wts[1] * wts[3]};  // [dx + 2 dy]
   Corners c;
 #pragma unroll
@@ -629,8 +644,10 @@ __global__ __launch_bounds__(kBlock) void render_forward_kernel(GridArgs g, RayA
       const int slot = __popcll(mask & ((1ull << lane) - 1ull));
       uint32_t* e = my_entry + slot * kEntryFwd;
       // corner k = dx + 2 dy + 4 dz (corners_of): lin[1] / lin[2] / lin[4] are the x / y / z upper neighbours
+      // bits 0..2: the step exists; bits 3..5: it is a jump into the next brick (bricked node order)
       const uint32_t steps = (cn.lin[1] != cn.lin[0] ? 1u : 0u) | (cn.lin[2] != cn.lin[0] ? 2u : 0u) |
-                             (cn.lin[4] != cn.lin[0] ? 4u : 0u);
+                             (cn.lin[4] != cn.lin[0] ? 4u : 0u) | (cn.lin[1] - cn.lin[0] == g.jump[0] ? 8u : 0u) |
+                             (cn.lin[2] - cn.lin[0] == g.jump[1] ? 16u : 0u) | (cn.lin[4] - cn.lin[0] == g.jump[2] ? 32u : 0u);
       e[0] = cn.lin[0];
       e[2] = (uint32_t)lane | (steps << 8);
 #pragma unroll
@@ -653,9 +670,9 @@ __global__ __launch_bounds__(kBlock) void render_forward_kernel(GridArgs g, RayA
         const uint32_t meta = e[2];
         dst_lane = (int)(meta & 0xffu);
         // corner k = dx + 2 dy + 4 dz; the steps to the upper nodes are whole voxels or 0 (clamped at the border)
-        const unsigned int sx = (meta & (1u << 8)) ? __umul24((unsigned)g.Y, (unsigned)g.Z) : 0u;
-        const unsigned int sy = (meta & (2u << 8)) ? (unsigned)g.Z : 0u;
-        const unsigned int sz = (meta & (4u << 8)) ? 1u : 0u;
+        const unsigned int sx = (meta & (1u << 8)) ? ((meta & (8u << 8)) ? g.jump[0] : g.step[0]) : 0u;
+        const unsigned int sy = (meta & (2u << 8)) ? ((meta & (16u << 8)) ? g.jump[1] : g.step[1]) : 0u;
+        const unsigned int sz = (meta & (4u << 8)) ? ((meta & (32u << 8)) ? g.jump[2] : g.step[2]) : 0u;
         Corners c;
 #pragma unroll
         for (int k = 0; k < 8; ++k) {
@@ -1010,7 +1027,7 @@ __global__ __launch_bounds__(kBlock) void render_backward_kernel(GridArgs g, Ray
           const float wx = __uint_as_float(en[2 + dx]), wy = __uint_as_float(en[4 + dy]), wz = __uint_as_float(en[6 + dz]);
           const float wc = (wx * wy) * wz;
           if (ok) {
-            const long long lin = ((long long)ix * g.Y + iy) * g.Z + iz;
+            const long long lin = node_lin(g, ix, iy, iz);
             if (lane_colour == 3) {
               float gv = (wc * __uint_as_float(en[8])) * g.rho;
               if (g.mode == RF_DENSITY_ABS) {
@@ -1545,7 +1562,7 @@ __global__ __launch_bounds__(kBrickThreads) void brick_accumulate_kernel(GridArg
       const int fx = col >> a.shift, fy = col & (B - 1);
       const int X = X0 + fx, Y = Y0 + fy, Z = Z0 + fz;
       if (X >= g.X || Y >= g.Y || Z >= g.Z) continue;
-      const long long lin = ((long long)X * g.Y + Y) * g.Z + Z;
+      const long long lin = node_lin(g, X, Y, Z);
       float4 v = total > 0 ? *reinterpret_cast<const float4*>(&acc[fx * SX + fy * SY + fz * CS + 4 * qd]) : make_float4(0.f, 0.f, 0.f, 0.f);
       if (qd == 0) {
         if (g.mode == RF_DENSITY_ABS) {  // d|x|/dx of the raw density, applied once per node
@@ -1594,7 +1611,7 @@ __global__ __launch_bounds__(kBrickThreads) void brick_accumulate_kernel(GridArg
         const int col3 = c2 / K, kk = c2 - col3 * K;  // reference order colour * K + k
         lds_c = (kk == 0) ? 1 + col3 : 4 + col3 * (K - 1) + (kk - 1);
       }
-      const long long lin = ((long long)X * g.Y + Y) * g.Z + Z;
+      const long long lin = node_lin(g, X, Y, Z);
       float v = total > 0 ? acc[fx * SX + fy * SY + fz * CS + lds_c] : 0.0f;
       if (lds_c == 0 && g.mode == RF_DENSITY_ABS) {  // d|x|/dx of the raw density, applied once per node
         const float dv = g.dens[lin * g.dstride] * g.rho;
@@ -1638,7 +1655,7 @@ __device__ __forceinline__ QueryCorner query_corner(int k, const int i0[3], cons
   const int ix = i0[0] + dx, iy = i0[1] + dy, iz = i0[2] + dz;
   QueryCorner c;
   c.ok = ix >= 0 && ix < g.X && iy >= 0 && iy < g.Y && iz >= 0 && iz < g.Z;
-  c.lin = ((long long)min(max(ix, 0), g.X - 1) * g.Y + min(max(iy, 0), g.Y - 1)) * g.Z + min(max(iz, 0), g.Z - 1);
+  c.lin = node_lin(g, min(max(ix, 0), g.X - 1), min(max(iy, 0), g.Y - 1), min(max(iz, 0), g.Z - 1));
   c.w = ((dx ? w1[0] : w0[0]) * (dy ? w1[1] : w0[1])) * (dz ? w1[2] : w0[2]);
   return c;
 }
@@ -1903,7 +1920,7 @@ __global__ void build_occupancy_kernel(GridArgs g, float threshold, uint32_t* oc
         for (int k = 0; k < 8; ++k) {
           const int x = cx - 1 + (k & 1), y = cy - 1 + ((k >> 1) & 1), z = cz - 1 + (k >> 2);
           if (x >= 0 && x < g.X && y >= 0 && y < g.Y && z >= 0 && z < g.Z)
-            occ_cell = occ_cell || (g.dens[(((long long)x * g.Y + y) * g.Z + z) * g.dstride] * g.rho > threshold);
+            occ_cell = occ_cell || (g.dens[(long long)node_lin(g, x, y, z) * g.dstride] * g.rho > threshold);
         }
       }
     }
@@ -2025,7 +2042,7 @@ __global__ void l1_loss_grad_kernel(const float* __restrict__ colour, const floa
 // ---------------------------------------------------------------------------------------------
 int check_grid(const RFGrid* g) {
   if (!g || !g->densities_dev) return RF_ERR_NULL_POINTER;
-  if (!g->features_dev && !(g->layout == RF_LAYOUT_SPLIT && g->num_features == 3)) return RF_ERR_NULL_POINTER;
+  if (!g->features_dev && !(g->layout != RF_LAYOUT_REFERENCE && g->num_features == 3)) return RF_ERR_NULL_POINTER;
   for (int a = 0; a < 3; ++a)
     if (g->dims[a] < 1 || g->dims[a] > 2046) return RF_ERR_BAD_SHAPE;
   const int F = g->num_features;
@@ -2033,7 +2050,7 @@ int check_grid(const RFGrid* g) {
   if (g->density_mode < RF_DENSITY_RELU || g->density_mode > RF_DENSITY_IDENTITY) return RF_ERR_UNSUPPORTED;
   if (g->layout == RF_LAYOUT_REFERENCE) {
     if (g->density_stride < 1 || g->feature_stride < F) return RF_ERR_BAD_SHAPE;
-  } else if (g->layout == RF_LAYOUT_SPLIT) {
+  } else if (g->layout == RF_LAYOUT_SPLIT || g->layout == RF_LAYOUT_BRICKED) {
     if (g->density_stride < 4 || (F > 3 && g->feature_stride < F - 3)) return RF_ERR_BAD_SHAPE;
   } else {
     return RF_ERR_UNSUPPORTED;
@@ -2060,7 +2077,22 @@ GridArgs to_args(const RFGrid* g) {
   }
   a.rho = g->density_scale;
   a.mode = g->density_mode;
-  a.layout = g->layout;
+  a.layout = g->layout == RF_LAYOUT_REFERENCE ? RF_LAYOUT_REFERENCE : RF_LAYOUT_SPLIT;  // channel arrangement
+  a.bricked = g->layout == RF_LAYOUT_BRICKED;
+  a.nby = (a.Y + 7) / 8;
+  a.nbz = (a.Z + 7) / 8;
+  if (a.bricked) {
+    a.step[0] = 64u;
+    a.step[1] = 8u;
+    a.step[2] = 1u;
+    a.jump[0] = (unsigned)a.nby * (unsigned)a.nbz * 512u - 7u * 64u;
+    a.jump[1] = (unsigned)a.nbz * 512u - 7u * 8u;
+    a.jump[2] = 512u - 7u;
+  } else {
+    a.step[0] = a.jump[0] = (unsigned)a.Y * (unsigned)a.Z;
+    a.step[1] = a.jump[1] = (unsigned)a.Z;
+    a.step[2] = a.jump[2] = 1u;
+  }
   return a;
 }
 
@@ -2270,7 +2302,7 @@ static int backward_impl(const RFGrid* grid, const RFRayBatch* rays, uint32_t fl
 int rf_render_backward(const RFGrid* grid, const RFRayBatch* rays, uint32_t flags, const RFRenderOut* fwd,
                        const RFRenderGrads* grads, float* grad_densities_dev, float* grad_features_dev, void* stream) {
   if (!grad_densities_dev) return RF_ERR_NULL_POINTER;
-  if (grid && !grad_features_dev && !(grid->layout == RF_LAYOUT_SPLIT && grid->num_features == 3)) return RF_ERR_NULL_POINTER;
+  if (grid && !grad_features_dev && !(grid->layout != RF_LAYOUT_REFERENCE && grid->num_features == 3)) return RF_ERR_NULL_POINTER;
   GradArgs gr = {};
   gr.gdens = grad_densities_dev;
   gr.gfeat = grad_features_dev;
@@ -2408,7 +2440,7 @@ int rf_brick_accumulate(const RFGrid* grid, int32_t brick_size, const RFBrickLis
   int rc = check_grid(grid);
   if (rc != RF_OK) return rc;
   if (!lists || !grad_densities_dev) return RF_ERR_NULL_POINTER;
-  if (!grad_features_dev && !(grid->layout == RF_LAYOUT_SPLIT && grid->num_features == 3)) return RF_ERR_NULL_POINTER;
+  if (!grad_features_dev && !(grid->layout != RF_LAYOUT_REFERENCE && grid->num_features == 3)) return RF_ERR_NULL_POINTER;
   if (num_lists < 1 || num_lists > 2) return RF_ERR_BAD_SHAPE;
   if (grid->num_features > 27) return RF_ERR_UNSUPPORTED;  // 3 rest waves cover 24 channels (SH degree <= 2)
   int shift, nb[3];
@@ -2462,7 +2494,7 @@ int rf_grid_query_backward(const RFGrid* grid, const float* points_dev, int64_t 
   if (rc != RF_OK) return rc;
   if (num_points == 0) return RF_OK;
   if (!points_dev || !grad_out_dev || !grad_densities_dev) return RF_ERR_NULL_POINTER;
-  if (!grad_features_dev && !(grid->layout == RF_LAYOUT_SPLIT && grid->num_features == 3)) return RF_ERR_NULL_POINTER;
+  if (!grad_features_dev && !(grid->layout != RF_LAYOUT_REFERENCE && grid->num_features == 3)) return RF_ERR_NULL_POINTER;
   if (num_points < 0) return RF_ERR_BAD_SHAPE;
   const GridArgs g = to_args(grid);
   const long long total = (long long)num_points * (g.F + 1);

@@ -248,7 +248,7 @@ class TrainStepper:
         # data parallel: with split storage the diffuse pass only touches `base`, so the all-reduce of the `rest`
         # gradients (201 of the 235 MB at degree 2) starts right after the specular backward and overlaps it
         dp = self.data_parallel and rfdist._collectives_on()
-        overlap = dp and self.diffuse and grid.storage == "split" and gf is not None
+        overlap = dp and self.diffuse and grid.storage != "reference" and gf is not None
         # ... and with equal chunks the exchange is split around a sharded Adam (reduce-scatter | update 1/N | all-gather)
         sharded = overlap and self.shard_optimizer and rfdist.can_shard(gd.numel()) and rfdist.can_shard(gf.numel())
         reduce_async = rfdist.reduce_scatter_mean_async if sharded else rfdist.all_reduce_mean_async

@@ -37,7 +37,8 @@ class AxisAlignedBoundingBox(NamedTuple):
     z_range: Tuple[float, float]
 
 
-STORAGES = ("reference", "split")
+STORAGES = ("reference", "split", "bricked")
+BRICK = 8  # edge of a storage brick in nodes (RF_LAYOUT_BRICKED)
 
 
 def pack_split(densities: Tensor, features: Tensor):
@@ -58,6 +59,40 @@ def unpack_split(base: Tensor, rest: Optional[Tensor]):
     K = rest.shape[-1] // 3 + 1
     f = torch.cat([sh0[..., None], rest.unflatten(-1, (3, K - 1))], dim=-1)
     return densities, f.flatten(-2).contiguous()
+
+
+def brick_nodes(t: Tensor) -> Tensor:
+    """[X,Y,Z,C] -> brick-major [NBX,NBY,NBZ,8,8,8,C] (dims padded with zeros to multiples of 8)."""
+    X, Y, Z, C = t.shape
+    px, py, pz = (-X) % BRICK, (-Y) % BRICK, (-Z) % BRICK
+    if px or py or pz:
+        t = torch.nn.functional.pad(t, (0, 0, 0, pz, 0, py, 0, px))
+    nbx, nby, nbz = (X + px) // BRICK, (Y + py) // BRICK, (Z + pz) // BRICK
+    return t.reshape(nbx, BRICK, nby, BRICK, nbz, BRICK, C).permute(0, 2, 4, 1, 3, 5, 6).contiguous()
+
+
+def unbrick_nodes(t: Tensor, dims) -> Tensor:
+    """brick-major [NBX,NBY,NBZ,8,8,8,C] -> [X,Y,Z,C] (padding dropped)."""
+    nbx, nby, nbz, _, _, _, C = t.shape
+    full = t.permute(0, 3, 1, 4, 2, 5, 6).reshape(nbx * BRICK, nby * BRICK, nbz * BRICK, C)
+    return full[: dims[0], : dims[1], : dims[2]].contiguous()
+
+
+def pack_storage(densities: Tensor, features: Tensor, storage: str):
+    """reference tensors -> the two tensors of ``storage`` ("split" or "bricked")."""
+    base, rest = pack_split(densities, features)
+    if storage == "bricked":
+        base, rest = brick_nodes(base), (None if rest is None else brick_nodes(rest))
+    return base, rest
+
+
+def unpack_storage(first: Tensor, second: Optional[Tensor], storage: str, dims):
+    """the two tensors of ``storage`` (parameters or gradients) -> reference tensors (densities, features)."""
+    if storage == "reference":
+        return first, second
+    if storage == "bricked":
+        first, second = unbrick_nodes(first, dims), (None if second is None else unbrick_nodes(second, dims))
+    return unpack_split(first, second)
 
 
 def _is_identity(fn) -> bool:
@@ -103,7 +138,9 @@ class VoxelGrid(Module):
         storage: str = "reference",
     ):
         """``storage`` (extension of this build) selects how the grid lives in HBM:
-        "reference" keeps the reference's two tensors; "split" keeps the MI355X-native pair
+        "reference" keeps the reference's two tensors; "bricked" = "split" with the nodes in brick-major order
+        (8^3-node bricks contiguous: cell corners ~1 KB apart, one contiguous write per brick in the binned backward);
+        "split" keeps the MI355X-native pair
         base [X,Y,Z,4] = (density, degree-0 RGB) + rest [X,Y,Z,3(K-1)] (RF_LAYOUT_SPLIT).  Either way the
         constructor takes, and state_dict / .densities / .features present, reference-layout tensors."""
         if storage not in STORAGES:
@@ -139,7 +176,7 @@ class VoxelGrid(Module):
             self._register_grid_tensor("_densities", densities)
             self._register_grid_tensor("_features", features)
         else:
-            base, rest = pack_split(densities, features)
+            base, rest = pack_storage(densities, features, storage)
             self._register_grid_tensor("_base", base)
             if rest is not None:
                 self._register_grid_tensor("_rest", rest)
@@ -162,13 +199,13 @@ class VoxelGrid(Module):
     def _export_reference_state(module, state, prefix, local_metadata):
         base = state.pop(prefix + "_base")
         rest = state.pop(prefix + "_rest", None)
-        dens, feat = unpack_split(base, rest)
+        dens, feat = unpack_storage(base, rest, module.storage, module.grid_dims)
         state[prefix + u_DENSITIES], state[prefix + u_FEATURES] = dens, feat
         return state
 
     def _import_reference_state(self, state, prefix, local_metadata, strict, missing, unexpected, errors):
         if prefix + u_DENSITIES in state:
-            base, rest = pack_split(state.pop(prefix + u_DENSITIES), state.pop(prefix + u_FEATURES))
+            base, rest = pack_storage(state.pop(prefix + u_DENSITIES), state.pop(prefix + u_FEATURES), self.storage)
             state[prefix + "_base"] = base
             if rest is not None:
                 state[prefix + "_rest"] = rest
@@ -186,7 +223,11 @@ class VoxelGrid(Module):
             return a.grad, b.grad
         if a.grad is None:
             return None, None
-        return unpack_split(a.grad, None if b is None else b.grad)
+        return unpack_storage(a.grad, None if b is None else b.grad, self.storage, self.grid_dims)
+
+    def unpack(self, first: Tensor, second: Optional[Tensor]):
+        """Any pair of tensors shaped like ``kernel_tensors()`` (e.g. a gradient bucket) -> reference layout."""
+        return unpack_storage(first, second, self.storage, self.grid_dims)
 
     def to_storage(self, storage: str) -> "VoxelGrid":
         """A new grid with the same content and configuration in the requested storage."""
@@ -201,6 +242,8 @@ class VoxelGrid(Module):
         split storage (in-place edits reach the grid, but it is not a leaf: use reference_gradients())."""
         if self.storage == "reference":
             return self._densities
+        if self.storage == "bricked":  # an assembled COPY (assign to the property to write)
+            return unbrick_nodes(self._base[..., :1], self.grid_dims)
         return self._base[..., :1]
 
     @densities.setter
@@ -210,7 +253,10 @@ class VoxelGrid(Module):
             self._densities = torch.nn.Parameter(value) if self._tunable and not isinstance(value, torch.nn.Parameter) else value
         else:
             with torch.no_grad():
-                self._base[..., :1].copy_(value)
+                if self.storage == "bricked":
+                    self._base[..., :1].copy_(brick_nodes(value.to(self._base.device, torch.float32)))
+                else:
+                    self._base[..., :1].copy_(value)
         self._occupancy = None
 
     @property
@@ -219,7 +265,7 @@ class VoxelGrid(Module):
         with split storage (assign to the property to write)."""
         if self.storage == "reference":
             return self._features
-        return unpack_split(self._base, self._rest)[1]
+        return unpack_storage(self._base, self._rest, self.storage, self.grid_dims)[1]
 
     @features.setter
     def features(self, value: Tensor) -> None:
@@ -228,7 +274,7 @@ class VoxelGrid(Module):
             self._features = torch.nn.Parameter(value) if self._tunable and not isinstance(value, torch.nn.Parameter) else value
         else:
             with torch.no_grad():
-                base, rest = pack_split(self._base[..., :1], value)
+                base, rest = pack_storage(self.densities, value.to(self._base.device), self.storage)
                 self._base.copy_(base)
                 if rest is not None:
                     self._rest.copy_(rest)
