@@ -385,11 +385,11 @@ def main():
         "config": {
             "workload": f"configs[2]: train step on {G}^3 SH-degree-{args.sh_degree} ReLU field (U(-1,1) init), {args.images} synthetic {H}x{W} images, "
             f"{R} random distinct pixels/GPU/step out of all {args.images}x{H}x{W} ({args.ray_selection} selection), {S} jittered samples/ray, specular+diffuse fwd+bwd, L1+L1, fused Adam"
-            + (", gradient all-reduce over RCCL" if world > 1 else ""),
+            + (", gradient exchange over RCCL: reduce-scatter -> Adam on 1/N of the grid per rank -> all-gather" if world > 1 else ""),
             "rays_per_gpu_per_step": R,
             "samples_per_ray": S,
             "renders_per_step": 2,
-            "parallelism": f"dp{world}",
+            "parallelism": f"dp{world}" + ("+zero1" if world > 1 and stepper.shard_optimizer else ""),
             "grid_storage": args.storage,
             "ray_selection": args.ray_selection,
             "backward": stepper.backward,

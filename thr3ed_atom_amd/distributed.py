@@ -24,14 +24,20 @@ def env_world() -> tuple:
 
 def init_from_env(backend: Optional[str] = None) -> tuple:
     """Join the process group described by torchrun's environment (RANK / LOCAL_RANK / WORLD_SIZE /
-    MASTER_ADDR / MASTER_PORT).  Returns (rank, local_rank, world_size); a world of 1 initialises nothing."""
+    MASTER_ADDR / MASTER_PORT).  Returns (rank, local_rank, world_size); a world of 1 initialises nothing.
+
+    Test hooks (a multi-process run on a box with ONE GPU): ``RF_DIST_BACKEND=gloo`` selects the backend (RCCL refuses
+    two ranks on one device; gloo carries device tensors through the host) and ``RF_SINGLE_DEVICE=1`` maps every rank to
+    device 0 -- the returned local_rank is then 0."""
     rank, local_rank, world = env_world()
+    if os.environ.get("RF_SINGLE_DEVICE"):
+        local_rank = 0
     if world > 1 and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         if backend is None:
-            backend = "nccl" if torch.cuda.is_available() else "gloo"
-        if backend == "nccl":
+            backend = os.environ.get("RF_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
+        if torch.cuda.is_available():
             torch.cuda.set_device(local_rank)
         dist.init_process_group(backend=backend, rank=rank, world_size=world)
     return rank, local_rank, world
