@@ -114,6 +114,12 @@ typedef struct RFRenderOut {
   float* sample_cache_dev; /* [N, S, 4] = (raw r, raw g, raw b, sigma)                                 */
   float* trans_cache_dev;  /* [N, S]    = transmittance T_i                                            */
   int32_t* stop_cache_dev; /* [N]       = number of samples the forward pass processed                 */
+  /* Optional (with the cache): the forward pass also COUNTS, per (brick, flags) key of the binned backward (see
+   * rf_render_backward_emit), the samples that can carry gradient -- T != 0, and sigma != 0 under ReLU -- into
+   * key_hist_dev [8 * nbricks] (added to; clear before the first use) and flags them in the sign bit of trans_cache, so
+   * that rf_render_backward_emit_direct can write their records straight to the final positions. */
+  int32_t* key_hist_dev;
+  int32_t brick_size;      /* 4 or 8 (only read when key_hist_dev != NULL)                             */
 } RFRenderOut;
 
 /* Upstream gradients of a render (all [N, ...] device arrays; any may be NULL = zero). */
@@ -205,6 +211,14 @@ int rf_expand_records(const RFGrid* grid, const float* records_dev, const int64_
                       int64_t capacity, const float* ray_basis_dev, int32_t render_diffuse, float* records_sorted_dev,
                       void* stream);
 int32_t rf_expanded_record_floats(int32_t num_features);
+/* Fused binning (no per-slot keys / records, no scatter pass): the FORWARD pass counted the records per key
+ * (RFRenderOut.key_hist_dev); rf_bin_offsets turns the counters into offsets + cursor; this backward variant then writes
+ * every counted sample's expanded record at the next free position of its key (atomic cursor) -- zeros for counted
+ * samples whose gradient vanishes -- and clears hist_clear_dev [8*nbricks] (may be NULL) for the next iteration.
+ * `fwd` must be the RFRenderOut of that forward call (its trans_cache carries the flags). */
+int rf_render_backward_emit_direct(const RFGrid* grid, const RFRayBatch* rays, uint32_t flags, const RFRenderOut* fwd,
+                                   const RFRenderGrads* grads, int32_t brick_size, int32_t* cursor_dev,
+                                   float* records_sorted_dev, int32_t* hist_clear_dev, void* stream);
 /* Counting-sort alternative to steps (2)+(3) (no torch.sort): pass hist_dev [8*nbricks] (int32, zero before the first
  * use) to rf_render_backward_emit, which adds the number of records per key; rf_bin_offsets turns it into offsets_dev
  * [8*nbricks+1] (positions start at 0: unkeyed slots take no room) and a copy cursor_dev [8*nbricks] (int32);

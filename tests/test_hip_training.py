@@ -433,21 +433,29 @@ def _binned_gradients(grid, rays, cfg, target, device, diffuse_too=True, accumul
     lists, keep = [], []
     for i, diffuse in enumerate((False, True) if diffuse_too else (False,)):
         flags = O.render_flags(cfg.white_bkgd, diffuse or cfg.render_diffuse, cfg.optimized_sampling, False)
-        colour, _, _, _, caches = O.render_forward_raw(grid, o, d, None, S, near, far, flags, save=True)
+        is_diffuse = diffuse or cfg.render_diffuse
+        hist = torch.zeros(num_bricks * 8, dtype=torch.int32, device=device) if binning in ("count", "fused") else None
+        colour, _, _, _, caches = O.render_forward_raw(grid, o, d, None, S, near, far, flags, save=True, key_hist=hist if binning == "fused" else None)
         g_colour = O.l1_loss_grad_hip(colour, target, sums[2 * i : 2 * i + 2])
         keys = torch.empty(n * S, dtype=torch.int16, device=device)
         rec = torch.empty((n * S, 8), device=device)
-        is_diffuse = diffuse or cfg.render_diffuse
         srt = torch.empty((n * S, O.expanded_record_floats(grid, is_diffuse)), device=device)
-        hist = torch.zeros(num_bricks * 8, dtype=torch.int32, device=device) if binning == "count" else None
-        O.render_backward_emit_raw(grid, o, d, None, S, near, far, flags, caches, g_colour, None, None, 8, keys, rec, None if diffuse else ray_basis, hist)
         offsets = torch.full((num_bricks * 8 + 1,), n * S, dtype=torch.int64, device=device)
-        if binning == "count":
-            cursor = torch.empty(num_bricks * 8, dtype=torch.int32, device=device)
-            O.bin_records_by_brick(grid, keys, rec, None if is_diffuse else ray_basis, is_diffuse, hist, cursor, srt, offsets)
-            assert int(hist.abs().sum()) == 0 and int(offsets[-1]) == int((keys >= 0).sum())
+        cursor = torch.empty(num_bricks * 8, dtype=torch.int32, device=device)
+        if binning == "fused":  # the forward pass counted; the backward pass writes expanded records at their final positions
+            counted = int(hist.sum())
+            assert counted == int((caches[1] < 0).sum())  # one flag per counted sample
+            O.bin_offsets(hist, offsets, cursor)
+            O.render_backward_emit_direct_raw(grid, o, d, None, S, near, far, flags, caches, g_colour, None, None, 8, cursor, srt, hist_clear=hist)
+            assert int(hist.abs().sum()) == 0 and int(offsets[-1]) == counted
+            assert torch.equal(cursor.to(torch.int64), offsets[1:])  # every class filled exactly
         else:
-            O.sort_records_by_brick(grid, keys, rec, None if is_diffuse else ray_basis, is_diffuse, srt, offsets, boundaries)
+            O.render_backward_emit_raw(grid, o, d, None, S, near, far, flags, caches, g_colour, None, None, 8, keys, rec, None if diffuse else ray_basis, hist)
+            if binning == "count":
+                O.bin_records_by_brick(grid, keys, rec, None if is_diffuse else ray_basis, is_diffuse, hist, cursor, srt, offsets)
+                assert int(hist.abs().sum()) == 0 and int(offsets[-1]) == int((keys >= 0).sum())
+            else:
+                O.sort_records_by_brick(grid, keys, rec, None if is_diffuse else ray_basis, is_diffuse, srt, offsets, boundaries)
         lists.append((srt, offsets, diffuse or cfg.render_diffuse))
         keep.append((keys, rec, caches))
     # the specular list first (it writes every channel), the diffuse list (base channels only) on top
@@ -462,7 +470,7 @@ def _binned_gradients(grid, rays, cfg, target, device, diffuse_too=True, accumul
     return gd, gf
 
 
-@pytest.mark.parametrize("accumulate,binning", [(False, "sort"), (True, "sort"), (False, "count")])
+@pytest.mark.parametrize("accumulate,binning", [(False, "sort"), (True, "sort"), (False, "count"), (False, "fused")])
 @pytest.mark.parametrize("storage", ["reference", "split", "bricked"])
 @pytest.mark.parametrize("case", ["grid16_sh2", "aniso_sh2_abs", "aniso_sh1_softplus", "cube20_sh0"])
 def test_binned_backward_equals_atomic_backward(hip_device, storage, case, accumulate, binning):

@@ -36,6 +36,7 @@ EXPORTED_SYMBOLS = [
     "rf_expand_records",
     "rf_expanded_record_floats",
     "rf_bin_offsets",
+    "rf_render_backward_emit_direct",
     "rf_scatter_records",
     "rf_brick_accumulate",
     "rf_grid_query",
@@ -87,6 +88,8 @@ class RFRenderOut(C.Structure):
         ("sample_cache_dev", C.c_void_p),
         ("trans_cache_dev", C.c_void_p),
         ("stop_cache_dev", C.c_void_p),
+        ("key_hist_dev", C.c_void_p),
+        ("brick_size", C.c_int32),
     ]
 
 
@@ -163,6 +166,9 @@ def load() -> C.CDLL:
     lib.rf_expanded_record_floats.argtypes = [i32]
     lib.rf_expanded_record_floats.restype = i32
     lib.rf_bin_offsets.argtypes = [vp, i32, vp, vp, vp]
+    lib.rf_render_backward_emit_direct.argtypes = [
+        C.POINTER(RFGrid), C.POINTER(RFRayBatch), u32, C.POINTER(RFRenderOut), C.POINTER(RFRenderGrads), i32, vp, vp, vp, vp,
+    ]
     lib.rf_scatter_records.argtypes = [C.POINTER(RFGrid), vp, vp, i64, vp, vp, i32, vp, vp, i32, vp]
     lib.rf_brick_accumulate.argtypes = [C.POINTER(RFGrid), i32, C.POINTER(RFBrickList), i32, vp, vp, i32, vp]
     lib.rf_grid_query.argtypes = [C.POINTER(RFGrid), vp, i64, vp, vp]

@@ -92,8 +92,12 @@ struct OutArgs {
   float* acc;
   float* disparity;
   float* cache;   // [N,S,4]
-  float* tcache;  // [N,S]
+  float* tcache;  // [N,S]; the sign bit marks the samples counted in `hist` (transmittance itself is >= 0)
   int* stop;      // [N]
+  // binned backward, fused binning: the forward pass counts, per (brick, flags) key, the samples that will emit a record
+  int* hist;        // [8 * nbricks] or NULL
+  int brick_shift;  // log2 of the brick edge (nodes)
+  int nby, nbz;     // bricks along y and z
 };
 
 struct GradArgs {
@@ -109,35 +113,15 @@ struct GradArgs {
   int brick_shift;  // log2 of the brick edge (nodes)
   int nby, nbz;     // bricks along y and z
   int* hist;        // [8 * nbricks] records per key, added to (may be NULL)
+  // direct mode (EMIT == 2): expanded records written straight to their final position
+  int* cursor;      // [8 * nbricks] next free position per key
+  float4* sorted;   // [capacity, record_quads(K)]
+  int* hist_clear;  // counters of the forward pass to clear for the next iteration (may be NULL)
+  int nkeys;
 };
 
 constexpr short kNoBrick = -1;  // sorts in front of every (brick, flags) key
 
-// Lanes hold the keys of 64 consecutive sample slots (-1 = none).  Consecutive samples of a ray mostly share their
-// key, so one atomic per RUN of equal keys is issued (by the run's first lane) instead of one per lane.  Returns this
-// lane's rank = counter value before the run + position inside the run (only meaningful for key >= 0); with
-// WANT_RANK = false the atomic is fire-and-forget.
-template <bool WANT_RANK>
-__device__ __forceinline__ int add_key_runs(int* counters, int key, int lane) {
-  const bool active = key >= 0;
-  const int prev = __shfl_up(key, 1);
-  const bool head = active && (lane == 0 || prev != key);
-  const unsigned long long heads = __ballot(head);
-  const unsigned long long ends = __ballot(head || !active);  // a run stops at the next head or inactive lane
-  const unsigned long long above = (lane == 63) ? 0ull : (ends & ~((2ull << lane) - 1ull));
-  const int run = (above ? __builtin_ctzll(above) : 64) - lane;
-  int base = 0;
-  if (head) {
-    if (WANT_RANK)
-      base = atomicAdd(&counters[key], run);
-    else
-      atomicAdd(&counters[key], run);
-  }
-  if (!WANT_RANK) return 0;
-  const unsigned long long below = heads & ((lane == 63) ? ~0ull : ((2ull << lane) - 1ull));
-  const int hl = below ? 63 - __builtin_clzll(below) : 0;
-  return __shfl(base, hl) + (lane - hl);
-}
 
 // 16-byte load/store at 4-byte alignment (a corner's 27 features start at a multiple of 108 B)
 struct __attribute__((packed, aligned(4))) f4u {
@@ -529,6 +513,66 @@ __device__ __forceinline__ LaneSlice lane_slice(const GridArgs& g, const float d
   return ls;
 }
 
+// Lanes hold the keys of 64 consecutive sample slots (-1 = none).  Consecutive samples of a ray mostly share their
+// key, so one atomic per RUN of equal keys is issued (by the run's first lane) instead of one per lane.  Returns this
+// lane's rank = counter value before the run + position inside the run (only meaningful for key >= 0); with
+// WANT_RANK = false the atomic is fire-and-forget.
+template <bool WANT_RANK>
+__device__ __forceinline__ int add_key_runs(int* counters, int key, int lane) {
+  const bool active = key >= 0;
+  const int prev = __shfl_up(key, 1);
+  const bool head = active && (lane == 0 || prev != key);
+  const unsigned long long heads = __ballot(head);
+  const unsigned long long ends = __ballot(head || !active);  // a run stops at the next head or inactive lane
+  const unsigned long long above = (lane == 63) ? 0ull : (ends & ~((2ull << lane) - 1ull));
+  const int run = (above ? __builtin_ctzll(above) : 64) - lane;
+  int base = 0;
+  if (head) {
+    if (WANT_RANK)
+      base = atomicAdd(&counters[key], run);
+    else
+      atomicAdd(&counters[key], run);
+  }
+  if (!WANT_RANK) return 0;
+  const unsigned long long below = heads & ((lane == 63) ? ~0ull : ((2ull << lane) - 1ull));
+  const int hl = below ? 63 - __builtin_clzll(below) : 0;
+  return __shfl(base, hl) + (lane - hl);
+}
+
+// LDS channel order of a node ("split order"): 0 = density, 1..3 = degree-0 R,G,B, 4 + r = rest channel r
+template <int K>
+__device__ __forceinline__ void lds_channel_meaning(int c, int& colour, int& basis_k) {
+  if (c == 0) {
+    colour = 3;
+    basis_k = 0;
+  } else if (c < 4) {
+    colour = c - 1;
+    basis_k = 0;
+  } else {
+    const int rr = c - 4;
+    constexpr int KR = K > 1 ? K - 1 : 1;
+    colour = (K > 1) ? rr / KR : 0;
+    basis_k = (K > 1) ? rr % KR + 1 : 0;
+  }
+}
+
+// float4s of an expanded record: (index x, y, z, -) followed by the per-channel values in LDS channel order
+__host__ __device__ constexpr int record_quads(int K) { return 1 + (3 * K + 1 + 3) / 4; }
+
+// key of a sample's cell in the binned backward = brick of the cell's lower node * 8 + flags; flag bit a = the cell's
+// UPPER node on axis a belongs to the next brick (and exists), i.e. the record also touches nodes of that neighbour
+__device__ __forceinline__ int brick_key(const int i0[3], const GridArgs& g, int shift, int nby, int nbz) {
+  const int dims3[3] = {g.X, g.Y, g.Z};
+  int b3[3], flags3 = 0;
+#pragma unroll
+  for (int a = 0; a < 3; ++a) {
+    const int lo = max(i0[a], 0), up = i0[a] + 1;
+    b3[a] = lo >> shift;
+    if (up < dims3[a] && (up >> shift) != b3[a]) flags3 |= 1 << a;
+  }
+  return (((b3[0] * nby + b3[1]) * nbz + b3[2]) << 3) | flags3;
+}
+
 // =============================================================================================
 // forward
 // =============================================================================================
@@ -765,8 +809,11 @@ __global__ __launch_bounds__(kBlock) void render_forward_kernel(GridArgs g, RayA
         cv.z = raw_b;
         cv.w = sigma;
         reinterpret_cast<float4*>(out.cache)[idx] = cv;
-        out.tcache[idx] = T;
+        // `need` samples are exactly those that can carry gradient (T != 0, and sigma != 0 under ReLU): they are counted
+        // per key below, and flagged here so that the backward pass emits exactly the counted ones
+        out.tcache[idx] = (out.hist && need) ? -T : T;
       }
+      if (out.hist) add_key_runs<false>(out.hist, need ? brick_key(sm.cell.i0, g, out.brick_shift, out.nby, out.nbz) : -1, lane);
     }
     wave_lds_fence();
     if (T_carry == 0.0f) break;  // every later weight is exactly 0
@@ -803,7 +850,9 @@ struct ScatterLayout {
 //   dL/dsigma_i = delta_i ( T_{i+1} e_i - sum_{j>i} w_j e_j ),   T_{i+1} = T_i (1 - alpha_i)   (division-free)
 // Chunks are walked from the far end so that the suffix sum is an exact running sum.
 // =============================================================================================
-template <int K, bool DIFFUSE, bool EMIT>
+// EMIT: 0 = atomic scatter into the gradient tensors; 1 = per-slot keys + 32-byte records (binned backward, sort or
+// scatter binning); 2 = expanded records written straight to their final position (the forward pass counted them)
+template <int K, bool DIFFUSE, int EMIT>
 __global__ __launch_bounds__(kBlock) void render_backward_kernel(GridArgs g, RayArgs r, OutArgs fwd, GradArgs gr,
                                                                  uint32_t flags) {
   using SL = ScatterLayout<K, DIFFUSE>;
@@ -826,7 +875,11 @@ __global__ __launch_bounds__(kBlock) void render_backward_kernel(GridArgs g, Ray
   const float gD = gr.gdepth ? gr.gdepth[ray] : 0.0f;
   const float gA = gr.gacc ? gr.gacc[ray] : 0.0f;
   const bool no_upstream = gC[0] == 0.f && gC[1] == 0.f && gC[2] == 0.f && gD == 0.f && gA == 0.f;
-  if (EMIT) {
+  if (EMIT == 2) {
+    if (gr.hist_clear)  // the forward pass's counters have been turned into offsets: clear them for the next iteration
+      for (long long k = (long long)blockIdx.x * blockDim.x + threadIdx.x; k < gr.nkeys; k += (long long)gridDim.x * blockDim.x) gr.hist_clear[k] = 0;
+  }
+  if (EMIT == 1) {
     // every sample slot of the ray gets a key (the sort runs over the dense array)
     const int done = (no_upstream) ? 0 : fwd.stop[ray];
     for (int s2 = ((done + kWave - 1) / kWave) * kWave + lane; s2 < r.S; s2 += kWave) gr.keys[ray * (long long)r.S + s2] = kNoBrick;
@@ -843,7 +896,7 @@ __global__ __launch_bounds__(kBlock) void render_backward_kernel(GridArgs g, Ray
       wave_lds_fence();
     }
   }
-  if (no_upstream) return;
+  if (no_upstream && EMIT != 2) return;  // (direct mode: the counted samples of this ray still need their -- zero -- records)
 
   // Scatter layout (measured on MI355X, tools/atomic_microbench.hip): float32 atomics retire at a fixed rate of
   // ~21 G 64-byte-sector requests/s however many dwords a request carries, so one instruction should cover as
@@ -936,6 +989,8 @@ __global__ __launch_bounds__(kBlock) void render_backward_kernel(GridArgs g, Ray
       sigma = cv.w;
       T = fwd.tcache[idx];
     }
+    const bool counted = have && (__float_as_uint(T) >> 31);  // flagged by a forward pass that counts records per key
+    T = fabsf(T);
     const float alpha = 1.0f - exp_fast(-(sigma * sm.delta));
     const float w = alpha * T;
     const float Tn = T * (1.0f - alpha);
@@ -964,23 +1019,47 @@ __global__ __launch_bounds__(kBlock) void render_backward_kernel(GridArgs g, Ray
 
     const bool live = have && sm.inside;
     const bool need = live && (g_pre != 0.f || g_raw[0] != 0.f || g_raw[1] != 0.f || g_raw[2] != 0.f);
-    if constexpr (EMIT) {
+    if constexpr (EMIT == 2) {
+      // every sample the forward pass counted gets its expanded record (zeros when its gradient happens to vanish) at
+      // the next position of its key class; `need` samples are always among the counted ones
+      const int key = counted ? brick_key(sm.cell.i0, g, gr.brick_shift, gr.nby, gr.nbz) : -1;
+      const int pos = add_key_runs<true>(gr.cursor, key, lane);
+      if (counted) {
+        constexpr int KE = DIFFUSE ? 1 : K;  // diffuse lists carry the base channels only
+        constexpr int CE = 3 * KE + 1;
+        constexpr int QE = record_quads(KE);
+        float Yd[16];
+        if constexpr (KE > 1)
+          sh_basis<K>(st.d[0] / st.dnorm, st.d[1] / st.dnorm, st.d[2] / st.dnorm, Yd);
+        else
+          Yd[0] = kC0;
+        const float graw[4] = {g_raw[0], g_raw[1], g_raw[2], g_pre * g.rho};  // colour 3 = density
+        float4* dst = gr.sorted + (long long)pos * QE;
+        dst[0] = make_float4(sm.cell.idx[0], sm.cell.idx[1], sm.cell.idx[2], 0.0f);
+#pragma unroll
+        for (int part = 1; part < QE; ++part) {
+          float v[4];
+#pragma unroll
+          for (int x = 0; x < 4; ++x) {
+            const int ch = 4 * (part - 1) + x;
+            int colour, basis_k;
+            lds_channel_meaning<KE>(ch < CE ? ch : 0, colour, basis_k);
+            float gv = graw[colour];
+            if (ch > 0) gv = gv * Yd[basis_k];
+            v[x] = (ch < CE) ? gv : 0.0f;
+          }
+          dst[part] = make_float4(v[0], v[1], v[2], v[3]);
+        }
+      }
+      continue;
+    }
+    if constexpr (EMIT == 1) {
       short key_of_lane = kNoBrick;
       if (sm.valid) {
         const long long slot = ray * (long long)r.S + s;
         short key = kNoBrick;
         if (need) {
-          // key = brick of the cell's lower node * 8 + flags; flag bit a = the cell's UPPER node on axis a belongs to
-          // the next brick (and exists), i.e. the record also touches nodes of that neighbour
-          const int dims3[3] = {g.X, g.Y, g.Z};
-          int b3[3], flags3 = 0;
-#pragma unroll
-          for (int a = 0; a < 3; ++a) {
-            const int lo = max(sm.cell.i0[a], 0), up = sm.cell.i0[a] + 1;
-            b3[a] = lo >> gr.brick_shift;
-            if (up < dims3[a] && (up >> gr.brick_shift) != b3[a]) flags3 |= 1 << a;
-          }
-          key = (short)((((b3[0] * gr.nby + b3[1]) * gr.nbz + b3[2]) << 3) | flags3);
+          key = (short)brick_key(sm.cell.i0, g, gr.brick_shift, gr.nby, gr.nbz);
           float4* rec = reinterpret_cast<float4*>(gr.records) + slot * 2;
           rec[0] = make_float4(sm.cell.idx[0], sm.cell.idx[1], sm.cell.idx[2], g_pre);
           rec[1] = make_float4(g_raw[0], g_raw[1], g_raw[2], __int_as_float((int)ray));
@@ -1078,25 +1157,7 @@ struct BrickArgs {
   int fmul;                // reference layout: feature index of degree-0 colour c is c * fmul (base-only lists on an SH grid)
 };
 
-// LDS channel order of a node ("split order"): 0 = density, 1..3 = degree-0 R,G,B, 4 + r = rest channel r
-template <int K>
-__device__ __forceinline__ void lds_channel_meaning(int c, int& colour, int& basis_k) {
-  if (c == 0) {
-    colour = 3;
-    basis_k = 0;
-  } else if (c < 4) {
-    colour = c - 1;
-    basis_k = 0;
-  } else {
-    const int rr = c - 4;
-    constexpr int KR = K > 1 ? K - 1 : 1;
-    colour = (K > 1) ? rr / KR : 0;
-    basis_k = (K > 1) ? rr % KR + 1 : 0;
-  }
-}
 
-// float4s of an expanded record: (index x, y, z, -) followed by the per-channel values in LDS channel order
-__host__ __device__ constexpr int record_quads(int K) { return 1 + (3 * K + 1 + 3) / 4; }
 
 // Sorted position p (>= *begin: the slots without gradient sort in front) receives the EXPANDED record of slot
 // perm[p]: its continuous index and, for every channel of a node, dL/d(interpolated channel) = dL/draw colour * SH basis
@@ -2125,6 +2186,9 @@ OutArgs to_args(const RFRenderOut* o) {
   a.cache = o->sample_cache_dev;
   a.tcache = o->trans_cache_dev;
   a.stop = o->stop_cache_dev;
+  a.hist = nullptr;
+  a.brick_shift = 0;
+  a.nby = a.nbz = 0;
   return a;
 }
 
@@ -2142,10 +2206,12 @@ void launch_forward(bool save, unsigned blocks, hipStream_t st, const GridArgs& 
 template <int K, bool DIFFUSE>
 void launch_backward(unsigned blocks, hipStream_t st, const GridArgs& g, const RayArgs& r, const OutArgs& o,
                      const GradArgs& gr, uint32_t flags) {
-  if (gr.keys)
-    hipLaunchKernelGGL((render_backward_kernel<K, DIFFUSE, true>), dim3(blocks), dim3(kBlock), 0, st, g, r, o, gr, flags);
+  if (gr.sorted)
+    hipLaunchKernelGGL((render_backward_kernel<K, DIFFUSE, 2>), dim3(blocks), dim3(kBlock), 0, st, g, r, o, gr, flags);
+  else if (gr.keys)
+    hipLaunchKernelGGL((render_backward_kernel<K, DIFFUSE, 1>), dim3(blocks), dim3(kBlock), 0, st, g, r, o, gr, flags);
   else
-    hipLaunchKernelGGL((render_backward_kernel<K, DIFFUSE, false>), dim3(blocks), dim3(kBlock), 0, st, g, r, o, gr, flags);
+    hipLaunchKernelGGL((render_backward_kernel<K, DIFFUSE, 0>), dim3(blocks), dim3(kBlock), 0, st, g, r, o, gr, flags);
 }
 
 unsigned grid_1d(long long n, int block, long long cap = 256LL * 16) {
@@ -2238,6 +2304,17 @@ int rf_ray_aabb_bounds(const float* origins_dev, const float* directions_dev, in
   return launch_status();
 }
 
+static int brick_geometry(const RFGrid* grid, int brick_size, int* shift, int nb[3]) {
+  if (brick_size != 4 && brick_size != 8) return RF_ERR_UNSUPPORTED;
+  *shift = (brick_size == 4) ? 2 : 3;
+  long long total = 1;
+  for (int a = 0; a < 3; ++a) {
+    nb[a] = (grid->dims[a] + brick_size - 1) / brick_size;
+    total *= nb[a];
+  }
+  return (total * 8 - 1 <= 0x7fff) ? RF_OK : RF_ERR_UNSUPPORTED;  // (brick, flags) must fit a positive 16-bit sort key
+}
+
 int rf_render_forward(const RFGrid* grid, const RFRayBatch* rays, uint32_t flags, const RFRenderOut* out,
                       void* stream) {
   int rc = check_grid(grid);
@@ -2253,7 +2330,17 @@ int rf_render_forward(const RFGrid* grid, const RFRayBatch* rays, uint32_t flags
 
   const GridArgs g = to_args(grid);
   const RayArgs r = to_args(rays);
-  const OutArgs o = to_args(out);
+  OutArgs o = to_args(out);
+  if (out->key_hist_dev) {  // count the records of the binned backward per (brick, flags) key
+    if (!save) return RF_ERR_NULL_POINTER;
+    int shift, nb[3];
+    rc = brick_geometry(grid, out->brick_size, &shift, nb);
+    if (rc != RF_OK) return rc;
+    o.hist = out->key_hist_dev;
+    o.brick_shift = shift;
+    o.nby = nb[1];
+    o.nbz = nb[2];
+  }
   const unsigned blocks = (unsigned)((rays->num_rays + kWavesPerBlock - 1) / kWavesPerBlock);
   hipStream_t st = (hipStream_t)stream;
   const bool diffuse = flags & RF_FLAG_RENDER_DIFFUSE;
@@ -2309,16 +2396,6 @@ int rf_render_backward(const RFGrid* grid, const RFRayBatch* rays, uint32_t flag
   return backward_impl(grid, rays, flags, fwd, grads, gr, stream);
 }
 
-static int brick_geometry(const RFGrid* grid, int brick_size, int* shift, int nb[3]) {
-  if (brick_size != 4 && brick_size != 8) return RF_ERR_UNSUPPORTED;
-  *shift = (brick_size == 4) ? 2 : 3;
-  long long total = 1;
-  for (int a = 0; a < 3; ++a) {
-    nb[a] = (grid->dims[a] + brick_size - 1) / brick_size;
-    total *= nb[a];
-  }
-  return (total * 8 - 1 <= 0x7fff) ? RF_OK : RF_ERR_UNSUPPORTED;  // (brick, flags) must fit a positive 16-bit sort key
-}
 
 int rf_render_backward_emit(const RFGrid* grid, const RFRayBatch* rays, uint32_t flags, const RFRenderOut* fwd,
                             const RFRenderGrads* grads, int32_t brick_size, int16_t* keys_dev, float* records_dev,
@@ -2336,6 +2413,26 @@ int rf_render_backward_emit(const RFGrid* grid, const RFRayBatch* rays, uint32_t
   gr.nby = nb[1];
   gr.nbz = nb[2];
   gr.hist = hist_dev;
+  return backward_impl(grid, rays, flags, fwd, grads, gr, stream);
+}
+
+int rf_render_backward_emit_direct(const RFGrid* grid, const RFRayBatch* rays, uint32_t flags, const RFRenderOut* fwd,
+                                   const RFRenderGrads* grads, int32_t brick_size, int32_t* cursor_dev,
+                                   float* records_sorted_dev, int32_t* hist_clear_dev, void* stream) {
+  if (!grid) return RF_ERR_NULL_POINTER;
+  if (!cursor_dev || !records_sorted_dev) return RF_ERR_NULL_POINTER;
+  if (grid->num_features > 27) return RF_ERR_UNSUPPORTED;
+  int shift, nb[3];
+  const int rc = brick_geometry(grid, brick_size, &shift, nb);
+  if (rc != RF_OK) return rc;
+  GradArgs gr = {};
+  gr.cursor = cursor_dev;
+  gr.sorted = reinterpret_cast<float4*>(records_sorted_dev);
+  gr.hist_clear = hist_clear_dev;
+  gr.nkeys = nb[0] * nb[1] * nb[2] * 8;
+  gr.brick_shift = shift;
+  gr.nby = nb[1];
+  gr.nbz = nb[2];
   return backward_impl(grid, rays, flags, fwd, grads, gr, stream);
 }
 

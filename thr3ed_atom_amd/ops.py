@@ -122,9 +122,11 @@ def _ray_batch(origins: Tensor, directions: Tensor, num_samples: int, near: floa
 
 
 def render_forward_raw(grid: VoxelGrid, origins: Tensor, directions: Tensor, t_rand: Optional[Tensor], num_samples: int,
-                       near: float, far: float, flags: int, save: bool):
+                       near: float, far: float, flags: int, save: bool, key_hist: Optional[Tensor] = None, brick_size: int = 8):
     """Enqueue rf_render_forward.  Returns (colour [N,3], depth [N,1], acc [N,1], disparity [N,1], caches) where
-    ``caches`` = (sample_cache [N,S,4], trans_cache [N,S], stop [N]) when ``save`` else None.  No autograd."""
+    ``caches`` = (sample_cache [N,S,4], trans_cache [N,S], stop [N]) when ``save`` else None.  No autograd.
+    ``key_hist`` (int32 [8 * num_bricks], with ``save``): the pass also counts, per (brick, flags) key, the samples that
+    will emit a record in ``render_backward_emit_direct_raw`` and flags them in the cache."""
     lib = _lib.load()
     for name, t in (("ray origins", origins), ("ray directions", directions)):
         _require_hip(t, name)
@@ -145,6 +147,8 @@ def render_forward_raw(grid: VoxelGrid, origins: Tensor, directions: Tensor, t_r
         stop = torch.empty((n,), dtype=torch.int32, device=dev)
         out.sample_cache_dev, out.trans_cache_dev, out.stop_cache_dev = cache.data_ptr(), tcache.data_ptr(), stop.data_ptr()
         caches = (cache, tcache, stop)
+        if key_hist is not None:
+            out.key_hist_dev, out.brick_size = key_hist.data_ptr(), int(brick_size)
     with _span(f"render_forward[{_variant(grid, flags)}{',save' if save else ''}]", dev):
         rc = lib.rf_render_forward(C.byref(rf_grid), C.byref(rb), int(flags), C.byref(out), _stream(dev))
     _lib.check(rc, "rf_render_forward")
@@ -200,6 +204,39 @@ def render_backward_emit_raw(grid: VoxelGrid, origins: Tensor, directions: Tenso
             _ptr(ray_basis), _ptr(hist), _stream(dev),
         )
     _lib.check(rc, "rf_render_backward_emit")
+
+
+def render_backward_emit_direct_raw(grid: VoxelGrid, origins: Tensor, directions: Tensor, t_rand: Optional[Tensor], num_samples: int,
+                                    near: float, far: float, flags: int, caches, g_colour: Optional[Tensor], g_depth: Optional[Tensor],
+                                    g_acc: Optional[Tensor], brick_size: int, cursor: Tensor, records_sorted: Tensor,
+                                    hist_clear: Optional[Tensor] = None) -> None:
+    """Enqueue rf_render_backward_emit_direct: the samples counted by the forward pass (``render_forward_raw(key_hist=)``,
+    then ``bin_offsets``) write their expanded records straight to their final positions in ``records_sorted``."""
+    lib = _lib.load()
+    dev = origins.device
+    rf_grid = grid.to_rf_grid(use_occupancy=bool(flags & _lib.FLAG_OCCUPANCY_SKIP))
+    rb, tv = _ray_batch(origins, directions, num_samples, near, far, t_rand)
+    grads = _lib.RFRenderGrads()
+    grads.grad_colour_dev, grads.grad_depth_dev, grads.grad_acc_dev = _ptr(g_colour), _ptr(g_depth), _ptr(g_acc)
+    cache, tcache, stop = caches
+    fwd = _lib.RFRenderOut()
+    fwd.sample_cache_dev, fwd.trans_cache_dev, fwd.stop_cache_dev = cache.data_ptr(), tcache.data_ptr(), stop.data_ptr()
+    with _span(f"render_backward_emit_direct[{_variant(grid, flags)}]", dev):
+        rc = lib.rf_render_backward_emit_direct(
+            C.byref(rf_grid), C.byref(rb), int(flags), C.byref(fwd), C.byref(grads), int(brick_size), cursor.data_ptr(),
+            records_sorted.data_ptr(), _ptr(hist_clear), _stream(dev),
+        )
+    _lib.check(rc, "rf_render_backward_emit_direct")
+
+
+def bin_offsets(hist: Tensor, offsets: Tensor, cursor: Tensor) -> Tensor:
+    """``hist`` (records per key) -> ``offsets`` [len + 1] (int64 exclusive prefix sums) and ``cursor`` (int32 copy)."""
+    lib = _lib.load()
+    dev = hist.device
+    with _span("bin_offsets", dev):
+        rc = lib.rf_bin_offsets(hist.data_ptr(), int(hist.numel()), offsets.data_ptr(), cursor.data_ptr(), _stream(dev))
+    _lib.check(rc, "rf_bin_offsets")
+    return offsets
 
 
 def expanded_record_floats(grid: VoxelGrid, render_diffuse: bool = False) -> int:

@@ -35,6 +35,8 @@ from .ops import (
     brick_counts,
     cast_selected_rays_hip,
     render_backward_emit_raw,
+    render_backward_emit_direct_raw,
+    bin_offsets,
     sort_records_by_brick,
     bin_records_by_brick,
     expanded_record_floats,
@@ -258,24 +260,35 @@ class TrainStepper:
             if cfg.consume_reference_rng:
                 torch.randn(n, S, dtype=torch.float32, device=origins.device)
             flags = render_flags(cfg.white_bkgd, diffuse, cfg.optimized_sampling, cfg.use_occupancy_mask)
-            colour, _, _, _, caches = render_forward_raw(grid, origins, directions, t_rand, S, near, far, flags, save=True)
+            use_bricks = binned and (not diffuse or self.deterministic)
+            fused_binning = use_bricks and not self.deterministic  # the forward pass counts the records per key
+            colour, _, _, _, caches = render_forward_raw(
+                grid, origins, directions, t_rand, S, near, far, flags, save=True,
+                key_hist=bins["hist"] if fused_binning else None, brick_size=self.brick_size,
+            )
             g_colour = l1_loss_grad_hip(colour, pixels, sums[2 * i : 2 * i + 2])
-            if binned and (not diffuse or self.deterministic):
+            if use_bricks:
                 # per-sample gradient records -> binned by (8^3-node brick, boundary flags) -> every brick summed in LDS
                 # without atomics and written with plain stores.  The specular pass overwrites the whole bucket (no
                 # zero-fill).  The diffuse pass (4 base channels = one 16-byte sector per corner) is as fast or faster
                 # through the atomic scatter (measured: 0.26 vs 0.26 ms on a random field, 0.13 vs 0.19 ms once the field
                 # is trained), so it goes through the bricks only when a fixed summation order is asked for; it then
                 # carries the base channels only, adds on top and reuses the same scratch buffers (stream order).
-                render_backward_emit_raw(
-                    grid, origins, directions, t_rand, S, near, far, flags, caches, g_colour, None, None, self.brick_size,
-                    bins["keys"], bins["records"], None if diffuse else bins["ray_basis"], None if self.deterministic else bins["hist"],
-                )
                 basis = None if diffuse else bins["ray_basis"]
-                if self.deterministic:  # stable 16-bit radix sort: fixed summation order
+                if fused_binning:
+                    # counting sort whose counting ran inside the forward pass: offsets, then the backward pass writes
+                    # the expanded records straight to their final positions (and clears the counters)
+                    offsets = bin_offsets(bins["hist"], bins["offsets"], bins["cursor"])
+                    render_backward_emit_direct_raw(
+                        grid, origins, directions, t_rand, S, near, far, flags, caches, g_colour, None, None, self.brick_size,
+                        bins["cursor"], bins["sorted"], hist_clear=bins["hist"],
+                    )
+                else:  # stable 16-bit radix sort of per-slot keys: fixed summation order
+                    render_backward_emit_raw(
+                        grid, origins, directions, t_rand, S, near, far, flags, caches, g_colour, None, None, self.brick_size,
+                        bins["keys"], bins["records"], basis, None,
+                    )
                     offsets = sort_records_by_brick(grid, bins["keys"], bins["records"], basis, diffuse, bins["sorted"], bins["offsets"], bins["boundaries"])
-                else:  # counting sort with atomic cursors
-                    offsets = bin_records_by_brick(grid, bins["keys"], bins["records"], basis, diffuse, bins["hist"], bins["cursor"], bins["sorted"], bins["offsets"])
                 brick_accumulate_raw(grid, self.brick_size, [(bins["sorted"], offsets, diffuse)], gd, gf, accumulate=diffuse)
             else:
                 render_backward_raw(grid, origins, directions, t_rand, S, near, far, flags, caches, g_colour, None, None, gd, gf)
