@@ -340,7 +340,7 @@ def main():
         },
     }
     spec = f"sh{args.sh_degree}"
-    pipeline = [k for k in ksum if k in (f"render_backward_emit[{spec}]", "sort_keys", "expand_records", f"scatter_records[{spec}]", f"brick_accumulate[{spec}]")]
+    pipeline = [k for k in ksum if k in (f"render_backward_emit[{spec}]", f"render_backward_emit_direct[{spec}]", "sort_keys", "expand_records", f"scatter_records[{spec}]", f"brick_accumulate[{spec}]")]
     if f"brick_accumulate[{spec}]" in ksum:
         # the whole specular backward (emit -> bin -> scatter-expand -> brick pass) against the same scatter payload
         # (bin_offsets, 10 us, is shared by both passes and counted once)
@@ -353,7 +353,7 @@ def main():
             "achieved": pbytes / 1e9 / (total_ms / 1e3),
             "frac": pbytes / 1e9 / (total_ms / 1e3) / HBM_PEAK_GBS,
         }
-        roofline["pipeline"]["note"] = "the binned specular backward as a whole (emit -> bin -> scatter-expand -> brick pass) against the scatter payload of SURVEY 8d"
+        roofline["pipeline"]["note"] = "the binned specular backward as a whole (scan -> emit at final positions -> brick pass; its counting runs inside the forward pass) against the scatter payload of SURVEY 8d"
     prof = os.path.join(ROOT, "profiles", "pmc_traffic.json")
     if os.path.exists(prof):
         try:
