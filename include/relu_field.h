@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define RF_ABI_VERSION 1
+#define RF_ABI_VERSION 2
 
 enum {
   RF_OK = 0,

@@ -15,6 +15,8 @@ LIB_PATH = os.path.join(CSRC_DIR, LIB_NAME)
 SOURCES = ["relu_field_kernels.hip"]
 HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared"]
 
+ABI_VERSION = 2  # RF_ABI_VERSION of include/relu_field.h (2: binned backward, RFRenderOut.key_hist_dev, bricked layout)
+
 # enums of relu_field.h
 DENSITY_MODES = {"relu": 0, "softplus": 1, "abs": 2, "identity": 3}
 LAYOUTS = {"reference": 0, "split": 1, "bricked": 2}
@@ -179,8 +181,8 @@ def load() -> C.CDLL:
     for name in EXPORTED_SYMBOLS:
         if name not in ("rf_error_string",):
             getattr(lib, name).restype = C.c_int
-    if lib.rf_abi_version() != 1:
-        raise RuntimeError(f"{LIB_PATH}: ABI version {lib.rf_abi_version()} != 1")
+    if lib.rf_abi_version() != ABI_VERSION:
+        raise RuntimeError(f"{LIB_PATH}: ABI version {lib.rf_abi_version()} != {ABI_VERSION} (stale build? run __graft_entry__.build())")
     _LIB = lib
     return lib
 
