@@ -1456,15 +1456,16 @@ __global__ __launch_bounds__(kBrickThreads) void brick_accumulate_kernel(GridArg
   auto issue = [&](int bb) {
     const int v = min(bb * kBrickBatch + (lane & (kBrickBatch - 1)), total - 1);
     while (s_rcum[sri + 1] <= v) ++sri;
+    // (positions, not pointers, go through the shuffle: a pointer rebuilt from integers would be a FLAT access, and FLAT
+    // loads in flight force every LDS wait in this kernel to drain completely)
     const long long pos = s_rstart[sri] + (v - s_rcum[sri]);
-    const float4* mine = (s_rlist[sri] ? a.lists[1].rec : a.lists[0].rec) + pos * Q;
-    const unsigned long long addr = reinterpret_cast<unsigned long long>(mine);
-    const int lo = (int)(uint32_t)addr, hi = (int)(uint32_t)(addr >> 32);
+    const int lo = (int)(uint32_t)pos, hi = (int)(uint32_t)((unsigned long long)pos >> 32) | (s_rlist[sri] << 30);
 #pragma unroll
     for (int t = 0; t < TPL; ++t) {
       const int src = sj + 8 * t;
-      const unsigned long long ra = ((unsigned long long)(uint32_t)__shfl(hi, src) << 32) | (uint32_t)__shfl(lo, src);
-      const float4* rec = reinterpret_cast<const float4*>(ra);
+      const uint32_t plo = (uint32_t)__shfl(lo, src), phi = (uint32_t)__shfl(hi, src);
+      const long long p = (long long)(((unsigned long long)(phi & 0x3fffffffu) << 32) | plo);
+      const float4* rec = ((phi >> 30) ? a.lists[1].rec : a.lists[0].rec) + p * Q;
       ridx[t] = rec[0];
       rval[t] = rec[vpart];
     }
@@ -1539,12 +1540,18 @@ __global__ __launch_bounds__(kBrickThreads) void brick_accumulate_kernel(GridArg
     const int steps = min(nb, H);  // records >= nb are padded (zero weight, trash address, far-away cell)
     const uint32_t* row = tb;
     const int aoff = 4 * q, goff = GOFF + 2 * ch;  // this lane's (addrA, wA, addrB, wB) and (gA.x, gA.y, gB.x, gB.y)
-    // one step: read-add-write of both records with the data in (aw, gg)
-    auto rmw = [&](const uint4& aw, const float4& gg, bool shared) {
+    // One step = the pair of records (j, j + 16).  Ordering inside a step matters: the accumulator reads are issued FIRST,
+    // then the table entries of the next step (which the following step needs only after ITS accumulator reads), so that
+    // the wait for the accumulators leaves the prefetch in flight.
+    uint4 aw = *reinterpret_cast<const uint4*>(row + aoff);
+    float4 gg = *reinterpret_cast<const float4*>(row + goff);
+#pragma unroll 2
+    for (int j = 0; j < steps; ++j) {
+      row += ROW;  // (the table has spare steps behind the last one)
       const float wA = __uint_as_float(aw.y), wB = __uint_as_float(aw.w);
       float2* dA = reinterpret_cast<float2*>(&acc[aw.x + ch]);
       float2* dB = reinterpret_cast<float2*>(&acc[aw.z + ch]);
-      if (shared) {
+      if ((shared_mask >> j) & 1u) {  // rare: the two cells share nodes -> one after the other
         float2 vA = *dA;
         vA.x = vA.x + wA * gg.x;
         vA.y = vA.y + wA * gg.y;
@@ -1553,33 +1560,21 @@ __global__ __launch_bounds__(kBrickThreads) void brick_accumulate_kernel(GridArg
         vB.x = vB.x + wB * gg.z;
         vB.y = vB.y + wB * gg.w;
         *dB = vB;
+        aw = *reinterpret_cast<const uint4*>(row + aoff);
+        gg = *reinterpret_cast<const float4*>(row + goff);
       } else {
         float2 vA = *dA, vB = *dB;
+        const uint4 aw_n = *reinterpret_cast<const uint4*>(row + aoff);
+        const float4 gg_n = *reinterpret_cast<const float4*>(row + goff);
         vA.x = vA.x + wA * gg.x;
         vA.y = vA.y + wA * gg.y;
         vB.x = vB.x + wB * gg.z;
         vB.y = vB.y + wB * gg.w;
         *dA = vA;
         *dB = vB;
+        aw = aw_n;
+        gg = gg_n;
       }
-    };
-    // four steps per iteration on two register sets X / Y that alternate by name (no register copies): while the
-    // read-add-writes of two steps run from one set, the entries of the next two steps are fetched into the other
-    uint4 awX0 = *reinterpret_cast<const uint4*>(row + aoff), awX1 = *reinterpret_cast<const uint4*>(row + ROW + aoff);
-    float4 gX0 = *reinterpret_cast<const float4*>(row + goff), gX1 = *reinterpret_cast<const float4*>(row + ROW + goff);
-    for (int j = 0; j < steps; j += 4) {
-      const uint32_t* rowY = row + 2 * ROW;
-      const uint4 awY0 = *reinterpret_cast<const uint4*>(rowY + aoff), awY1 = *reinterpret_cast<const uint4*>(rowY + ROW + aoff);
-      const float4 gY0 = *reinterpret_cast<const float4*>(rowY + goff), gY1 = *reinterpret_cast<const float4*>(rowY + ROW + goff);
-      rmw(awX0, gX0, (shared_mask >> j) & 1u);
-      if (j + 1 < steps) rmw(awX1, gX1, (shared_mask >> (j + 1)) & 1u);
-      row += 4 * ROW;  // (the table has two spare steps behind the last one)
-      awX0 = *reinterpret_cast<const uint4*>(row + aoff);
-      awX1 = *reinterpret_cast<const uint4*>(row + ROW + aoff);
-      gX0 = *reinterpret_cast<const float4*>(row + goff);
-      gX1 = *reinterpret_cast<const float4*>(row + ROW + goff);
-      if (j + 2 < steps) rmw(awY0, gY0, (shared_mask >> (j + 2)) & 1u);
-      if (j + 3 < steps) rmw(awY1, gY1, (shared_mask >> (j + 3)) & 1u);
     }
   };
 
