@@ -694,3 +694,28 @@ def test_global_batch_slices_reproduce_the_single_gpu_step(hip_device, monkeypat
     g_avg = 0.5 * (parts[0][3] + parts[1][3])
     assert float(g_full.abs().max()) > 0
     np.testing.assert_allclose(g_avg.cpu().numpy(), g_full.cpu().numpy(), rtol=2e-4, atol=2e-6 * float(g_full.abs().max()))
+
+
+def test_deterministic_binned_step_is_bit_reproducible(hip_device):
+    """``deterministic=True`` sends both passes through the bricks with the stable radix sort: no float atomics anywhere,
+    so two runs of the same training iterations give bit-identical gradients and parameters (the atomic scatter and the
+    counting sort's atomic cursors do not promise that)."""
+    g = load_golden("g9_trainer_trajectory.npz")
+    G, deg, hw, n_img, n_rays, steps, S = (int(v) for v in g["config"])
+    F = 3 * (deg + 1) ** 2
+    runs = []
+    for _ in range(2):
+        grid = relu_grid(hip_device, T(hash_uniform((G, G, G, 1), 901)), T(hash_uniform((G, G, G, F), 900 + F)), G, storage="split")
+        cfg = rf.SHVoxGridRenderConfig(S, rf.CameraBounds(float(g["near"]), float(g["far"])), perturb_sampled_points=False, white_bkgd=True)
+        model = rf.VolumetricModel(grid, rf.render_sh_voxel_grid, cfg, device=hip_device)
+        stepper = TrainStepper(model, n_rays, learning_rate=float(g["lr"]), backward="binned", deterministic=True)
+        grads = []
+        for it in range(3):
+            rays = rf.Rays(T(g["origins"][it]).to(hip_device), T(g["directions"][it]).to(hip_device))
+            stats = stepper.step_on(rays, T(g["pixels"][it]).to(hip_device))
+            grads.append(stepper.flat.flat_grad.clone())
+            np.testing.assert_allclose(stats.specular_loss.item(), g["specular_loss"][it], rtol=1e-5)
+        runs.append((grads, stepper.flat.flat_param.clone()))
+    for a, b in zip(runs[0][0], runs[1][0]):
+        assert torch.equal(a, b)
+    assert torch.equal(runs[0][1], runs[1][1])
