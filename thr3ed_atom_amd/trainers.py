@@ -38,7 +38,6 @@ from .ops import (
     render_backward_emit_direct_raw,
     bin_offsets,
     sort_records_by_brick,
-    bin_records_by_brick,
     expanded_record_floats,
     l1_loss_grad_hip,
     render_backward_raw,

@@ -1,4 +1,4 @@
-import cProfile, pstats, sys, os, time
+import cProfile, pstats, sys, os
 sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", "/root/repo"))
 sys.argv = ["bench.py", "--steps", "200", "--warmup", "10", "--cpu-rays", "0", "--render-frames", "0"]
 import runpy
