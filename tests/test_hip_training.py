@@ -719,3 +719,26 @@ def test_deterministic_binned_step_is_bit_reproducible(hip_device):
     for a, b in zip(runs[0][0], runs[1][0]):
         assert torch.equal(a, b)
     assert torch.equal(runs[0][1], runs[1][1])
+
+
+def test_binned_backward_with_mostly_empty_bricks(hip_device):
+    """A handful of rays on a 40^3 grid (125 bricks, most of them untouched): the overwrite mode must leave exact zeros
+    in every empty brick and the atomic path's gradient elsewhere, starting from garbage."""
+    from thr3ed_atom_amd import ops as O
+
+    G, F, S = 40, 27, 48
+    cam = hotdog_like_camera()
+    grid = relu_grid(hip_device, T(hash_uniform((G, G, G, 1), 31)), T(hash_uniform((G, G, G, F), 32)), G, storage="split")
+    pose = rf.pose_spherical(30.0, -30.0, cam["radius"])
+    rays = rf.flatten_rays(rf.cast_rays(rf.CameraIntrinsics(3, 3, 40.0), pose, hip_device))  # 9 rays through the centre
+    cfg = rf.SHVoxGridRenderConfig(S, rf.CameraBounds(cam["near"], cam["far"]), perturb_sampled_points=False, white_bkgd=True)
+    target = T(hash_uniform((len(rays), 3), 5, 0.0, 1.0)).to(hip_device)
+    out = rf.render_sh_voxel_grid(grid, rays, cfg)
+    torch.nn.functional.l1_loss(out.colour, target).backward()
+    ref_d, ref_f = grid.reference_gradients()
+    gd, gf = _binned_gradients(grid, rays, cfg, target, hip_device, diffuse_too=False, binning="fused")
+    gd, gf = grid.unpack(gd, gf)
+    assert float((ref_f == 0).float().mean()) > 0.9  # most of the grid is untouched
+    np.testing.assert_allclose(gd.cpu().numpy(), ref_d.cpu().numpy(), rtol=2e-4, atol=2e-6 * float(ref_d.abs().max()))
+    np.testing.assert_allclose(gf.cpu().numpy(), ref_f.cpu().numpy(), rtol=2e-4, atol=2e-6 * float(ref_f.abs().max()))
+    assert torch.equal(gf == 0, ref_f == 0) or float(((gf == 0) != (ref_f == 0)).float().mean()) < 1e-3

@@ -862,6 +862,12 @@ __global__ __launch_bounds__(kBlock) void render_backward_kernel(GridArgs g, Ray
   const int lane = threadIdx.x & (kWave - 1);
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const long long ray = (long long)blockIdx.x * kWavesPerBlock + wave;
+  if (EMIT == 2) {
+    // the forward pass's counters have been turned into offsets: clear them for the next iteration (every thread of the
+    // grid takes part, including the waves without a ray)
+    if (gr.hist_clear)
+      for (long long k = (long long)blockIdx.x * blockDim.x + threadIdx.x; k < gr.nkeys; k += (long long)gridDim.x * blockDim.x) gr.hist_clear[k] = 0;
+  }
   if (ray >= r.n) return;
 
   const RayState st = load_ray(r, g, ray, flags);
@@ -875,10 +881,6 @@ __global__ __launch_bounds__(kBlock) void render_backward_kernel(GridArgs g, Ray
   const float gD = gr.gdepth ? gr.gdepth[ray] : 0.0f;
   const float gA = gr.gacc ? gr.gacc[ray] : 0.0f;
   const bool no_upstream = gC[0] == 0.f && gC[1] == 0.f && gC[2] == 0.f && gD == 0.f && gA == 0.f;
-  if (EMIT == 2) {
-    if (gr.hist_clear)  // the forward pass's counters have been turned into offsets: clear them for the next iteration
-      for (long long k = (long long)blockIdx.x * blockDim.x + threadIdx.x; k < gr.nkeys; k += (long long)gridDim.x * blockDim.x) gr.hist_clear[k] = 0;
-  }
   if (EMIT == 1) {
     // every sample slot of the ray gets a key (the sort runs over the dense array)
     const int done = (no_upstream) ? 0 : fwd.stop[ray];
