@@ -742,3 +742,64 @@ def test_binned_backward_with_mostly_empty_bricks(hip_device):
     np.testing.assert_allclose(gd.cpu().numpy(), ref_d.cpu().numpy(), rtol=2e-4, atol=2e-6 * float(ref_d.abs().max()))
     np.testing.assert_allclose(gf.cpu().numpy(), ref_f.cpu().numpy(), rtol=2e-4, atol=2e-6 * float(ref_f.abs().max()))
     assert torch.equal(gf == 0, ref_f == 0) or float(((gf == 0) != (ref_f == 0)).float().mean()) < 1e-3
+
+
+@pytest.mark.parametrize("seed", list(range(8)))
+def test_binned_backward_randomised_shapes(hip_device, seed):
+    """Fused-binning backward == atomic backward on randomly drawn grid sizes (partial bricks), ray counts (not multiples
+    of the wave count), sample counts, SH degrees, density modes, storages and brick sizes."""
+    from thr3ed_atom_amd import ops as O
+
+    rng = np.random.RandomState(100 + seed)
+    dims = tuple(int(v) for v in rng.randint(5, 30, size=3))
+    deg = int(rng.randint(0, 3))
+    F = 3 * (deg + 1) ** 2
+    S = int(rng.choice([17, 33, 64, 70]))
+    n_rays = int(rng.choice([1, 3, 37, 130]))
+    mode = ["relu", "softplus", "abs"][int(rng.randint(0, 3))]
+    storage = ["reference", "split", "bricked"][int(rng.randint(0, 3))]
+    acts = {"relu": (torch.nn.Identity(), torch.nn.ReLU()), "softplus": (torch.nn.Identity(), torch.nn.Softplus()), "abs": (torch.abs, torch.nn.Identity())}[mode]
+    cam = hotdog_like_camera()
+    voxel = tuple(3.0 / d for d in dims)
+    grid = rf.VoxelGrid(T(hash_uniform((*dims, 1), 300 + seed)).to(hip_device), T(hash_uniform((*dims, F), 400 + seed)).to(hip_device), rf.VoxelSize(*voxel),
+                        density_preactivation=acts[0], density_postactivation=acts[1], expected_density_scale=5.0 if mode != "abs" else 1.0,
+                        tunable=True, storage=storage)
+    pose = rf.pose_spherical(float(rng.uniform(0, 360)), float(rng.uniform(-60, -10)), cam["radius"])
+    side = int(np.ceil(np.sqrt(n_rays)))
+    rays = rf.flatten_rays(rf.cast_rays(rf.CameraIntrinsics(side, side, 0.9 * side), pose, hip_device))[:n_rays]
+    cfg = rf.SHVoxGridRenderConfig(S, rf.CameraBounds(cam["near"], cam["far"]), perturb_sampled_points=False, white_bkgd=bool(seed & 1))
+    target = T(hash_uniform((n_rays, 3), 5 + seed, 0.0, 1.0)).to(hip_device)
+    spec = rf.render_sh_voxel_grid(grid, rays, cfg)
+    diff = rf.render_sh_voxel_grid(grid, rays, rf.SHVoxGridRenderConfig(S, cfg.camera_bounds, perturb_sampled_points=False, white_bkgd=cfg.white_bkgd, render_diffuse=True))
+    (torch.nn.functional.l1_loss(spec.colour, target) + torch.nn.functional.l1_loss(diff.colour, target)).backward()
+    ref_d, ref_f = grid.reference_gradients()
+    gd, gf = _binned_gradients(grid, rays, cfg, target, hip_device, binning="fused")
+    gd, gf = grid.unpack(gd, gf)
+    np.testing.assert_allclose(gd.cpu().numpy(), ref_d.cpu().numpy(), rtol=3e-4, atol=3e-6 * float(ref_d.abs().max()) + 1e-12)
+    np.testing.assert_allclose(gf.cpu().numpy(), ref_f.cpu().numpy(), rtol=3e-4, atol=3e-6 * float(ref_f.abs().max()) + 1e-12)
+
+
+@pytest.mark.parametrize("n_rays,storage", [(37, "split"), (130, "bricked"), (1, "split")])
+def test_binned_and_atomic_train_steps_agree_for_odd_batches(hip_device, n_rays, storage):
+    """Several fused training iterations with jitter on ray batches that fill neither a workgroup nor a wavefront quad:
+    the binned step (forward-side counting, direct emit, bricks) must track the atomic step -- this is the trainer-level
+    guard for stale per-key counters or cursors between iterations."""
+    G, deg, S = 24, 2, 40
+    F = 3 * (deg + 1) ** 2
+    cam = hotdog_like_camera()
+    pose = rf.pose_spherical(50.0, -35.0, cam["radius"])
+    side = int(np.ceil(np.sqrt(n_rays)))
+    rays = rf.flatten_rays(rf.cast_rays(rf.CameraIntrinsics(side, side, 0.9 * side), pose, hip_device))[:n_rays]
+    target = T(hash_uniform((n_rays, 3), 9, 0.0, 1.0)).to(hip_device)
+    finals = []
+    for backward in ("atomic", "binned"):
+        grid = relu_grid(hip_device, T(hash_uniform((G, G, G, 1), 901)), T(hash_uniform((G, G, G, F), 900 + F)), G, storage=storage)
+        cfg = rf.SHVoxGridRenderConfig(S, rf.CameraBounds(cam["near"], cam["far"]), perturb_sampled_points=True, white_bkgd=True)
+        model = rf.VolumetricModel(grid, rf.render_sh_voxel_grid, cfg, device=hip_device)
+        stepper = TrainStepper(model, n_rays, learning_rate=0.01, backward=backward)
+        torch.manual_seed(77)  # same jitter in both runs
+        for _ in range(4):
+            stepper.step_on(rays, target)
+        finals.append(torch.cat([t.detach().reshape(-1) for t in grid.unpack(*grid.kernel_tensors())]))
+    # Adam normalises the step, so summation-order noise on tiny gradients shows up at the 1e-3 * lr level at worst
+    assert float((finals[0] - finals[1]).abs().max()) < 2e-3 and float((finals[0] - finals[1]).abs().mean()) < 1e-6
