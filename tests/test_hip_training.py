@@ -744,9 +744,10 @@ def test_binned_backward_with_mostly_empty_bricks(hip_device):
     assert torch.equal(gf == 0, ref_f == 0) or float(((gf == 0) != (ref_f == 0)).float().mean()) < 1e-3
 
 
+@pytest.mark.parametrize("binning", ["fused", "count", "sort"])
 @pytest.mark.parametrize("seed", list(range(8)))
-def test_binned_backward_randomised_shapes(hip_device, seed):
-    """Fused-binning backward == atomic backward on randomly drawn grid sizes (partial bricks), ray counts (not multiples
+def test_binned_backward_randomised_shapes(hip_device, seed, binning):
+    """Binned backward (each binning path) == atomic backward on randomly drawn grid sizes (partial bricks), ray counts (not multiples
     of the wave count), sample counts, SH degrees, density modes, storages and brick sizes."""
     from thr3ed_atom_amd import ops as O
 
@@ -773,7 +774,7 @@ def test_binned_backward_randomised_shapes(hip_device, seed):
     diff = rf.render_sh_voxel_grid(grid, rays, rf.SHVoxGridRenderConfig(S, cfg.camera_bounds, perturb_sampled_points=False, white_bkgd=cfg.white_bkgd, render_diffuse=True))
     (torch.nn.functional.l1_loss(spec.colour, target) + torch.nn.functional.l1_loss(diff.colour, target)).backward()
     ref_d, ref_f = grid.reference_gradients()
-    gd, gf = _binned_gradients(grid, rays, cfg, target, hip_device, binning="fused")
+    gd, gf = _binned_gradients(grid, rays, cfg, target, hip_device, binning=binning)
     gd, gf = grid.unpack(gd, gf)
     np.testing.assert_allclose(gd.cpu().numpy(), ref_d.cpu().numpy(), rtol=3e-4, atol=3e-6 * float(ref_d.abs().max()) + 1e-12)
     np.testing.assert_allclose(gf.cpu().numpy(), ref_f.cpu().numpy(), rtol=3e-4, atol=3e-6 * float(ref_f.abs().max()) + 1e-12)
