@@ -414,14 +414,14 @@ def test_keyed_ray_selection(hip_device):
     assert torch.equal(r1.origins, r2.origins) and torch.equal(p1, p2) and len(r1) == 512
 
 
-def _binned_gradients(grid, rays, cfg, target, device, diffuse_too=True, accumulate=False, binning="sort"):
+def _binned_gradients(grid, rays, cfg, target, device, diffuse_too=True, accumulate=False, binning="sort", brick=8):
     """(dL/d first, dL/d second) of L1(spec) [+ L1(diffuse)] through the emit -> sort -> brick-accumulate path"""
     from thr3ed_atom_amd import ops as O
 
     o, d = rays.origins.contiguous(), rays.directions.contiguous()
     n, S = o.shape[0], cfg.num_samples_per_ray
     near, far = float(np.float32(cfg.camera_bounds.near)), float(np.float32(cfg.camera_bounds.far))
-    nb = O.brick_counts(grid, 8)
+    nb = O.brick_counts(grid, brick)
     num_bricks = nb[0] * nb[1] * nb[2]
     boundaries = torch.arange(num_bricks * 8, dtype=torch.int16, device=device)
     ray_basis = torch.zeros((n, 16), device=device)
@@ -435,7 +435,7 @@ def _binned_gradients(grid, rays, cfg, target, device, diffuse_too=True, accumul
         flags = O.render_flags(cfg.white_bkgd, diffuse or cfg.render_diffuse, cfg.optimized_sampling, False)
         is_diffuse = diffuse or cfg.render_diffuse
         hist = torch.zeros(num_bricks * 8, dtype=torch.int32, device=device) if binning in ("count", "fused") else None
-        colour, _, _, _, caches = O.render_forward_raw(grid, o, d, None, S, near, far, flags, save=True, key_hist=hist if binning == "fused" else None)
+        colour, _, _, _, caches = O.render_forward_raw(grid, o, d, None, S, near, far, flags, save=True, key_hist=hist if binning == "fused" else None, brick_size=brick)
         g_colour = O.l1_loss_grad_hip(colour, target, sums[2 * i : 2 * i + 2])
         keys = torch.empty(n * S, dtype=torch.int16, device=device)
         rec = torch.empty((n * S, 8), device=device)
@@ -446,11 +446,11 @@ def _binned_gradients(grid, rays, cfg, target, device, diffuse_too=True, accumul
             counted = int(hist.sum())
             assert counted == int((caches[1] < 0).sum())  # one flag per counted sample
             O.bin_offsets(hist, offsets, cursor)
-            O.render_backward_emit_direct_raw(grid, o, d, None, S, near, far, flags, caches, g_colour, None, None, 8, cursor, srt, hist_clear=hist)
+            O.render_backward_emit_direct_raw(grid, o, d, None, S, near, far, flags, caches, g_colour, None, None, brick, cursor, srt, hist_clear=hist)
             assert int(hist.abs().sum()) == 0 and int(offsets[-1]) == counted
             assert torch.equal(cursor.to(torch.int64), offsets[1:])  # every class filled exactly
         else:
-            O.render_backward_emit_raw(grid, o, d, None, S, near, far, flags, caches, g_colour, None, None, 8, keys, rec, None if diffuse else ray_basis, hist)
+            O.render_backward_emit_raw(grid, o, d, None, S, near, far, flags, caches, g_colour, None, None, brick, keys, rec, None if diffuse else ray_basis, hist)
             if binning == "count":
                 O.bin_records_by_brick(grid, keys, rec, None if is_diffuse else ray_basis, is_diffuse, hist, cursor, srt, offsets)
                 assert int(hist.abs().sum()) == 0 and int(offsets[-1]) == int((keys >= 0).sum())
@@ -460,10 +460,10 @@ def _binned_gradients(grid, rays, cfg, target, device, diffuse_too=True, accumul
         keep.append((keys, rec, caches))
     # the specular list first (it writes every channel), the diffuse list (base channels only) on top
     for k, one in enumerate(lists):
-        O.brick_accumulate_raw(grid, 8, [one], gd, gf, accumulate=accumulate or k > 0)
+        O.brick_accumulate_raw(grid, brick, [one], gd, gf, accumulate=accumulate or k > 0)
     if accumulate:  # adding the same lists once more doubles the result
         for one in lists:
-            O.brick_accumulate_raw(grid, 8, [one], gd, gf, accumulate=True)
+            O.brick_accumulate_raw(grid, brick, [one], gd, gf, accumulate=True)
         gd.mul_(0.5)
         if gf is not None:
             gf.mul_(0.5)
@@ -774,7 +774,7 @@ def test_binned_backward_randomised_shapes(hip_device, seed, binning):
     diff = rf.render_sh_voxel_grid(grid, rays, rf.SHVoxGridRenderConfig(S, cfg.camera_bounds, perturb_sampled_points=False, white_bkgd=cfg.white_bkgd, render_diffuse=True))
     (torch.nn.functional.l1_loss(spec.colour, target) + torch.nn.functional.l1_loss(diff.colour, target)).backward()
     ref_d, ref_f = grid.reference_gradients()
-    gd, gf = _binned_gradients(grid, rays, cfg, target, hip_device, binning=binning)
+    gd, gf = _binned_gradients(grid, rays, cfg, target, hip_device, binning=binning, brick=8 if seed & 2 else 4)
     gd, gf = grid.unpack(gd, gf)
     np.testing.assert_allclose(gd.cpu().numpy(), ref_d.cpu().numpy(), rtol=3e-4, atol=3e-6 * float(ref_d.abs().max()) + 1e-12)
     np.testing.assert_allclose(gf.cpu().numpy(), ref_f.cpu().numpy(), rtol=3e-4, atol=3e-6 * float(ref_f.abs().max()) + 1e-12)
