@@ -182,7 +182,8 @@ int rf_render_backward(const RFGrid* grid, const RFRayBatch* rays, uint32_t flag
  *     and, for EVERY sample slot, keys_dev [N*S] = brick * 8 + flags, where brick = id of the brick (brick_size^3
  *     nodes, brick_size in {4, 8}) holding the LOWER node of the sample's cell and flag bit a says that the cell's
  *     upper node on axis a belongs to the next brick; -1 for samples without gradient.  ray_basis_dev [N,16] (may
- *     be NULL for the diffuse pass) receives the signed SH basis of each ray.  At most 4096 bricks (16-bit keys).
+ *     be NULL for the diffuse pass) receives the signed SH basis of each ray.  At most 4096 bricks (16-bit keys; the fused binning
+ *     below has no such limit).
  *     hist_dev (may be NULL): see rf_bin_offsets below.
  * (2) the caller sorts keys (torch.sort) -> permutation, and offsets [8*nbricks+1] (searchsorted; last = N*S);
  * (3) rf_expand_records: for *begin_dev (= offsets[0]) <= i < capacity, records_sorted[i] = the EXPANDED record of slot

@@ -804,3 +804,29 @@ def test_binned_and_atomic_train_steps_agree_for_odd_batches(hip_device, n_rays,
         finals.append(torch.cat([t.detach().reshape(-1) for t in grid.unpack(*grid.kernel_tensors())]))
     # Adam normalises the step, so summation-order noise on tiny gradients shows up at the 1e-3 * lr level at worst
     assert float((finals[0] - finals[1]).abs().max()) < 2e-3 and float((finals[0] - finals[1]).abs().mean()) < 1e-6
+
+
+def test_fused_binning_beyond_4096_bricks(hip_device):
+    """The fused binning has no 16-bit key arrays, so it also serves grids of more than 4096 bricks (here 136^3 nodes =
+    17^3 = 4913 bricks); the per-slot-key variants refuse such a grid instead of wrapping their keys."""
+    from thr3ed_atom_amd import ops as O
+
+    G, S = 136, 64
+    cam = hotdog_like_camera()
+    grid = rf.VoxelGrid(T(hash_uniform((G, G, G, 1), 41)).to(hip_device), T(hash_uniform((G, G, G, 3), 42)).to(hip_device), rf.VoxelSize(3.0 / G, 3.0 / G, 3.0 / G),
+                        density_preactivation=torch.nn.Identity(), density_postactivation=torch.nn.ReLU(), expected_density_scale=20.0,
+                        tunable=True, storage="split")
+    pose = rf.pose_spherical(30.0, -30.0, cam["radius"])
+    rays = rf.flatten_rays(rf.cast_rays(rf.CameraIntrinsics(12, 12, 16.0), pose, hip_device))
+    cfg = rf.SHVoxGridRenderConfig(S, rf.CameraBounds(cam["near"], cam["far"]), perturb_sampled_points=False, white_bkgd=True)
+    target = T(hash_uniform((len(rays), 3), 5, 0.0, 1.0)).to(hip_device)
+    out = rf.render_sh_voxel_grid(grid, rays, cfg)
+    torch.nn.functional.l1_loss(out.colour, target).backward()
+    ref_d, ref_f = grid.reference_gradients()
+    gd, gf = _binned_gradients(grid, rays, cfg, target, hip_device, diffuse_too=False, binning="fused")
+    gd, gf = grid.unpack(gd, gf)
+    assert float(ref_f.abs().max()) > 0
+    np.testing.assert_allclose(gd.cpu().numpy(), ref_d.cpu().numpy(), rtol=3e-4, atol=3e-6 * float(ref_d.abs().max()))
+    np.testing.assert_allclose(gf.cpu().numpy(), ref_f.cpu().numpy(), rtol=3e-4, atol=3e-6 * float(ref_f.abs().max()))
+    with pytest.raises(RuntimeError, match="unsupported|not supported|UNSUPPORTED"):
+        _binned_gradients(grid, rays, cfg, target, hip_device, diffuse_too=False, binning="sort")

@@ -2233,7 +2233,7 @@ const char* rf_error_string(int code) {
     case RF_ERR_BAD_SHAPE:
       return "bad shape, size or stride";
     case RF_ERR_UNSUPPORTED:
-      return "unsupported configuration (SH degree must be 0..3, density mode must be a RF_DENSITY_* value)";
+      return "unsupported configuration (SH degree must be 0..3 -- 0..2 for the binned backward --, density mode a RF_DENSITY_* value, brick size 4 or 8 with at most 4096 bricks for 16-bit keys)";
     case RF_ERR_LAUNCH:
       return "HIP kernel launch failed";
     default:
@@ -2301,7 +2301,9 @@ int rf_ray_aabb_bounds(const float* origins_dev, const float* directions_dev, in
   return launch_status();
 }
 
-static int brick_geometry(const RFGrid* grid, int brick_size, int* shift, int nb[3]) {
+// short_keys: the (brick, flags) key must fit a positive 16-bit sort key (per-slot key arrays of rf_render_backward_emit);
+// the fused binning only needs the counters to be addressable (2^21 keys = grids up to 512^3 at 8^3 bricks)
+static int brick_geometry(const RFGrid* grid, int brick_size, int* shift, int nb[3], bool short_keys) {
   if (brick_size != 4 && brick_size != 8) return RF_ERR_UNSUPPORTED;
   *shift = (brick_size == 4) ? 2 : 3;
   long long total = 1;
@@ -2309,7 +2311,7 @@ static int brick_geometry(const RFGrid* grid, int brick_size, int* shift, int nb
     nb[a] = (grid->dims[a] + brick_size - 1) / brick_size;
     total *= nb[a];
   }
-  return (total * 8 - 1 <= 0x7fff) ? RF_OK : RF_ERR_UNSUPPORTED;  // (brick, flags) must fit a positive 16-bit sort key
+  return (total * 8 - 1 <= (short_keys ? 0x7fffLL : (1LL << 21) - 1)) ? RF_OK : RF_ERR_UNSUPPORTED;
 }
 
 int rf_render_forward(const RFGrid* grid, const RFRayBatch* rays, uint32_t flags, const RFRenderOut* out,
@@ -2331,7 +2333,7 @@ int rf_render_forward(const RFGrid* grid, const RFRayBatch* rays, uint32_t flags
   if (out->key_hist_dev) {  // count the records of the binned backward per (brick, flags) key
     if (!save) return RF_ERR_NULL_POINTER;
     int shift, nb[3];
-    rc = brick_geometry(grid, out->brick_size, &shift, nb);
+    rc = brick_geometry(grid, out->brick_size, &shift, nb, false);
     if (rc != RF_OK) return rc;
     o.hist = out->key_hist_dev;
     o.brick_shift = shift;
@@ -2400,7 +2402,7 @@ int rf_render_backward_emit(const RFGrid* grid, const RFRayBatch* rays, uint32_t
   if (!grid) return RF_ERR_NULL_POINTER;
   if (!keys_dev || !records_dev) return RF_ERR_NULL_POINTER;
   int shift, nb[3];
-  const int rc = brick_geometry(grid, brick_size, &shift, nb);
+  const int rc = brick_geometry(grid, brick_size, &shift, nb, true);
   if (rc != RF_OK) return rc;
   GradArgs gr = {};
   gr.keys = keys_dev;
@@ -2420,7 +2422,7 @@ int rf_render_backward_emit_direct(const RFGrid* grid, const RFRayBatch* rays, u
   if (!cursor_dev || !records_sorted_dev) return RF_ERR_NULL_POINTER;
   if (grid->num_features > 27) return RF_ERR_UNSUPPORTED;
   int shift, nb[3];
-  const int rc = brick_geometry(grid, brick_size, &shift, nb);
+  const int rc = brick_geometry(grid, brick_size, &shift, nb, false);
   if (rc != RF_OK) return rc;
   GradArgs gr = {};
   gr.cursor = cursor_dev;
@@ -2469,7 +2471,7 @@ int rf_expand_records(const RFGrid* grid, const float* records_dev, const int64_
 
 int rf_bin_offsets(const int32_t* hist_dev, int32_t num_keys, int64_t* offsets_dev, int32_t* cursor_dev, void* stream) {
   if (!hist_dev || !offsets_dev || !cursor_dev) return RF_ERR_NULL_POINTER;
-  if (num_keys < 1 || num_keys > 32768) return RF_ERR_BAD_SHAPE;
+  if (num_keys < 1 || num_keys > (1 << 21)) return RF_ERR_BAD_SHAPE;
   hipLaunchKernelGGL(bin_offsets_kernel, dim3((num_keys + 1023) / 1024), dim3(1024), 0, (hipStream_t)stream, hist_dev, num_keys,
                      reinterpret_cast<long long*>(offsets_dev), cursor_dev);
   return launch_status();
@@ -2538,7 +2540,7 @@ int rf_brick_accumulate(const RFGrid* grid, int32_t brick_size, const RFBrickLis
   if (num_lists < 1 || num_lists > 2) return RF_ERR_BAD_SHAPE;
   if (grid->num_features > 27) return RF_ERR_UNSUPPORTED;  // 3 rest waves cover 24 channels (SH degree <= 2)
   int shift, nb[3];
-  rc = brick_geometry(grid, brick_size, &shift, nb);
+  rc = brick_geometry(grid, brick_size, &shift, nb, false);
   if (rc != RF_OK) return rc;
   BrickArgs a = {};
   a.nlists = num_lists;

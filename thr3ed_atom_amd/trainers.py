@@ -157,7 +157,7 @@ class TrainStepper:
         # (DESIGN.md section 4); the diffuse pass stays on the atomic scatter.  deterministic=True sends both passes
         # through the bricks and bins with a stable radix sort instead of the counting sort: no atomics anywhere, fixed
         # float32 summation order, run-to-run bit-identical gradients (slower).
-        # "auto" = binned where it was measured faster (fused step, SH degree 2, grid of at most 4096 bricks), else atomic.
+        # "auto" = binned where it was measured faster (fused step, SH degree 2), else atomic.
         if backward not in ("auto", "atomic", "binned"):
             raise ValueError("backward must be 'auto', 'atomic' or 'binned'")
         self.deterministic = bool(deterministic)
@@ -183,7 +183,7 @@ class TrainStepper:
         self.optimizer = FusedAdam(self.flat, lr=learning_rate, betas=(0.9, 0.999))
         if backward == "auto":
             nb = brick_counts(grid, self.brick_size)
-            backward = "binned" if (self.fused and grid.sh_degree == 2 and nb[0] * nb[1] * nb[2] <= 4096) else "atomic"
+            backward = "binned" if (self.fused and grid.sh_degree == 2 and nb[0] * nb[1] * nb[2] * 8 <= (1 << 21)) else "atomic"
         self.backward = backward
 
     def select(self, dataset: PosedImagesInMemory, image_ids: Tensor):
@@ -321,18 +321,21 @@ class TrainStepper:
             grid = self.vol_mod.thre3d_repr
             nb = brick_counts(grid, self.brick_size)
             num_bricks = nb[0] * nb[1] * nb[2]
-            if num_bricks > 4096:
-                raise ValueError("backward='binned' needs at most 4096 bricks ((brick, flags) keys are 16-bit sort keys)")
+            if num_bricks > 4096 and self.deterministic:
+                raise ValueError("deterministic binned backward needs at most 4096 bricks ((brick, flags) keys are 16-bit sort keys)")
+            if num_bricks * 8 > (1 << 21):
+                raise ValueError("backward='binned' needs at most 2^18 bricks")
             if grid.sh_degree > 2:
                 raise ValueError("backward='binned' supports SH degree <= 2 (the brick accumulators must fit the 160 KB LDS)")
             b = {
                 "shape": (n, S),
                 "num_bricks": num_bricks,
-                "keys": torch.empty(n * S, dtype=torch.int16, device=device),
-                "records": torch.empty((n * S, 8), dtype=torch.float32, device=device),
+                # per-slot keys / 32-byte records: only the deterministic (radix sort) path needs them
+                "keys": torch.empty(n * S if self.deterministic else 0, dtype=torch.int16, device=device),
+                "records": torch.empty((n * S if self.deterministic else 0, 8), dtype=torch.float32, device=device),
                 "sorted": torch.empty((n * S, expanded_record_floats(grid)), dtype=torch.float32, device=device),
                 "ray_basis": torch.zeros((n, 16), dtype=torch.float32, device=device),
-                "boundaries": torch.arange(num_bricks * 8, dtype=torch.int16, device=device),
+                "boundaries": torch.arange(num_bricks * 8, dtype=torch.int16, device=device) if self.deterministic else None,
                 "offsets": torch.full((num_bricks * 8 + 1,), n * S, dtype=torch.int64, device=device),
                 "hist": torch.zeros(num_bricks * 8, dtype=torch.int32, device=device),
                 "cursor": torch.empty(num_bricks * 8, dtype=torch.int32, device=device),
