@@ -658,7 +658,8 @@ def test_data_parallel_step_through_rccl_single_rank(hip_device, shard_optimizer
             dist.destroy_process_group()
 
 
-def test_global_batch_slices_reproduce_the_single_gpu_step(hip_device, monkeypatch):
+@pytest.mark.parametrize("selection", ["keyed", "randperm"])
+def test_global_batch_slices_reproduce_the_single_gpu_step(hip_device, monkeypatch, selection):
     """Strong scaling: with ``global_batch=True`` the ranks draw the SAME keyed permutation and take disjoint
     contiguous slices of it; the average of their gradient buckets is the single-GPU gradient.  Two ranks are played
     one after the other on this GPU (stand-in rank / world size, collectives off)."""
@@ -676,7 +677,7 @@ def test_global_batch_slices_reproduce_the_single_gpu_step(hip_device, monkeypat
         grid = relu_grid(hip_device, T(hash_uniform((G, G, G, 1), 901)), T(hash_uniform((G, G, G, F), 900 + F)), G, storage="split")
         cfg = rf.SHVoxGridRenderConfig(S, data.camera_bounds, perturb_sampled_points=False, white_bkgd=True)
         model = rf.VolumetricModel(grid, rf.render_sh_voxel_grid, cfg, device=hip_device)
-        stepper = TrainStepper(model, R, learning_rate=0.03, global_batch=world > 1)
+        stepper = TrainStepper(model, R, learning_rate=0.03, global_batch=True, ray_selection=selection)
         monkeypatch.setattr(rfdist, "world_size", lambda: world)
         monkeypatch.setattr(rfdist, "rank", lambda: rank)
         monkeypatch.setattr(rfdist, "_collectives_on", lambda: False)
