@@ -176,60 +176,71 @@ int rf_render_backward(const RFGrid* grid, const RFRayBatch* rays, uint32_t flag
                        const RFRenderGrads* grads, float* grad_densities_dev, float* grad_features_dev,
                        void* stream);
 
-/* ---- binned backward: the same adjoint as rf_render_backward without a single atomic -----------------------------
- * (1) rf_render_backward_emit: instead of scattering, write per contributing sample a 32-byte record
- *     records_dev [N*S, 8] = (continuous index x, y, z, dL/d pre-activation density, dL/d raw r, g, b, ray id bits)
- *     and, for EVERY sample slot, keys_dev [N*S] = brick * 8 + flags, where brick = id of the brick (brick_size^3
- *     nodes, brick_size in {4, 8}) holding the LOWER node of the sample's cell and flag bit a says that the cell's
- *     upper node on axis a belongs to the next brick; -1 for samples without gradient.  ray_basis_dev [N,16] (may
- *     be NULL for the diffuse pass) receives the signed SH basis of each ray.  At most 4096 bricks (16-bit keys; the fused binning
- *     below has no such limit).
- *     hist_dev (may be NULL): see rf_bin_offsets below.
- * (2) the caller sorts keys (torch.sort) -> permutation, and offsets [8*nbricks+1] (searchsorted; last = N*S);
- * (3) rf_expand_records: for *begin_dev (= offsets[0]) <= i < capacity, records_sorted[i] = the EXPANDED record of slot
- *     perm[i]: rf_expanded_record_floats(F) floats = (index x, y, z, 0) followed by dL/d(interpolated channel) for
- *     every channel of a node (density first, then degree-0 r, g, b, then colour-major higher degrees), i.e. the SH
- *     basis of the record's ray already multiplied in;
- * (4) rf_brick_accumulate: one workgroup per brick OWNS the brick's nodes: it reads exactly the record classes
- *     that touch them (its own brick's and, per flags, up to 7 lower neighbours'), sums them in LDS with plain
- *     read-add-writes (each wavefront owns a disjoint channel group, so nothing races and no LDS atomics are
- *     needed) and writes the brick with plain coalesced stores: accumulate = 0 overwrites EVERY element of the
- *     gradient tensors (no zero-fill needed), accumulate = 1 adds.  Up to two record lists of the same kind are
- *     folded in one pass.  SH degree <= 2.  Lists of a render_diffuse pass carry the 4 base channels only (records of
- *     rf_expanded_record_floats(3) = 8 floats, whatever the grid's degree): their bricks need 8 KB of LDS instead of
- *     60 and only density + degree-0 gradients are written (with accumulate = 0: only THOSE are overwritten).  With
- *     the sort of step (2) the sum order is fixed: results are run-to-run deterministic, unlike the atomic scatter. */
+/* ---- binned backward: the same adjoint as rf_render_backward without float atomics ----------------------------------
+ * The atomic scatter of rf_render_backward is bound by the memory-side atomic unit.  The binned variant turns every
+ * contributing sample into a RECORD, puts the records in (brick, flags) order and lets one workgroup per brick sum them
+ * in LDS under exclusive ownership:
+ *
+ *   key  = brick * 8 + flags;  brick = id ((bx * NBY + by) * NBZ + bz) of the brick (brick_size^3 nodes, brick_size in
+ *          {4, 8}) holding the LOWER node of the sample's cell;  flag bit a = the cell's upper node on axis a belongs to
+ *          the next brick (so the record also touches that neighbour's nodes).
+ *   expanded record = rf_expanded_record_floats(F) floats: (continuous index x, y, z, 0) followed by dL/d(interpolated
+ *          channel) for every channel of a node -- density first, then degree-0 r, g, b, then colour-major higher
+ *          degrees -- i.e. the SH basis of the record's ray already multiplied in.  Lists of a render_diffuse pass carry
+ *          the 4 base channels only: rf_expanded_record_floats(3) = 8 floats, whatever the grid's degree.
+ *   offsets [8 * nbricks + 1] (int64): start of every key class in the record list (last = end).
+ *
+ * Three front ends produce (records in key order, offsets); rf_brick_accumulate consumes them:
+ *   A. fused (default of the trainer): rf_render_forward with RFRenderOut.key_hist_dev COUNTS the records per key ->
+ *      rf_bin_offsets -> rf_render_backward_emit_direct writes each record at the next free position of its key.
+ *      No per-slot arrays; integer atomics only (counters, cursors); any number of bricks up to 2^18.
+ *   B. counting sort after the fact: rf_render_backward_emit (per-slot 16-bit keys + 32-byte records, hist_dev) ->
+ *      rf_bin_offsets -> rf_scatter_records.
+ *   C. deterministic: rf_render_backward_emit -> torch.sort of the keys (stable radix) + searchsorted ->
+ *      rf_expand_records.  Fixed float32 summation order: bit-reproducible gradients.
+ *   B and C use 16-bit keys: at most 4096 bricks.  The order inside a key class depends on atomic timing in A and B.
+ *
+ * rf_brick_accumulate: one workgroup per brick OWNS the brick's nodes: it reads exactly the key classes that touch them
+ * (its own and, per flags, up to 7 lower neighbours'), sums them in LDS with plain read-add-writes (wavefronts own disjoint
+ * channels: no races, no LDS atomics) and writes the brick with plain coalesced stores: accumulate = 0 OVERWRITES every
+ * element of the gradient tensors (no zero-fill needed; diffuse lists: only density + degree-0 gradients), accumulate = 1
+ * adds.  Up to two lists of the same kind per call.  SH degree <= 2. */
 typedef struct RFBrickList {
-  const float* records_sorted_dev; /* [capacity, rf_expanded_record_floats(F)] (diffuse: F = 3) */
-  const int64_t* offsets_dev;      /* [8 * nbricks + 1] start of each (brick, flags) class */
-  int32_t render_diffuse;          /* records come from a render_diffuse pass       */
+  const float* records_sorted_dev; /* [capacity, rf_expanded_record_floats(F)] (diffuse lists: F = 3) */
+  const int64_t* offsets_dev;      /* [8 * nbricks + 1] start of each (brick, flags) class            */
+  int32_t render_diffuse;          /* records come from a render_diffuse pass                         */
 } RFBrickList;
 
-int rf_render_backward_emit(const RFGrid* grid, const RFRayBatch* rays, uint32_t flags, const RFRenderOut* fwd,
-                            const RFRenderGrads* grads, int32_t brick_size, int16_t* keys_dev, float* records_dev,
-                            float* ray_basis_dev, int32_t* hist_dev, void* stream);
-int rf_expand_records(const RFGrid* grid, const float* records_dev, const int64_t* perm_dev, const int64_t* begin_dev,
-                      int64_t capacity, const float* ray_basis_dev, int32_t render_diffuse, float* records_sorted_dev,
-                      void* stream);
 int32_t rf_expanded_record_floats(int32_t num_features);
-/* Fused binning (no per-slot keys / records, no scatter pass): the FORWARD pass counted the records per key
- * (RFRenderOut.key_hist_dev); rf_bin_offsets turns the counters into offsets + cursor; this backward variant then writes
- * every counted sample's expanded record at the next free position of its key (atomic cursor) -- zeros for counted
- * samples whose gradient vanishes -- and clears hist_clear_dev [8*nbricks] (may be NULL) for the next iteration.
- * `fwd` must be the RFRenderOut of that forward call (its trans_cache carries the flags). */
+
+/* exclusive prefix sums of the per-key counters hist_dev [num_keys] -> offsets_dev [num_keys + 1] (positions start at 0)
+ * and an int32 copy cursor_dev [num_keys] for the atomic cursors of A / B */
+int rf_bin_offsets(const int32_t* hist_dev, int32_t num_keys, int64_t* offsets_dev, int32_t* cursor_dev, void* stream);
+
+/* A: every sample counted (and flagged in trans_cache) by the forward call that produced `fwd` writes its expanded
+ * record -- zeros if its gradient happens to vanish -- at the next free position of its key; hist_clear_dev
+ * [8 * nbricks] (may be NULL) is cleared for the next iteration. */
 int rf_render_backward_emit_direct(const RFGrid* grid, const RFRayBatch* rays, uint32_t flags, const RFRenderOut* fwd,
                                    const RFRenderGrads* grads, int32_t brick_size, int32_t* cursor_dev,
                                    float* records_sorted_dev, int32_t* hist_clear_dev, void* stream);
-/* Counting-sort alternative to steps (2)+(3) (no torch.sort): pass hist_dev [8*nbricks] (int32, zero before the first
- * use) to rf_render_backward_emit, which adds the number of records per key; rf_bin_offsets turns it into offsets_dev
- * [8*nbricks+1] (positions start at 0: unkeyed slots take no room) and a copy cursor_dev [8*nbricks] (int32);
- * rf_scatter_records then writes every keyed slot's expanded record at the next free position of its key (atomic
- * cursor: the order inside a class, hence the float32 summation order, is not run-to-run reproducible) and, when
- * hist_dev is given, clears its num_keys counters for the next iteration. */
-int rf_bin_offsets(const int32_t* hist_dev, int32_t num_keys, int64_t* offsets_dev, int32_t* cursor_dev, void* stream);
+
+/* B / C: per contributing sample a 32-byte record records_dev [N*S, 8] = (index x, y, z, dL/d pre-activation density,
+ * dL/d raw r, g, b, ray id bits) and, for EVERY slot, keys_dev [N*S] (-1 = no gradient).  ray_basis_dev [N,16] (may be
+ * NULL for a diffuse pass) receives the signed SH basis of each ray; hist_dev [8 * nbricks] (may be NULL; zero before the
+ * first use) is incremented by the number of records per key (B). */
+int rf_render_backward_emit(const RFGrid* grid, const RFRayBatch* rays, uint32_t flags, const RFRenderOut* fwd,
+                            const RFRenderGrads* grads, int32_t brick_size, int16_t* keys_dev, float* records_dev,
+                            float* ray_basis_dev, int32_t* hist_dev, void* stream);
+/* B: every keyed slot's expanded record goes to the next free position of its key; clears hist_dev (may be NULL) */
 int rf_scatter_records(const RFGrid* grid, const int16_t* keys_dev, const float* records_dev, int64_t capacity,
                        int32_t* cursor_dev, const float* ray_basis_dev, int32_t render_diffuse, float* records_sorted_dev,
                        int32_t* hist_dev, int32_t num_keys, void* stream);
+/* C: records_sorted[i] = expanded record of slot perm_dev[i] for *begin_dev (= offsets[0]: unkeyed slots sort in front)
+ * <= i < capacity */
+int rf_expand_records(const RFGrid* grid, const float* records_dev, const int64_t* perm_dev, const int64_t* begin_dev,
+                      int64_t capacity, const float* ray_basis_dev, int32_t render_diffuse, float* records_sorted_dev,
+                      void* stream);
+
 int rf_brick_accumulate(const RFGrid* grid, int32_t brick_size, const RFBrickList* lists, int32_t num_lists,
                         float* grad_densities_dev, float* grad_features_dev, int32_t accumulate, void* stream);
 
