@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define RF_ABI_VERSION 2
+#define RF_ABI_VERSION 3
 
 enum {
   RF_OK = 0,
@@ -204,7 +204,9 @@ int rf_render_backward(const RFGrid* grid, const RFRayBatch* rays, uint32_t flag
  * (its own and, per flags, up to 7 lower neighbours'), sums them in LDS with plain read-add-writes (wavefronts own disjoint
  * channels: no races, no LDS atomics) and writes the brick with plain coalesced stores: accumulate = 0 OVERWRITES every
  * element of the gradient tensors (no zero-fill needed; diffuse lists: only density + degree-0 gradients), accumulate = 1
- * adds.  Up to two lists of the same kind per call.  SH degree <= 2. */
+ * adds.  Up to two lists per call: two of the same kind, or (specular list, render_diffuse list) in that order = BOTH renders
+ * of a training iteration (modules/trainers.py:306-341) in one pass: the 4-channel diffuse records are summed first, with LDS
+ * float64 atomics (order-insensitive to ~1e-16; rounded to float32 once), the full records on top of them.  SH degree <= 2. */
 typedef struct RFBrickList {
   const float* records_sorted_dev; /* [capacity, rf_expanded_record_floats(F)] (diffuse lists: F = 3) */
   const int64_t* offsets_dev;      /* [8 * nbricks + 1] start of each (brick, flags) class            */
@@ -243,6 +245,26 @@ int rf_expand_records(const RFGrid* grid, const float* records_dev, const int64_
 
 int rf_brick_accumulate(const RFGrid* grid, int32_t brick_size, const RFBrickList* lists, int32_t num_lists,
                         float* grad_densities_dev, float* grad_features_dev, int32_t accumulate, void* stream);
+
+/* The optimizer of the training iteration (torch.optim.Adam(betas, eps), modules/trainers.py:242-250,339-341) fused into the
+ * brick pass: the workgroup that owns a brick holds the COMPLETE gradient of its parameters in LDS (when the lists carry
+ * every render of the iteration), so it applies the Adam update right there -- the gradient tensor never exists in HBM and
+ * the separate optimizer pass (7 x 4 B per parameter) becomes 6 x 4 B inside this one.  Same arithmetic as rf_adam_step.
+ * Requirements: RF_LAYOUT_SPLIT / RF_LAYOUT_BRICKED with F in {3, 27} (whole float4s per node), all six pointers 16-byte
+ * aligned, param_*_dev the very tensors `grid` describes.  Bricks without records still take their (zero-gradient) step. */
+typedef struct RFAdamState {
+  float* param_first_dev;      /* = grid->densities_dev (base)  */
+  float* param_second_dev;     /* = grid->features_dev  (rest; NULL when F == 3) */
+  float* exp_avg_first_dev;    /* first moments, same shapes    */
+  float* exp_avg_second_dev;
+  float* exp_avg_sq_first_dev; /* second moments                */
+  float* exp_avg_sq_second_dev;
+  float lr, beta1, beta2, eps;
+  int32_t step;                /* 1-based step count (bias correction) */
+} RFAdamState;
+
+int rf_brick_accumulate_adam(const RFGrid* grid, int32_t brick_size, const RFBrickList* lists, int32_t num_lists,
+                             const RFAdamState* adam, void* stream);
 
 /* VoxelGrid.forward (thre3d_reprs/voxels.py:276-331) as a standalone point query: points_dev [M,3] (any
  * points: zeros padding outside the grid, no AABB mask) -> out_dev [M, F+1] = (F interpolated features in the

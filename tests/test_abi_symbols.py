@@ -31,7 +31,7 @@ def test_every_declared_symbol_is_exported(lib):
 
 
 def test_abi_version_and_error_strings(lib):
-    assert lib.rf_abi_version() == 2
+    assert lib.rf_abi_version() == _lib.ABI_VERSION == 3
     assert lib.rf_error_string(0) == b"ok"
     for code in (-1, -2, -3, -4):
         assert lib.rf_error_string(code) not in (b"ok", b"unknown error code")
@@ -59,6 +59,43 @@ def test_argument_validation_needs_no_gpu(lib):
     r.num_samples = 8
     assert lib.rf_render_forward(C.byref(g), C.byref(r), 0, C.byref(o), None) == 0  # zero rays: no-op
     assert lib.rf_cast_rays(4, 4, 1.0, None, None, None, None, None) == -1
+
+
+def test_node_count_guard_and_fused_optimizer_validation(lib):
+    """check_grid rejects grids whose node count does not fit the kernels' 32-bit node indices; rf_brick_accumulate_adam
+    validates layout / alignment / aliasing before any launch."""
+    import ctypes as C
+
+    g = _lib.RFGrid()
+    g.densities_dev, g.features_dev = 16, 32
+    g.num_features, g.density_stride, g.feature_stride = 3, 1, 3
+    g.dims[0], g.dims[1], g.dims[2] = 2046, 2046, 2046  # 8.6e9 nodes
+    r, o = _lib.RFRayBatch(), _lib.RFRenderOut()
+    r.num_samples = 8
+    assert lib.rf_render_forward(C.byref(g), C.byref(r), 0, C.byref(o), None) == -2
+    g.dims[0], g.dims[1], g.dims[2] = 1500, 1500, 1500  # 3.4e9 nodes: fits
+    assert lib.rf_render_forward(C.byref(g), C.byref(r), 0, C.byref(o), None) == 0
+    # fused optimizer: reference layout is refused, so are misaligned moments and parameters that are not the grid's tensors
+    g.dims[0], g.dims[1], g.dims[2] = 16, 16, 16
+    g.num_features, g.density_stride, g.feature_stride = 27, 1, 27
+    lists = (_lib.RFBrickList * 2)()
+    for i in range(2):
+        lists[i].records_sorted_dev, lists[i].offsets_dev, lists[i].render_diffuse = 64, 64, i
+    st = _lib.RFAdamState()
+    st.param_first_dev, st.param_second_dev = 16, 32
+    st.exp_avg_first_dev = st.exp_avg_second_dev = st.exp_avg_sq_first_dev = st.exp_avg_sq_second_dev = 64
+    st.lr, st.beta1, st.beta2, st.eps, st.step = 0.03, 0.9, 0.999, 1e-8, 1
+    assert lib.rf_brick_accumulate_adam(C.byref(g), 8, lists, 2, C.byref(st), None) == -3  # reference layout
+    g.layout, g.density_stride, g.feature_stride = 1, 4, 24
+    st.exp_avg_first_dev = 68
+    assert lib.rf_brick_accumulate_adam(C.byref(g), 8, lists, 2, C.byref(st), None) == -2  # misaligned
+    st.exp_avg_first_dev, st.param_first_dev = 64, 48
+    assert lib.rf_brick_accumulate_adam(C.byref(g), 8, lists, 2, C.byref(st), None) == -2  # not the grid's tensor
+    st.param_first_dev, st.step = 16, 0
+    assert lib.rf_brick_accumulate_adam(C.byref(g), 8, lists, 2, C.byref(st), None) == -2  # step counts from 1
+    assert lib.rf_brick_accumulate_adam(C.byref(g), 8, lists, 2, None, None) == -1
+    lists[0].render_diffuse, lists[1].render_diffuse = 1, 0
+    assert lib.rf_brick_accumulate(C.byref(g), 8, lists, 2, 64, 64, 0, None) == -2  # the specular list comes first
 
 
 def test_product_path_raises_without_gpu_tensors():

@@ -1,0 +1,179 @@
+"""Oracle comparisons at the sizes BASELINE.json quotes its metric on -- the exact configurations bench.py times:
+
+  * configs[2]: the fused training step (split storage, binned backward, both renders merged into one brick pass,
+    optimizer fused into the brick flush) on the 128^3 / SH-2 field with 256 jittered samples per ray;
+  * configs[4]: the 256^3 / 512-sample render of a sparse scene WITH the exact occupancy mask;
+  * configs[1]: depth of the full-size forward render under the float64-anchored rule of SURVEY H1.
+
+The oracle (oracle/relu_field_oracle.py, CPU, the same ATen ops the reference calls) is the checker; everything under test
+goes through the C ABI."""
+import numpy as np
+import pytest
+import torch
+
+import thr3ed_atom_amd as rf
+from thr3ed_atom_amd.trainers import TrainStepper
+from thr3ed_atom_amd.voxels import unpack_split
+from oracle import relu_field_oracle as orc
+from tests.helpers import hash_uniform, hotdog_like_camera
+
+pytestmark = pytest.mark.gpu
+
+RHO = 100.0 / 3.0
+
+
+def T(a):
+    return torch.from_numpy(np.asarray(a))
+
+
+def _uniform_grid(dev, G, F, seed, storage, sparse=False):
+    gen = torch.Generator(device=dev)
+    gen.manual_seed(seed)
+    dens = torch.empty((G, G, G, 1), device=dev).uniform_(-1, 1, generator=gen)
+    feat = torch.empty((G, G, G, F), device=dev).uniform_(-1, 1, generator=gen)
+    if sparse:  # raw density = 0.5 - |p / 1.5| + 0.05 U(-1, 1)
+        ax = ((torch.arange(G, device=dev, dtype=torch.float32) + 0.5) / G * 3.0 - 1.5) / 1.5
+        r = torch.sqrt(ax[:, None, None] ** 2 + ax[None, :, None] ** 2 + ax[None, None, :] ** 2)
+        dens = (0.5 - r + 0.05 * dens[..., 0])[..., None].contiguous()
+    grid = rf.VoxelGrid(dens, feat, rf.VoxelSize(3.0 / G, 3.0 / G, 3.0 / G), density_preactivation=torch.nn.Identity(),
+                        density_postactivation=torch.nn.ReLU(), expected_density_scale=RHO, tunable=True, storage=storage)
+    return grid, dens.cpu(), feat.cpu()
+
+
+def _frame_rays(dev, n, seed):
+    cam = hotdog_like_camera()
+    pose = rf.pose_spherical(30.0, -30.0, cam["radius"])
+    rays = rf.flatten_rays(rf.cast_rays(rf.CameraIntrinsics(800, 800, 1111.111), pose, dev))
+    idx = torch.from_numpy(np.random.RandomState(seed).choice(len(rays), n, replace=False)).to(dev)
+    return rays[idx], cam
+
+
+def _oracle_step(dens, feat, rays, pixels, t_rands, cam, G, S):
+    cd, cf = dens.clone().requires_grad_(True), feat.clone().requires_grad_(True)
+    aabb = orc.make_aabb((G,) * 3, (3.0 / G,) * 3)
+    losses = []
+    for diffuse, tr in zip((False, True), t_rands):
+        out = orc.render(cd, cf, rays.origins.cpu(), rays.directions.cpu(), aabb, cam["near"], cam["far"], S, RHO, "relu",
+                         white_bkgd=True, render_diffuse=diffuse, t_rand=tr.cpu(), interp="aten")
+        losses.append(torch.nn.functional.l1_loss(out["colour"], pixels.cpu()))
+    (losses[0] + losses[1]).backward()
+    return cd, cf, losses
+
+
+@pytest.mark.parametrize("fuse_optimizer", [False, True])
+def test_bench_train_step_against_oracle_at_baseline_size(hip_device, fuse_optimizer):
+    """The path bench.py times -- TrainStepper(fused=True, backward='binned') on split storage at 128^3 / SH-2 / 256 jittered
+    samples -- against the oracle's autograd + torch.optim.Adam on the same 2048 rays and the same jitter: losses, the whole
+    flat gradient (fuse_optimizer=False keeps the gradient bucket) and the parameters after the Adam update
+    (fuse_optimizer=True: the update happens inside the brick flush, no gradient bucket exists)."""
+    G, S, n = 128, 256, 2048
+    grid, dens, feat = _uniform_grid(hip_device, G, 27, 42, "split")
+    rays, cam = _frame_rays(hip_device, n, 3)
+    pixels = T(hash_uniform((n, 3), 9, 0.0, 1.0)).to(hip_device)
+    t_rands = [T(hash_uniform((n, S), 70 + i, 0.0, 1.0)).clamp_(0.0, 1.0 - 2.0**-24).to(hip_device) for i in range(2)]
+    cfg = rf.SHVoxGridRenderConfig(S, rf.CameraBounds(cam["near"], cam["far"]), perturb_sampled_points=True, white_bkgd=True)
+    model = rf.VolumetricModel(grid, rf.render_sh_voxel_grid, cfg, device=hip_device)
+    stepper = TrainStepper(model, n, learning_rate=0.03, fused=True, backward="binned", fuse_optimizer=fuse_optimizer)
+    assert stepper.backward == "binned" and stepper.fuse_optimizer == fuse_optimizer and stepper.merged_bricks
+    stats = stepper.step_on(rays, pixels, t_rand=t_rands)
+    torch.cuda.synchronize()
+
+    cd, cf, losses = _oracle_step(dens, feat, rays, pixels, t_rands, cam, G, S)
+    np.testing.assert_allclose(stats.specular_loss.item(), losses[0].item(), rtol=2e-5)
+    np.testing.assert_allclose(stats.diffuse_loss.item(), losses[1].item(), rtol=2e-5)
+    if not fuse_optimizer:
+        gd, gf = unpack_split(*stepper.flat.views_for_accumulation())
+        for ours, ref in ((gd, cd.grad), (gf, cf.grad)):
+            ref = ref.numpy()
+            assert np.abs(ref).max() > 0
+            np.testing.assert_allclose(ours.cpu().numpy(), ref, rtol=1e-3, atol=1e-5 * np.abs(ref).max())
+    # parameters after the first Adam step: p - lr * g / (|g| + 1e-8) -- entries whose gradient is ~1e-8 amplify float32
+    # summation-order noise, everything else must agree tightly (same criterion as the G9 trajectory test)
+    opt = torch.optim.Adam([{"params": [cd, cf], "lr": 0.03}], betas=(0.9, 0.999))
+    opt.step()
+    for ours, ref in ((grid.densities, cd), (grid.features, cf)):
+        err = np.abs(ours.detach().cpu().numpy() - ref.detach().numpy())
+        assert np.mean(err <= 2e-5) >= 0.999 and err.max() <= 0.03 * 2 + 1e-6
+
+
+def test_fused_optimizer_step_equals_bucket_step(hip_device):
+    """Adam inside the brick flush == gradient bucket + rf_adam_step, over several steps (same rays, same jitter):
+    parameters and both moments agree to float32 rounding of the gradient sums."""
+    G, S, n = 32, 64, 1024
+    rays, cam = _frame_rays(hip_device, n, 5)
+    pixels = T(hash_uniform((n, 3), 19, 0.0, 1.0)).to(hip_device)
+    cfg = rf.SHVoxGridRenderConfig(S, rf.CameraBounds(cam["near"], cam["far"]), perturb_sampled_points=True, white_bkgd=True)
+    steppers = []
+    for fuse in (False, True):
+        grid, _, _ = _uniform_grid(hip_device, G, 27, 7, "split")
+        model = rf.VolumetricModel(grid, rf.render_sh_voxel_grid, cfg, device=hip_device)
+        steppers.append(TrainStepper(model, n, learning_rate=0.03, fused=True, backward="binned", fuse_optimizer=fuse))
+    for it in range(4):
+        t_rands = [T(hash_uniform((n, S), 100 + 2 * it + i, 0.0, 1.0)).clamp_(0.0, 1.0 - 2.0**-24).to(hip_device) for i in range(2)]
+        a = steppers[0].step_on(rays, pixels, t_rand=t_rands)
+        b = steppers[1].step_on(rays, pixels, t_rand=t_rands)
+        np.testing.assert_allclose(a.specular_loss.item(), b.specular_loss.item(), rtol=1e-5)
+    for name in ("flat_param",):
+        x, y = getattr(steppers[0].flat, name), getattr(steppers[1].flat, name)
+        err = (x - y).abs()
+        assert float((err <= 2e-5).float().mean()) >= 0.999 and float(err.max()) <= 0.03 * 2 * 4 + 1e-6
+    for x, y in ((steppers[0].optimizer.exp_avg, steppers[1].optimizer.exp_avg), (steppers[0].optimizer.exp_avg_sq, steppers[1].optimizer.exp_avg_sq)):
+        np.testing.assert_allclose(y.cpu().numpy(), x.cpu().numpy(), rtol=2e-3, atol=1e-6 * float(x.abs().max()))
+    assert steppers[0].optimizer.step_count == steppers[1].optimizer.step_count == 4
+
+
+def test_highres_occupancy_render_against_oracle_at_config4_size(hip_device):
+    """configs[4] at size: 256^3 SH-2 sparse ReLU field, 512 samples per ray, use_occupancy_mask=True -- a 2048-ray spot check of
+    colour / depth / accumulated weight and of the gradients against the oracle, which (like the reference,
+    process.py:80-84) gathers every sample and masks afterwards."""
+    G, S, n = 256, 512, 2048
+    grid, dens, feat = _uniform_grid(hip_device, G, 27, 11, "split", sparse=True)
+    rays, cam = _frame_rays(hip_device, n, 4)
+    target = T(hash_uniform((n, 3), 29, 0.0, 1.0)).to(hip_device)
+    t_rand = T(hash_uniform((n, S), 31, 0.0, 1.0)).clamp_(0.0, 1.0 - 2.0**-24).to(hip_device)
+    cfg = rf.SHVoxGridRenderConfig(S, rf.CameraBounds(cam["near"], cam["far"]), perturb_sampled_points=True, white_bkgd=True, use_occupancy_mask=True)
+    out = rf.render_sh_voxel_grid(grid, rays, cfg, t_rand=t_rand)
+    occ = grid.occupancy
+    assert occ is not None
+    frac = float(sum(bin(int(w) & 0xFFFFFFFF).count("1") for w in occ.cpu().tolist())) / (G + 1) ** 3
+    assert 0.02 < frac < 0.2, frac  # most of the scene is provably empty
+    torch.nn.functional.l1_loss(out.colour, target).backward()
+    gd, gf = grid.reference_gradients()
+
+    cd, cf = dens.clone().requires_grad_(True), feat.clone().requires_grad_(True)
+    ref = orc.render(cd, cf, rays.origins.cpu(), rays.directions.cpu(), orc.make_aabb((G,) * 3, (3.0 / G,) * 3), cam["near"], cam["far"], S,
+                     RHO, "relu", white_bkgd=True, t_rand=t_rand.cpu(), interp="aten")
+    torch.nn.functional.l1_loss(ref["colour"], target.cpu()).backward()
+    np.testing.assert_allclose(out.colour.detach().cpu().numpy(), ref["colour"].detach().numpy(), rtol=0, atol=1e-5)
+    np.testing.assert_allclose(out.extra["accumulated_weight"].detach().cpu().numpy(), ref["acc"].detach().numpy(), rtol=0, atol=1e-5)
+    # depth: float64-anchored: the HIP float32 result may be as far from the float64 value as the reference's own
+    # float32 result is, plus 1e-5
+    o64, d64 = rays.origins.cpu().double(), rays.directions.cpu().double()
+    ref64 = orc.render(dens.double(), feat.double(), o64, d64, orc.make_aabb((G,) * 3, (3.0 / G,) * 3), cam["near"], cam["far"], S, RHO, "relu",
+                       white_bkgd=True, t_rand=t_rand.cpu().double())
+    band = (ref["depth"].detach().double() - ref64["depth"]).abs() + 1e-5
+    assert bool(((out.depth.detach().cpu().double() - ref64["depth"]).abs() <= band).all())
+    assert float(out.colour.min()) < 0.9  # the blob is visible
+    for ours, r in ((gd, cd.grad), (gf, cf.grad)):
+        r = r.numpy()
+        assert np.abs(r).max() > 0
+        np.testing.assert_allclose(ours.cpu().numpy(), r, rtol=1e-3, atol=1e-5 * np.abs(r).max())
+
+
+def test_full_size_depth_within_float64_anchored_band(hip_device):
+    """configs[1] geometry (128^3 SH-2, 256 samples): depth / colour / acc of 4096 rays of the 800x800 frame, split storage,
+    under the float64 rule |hip - ref64| <= |ref32 - ref64| + 1e-5 (no blanket loosening of the 1e-5 bound)."""
+    G, S, n = 128, 256, 4096
+    grid, dens, feat = _uniform_grid(hip_device, G, 27, 42, "split")
+    rays, cam = _frame_rays(hip_device, n, 8)
+    cfg = rf.SHVoxGridRenderConfig(S, rf.CameraBounds(cam["near"], cam["far"]), perturb_sampled_points=False, white_bkgd=True)
+    with torch.no_grad():
+        out = rf.render_sh_voxel_grid(grid, rays, cfg)
+    aabb = orc.make_aabb((G,) * 3, (3.0 / G,) * 3)
+    o, d = rays.origins.cpu(), rays.directions.cpu()
+    ref32 = orc.render(dens, feat, o, d, aabb, cam["near"], cam["far"], S, RHO, "relu", white_bkgd=True, interp="aten")
+    ref64 = orc.render(dens.double(), feat.double(), o.double(), d.double(), aabb, cam["near"], cam["far"], S, RHO, "relu", white_bkgd=True)
+    for ours, key in ((out.depth, "depth"), (out.colour, "colour"), (out.extra["accumulated_weight"], "acc")):
+        band = (ref32[key].double() - ref64[key]).abs() + 1e-5
+        assert bool(((ours.cpu().double() - ref64[key]).abs() <= band).all()), key
+    np.testing.assert_allclose(out.colour.cpu().numpy(), ref32["colour"].numpy(), rtol=0, atol=1e-5)

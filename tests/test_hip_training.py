@@ -431,6 +431,9 @@ def _binned_gradients(grid, rays, cfg, target, device, diffuse_too=True, accumul
     gf = None if second is None else (torch.full_like(second, -3.0) if not accumulate else torch.zeros_like(second))
     sums = torch.zeros(4, device=device)
     lists, keep = [], []
+    merged = binning == "merged"  # fused counting for both lists, then ONE brick pass over (specular, diffuse)
+    if merged:
+        binning = "fused"
     for i, diffuse in enumerate((False, True) if diffuse_too else (False,)):
         flags = O.render_flags(cfg.white_bkgd, diffuse or cfg.render_diffuse, cfg.optimized_sampling, False)
         is_diffuse = diffuse or cfg.render_diffuse
@@ -458,6 +461,14 @@ def _binned_gradients(grid, rays, cfg, target, device, diffuse_too=True, accumul
                 O.sort_records_by_brick(grid, keys, rec, None if is_diffuse else ray_basis, is_diffuse, srt, offsets, boundaries)
         lists.append((srt, offsets, diffuse or cfg.render_diffuse))
         keep.append((keys, rec, caches))
+    if merged:
+        O.brick_accumulate_raw(grid, brick, lists, gd, gf, accumulate=accumulate)
+        if accumulate:
+            O.brick_accumulate_raw(grid, brick, lists, gd, gf, accumulate=True)
+            gd.mul_(0.5)
+            if gf is not None:
+                gf.mul_(0.5)
+        return gd, gf
     # the specular list first (it writes every channel), the diffuse list (base channels only) on top
     for k, one in enumerate(lists):
         O.brick_accumulate_raw(grid, brick, [one], gd, gf, accumulate=accumulate or k > 0)
@@ -470,7 +481,7 @@ def _binned_gradients(grid, rays, cfg, target, device, diffuse_too=True, accumul
     return gd, gf
 
 
-@pytest.mark.parametrize("accumulate,binning", [(False, "sort"), (True, "sort"), (False, "count"), (False, "fused")])
+@pytest.mark.parametrize("accumulate,binning", [(False, "sort"), (True, "sort"), (False, "count"), (False, "fused"), (False, "merged"), (True, "merged")])
 @pytest.mark.parametrize("storage", ["reference", "split", "bricked"])
 @pytest.mark.parametrize("case", ["grid16_sh2", "aniso_sh2_abs", "aniso_sh1_softplus", "cube20_sh0"])
 def test_binned_backward_equals_atomic_backward(hip_device, storage, case, accumulate, binning):
@@ -745,7 +756,7 @@ def test_binned_backward_with_mostly_empty_bricks(hip_device):
     assert torch.equal(gf == 0, ref_f == 0) or float(((gf == 0) != (ref_f == 0)).float().mean()) < 1e-3
 
 
-@pytest.mark.parametrize("binning", ["fused", "count", "sort"])
+@pytest.mark.parametrize("binning", ["fused", "count", "sort", "merged"])
 @pytest.mark.parametrize("seed", list(range(8)))
 def test_binned_backward_randomised_shapes(hip_device, seed, binning):
     """Binned backward (each binning path) == atomic backward on randomly drawn grid sizes (partial bricks), ray counts (not multiples

@@ -15,7 +15,7 @@ LIB_PATH = os.path.join(CSRC_DIR, LIB_NAME)
 SOURCES = ["relu_field_kernels.hip"]
 HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared"]
 
-ABI_VERSION = 2  # RF_ABI_VERSION of include/relu_field.h (2: binned backward, RFRenderOut.key_hist_dev, bricked layout)
+ABI_VERSION = 3  # RF_ABI_VERSION of include/relu_field.h (3: mixed brick lists, optimizer fused into the brick flush)
 
 # enums of relu_field.h
 DENSITY_MODES = {"relu": 0, "softplus": 1, "abs": 2, "identity": 3}
@@ -41,6 +41,7 @@ EXPORTED_SYMBOLS = [
     "rf_render_backward_emit_direct",
     "rf_scatter_records",
     "rf_brick_accumulate",
+    "rf_brick_accumulate_adam",
     "rf_grid_query",
     "rf_grid_query_backward",
     "rf_build_occupancy",
@@ -111,6 +112,22 @@ class RFBrickList(C.Structure):
     ]
 
 
+class RFAdamState(C.Structure):
+    _fields_ = [
+        ("param_first_dev", C.c_void_p),
+        ("param_second_dev", C.c_void_p),
+        ("exp_avg_first_dev", C.c_void_p),
+        ("exp_avg_second_dev", C.c_void_p),
+        ("exp_avg_sq_first_dev", C.c_void_p),
+        ("exp_avg_sq_second_dev", C.c_void_p),
+        ("lr", C.c_float),
+        ("beta1", C.c_float),
+        ("beta2", C.c_float),
+        ("eps", C.c_float),
+        ("step", C.c_int32),
+    ]
+
+
 def build(force: bool = False, verbose: bool = False) -> str:
     """Cross-compile the HIP sources for gfx950 into csrc/librelu_field_hip.so (hipcc needs no GPU)."""
     srcs = [os.path.join(CSRC_DIR, s) for s in SOURCES]
@@ -173,6 +190,7 @@ def load() -> C.CDLL:
     ]
     lib.rf_scatter_records.argtypes = [C.POINTER(RFGrid), vp, vp, i64, vp, vp, i32, vp, vp, i32, vp]
     lib.rf_brick_accumulate.argtypes = [C.POINTER(RFGrid), i32, C.POINTER(RFBrickList), i32, vp, vp, i32, vp]
+    lib.rf_brick_accumulate_adam.argtypes = [C.POINTER(RFGrid), i32, C.POINTER(RFBrickList), i32, C.POINTER(RFAdamState), vp]
     lib.rf_grid_query.argtypes = [C.POINTER(RFGrid), vp, i64, vp, vp]
     lib.rf_grid_query_backward.argtypes = [C.POINTER(RFGrid), vp, i64, vp, vp, vp, vp]
     lib.rf_build_occupancy.argtypes = [C.POINTER(RFGrid), f32, vp, vp]

@@ -23,6 +23,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <atomic>
+
 #include "relu_field.h"
 
 namespace {
@@ -1150,13 +1152,29 @@ struct BrickList {
   int diffuse;
 };
 
+// fused optimizer of the brick flush (torch.optim.Adam arithmetic, the same expressions as adam_kernel): the workgroup that
+// owns a brick holds its complete gradient in LDS, so the update is applied there and the gradient never goes to HBM
+struct AdamArgs {
+  float* p1;  // parameters, first / second tensor (the tensors GridArgs describes, writable)
+  float* p2;
+  float* m1;  // exp_avg
+  float* m2;
+  float* v1;  // exp_avg_sq
+  float* v2;
+  float step;      // lr / (1 - beta1^t)
+  float b1, b2, eps;
+  float bc2_sqrt;  // sqrt(1 - beta2^t)
+};
+
 struct BrickArgs {
   BrickList lists[2];
   int nlists;
+  int mixed;               // lists[0] = full records of a specular pass, lists[1] = base-channel records of a render_diffuse pass
   int shift;               // log2(B)
   int nbx, nby, nbz;
   int accumulate;          // 0: grad = brick sum (no zero-fill needed), 1: grad += brick sum
   int fmul;                // reference layout: feature index of degree-0 colour c is c * fmul (base-only lists on an SH grid)
+  AdamArgs adam;           // only read by the ADAM instantiation
 };
 
 
@@ -1363,7 +1381,7 @@ __device__ __forceinline__ bool cells_share_nodes(uint32_t ca, uint32_t cb) {
   return (unsigned)(dx + 1) <= 2u && (unsigned)(dy + 1) <= 2u && (unsigned)(dz + 1) <= 2u;
 }
 
-template <int K>
+template <int K, bool ADAM>
 __global__ __launch_bounds__(kBrickThreads) void brick_accumulate_kernel(GridArgs g, BrickArgs a, float* gdens,
                                                                          float* gfeat) {
   constexpr int C = 3 * K + 1;
@@ -1397,10 +1415,15 @@ __global__ __launch_bounds__(kBrickThreads) void brick_accumulate_kernel(GridArg
   const int X0 = bx << a.shift, Y0 = by << a.shift, Z0 = bz << a.shift;
 
   // ---- which sorted ranges reach into this brick: 14 (offset to the source brick o, run of flag classes f with
-  // (f & o) == o) per list, fetched by 14 lanes each and compacted with a wave scan
-  if (wave == 0) {
+  // (f & o) == o) per list, fetched by 14 lanes each and compacted with a wave scan.  Wave 0 does it for the lists that go
+  // through the table path, wave 1 for the base-channel list of a mixed call (it has its own, smaller, range table).
+  __shared__ long long s_dstart[14];
+  __shared__ int s_dcum[16];  // [15] = total
+  if (wave < 2) {
+    const bool second = wave == 1;            // the diffuse list of a mixed call
+    const int nl = second ? (a.mixed ? 1 : 0) : (a.mixed ? 1 : a.nlists);
     const int li = lane / 14, e = lane - li * 14;
-    const bool in_use = lane < 14 * a.nlists;
+    const bool in_use = lane < 14 * nl;
     // nibble tables over e: source offset, first and last flag class of the run
     const int o = (int)((0x76554332211110ull >> (4 * e)) & 7), f0 = (int)((0x76754736275310ull >> (4 * e)) & 7),
               f1 = (int)((0x77757737375317ull >> (4 * e)) & 7);
@@ -1408,7 +1431,7 @@ __global__ __launch_bounds__(kBrickThreads) void brick_accumulate_kernel(GridArg
     long long rs = 0;
     int cnt = 0;
     if (in_use && sx >= 0 && sy >= 0 && sz >= 0) {
-      const long long* off = (li ? a.lists[1].offsets : a.lists[0].offsets) + ((long long)((sx * a.nby + sy) * a.nbz + sz) << 3);
+      const long long* off = ((li || second) ? a.lists[1].offsets : a.lists[0].offsets) + ((long long)((sx * a.nby + sy) * a.nbz + sz) << 3);
       rs = off[f0];
       cnt = (int)(off[f1 + 1] - rs);
     }
@@ -1420,20 +1443,90 @@ __global__ __launch_bounds__(kBrickThreads) void brick_accumulate_kernel(GridArg
       if (lane >= d) cum += up;
     }
     const int slot = __popcll(nonempty & ((1ull << lane) - 1ull));
-    if (cnt > 0) {
-      s_rstart[slot] = rs;
-      s_rlist[slot] = li;
-      s_rcum[slot + 1] = cum;
+    if (!second) {
+      if (cnt > 0) {
+        s_rstart[slot] = rs;
+        s_rlist[slot] = li;
+        s_rcum[slot + 1] = cum;
+      }
+      if (lane == 0) s_rcum[0] = 0;
+      if (lane == 31) s_rcum[kMaxRanges] = cum;  // total (lanes >= 28 carry cnt = 0)
+    } else {
+      if (cnt > 0) {
+        s_dstart[slot] = rs;
+        s_dcum[slot + 1] = cum;
+      }
+      if (lane == 0) s_dcum[0] = 0;
+      if (lane == 31) s_dcum[15] = cum;
     }
-    if (lane == 0) s_rcum[0] = 0;
-    if (lane == 31) s_rcum[kMaxRanges] = cum;  // total (lanes >= 28 carry cnt = 0)
   }
   __syncthreads();
   const int total = s_rcum[kMaxRanges];
-  if (total == 0 && a.accumulate) return;  // nothing reaches this brick
-  if (total > 0) {
+  const int total_d = a.mixed ? s_dcum[15] : 0;
+  const bool any = total > 0 || total_d > 0;
+  if (!any && a.accumulate) return;  // nothing reaches this brick
+
+  // ---- mixed call: the base-channel (render_diffuse) records first, summed with LDS float64 atomics.  A 4-channel record
+  // would occupy a quarter of the lanes of the table path below at the price of a full record; ds_add_f64 is fire-and-forget
+  // and needs neither ownership nor ordering, so all four waves take two records per instruction (32 lanes = 8 corners x 4
+  // channels each).  Measured (tools/lds_microbench4.hip): 21 clk per record per CU, ds_add_f32 would take 30x longer.  The
+  // float64 sums (order-insensitive to ~1e-16) are rounded to float32 once and become the INITIAL value of the float32
+  // accumulators of the table path.  The doubles live in the first 16 KB of `acc`.
+  double dsum[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) dsum[j] = 0.0;
+  const int nd4 = B * B * B * 4;
+  if (total_d > 0) {
+    double* dacc = reinterpret_cast<double*>(acc);
+    for (int i = tid; i < nd4; i += kBrickThreads) dacc[i] = 0.0;
+    __syncthreads();
+    const int half = lane >> 5, qd = (lane >> 2) & 7, cd = lane & 3;
+    const int dd[3] = {(qd >> 2) & 1, (qd >> 1) & 1, qd & 1};
+    const int org[3] = {X0, Y0, Z0};
+    const int dim[3] = {g.X, g.Y, g.Z};
+    int ri = 0;
+    for (int v = wave * 2 + half; v < total_d; v += 2 * (kBrickThreads / kWave)) {
+      while (s_dcum[ri + 1] <= v) ++ri;
+      const float4* rec = a.lists[1].rec + (s_dstart[ri] + (v - s_dcum[ri])) * 2;
+      const float4 ridx = rec[0];
+      const float val = reinterpret_cast<const float*>(rec + 1)[cd];
+      const float idx[3] = {ridx.x, ridx.y, ridx.z};
+      int n3[3];
+      float w3[3];
+      bool owned = true;
+#pragma unroll
+      for (int ax = 0; ax < 3; ++ax) {
+        const float fl = floorf(idx[ax]);
+        w3[ax] = dd[ax] ? (idx[ax] - fl) : ((fl + 1.0f) - idx[ax]);  // same arithmetic as locate()
+        n3[ax] = (int)fl - org[ax] + dd[ax];
+        owned = owned && n3[ax] >= 0 && n3[ax] < B && org[ax] + n3[ax] < dim[ax];
+      }
+      if (owned) {
+        const float wc = (w3[0] * w3[1]) * w3[2];
+        atomicAdd(&dacc[(((n3[0] << a.shift) + n3[1]) << a.shift) * 4 + n3[2] * 4 + cd], (double)(wc * val));
+      }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < 8; ++j)
+      if (tid + j * kBrickThreads < nd4) dsum[j] = dacc[tid + j * kBrickThreads];
+    __syncthreads();
+  }
+  if (any) {
     float4* acc4 = reinterpret_cast<float4*>(acc);
     for (int i = tid; i < acc_words / 4; i += kBrickThreads) acc4[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+  }
+  if (total_d > 0) {
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int e = tid + j * kBrickThreads;
+      if (e < nd4) {
+        const int node = e >> 2;
+        const int nz = node & (B - 1), ny = (node >> a.shift) & (B - 1), nx = node >> (2 * a.shift);
+        acc[nx * SX + ny * SY + nz * CS + (e & 3)] = (float)dsum[j];
+      }
+    }
   }
 
   const int nbatches = (total + kBrickBatch - 1) / kBrickBatch;
@@ -1621,20 +1714,44 @@ __global__ __launch_bounds__(kBrickThreads) void brick_accumulate_kernel(GridArg
       const int X = X0 + fx, Y = Y0 + fy, Z = Z0 + fz;
       if (X >= g.X || Y >= g.Y || Z >= g.Z) continue;
       const long long lin = node_lin(g, X, Y, Z);
-      float4 v = total > 0 ? *reinterpret_cast<const float4*>(&acc[fx * SX + fy * SY + fz * CS + 4 * qd]) : make_float4(0.f, 0.f, 0.f, 0.f);
-      if (qd == 0) {
-        if (g.mode == RF_DENSITY_ABS) {  // d|x|/dx of the raw density, applied once per node
-          const float dv = g.dens[lin * g.dstride] * g.rho;
-          v.x = (dv > 0.f) ? v.x : ((dv < 0.f) ? -v.x : 0.0f);
+      float4 v = any ? *reinterpret_cast<const float4*>(&acc[fx * SX + fy * SY + fz * CS + 4 * qd]) : make_float4(0.f, 0.f, 0.f, 0.f);
+      if (qd == 0 && g.mode == RF_DENSITY_ABS) {  // d|x|/dx of the raw density, applied once per node
+        const float dv = g.dens[lin * g.dstride] * g.rho;
+        v.x = (dv > 0.f) ? v.x : ((dv < 0.f) ? -v.x : 0.0f);
+      }
+      const long long off = (qd == 0) ? lin * g.dstride : lin * g.fstride + 4 * (qd - 1);
+      if constexpr (ADAM) {
+        // the optimizer step on the 4 parameters this thread holds the complete gradient of (adam_kernel's expressions):
+        // parameters with ordinary accesses (the next forward pass reads them), moments streamed non-temporally
+        const AdamArgs& ad = a.adam;
+        float4* pp = reinterpret_cast<float4*>((qd == 0 ? ad.p1 : ad.p2) + off);
+        vf4* mp = reinterpret_cast<vf4*>((qd == 0 ? ad.m1 : ad.m2) + off);
+        vf4* vp = reinterpret_cast<vf4*>((qd == 0 ? ad.v1 : ad.v2) + off);
+        const float4 p4 = *pp;
+        const vf4 m4 = __builtin_nontemporal_load(mp), v4 = __builtin_nontemporal_load(vp);
+        const float gg[4] = {v.x, v.y, v.z, v.w};
+        float pn[4] = {p4.x, p4.y, p4.z, p4.w};
+        vf4 mn, vn;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+          const float mm = m4[c] + (gg[c] - m4[c]) * (1.0f - ad.b1);
+          const float vv = v4[c] * ad.b2 + (gg[c] * gg[c]) * (1.0f - ad.b2);
+          pn[c] = pn[c] - ad.step * (mm / (sqrtf(vv) / ad.bc2_sqrt + ad.eps));
+          mn[c] = mm;
+          vn[c] = vv;
         }
-        float4* dst = reinterpret_cast<float4*>(gdens + lin * g.dstride);
+        *pp = make_float4(pn[0], pn[1], pn[2], pn[3]);
+        __builtin_nontemporal_store(mn, mp);
+        __builtin_nontemporal_store(vn, vp);
+      } else if (qd == 0) {
+        float4* dst = reinterpret_cast<float4*>(gdens + off);
         if (a.accumulate) {
           const float4 o = *dst;
           v = make_float4(o.x + v.x, o.y + v.y, o.z + v.z, o.w + v.w);
         }
         *dst = v;
       } else {
-        float4* dst = reinterpret_cast<float4*>(gfeat + lin * g.fstride + 4 * (qd - 1));
+        float4* dst = reinterpret_cast<float4*>(gfeat + off);
         if (a.accumulate) {
           const float4 o = *dst;
           v = make_float4(o.x + v.x, o.y + v.y, o.z + v.z, o.w + v.w);
@@ -1670,7 +1787,7 @@ __global__ __launch_bounds__(kBrickThreads) void brick_accumulate_kernel(GridArg
         lds_c = (kk == 0) ? 1 + col3 : 4 + col3 * (K - 1) + (kk - 1);
       }
       const long long lin = node_lin(g, X, Y, Z);
-      float v = total > 0 ? acc[fx * SX + fy * SY + fz * CS + lds_c] : 0.0f;
+      float v = any ? acc[fx * SX + fy * SY + fz * CS + lds_c] : 0.0f;
       if (lds_c == 0 && g.mode == RF_DENSITY_ABS) {  // d|x|/dx of the raw density, applied once per node
         const float dv = g.dens[lin * g.dstride] * g.rho;
         v = (dv > 0.f) ? v : ((dv < 0.f) ? -v : 0.0f);
@@ -2113,6 +2230,13 @@ int check_grid(const RFGrid* g) {
   } else {
     return RF_ERR_UNSUPPORTED;
   }
+  // node indices are 32-bit in the kernels (node_lin: 24-bit multiplies into an unsigned int; element offsets are 64-bit):
+  // the node count, padded to whole bricks for the bricked order, must stay below 2^32
+  {
+    unsigned long long nodes = 1;
+    for (int a = 0; a < 3; ++a) nodes *= (unsigned long long)(g->layout == RF_LAYOUT_BRICKED ? (g->dims[a] + 7) / 8 * 8 : g->dims[a]);
+    if (nodes >= (1ull << 32)) return RF_ERR_BAD_SHAPE;
+  }
   return RF_OK;
 }
 
@@ -2514,31 +2638,38 @@ int rf_scatter_records(const RFGrid* grid, const int16_t* keys_dev, const float*
 int32_t rf_expanded_record_floats(int32_t num_features) { return 4 * record_quads(num_features / 3); }
 
 extern "C++" {
-template <int K>
+template <int K, bool ADAM>
 static int launch_brick(const GridArgs& g, const BrickArgs& a, int nbricks, float* gd, float* gf, hipStream_t st) {
   const int B = 1 << a.shift;
   const size_t lds = (size_t)brick_acc_words(B, 3 * K + 1) * sizeof(float);
   if (lds > 150 * 1024) return RF_ERR_UNSUPPORTED;  // 160 KB per CU minus the kernel's static staging buffers
-  static size_t configured = 0;  // raise the dynamic-LDS limit of this instantiation when a larger one is needed
-  if (lds > configured) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&brick_accumulate_kernel<K>),
+  // raise the dynamic-LDS limit of this instantiation when a larger one is needed (a per-device function attribute)
+  static std::atomic<size_t> configured[64];
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return RF_ERR_LAUNCH;
+  if (lds > configured[dev].load(std::memory_order_relaxed)) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&brick_accumulate_kernel<K, ADAM>),
                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
       return RF_ERR_LAUNCH;
-    configured = lds;
+    configured[dev].store(lds, std::memory_order_relaxed);
   }
-  hipLaunchKernelGGL((brick_accumulate_kernel<K>), dim3(nbricks), dim3(kBrickThreads), lds, st, g, a, gd, gf);
+  hipLaunchKernelGGL((brick_accumulate_kernel<K, ADAM>), dim3(nbricks), dim3(kBrickThreads), lds, st, g, a, gd, gf);
   return launch_status();
 }
 }  // extern "C++"
 
-int rf_brick_accumulate(const RFGrid* grid, int32_t brick_size, const RFBrickList* lists, int32_t num_lists,
-                        float* grad_densities_dev, float* grad_features_dev, int32_t accumulate, void* stream) {
+static int brick_accumulate_impl(const RFGrid* grid, int32_t brick_size, const RFBrickList* lists, int32_t num_lists,
+                                 float* grad_densities_dev, float* grad_features_dev, int32_t accumulate,
+                                 const RFAdamState* adam, void* stream) {
   int rc = check_grid(grid);
   if (rc != RF_OK) return rc;
-  if (!lists || !grad_densities_dev) return RF_ERR_NULL_POINTER;
-  if (!grad_features_dev && !(grid->layout != RF_LAYOUT_REFERENCE && grid->num_features == 3)) return RF_ERR_NULL_POINTER;
+  if (!lists) return RF_ERR_NULL_POINTER;
+  if (!adam) {
+    if (!grad_densities_dev) return RF_ERR_NULL_POINTER;
+    if (!grad_features_dev && !(grid->layout != RF_LAYOUT_REFERENCE && grid->num_features == 3)) return RF_ERR_NULL_POINTER;
+  }
   if (num_lists < 1 || num_lists > 2) return RF_ERR_BAD_SHAPE;
-  if (grid->num_features > 27) return RF_ERR_UNSUPPORTED;  // 3 rest waves cover 24 channels (SH degree <= 2)
+  if (grid->num_features > 27) return RF_ERR_UNSUPPORTED;  // the accumulators of a brick must fit the LDS (SH degree <= 2)
   int shift, nb[3];
   rc = brick_geometry(grid, brick_size, &shift, nb, false);
   if (rc != RF_OK) return rc;
@@ -2550,7 +2681,9 @@ int rf_brick_accumulate(const RFGrid* grid, int32_t brick_size, const RFBrickLis
     a.lists[i].offsets = reinterpret_cast<const long long*>(lists[i].offsets_dev);
     a.lists[i].diffuse = lists[i].render_diffuse || grid->num_features == 3;
   }
-  if (num_lists == 2 && a.lists[0].diffuse != a.lists[1].diffuse) return RF_ERR_BAD_SHAPE;  // record formats differ
+  // two lists: either the same kind (both through the table path) or (specular, diffuse) = a mixed call
+  a.mixed = num_lists == 2 && !a.lists[0].diffuse && a.lists[1].diffuse;
+  if (num_lists == 2 && a.lists[0].diffuse && !a.lists[1].diffuse) return RF_ERR_BAD_SHAPE;  // the specular list comes first
   const int base_only = a.lists[0].diffuse;  // 4 accumulator channels per node, written to the base channels only
   a.fmul = base_only ? grid->num_features / 3 : 1;
   a.shift = shift;
@@ -2561,14 +2694,59 @@ int rf_brick_accumulate(const RFGrid* grid, int32_t brick_size, const RFBrickLis
   const GridArgs g = to_args(grid);
   const int nbricks = nb[0] * nb[1] * nb[2];
   hipStream_t st = (hipStream_t)stream;
-  switch (base_only ? 1 : grid->num_features / 3) {
-    case 1:
-      return launch_brick<1>(g, a, nbricks, grad_densities_dev, grad_features_dev, st);
-    case 4:
-      return launch_brick<4>(g, a, nbricks, grad_densities_dev, grad_features_dev, st);
-    default:
-      return launch_brick<9>(g, a, nbricks, grad_densities_dev, grad_features_dev, st);
+  const int K = base_only ? 1 : grid->num_features / 3;
+  if (adam) {
+    // the update needs the complete gradient of every parameter in the owning workgroup: all channels covered by the lists
+    // (base-only lists on an SH grid leave the higher-degree channels to someone else), whole float4s, overwrite semantics
+    const int C = 3 * K + 1;
+    if (accumulate || grid->layout == RF_LAYOUT_REFERENCE || (C & 3) || (base_only && grid->num_features != 3)) return RF_ERR_UNSUPPORTED;
+    if ((grid->density_stride & 3) || (C > 4 && (grid->feature_stride & 3))) return RF_ERR_UNSUPPORTED;
+    if (!adam->param_first_dev || !adam->exp_avg_first_dev || !adam->exp_avg_sq_first_dev) return RF_ERR_NULL_POINTER;
+    if (C > 4 && (!adam->param_second_dev || !adam->exp_avg_second_dev || !adam->exp_avg_sq_second_dev)) return RF_ERR_NULL_POINTER;
+    if (adam->param_first_dev != grid->densities_dev || (C > 4 && adam->param_second_dev != grid->features_dev)) return RF_ERR_BAD_SHAPE;
+    if (adam->step < 1) return RF_ERR_BAD_SHAPE;
+    const uintptr_t align = (uintptr_t)adam->param_first_dev | (uintptr_t)adam->exp_avg_first_dev | (uintptr_t)adam->exp_avg_sq_first_dev |
+                            (C > 4 ? ((uintptr_t)adam->param_second_dev | (uintptr_t)adam->exp_avg_second_dev | (uintptr_t)adam->exp_avg_sq_second_dev) : 0);
+    if (align & 15u) return RF_ERR_BAD_SHAPE;
+    const double bc1 = 1.0 - pow((double)adam->beta1, (double)adam->step);
+    const double bc2 = 1.0 - pow((double)adam->beta2, (double)adam->step);
+    a.adam.p1 = adam->param_first_dev;
+    a.adam.p2 = adam->param_second_dev;
+    a.adam.m1 = adam->exp_avg_first_dev;
+    a.adam.m2 = adam->exp_avg_second_dev;
+    a.adam.v1 = adam->exp_avg_sq_first_dev;
+    a.adam.v2 = adam->exp_avg_sq_second_dev;
+    a.adam.step = adam->lr / (float)bc1;  // (float division, like rf_adam_step's kernel: step = lr / bc1)
+    a.adam.b1 = adam->beta1;
+    a.adam.b2 = adam->beta2;
+    a.adam.eps = adam->eps;
+    a.adam.bc2_sqrt = (float)sqrt(bc2);
+    switch (K) {
+      case 1:
+        return launch_brick<1, true>(g, a, nbricks, nullptr, nullptr, st);
+      default:
+        return launch_brick<9, true>(g, a, nbricks, nullptr, nullptr, st);
+    }
   }
+  switch (K) {
+    case 1:
+      return launch_brick<1, false>(g, a, nbricks, grad_densities_dev, grad_features_dev, st);
+    case 4:
+      return launch_brick<4, false>(g, a, nbricks, grad_densities_dev, grad_features_dev, st);
+    default:
+      return launch_brick<9, false>(g, a, nbricks, grad_densities_dev, grad_features_dev, st);
+  }
+}
+
+int rf_brick_accumulate(const RFGrid* grid, int32_t brick_size, const RFBrickList* lists, int32_t num_lists,
+                        float* grad_densities_dev, float* grad_features_dev, int32_t accumulate, void* stream) {
+  return brick_accumulate_impl(grid, brick_size, lists, num_lists, grad_densities_dev, grad_features_dev, accumulate, nullptr, stream);
+}
+
+int rf_brick_accumulate_adam(const RFGrid* grid, int32_t brick_size, const RFBrickList* lists, int32_t num_lists,
+                             const RFAdamState* adam, void* stream) {
+  if (!adam) return RF_ERR_NULL_POINTER;
+  return brick_accumulate_impl(grid, brick_size, lists, num_lists, nullptr, nullptr, 0, adam, stream);
 }
 
 int rf_grid_query(const RFGrid* grid, const float* points_dev, int64_t num_points, float* out_dev, void* stream) {

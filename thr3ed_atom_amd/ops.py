@@ -297,6 +297,28 @@ def brick_accumulate_raw(grid: VoxelGrid, brick_size: int, lists, grad_first: Te
     _lib.check(rc, "rf_brick_accumulate")
 
 
+def brick_accumulate_adam_raw(grid: VoxelGrid, brick_size: int, lists, exp_avg, exp_avg_sq, lr: float, beta1: float, beta2: float,
+                              eps: float, step: int) -> None:
+    """Enqueue rf_brick_accumulate_adam: the brick pass over ``lists`` (as in ``brick_accumulate_raw``; all renders of the
+    iteration) with the Adam update of the grid's own tensors applied in the flush.  ``exp_avg`` / ``exp_avg_sq`` are pairs of
+    tensors shaped like ``grid.kernel_tensors()`` (second entry None when the grid has no second tensor)."""
+    lib = _lib.load()
+    first, second = grid.kernel_tensors()
+    dev = first.device
+    arr = (_lib.RFBrickList * len(lists))()
+    for i, (rec, off, diffuse) in enumerate(lists):
+        arr[i].records_sorted_dev, arr[i].offsets_dev, arr[i].render_diffuse = rec.data_ptr(), off.data_ptr(), int(bool(diffuse))
+    st = _lib.RFAdamState()
+    st.param_first_dev, st.param_second_dev = first.data_ptr(), _ptr(second)
+    st.exp_avg_first_dev, st.exp_avg_second_dev = exp_avg[0].data_ptr(), _ptr(exp_avg[1])
+    st.exp_avg_sq_first_dev, st.exp_avg_sq_second_dev = exp_avg_sq[0].data_ptr(), _ptr(exp_avg_sq[1])
+    st.lr, st.beta1, st.beta2, st.eps, st.step = float(lr), float(beta1), float(beta2), float(eps), int(step)
+    rf_grid = grid.to_rf_grid()
+    with _span(f"brick_accumulate_adam[{'diffuse' if lists[0][2] or grid.sh_degree == 0 else 'sh' + str(grid.sh_degree)}]", dev):
+        rc = lib.rf_brick_accumulate_adam(C.byref(rf_grid), int(brick_size), arr, len(lists), C.byref(st), _stream(dev))
+    _lib.check(rc, "rf_brick_accumulate_adam")
+
+
 class _ReluFieldRender(torch.autograd.Function):
     @staticmethod
     def forward(ctx, first, second, origins, directions, t_rand, grid: VoxelGrid, num_samples, near, far, flags, need_grad):
@@ -442,8 +464,8 @@ def relu_field_render(
         raise AssertionError("the render op works with FLAT rays [N, 3] only")
     if int(num_samples) < 1:
         raise ValueError("num_samples must be >= 1")
-    if use_occupancy and grid.occupancy is None:
-        grid.build_occupancy()
+    if use_occupancy and not grid.occupancy_current():
+        grid.build_occupancy()  # no mask yet, or the densities changed since it was built (optimizer step, in-place edit)
     flags = render_flags(white_bkgd, render_diffuse, optimized_sampling, use_occupancy)
     # the per-sample cache for the backward pass is only written when a gradient can be asked for
     # grid tensors in storage order: (densities, features) or, for split storage, (base, rest)

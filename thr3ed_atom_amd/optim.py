@@ -113,6 +113,7 @@ class FusedAdam:
                     self.flat.flat_param[lo:hi], grad, self.exp_avg[lo:hi], self.exp_avg_sq[lo:hi],
                     self.lr, self.betas[0], self.betas[1], self.eps, self.step_count, zero_grad,
                 )
+        self.flat.grid.invalidate_occupancy()  # the kernel wrote the densities through raw pointers
 
 
 class ExponentialLR:

@@ -31,6 +31,7 @@ from . import distributed as rfdist
 from .camera import CameraBounds, CameraIntrinsics, compute_thre3d_grid_sizes, mse2psnr, scale_camera_intrinsics
 from .constants import CAMERA_BOUNDS, CAMERA_INTRINSICS, HEMISPHERICAL_RADIUS
 from .ops import (
+    brick_accumulate_adam_raw,
     brick_accumulate_raw,
     brick_counts,
     cast_selected_rays_hip,
@@ -139,6 +140,8 @@ class TrainStepper:
         deterministic: bool = False,
         shard_optimizer: bool = True,
         global_batch: bool = False,
+        merge_bricks: Optional[bool] = None,
+        fuse_optimizer: Optional[bool] = None,
     ):
         """``ray_selection``: "randperm" draws torch.randperm over all B*H*W pixels exactly like the reference
         (utils/misc.py:123) and keeps the first ``ray_batch_size``; "keyed" draws the same kind of sample
@@ -185,6 +188,22 @@ class TrainStepper:
             nb = brick_counts(grid, self.brick_size)
             backward = "binned" if (self.fused and grid.sh_degree == 2 and nb[0] * nb[1] * nb[2] * 8 <= (1 << 21)) else "atomic"
         self.backward = backward
+        # merge_bricks (binned, non-deterministic steps with the diffuse regulariser): BOTH renders emit their records first and
+        # ONE brick pass sums them -- the 4-channel diffuse records with LDS float64 atomics, the specular records on top -- so
+        # the atomic diffuse scatter (0.28 ms at 0.13 of the HBM roofline in round 1) disappears.  Default: on, except under
+        # data parallelism, where the order "specular bricks -> exchange of the `rest` gradients overlapped with the diffuse
+        # pass" is kept.
+        single = not (self.data_parallel and rfdist._collectives_on())
+        can_merge = self.fused and backward == "binned" and not self.deterministic and self.diffuse
+        self.merged_bricks = can_merge and (single if merge_bricks is None else bool(merge_bricks))
+        if merge_bricks and not can_merge:
+            raise ValueError("merge_bricks needs the fused, binned, non-deterministic step with the diffuse render")
+        # fuse_optimizer (merged steps on one GPU, split/bricked storage, SH degree 0 or 2 = whole float4s per node): the brick
+        # flush applies the Adam update itself (rf_brick_accumulate_adam) -- no gradient bucket in HBM, no separate optimizer pass
+        can_fuse = self.merged_bricks and single and grid.storage != "reference" and (grid.num_features + 1) % 4 == 0
+        self.fuse_optimizer = can_fuse if fuse_optimizer is None else bool(fuse_optimizer)
+        if self.fuse_optimizer and not can_fuse:
+            raise ValueError("fuse_optimizer needs a merged brick pass on a single process, split or bricked storage and SH degree 0 or 2")
 
     def select(self, dataset: PosedImagesInMemory, image_ids: Tensor):
         """Synchronous random subset of rays and pixels of the given images
@@ -193,7 +212,13 @@ class TrainStepper:
         hw = intr.height * intr.width
         dev = dataset.pixels.device
         total = min(self.ray_batch_size, image_ids.numel() * hw)
-        lo, hi = rfdist.shard_range(total) if (self.global_batch and self.data_parallel) else (0, total)
+        lo, hi = 0, total
+        if self.global_batch and self.data_parallel:
+            # equal shares only: every rank scales its L1 gradient by 1 / (3 * own rays) and the ranks are averaged with equal
+            # weight, which is the global-batch mean only when all ranks hold the same number of rays
+            if total % rfdist.world_size() != 0:
+                raise ValueError(f"global_batch: the ray batch ({total}) must be divisible by the world size ({rfdist.world_size()})")
+            lo, hi = rfdist.shard_range(total)
         if self.ray_selection == "keyed":
             key = int(torch.randint(-(2**63), 2**63 - 1, (1,), dtype=torch.int64).item())
             o, d, px = select_rays_and_pixels_hip(intr.height, intr.width, float(intr.focal), dataset.poses, image_ids, dataset.pixels, hi - lo, key, first_index=lo)
@@ -206,13 +231,20 @@ class TrainStepper:
         pixels = dataset.pixels[image_ids[b] * hw + (perm - b * hw)]
         return Rays(origins, directions), pixels
 
-    def step_on(self, rays: Rays, pixels: Tensor) -> StepStats:
+    def step_on(self, rays: Rays, pixels: Tensor, t_rand=None) -> StepStats:
+        """One iteration on the given rays / target pixels.  ``t_rand`` = (jitter of the specular render, jitter of the diffuse
+        render), each [N, S] in [0, 1), replaces the draws of ``perturb_sampled_points`` (parity tests)."""
         vol_mod = self.vol_mod
         cfg = vol_mod.render_config
-        if cfg.use_occupancy_mask:
-            vol_mod.thre3d_repr.build_occupancy()  # densities changed in the last Adam step
+        grid = vol_mod.thre3d_repr
+        if cfg.use_occupancy_mask and not grid.occupancy_current():
+            grid.build_occupancy()  # densities changed in the last optimizer step
         if self.fused:
-            return self._fused_step_on(rays, pixels)
+            stats = self._merged_step_on(rays, pixels, t_rand) if self.merged_bricks else self._fused_step_on(rays, pixels, t_rand)
+            grid.invalidate_occupancy()
+            return stats
+        if t_rand is not None:
+            raise ValueError("t_rand is only taken by the fused step (pass t_rand= to render_sh_voxel_grid on the autograd path)")
         self.optimizer.zero_grad()
         spec = vol_mod.render_rays(rays).colour
         total = l1_loss(spec, pixels)
@@ -227,10 +259,69 @@ class TrainStepper:
         if self.data_parallel:
             rfdist.all_reduce_mean_(self.flat.flat_grad)
         self.optimizer.step()
+        grid.invalidate_occupancy()
         self._grad_clean = False
         return StepStats(spec_loss, diff_loss, spec_mse, diff_mse)
 
-    def _fused_step_on(self, rays: Rays, pixels: Tensor) -> StepStats:
+    def _draw_jitter(self, cfg, n: int, S: int, device, given, i: int):
+        if given is not None:
+            t = given[i].detach().to(device, torch.float32).contiguous()
+            if tuple(t.shape) != (n, S):
+                raise ValueError(f"t_rand[{i}] must be [{n}, {S}], got {tuple(t.shape)}")
+            return t
+        t = torch.rand(n, S, dtype=torch.float32, device=device) if cfg.perturb_sampled_points else None
+        if cfg.consume_reference_rng:
+            torch.randn(n, S, dtype=torch.float32, device=device)
+        return t
+
+    def _merged_step_on(self, rays: Rays, pixels: Tensor, t_rand=None) -> StepStats:
+        """Both renders forward (each counts its records per key), both adjoints emitted as records at their final positions,
+        ONE brick pass over the two lists; the Adam update inside its flush when ``fuse_optimizer``."""
+        vol_mod, grid = self.vol_mod, self.vol_mod.thre3d_repr
+        cfg = vol_mod.render_config
+        _check_supported(cfg)
+        origins = rays.origins.detach().to(torch.float32).contiguous()
+        directions = rays.directions.detach().to(torch.float32).contiguous()
+        pixels = pixels.detach().to(torch.float32).contiguous()
+        n, S = origins.shape[0], int(cfg.num_samples_per_ray)
+        dev = origins.device
+        near, far = float(np.float32(cfg.camera_bounds.near)), float(np.float32(cfg.camera_bounds.far))
+        bins = self._bin_buffers(n, S, dev)
+        sums = torch.zeros(4, dtype=torch.float32, device=dev)
+        passes = []
+        for i, diffuse in enumerate((False, True)):
+            jit = self._draw_jitter(cfg, n, S, dev, t_rand, i)
+            flags = render_flags(cfg.white_bkgd, diffuse, cfg.optimized_sampling, cfg.use_occupancy_mask)
+            b = bins["diffuse"] if diffuse else bins
+            colour, _, _, _, caches = render_forward_raw(grid, origins, directions, jit, S, near, far, flags, save=True, key_hist=b["hist"], brick_size=self.brick_size)
+            g_colour = l1_loss_grad_hip(colour, pixels, sums[2 * i : 2 * i + 2])
+            passes.append((diffuse, jit, flags, b, caches, g_colour))
+        lists = []
+        for diffuse, jit, flags, b, caches, g_colour in passes:
+            offsets = bin_offsets(b["hist"], b["offsets"], b["cursor"])
+            render_backward_emit_direct_raw(grid, origins, directions, jit, S, near, far, flags, caches, g_colour, None, None, self.brick_size,
+                                            b["cursor"], b["sorted"], hist_clear=b["hist"])
+            lists.append((b["sorted"], offsets, diffuse))
+        opt = self.optimizer
+        if self.fuse_optimizer:
+            opt.step_count += 1
+            nd = self.flat.flat_gradient_parts()[0].numel()
+            has_second = self.flat.flat_gradient_parts()[1] is not None
+            halves = lambda t: (t[:nd], t[nd:] if has_second else None)
+            brick_accumulate_adam_raw(grid, self.brick_size, lists, halves(opt.exp_avg), halves(opt.exp_avg_sq), opt.lr, opt.betas[0], opt.betas[1],
+                                      opt.eps, opt.step_count)
+            self._grad_clean = True  # the bucket is not used at all
+        else:
+            gd, gf = self.flat.views_for_accumulation()
+            brick_accumulate_raw(grid, self.brick_size, lists, gd, gf, accumulate=False)  # overwrites the whole bucket
+            if self.data_parallel and rfdist._collectives_on():
+                rfdist.all_reduce_mean_(self.flat.flat_grad)
+            opt.step()
+            self._grad_clean = False
+        means = sums / float(3 * n)
+        return StepStats(means[0], means[2], means[1], means[3])
+
+    def _fused_step_on(self, rays: Rays, pixels: Tensor, t_rand_given=None) -> StepStats:
         vol_mod, grid = self.vol_mod, self.vol_mod.thre3d_repr
         cfg = vol_mod.render_config
         _check_supported(cfg)
@@ -255,9 +346,7 @@ class TrainStepper:
         reduce_async = rfdist.reduce_scatter_mean_async if sharded else rfdist.all_reduce_mean_async
         pending = []
         for i, diffuse in enumerate((False, True) if self.diffuse else (False,)):
-            t_rand = torch.rand(n, S, dtype=torch.float32, device=origins.device) if cfg.perturb_sampled_points else None
-            if cfg.consume_reference_rng:
-                torch.randn(n, S, dtype=torch.float32, device=origins.device)
+            t_rand = self._draw_jitter(cfg, n, S, origins.device, t_rand_given, i)
             flags = render_flags(cfg.white_bkgd, diffuse, cfg.optimized_sampling, cfg.use_occupancy_mask)
             use_bricks = binned and (not diffuse or self.deterministic)
             fused_binning = use_bricks and not self.deterministic  # the forward pass counts the records per key
@@ -340,6 +429,13 @@ class TrainStepper:
                 "hist": torch.zeros(num_bricks * 8, dtype=torch.int32, device=device),
                 "cursor": torch.empty(num_bricks * 8, dtype=torch.int32, device=device),
             }
+            if self.merged_bricks:  # the diffuse render's own list (8-float records: index quad + the 4 base channels)
+                b["diffuse"] = {
+                    "sorted": torch.empty((n * S, expanded_record_floats(grid, True)), dtype=torch.float32, device=device),
+                    "offsets": torch.full((num_bricks * 8 + 1,), n * S, dtype=torch.int64, device=device),
+                    "hist": torch.zeros(num_bricks * 8, dtype=torch.int32, device=device),
+                    "cursor": torch.empty(num_bricks * 8, dtype=torch.int32, device=device),
+                }
             self._bins = b
         return b
 
@@ -376,13 +472,15 @@ def train_sh_vox_grid_vol_mod_with_posed_images(
     """Same arguments (minus the feedback/visualisation ones) and same schedule as the reference's
     trainer.  Returns the trained model; ``history`` (if given) collects the logged scalars.
     ``storage`` selects the HBM layout the grid is trained in ("split" = MI355X-native, "reference", or
-    None = keep the model's); checkpoints and ``.densities`` / ``.features`` stay in the reference layout.
+    None = keep the model's); checkpoints and ``.densities`` / ``.features`` stay in the reference layout and the
+    returned model's grid is converted back to the storage it came in.
     ``global_batch`` (data parallel): ``ray_batch_size`` is split over the ranks instead of drawn per rank (seed all
     ranks equally)."""
     grid = vol_mod.thre3d_repr
     assert isinstance(grid, VoxelGrid), f"cannot use a {type(grid)} with this TrainProcedure"
     assert vol_mod.render_procedure is render_sh_voxel_grid, "non SH-based VoxelGrids cannot be used with this TrainProcedure"
     is_main = rfdist.rank() == 0
+    incoming_storage = grid.storage
 
     stage_sizes = compute_thre3d_grid_sizes(grid.grid_dims, num_stages, scale_factor)
     stage_sets = [train_dataset]
@@ -461,6 +559,11 @@ def train_sh_vox_grid_vol_mod_with_posed_images(
                     vol_mod.thre3d_repr, stage_sizes[stage]
                 ).to(vol_mod.device)
     save("model_final.pth")
+    if vol_mod.thre3d_repr.storage != incoming_storage:
+        # hand the grid back in the storage it came in (normally "reference"): there ``.densities`` / ``.features`` are
+        # the Parameters themselves again, so reference-style code (in-place edits, ``.grad``, ``parameters()``) behaves
+        with torch.no_grad():
+            vol_mod.thre3d_repr = vol_mod.thre3d_repr.to_storage(incoming_storage).to(vol_mod.device)
     if is_main:
         log(f"Total actual training time: {trained_seconds:.1f} s")
     return vol_mod

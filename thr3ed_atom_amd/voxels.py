@@ -404,11 +404,26 @@ class VoxelGrid(Module):
         stream = torch.cuda.current_stream(dev).cuda_stream
         _lib.check(_lib.load().rf_build_occupancy(grid, float(threshold), occ.data_ptr(), stream), "rf_build_occupancy")
         self._occupancy = occ
+        d = self.kernel_tensors()[0]
+        self._occupancy_stamp = (d.data_ptr(), d._version)
         return occ
 
     @property
     def occupancy(self) -> Optional[Tensor]:
         return self._occupancy
+
+    def invalidate_occupancy(self) -> None:
+        """The densities were changed behind autograd's back (a fused optimizer kernel writes through raw pointers): the
+        mask has to be rebuilt before its next use."""
+        self._occupancy_stamp = None
+
+    def occupancy_current(self) -> bool:
+        """True when a mask exists AND the density tensor is the one (same storage, same in-place version counter) it was
+        built from.  ``torch.optim`` steps bump the version counter; the fused optimizer calls invalidate_occupancy()."""
+        if self._occupancy is None:
+            return False
+        d = self.kernel_tensors()[0]
+        return self.__dict__.get("_occupancy_stamp") == (d.data_ptr(), d._version)
 
 
 def scale_voxel_grid_with_required_output_size(
