@@ -11,7 +11,7 @@ from typing import Optional
 CSRC_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc")
 INCLUDE_DIR = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "include")
 LIB_NAME = "librelu_field_hip.so"
-LIB_PATH = os.path.join(CSRC_DIR, LIB_NAME)
+LIB_PATH = os.environ.get("RF_LIB_PATH") or os.path.join(CSRC_DIR, LIB_NAME)  # RF_LIB_PATH: development builds (tools/)
 SOURCES = ["relu_field_kernels.hip"]
 HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared"]
 

@@ -24,6 +24,7 @@
 #include <stdint.h>
 
 #include <atomic>
+#include <cstdlib>
 
 #include "relu_field.h"
 
@@ -1174,6 +1175,7 @@ struct BrickArgs {
   int nbx, nby, nbz;
   int accumulate;          // 0: grad = brick sum (no zero-fill needed), 1: grad += brick sum
   int fmul;                // reference layout: feature index of degree-0 colour c is c * fmul (base-only lists on an SH grid)
+  int stagger;             // ADAM: number of first-generation workgroups that start with a pseudo-random delay (0 = off)
   AdamArgs adam;           // only read by the ADAM instantiation
 };
 
@@ -1381,8 +1383,26 @@ __device__ __forceinline__ bool cells_share_nodes(uint32_t ca, uint32_t cb) {
   return (unsigned)(dx + 1) <= 2u && (unsigned)(dy + 1) <= 2u && (unsigned)(dz + 1) <= 2u;
 }
 
+// Phase timing of the brick pass (development builds only: -DRF_BRICK_PROFILE; tools/brick_phase_profile.py): thread 0 of
+// every workgroup adds the s_memtime span of each phase to a global table.
+#ifdef RF_BRICK_PROFILE
+__device__ unsigned long long g_brick_prof[8];
+#define RF_PROF_MARK(slot)                                                       \
+  do {                                                                           \
+    if (threadIdx.x == 0) {                                                      \
+      const unsigned long long now_ = __builtin_readcyclecounter();              \
+      atomicAdd(&g_brick_prof[slot], now_ - prof_t_);                            \
+      prof_t_ = now_;                                                            \
+    }                                                                            \
+  } while (0)
+#define RF_PROF_START() unsigned long long prof_t_ = __builtin_readcyclecounter()
+#else
+#define RF_PROF_MARK(slot) do { } while (0)
+#define RF_PROF_START() do { } while (0)
+#endif
+
 template <int K, bool ADAM>
-__global__ __launch_bounds__(kBrickThreads) void brick_accumulate_kernel(GridArgs g, BrickArgs a, float* gdens,
+__global__ __launch_bounds__(kBrickThreads, 2) void brick_accumulate_kernel(GridArgs g, BrickArgs a, float* gdens,
                                                                          float* gfeat) {
   constexpr int C = 3 * K + 1;
   constexpr int C4 = (C + 3) / 4 * 4;
@@ -1398,7 +1418,8 @@ __global__ __launch_bounds__(kBrickThreads) void brick_accumulate_kernel(GridArg
   constexpr int CELL = GOFF + 2 * C4;             // words: the two packed cells
   constexpr int ROW = (CELL + 2 + 3) / 4 * 4;     // words per step, 16-byte aligned
   extern __shared__ __attribute__((aligned(16))) float acc[];  // node (x, y, z), channel c at x * SX + y * SY + z * CS + c
-  __shared__ __attribute__((aligned(16))) uint32_t table[2][(kBrickBatch / 2 + 2) * ROW];  // separate object: never aliases acc; + 2 spare steps (prefetch)
+  constexpr int TW = (kBrickBatch / 2 + 2) * ROW > kBrickThreads * 4 ? (kBrickBatch / 2 + 2) * ROW : kBrickThreads * 4;  // (also the staging buffers of the diffuse phase)
+  __shared__ __attribute__((aligned(16))) uint32_t table[2][TW];  // separate object: never aliases acc; + 2 spare steps (prefetch)
   __shared__ long long s_rstart[kMaxRanges];
   __shared__ int s_rlist[kMaxRanges];
   __shared__ int s_rcum[kMaxRanges + 1];  // cumulative record counts of the non-empty ranges
@@ -1407,12 +1428,23 @@ __global__ __launch_bounds__(kBrickThreads) void brick_accumulate_kernel(GridArg
   const int TRASH = B * SX;  // contributions to nodes this brick does not own land here and are never written out
   const int acc_words = TRASH + 64;
 
+  RF_PROF_START();
   const int tid = threadIdx.x;
   const int lane = tid & (kWave - 1);
   const int wave = tid >> 6;
   const int brick = blockIdx.x;
   const int bz = brick % a.nbz, by = (brick / a.nbz) % a.nby, bx = brick / (a.nbz * a.nby);
   const int X0 = bx << a.shift, Y0 = by << a.shift, Z0 = bz << a.shift;
+  if constexpr (ADAM) {
+    // De-phase the first generation of workgroups.  Every workgroup alternates between LDS-bound phases (no HBM traffic)
+    // and a flush that streams 344 KB; launched together, the 512 resident workgroups reach their flushes together, HBM
+    // saturates for the flushes and idles in between (measured: the flushes ran at exactly HBM rate, 14 GB/s each).  A
+    // pseudo-random start offset of up to ~40 us spreads the flushes over time; later generations inherit the spread.
+    if ((a.stagger & 0xffff) && blockIdx.x < (unsigned)(a.stagger & 0xffff)) {
+      const unsigned int h = (blockIdx.x * 2654435761u) >> 28;  // 0..15
+      for (unsigned int k = 0; k < h; ++k) __builtin_amdgcn_s_sleep(100);  // ~6400 clk each
+    }
+  }
 
   // ---- which sorted ranges reach into this brick: 14 (offset to the source brick o, run of flag classes f with
   // (f & o) == o) per list, fetched by 14 lanes each and compacted with a wave scan.  Wave 0 does it for the lists that go
@@ -1465,6 +1497,7 @@ __global__ __launch_bounds__(kBrickThreads) void brick_accumulate_kernel(GridArg
   const int total_d = a.mixed ? s_dcum[15] : 0;
   const bool any = total > 0 || total_d > 0;
   if (!any && a.accumulate) return;  // nothing reaches this brick
+  RF_PROF_MARK(0);  // range set-up
 
   // ---- mixed call: the base-channel (render_diffuse) records first, summed with LDS float64 atomics.  A 4-channel record
   // would occupy a quarter of the lanes of the table path below at the price of a full record; ds_add_f64 is fire-and-forget
@@ -1484,26 +1517,45 @@ __global__ __launch_bounds__(kBrickThreads) void brick_accumulate_kernel(GridArg
     const int dd[3] = {(qd >> 2) & 1, (qd >> 1) & 1, qd & 1};
     const int org[3] = {X0, Y0, Z0};
     const int dim[3] = {g.X, g.Y, g.Z};
+    // the records are streamed through LDS (the idle table buffers): the whole workgroup fetches 128 records (4 KB) per
+    // round with coalesced 16-byte loads, one round ahead of their use; a wave then takes its records from LDS, where
+    // a miss costs 65 cycles instead of microseconds
+    constexpr int RPR = kBrickThreads / 2;  // records per round (two float4 per record)
+    static_assert(2 * kBrickThreads * 4 <= (int)(sizeof(table) / sizeof(uint32_t)), "two staging buffers fit the table");
+    float4* stage = reinterpret_cast<float4*>(&table[0][0]);
+    const int nrounds = (total_d + RPR - 1) / RPR;
     int ri = 0;
-    for (int v = wave * 2 + half; v < total_d; v += 2 * (kBrickThreads / kWave)) {
+    auto fetch = [&](int round) -> float4 {
+      const int v = min(round * RPR + (tid >> 1), total_d - 1);  // clamped: unconditional loads
       while (s_dcum[ri + 1] <= v) ++ri;
-      const float4* rec = a.lists[1].rec + (s_dstart[ri] + (v - s_dcum[ri])) * 2;
-      const float4 ridx = rec[0];
-      const float val = reinterpret_cast<const float*>(rec + 1)[cd];
-      const float idx[3] = {ridx.x, ridx.y, ridx.z};
-      int n3[3];
-      float w3[3];
-      bool owned = true;
+      return a.lists[1].rec[(s_dstart[ri] + (v - s_dcum[ri])) * 2 + (tid & 1)];
+    };
+    float4 inflight = fetch(0);
+    for (int round = 0; round < nrounds; ++round) {
+      float4* buf = stage + (round & 1) * kBrickThreads;
+      buf[tid] = inflight;
+      __syncthreads();
+      if (round + 1 < nrounds) inflight = fetch(round + 1);
+      const int nrec = min(RPR, total_d - round * RPR);
+#pragma unroll 4
+      for (int r = wave * 2 + half; r < nrec; r += 2 * (kBrickThreads / kWave)) {
+        const float4 ridx = buf[2 * r];
+        const float val = reinterpret_cast<const float*>(buf + 2 * r + 1)[cd];
+        const float idx[3] = {ridx.x, ridx.y, ridx.z};
+        int n3[3];
+        float w3[3];
+        bool owned = true;
 #pragma unroll
-      for (int ax = 0; ax < 3; ++ax) {
-        const float fl = floorf(idx[ax]);
-        w3[ax] = dd[ax] ? (idx[ax] - fl) : ((fl + 1.0f) - idx[ax]);  // same arithmetic as locate()
-        n3[ax] = (int)fl - org[ax] + dd[ax];
-        owned = owned && n3[ax] >= 0 && n3[ax] < B && org[ax] + n3[ax] < dim[ax];
-      }
-      if (owned) {
-        const float wc = (w3[0] * w3[1]) * w3[2];
-        atomicAdd(&dacc[(((n3[0] << a.shift) + n3[1]) << a.shift) * 4 + n3[2] * 4 + cd], (double)(wc * val));
+        for (int ax = 0; ax < 3; ++ax) {
+          const float fl = floorf(idx[ax]);
+          w3[ax] = dd[ax] ? (idx[ax] - fl) : ((fl + 1.0f) - idx[ax]);  // same arithmetic as locate()
+          n3[ax] = (int)fl - org[ax] + dd[ax];
+          owned = owned && n3[ax] >= 0 && n3[ax] < B && org[ax] + n3[ax] < dim[ax];
+        }
+        if (owned) {
+          const float wc = (w3[0] * w3[1]) * w3[2];
+          atomicAdd(&dacc[(((n3[0] << a.shift) + n3[1]) << a.shift) * 4 + n3[2] * 4 + cd], (double)(wc * val));
+        }
       }
     }
     __syncthreads();
@@ -1512,6 +1564,7 @@ __global__ __launch_bounds__(kBrickThreads) void brick_accumulate_kernel(GridArg
       if (tid + j * kBrickThreads < nd4) dsum[j] = dacc[tid + j * kBrickThreads];
     __syncthreads();
   }
+  RF_PROF_MARK(1);  // diffuse records (float64 atomics)
   if (any) {
     float4* acc4 = reinterpret_cast<float4*>(acc);
     for (int i = tid; i < acc_words / 4; i += kBrickThreads) acc4[i] = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -1675,6 +1728,7 @@ __global__ __launch_bounds__(kBrickThreads) void brick_accumulate_kernel(GridArg
 
   // producers run one batch ahead of the consumers (tables are double buffered); the loads of a producer wave's next
   // batch (two batches later) are issued as soon as it has built the current one
+  RF_PROF_MARK(2);  // zero-fill + initial values
   if (total > 0 && producer) {
     if (parity == 0) {
       issue(0);
@@ -1697,6 +1751,7 @@ __global__ __launch_bounds__(kBrickThreads) void brick_accumulate_kernel(GridArg
     __syncthreads();
   }
 
+  RF_PROF_MARK(3);  // table path: producer / consumer batches
   // ---- write the brick out: plain stores (exclusive owner), contiguous runs along z
   const bool split = g.layout == RF_LAYOUT_SPLIT;
   if (split && (C & 3) == 0 && (g.dstride & 3) == 0 && (C == 4 || (g.fstride & 3) == 0)) {
@@ -1704,46 +1759,102 @@ __global__ __launch_bounds__(kBrickThreads) void brick_accumulate_kernel(GridArg
     constexpr int QN = C / 4;  // float4s per node
     constexpr int QR = QN > 1 ? QN - 1 : 1;
     const int nq = B * B * B * QN;
-    for (int i = tid; i < nq; i += kBrickThreads) {
-      // i -> (column (x, y), quad group, z, quad) with the quads of one tensor contiguous along z
-      const int col = i / (B * QN), r = i - col * (B * QN);
+    // i -> (column (x, y), quad group, z, quad) with the quads of one tensor contiguous along z
+    auto quad_of = [&](int i, int& fx, int& fy, int& fz, int& qd) -> bool {
+      const int col = (i >> a.shift) / QN, r = i - col * (B * QN);  // (division by a constant)
       const bool first = r < B;  // the B base quads of the column come first
-      const int fz = first ? r : (r - B) / QR;
-      const int qd = first ? 0 : 1 + (r - B) - fz * QR;
-      const int fx = col >> a.shift, fy = col & (B - 1);
-      const int X = X0 + fx, Y = Y0 + fy, Z = Z0 + fz;
-      if (X >= g.X || Y >= g.Y || Z >= g.Z) continue;
-      const long long lin = node_lin(g, X, Y, Z);
+      fz = first ? r : (r - B) / QR;
+      qd = first ? 0 : 1 + (r - B) - fz * QR;
+      fx = col >> a.shift;
+      fy = col & (B - 1);
+      return i < nq && X0 + fx < g.X && Y0 + fy < g.Y && Z0 + fz < g.Z;
+    };
+    if constexpr (ADAM) {
+      // The optimizer step on the parameters this workgroup holds the complete gradient of (adam_kernel's expressions):
+      // parameters with ordinary accesses (the next forward pass reads them), moments streamed non-temporally.  The flush is
+      // the only phase of the kernel that waits on HBM: a thread issues the 3 x U loads of U quads before it touches the
+      // first one (one quad at a time kept ~24 KB per CU in flight and ran at a third of the HBM rate).
+      // A thread issues ALL its loads (3 tensors x up to 14 quads at degree 2 = 168 registers; the accumulation registers are
+      // dead by now and the kernel is LDS-limited to 2 waves per SIMD, i.e. 256 registers per lane) before it touches the
+      // first one.  Element offsets are kept as 32-bit (host-checked) to stay inside that budget.
+      constexpr int U = (QN == 7) ? 12 : 2;
+      const AdamArgs& ad = a.adam;
+      for (int i0 = tid; i0 < nq; i0 += kBrickThreads * U) {
+        unsigned int off[U];  // bit 31: rest tensor; 0xffffffff: nothing to do
+        float4 p4[U];
+        vf4 m4[U], v4[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+          int fx, fy, fz, qd;
+          const bool ok = quad_of(i0 + u * kBrickThreads, fx, fy, fz, qd);
+          const unsigned int lin = ok ? node_lin(g, X0 + fx, Y0 + fy, Z0 + fz) : 0u;
+          const unsigned int o = qd == 0 ? lin * (unsigned)g.dstride : (lin * (unsigned)g.fstride + 4u * (unsigned)(qd - 1)) | 0x80000000u;
+          off[u] = ok ? o : 0xffffffffu;
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+          if (off[u] != 0xffffffffu) {
+            const bool rest = off[u] >> 31;
+            const unsigned int o = off[u] & 0x7fffffffu;
+#ifdef RF_BRICK_PROFILE
+            if (a.stagger & 0x10000) { p4[u] = make_float4(0.f, 0.f, 0.f, 0.f); m4[u] = vf4{0.f, 0.f, 0.f, 0.f}; v4[u] = vf4{1.f, 1.f, 1.f, 1.f}; continue; }
+#endif
+            p4[u] = *reinterpret_cast<const float4*>((rest ? ad.p2 : ad.p1) + o);
+            m4[u] = __builtin_nontemporal_load(reinterpret_cast<const vf4*>((rest ? ad.m2 : ad.m1) + o));
+            v4[u] = __builtin_nontemporal_load(reinterpret_cast<const vf4*>((rest ? ad.v2 : ad.v1) + o));
+          }
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+          if (off[u] == 0xffffffffu) continue;
+          const bool rest = off[u] >> 31;
+          const unsigned int o = off[u] & 0x7fffffffu;
+          int fx, fy, fz, qd;
+          quad_of(i0 + u * kBrickThreads, fx, fy, fz, qd);
+          const float4 gq = any ? *reinterpret_cast<const float4*>(&acc[fx * SX + fy * SY + fz * CS + 4 * qd]) : make_float4(0.f, 0.f, 0.f, 0.f);
+          float gg[4] = {gq.x, gq.y, gq.z, gq.w};
+          float pn[4] = {p4[u].x, p4[u].y, p4[u].z, p4[u].w};
+          if (!rest && g.mode == RF_DENSITY_ABS) {  // d|x|/dx of the raw density (the parameter before its update)
+            const float dv = pn[0] * g.rho;
+            gg[0] = (dv > 0.f) ? gg[0] : ((dv < 0.f) ? -gg[0] : 0.0f);
+          }
+          vf4 mn, vn;
+#ifdef RF_BRICK_PROFILE
+          if (a.stagger & 0x40000) {
+#pragma unroll
+            for (int c = 0; c < 4; ++c) { mn[c] = m4[u][c] + gg[c]; vn[c] = v4[u][c]; pn[c] += gg[c]; }
+          } else
+#endif
+#pragma unroll
+          for (int c = 0; c < 4; ++c) {
+            const float mm = m4[u][c] + (gg[c] - m4[u][c]) * (1.0f - ad.b1);
+            const float vv = v4[u][c] * ad.b2 + (gg[c] * gg[c]) * (1.0f - ad.b2);
+            pn[c] = pn[c] - ad.step * (mm / (sqrtf(vv) / ad.bc2_sqrt + ad.eps));
+            mn[c] = mm;
+            vn[c] = vv;
+          }
+#ifdef RF_BRICK_PROFILE
+          if (a.stagger & 0x20000) { if (pn[0] == 123.456f) *reinterpret_cast<float4*>((rest ? ad.p2 : ad.p1) + o) = make_float4(mn[0], vn[1], pn[2], pn[3]); continue; }
+#endif
+          *reinterpret_cast<float4*>((rest ? ad.p2 : ad.p1) + o) = make_float4(pn[0], pn[1], pn[2], pn[3]);
+          __builtin_nontemporal_store(mn, reinterpret_cast<vf4*>((rest ? ad.m2 : ad.m1) + o));
+          __builtin_nontemporal_store(vn, reinterpret_cast<vf4*>((rest ? ad.v2 : ad.v1) + o));
+        }
+      }
+      RF_PROF_MARK(4);  // flush (stores issued, not necessarily retired)
+      return;
+    }
+    for (int i = tid; i < nq; i += kBrickThreads) {
+      int fx, fy, fz, qd;
+      if (!quad_of(i, fx, fy, fz, qd)) continue;
+      const long long lin = node_lin(g, X0 + fx, Y0 + fy, Z0 + fz);
       float4 v = any ? *reinterpret_cast<const float4*>(&acc[fx * SX + fy * SY + fz * CS + 4 * qd]) : make_float4(0.f, 0.f, 0.f, 0.f);
       if (qd == 0 && g.mode == RF_DENSITY_ABS) {  // d|x|/dx of the raw density, applied once per node
         const float dv = g.dens[lin * g.dstride] * g.rho;
         v.x = (dv > 0.f) ? v.x : ((dv < 0.f) ? -v.x : 0.0f);
       }
       const long long off = (qd == 0) ? lin * g.dstride : lin * g.fstride + 4 * (qd - 1);
-      if constexpr (ADAM) {
-        // the optimizer step on the 4 parameters this thread holds the complete gradient of (adam_kernel's expressions):
-        // parameters with ordinary accesses (the next forward pass reads them), moments streamed non-temporally
-        const AdamArgs& ad = a.adam;
-        float4* pp = reinterpret_cast<float4*>((qd == 0 ? ad.p1 : ad.p2) + off);
-        vf4* mp = reinterpret_cast<vf4*>((qd == 0 ? ad.m1 : ad.m2) + off);
-        vf4* vp = reinterpret_cast<vf4*>((qd == 0 ? ad.v1 : ad.v2) + off);
-        const float4 p4 = *pp;
-        const vf4 m4 = __builtin_nontemporal_load(mp), v4 = __builtin_nontemporal_load(vp);
-        const float gg[4] = {v.x, v.y, v.z, v.w};
-        float pn[4] = {p4.x, p4.y, p4.z, p4.w};
-        vf4 mn, vn;
-#pragma unroll
-        for (int c = 0; c < 4; ++c) {
-          const float mm = m4[c] + (gg[c] - m4[c]) * (1.0f - ad.b1);
-          const float vv = v4[c] * ad.b2 + (gg[c] * gg[c]) * (1.0f - ad.b2);
-          pn[c] = pn[c] - ad.step * (mm / (sqrtf(vv) / ad.bc2_sqrt + ad.eps));
-          mn[c] = mm;
-          vn[c] = vv;
-        }
-        *pp = make_float4(pn[0], pn[1], pn[2], pn[3]);
-        __builtin_nontemporal_store(mn, mp);
-        __builtin_nontemporal_store(vn, vp);
-      } else if (qd == 0) {
+      if (qd == 0) {
         float4* dst = reinterpret_cast<float4*>(gdens + off);
         if (a.accumulate) {
           const float4 o = *dst;
@@ -2346,6 +2457,19 @@ unsigned grid_1d(long long n, int block, long long cap = 256LL * 16) {
 
 extern "C" {
 
+#ifdef RF_BRICK_PROFILE
+// development builds only: read (and optionally clear) the phase table of the brick pass; synchronises the device
+int rf_debug_brick_profile(unsigned long long* out_host, int reset) {
+  if (hipDeviceSynchronize() != hipSuccess) return RF_ERR_LAUNCH;
+  if (out_host && hipMemcpyFromSymbol(out_host, HIP_SYMBOL(g_brick_prof), sizeof(g_brick_prof)) != hipSuccess) return RF_ERR_LAUNCH;
+  if (reset) {
+    unsigned long long zero[8] = {};
+    if (hipMemcpyToSymbol(HIP_SYMBOL(g_brick_prof), zero, sizeof(zero)) != hipSuccess) return RF_ERR_LAUNCH;
+  }
+  return RF_OK;
+}
+#endif
+
 int rf_abi_version(void) { return RF_ABI_VERSION; }
 
 const char* rf_error_string(int code) {
@@ -2705,6 +2829,12 @@ static int brick_accumulate_impl(const RFGrid* grid, int32_t brick_size, const R
     if (C > 4 && (!adam->param_second_dev || !adam->exp_avg_second_dev || !adam->exp_avg_sq_second_dev)) return RF_ERR_NULL_POINTER;
     if (adam->param_first_dev != grid->densities_dev || (C > 4 && adam->param_second_dev != grid->features_dev)) return RF_ERR_BAD_SHAPE;
     if (adam->step < 1) return RF_ERR_BAD_SHAPE;
+    {  // the flush keeps element offsets in 31 bits
+      unsigned long long nodes = 1;
+      for (int ax = 0; ax < 3; ++ax) nodes *= (unsigned long long)((grid->dims[ax] + 7) / 8 * 8);
+      const unsigned long long smax = (unsigned long long)(grid->density_stride > grid->feature_stride ? grid->density_stride : grid->feature_stride);
+      if (nodes * smax >= (1ull << 31)) return RF_ERR_UNSUPPORTED;
+    }
     const uintptr_t align = (uintptr_t)adam->param_first_dev | (uintptr_t)adam->exp_avg_first_dev | (uintptr_t)adam->exp_avg_sq_first_dev |
                             (C > 4 ? ((uintptr_t)adam->param_second_dev | (uintptr_t)adam->exp_avg_second_dev | (uintptr_t)adam->exp_avg_sq_second_dev) : 0);
     if (align & 15u) return RF_ERR_BAD_SHAPE;
@@ -2721,6 +2851,10 @@ static int brick_accumulate_impl(const RFGrid* grid, int32_t brick_size, const R
     a.adam.b2 = adam->beta2;
     a.adam.eps = adam->eps;
     a.adam.bc2_sqrt = (float)sqrt(bc2);
+    {
+      const char* e = getenv("RF_BRICK_STAGGER");
+      a.stagger = e ? atoi(e) : 0;
+    }
     switch (K) {
       case 1:
         return launch_brick<1, true>(g, a, nbricks, nullptr, nullptr, st);

@@ -18,6 +18,7 @@ What is done the MI355X way instead of translated:
     reduce-scatter, Adam on 1/N of the grid per rank, all-gather of the parameters (distributed.py).
 """
 import dataclasses
+import os
 import time
 from pathlib import Path
 from typing import Callable, Dict, Iterator, List, Optional
@@ -171,7 +172,7 @@ class TrainStepper:
         # contiguous slice of it, so that N ranks reproduce the single-GPU iteration up to float summation order.
         # Default (False) = weak scaling: every rank draws its own ``ray_batch_size`` rays.
         self.global_batch = bool(global_batch)
-        self.brick_size = 8
+        self.brick_size = int(os.environ.get("RF_BRICK_SIZE", "8"))  # (experiments: 4)
         self._bins = None
         grid = vol_mod.thre3d_repr
         if not isinstance(grid, VoxelGrid):
