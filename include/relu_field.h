@@ -68,7 +68,10 @@ enum {
   RF_FLAG_WHITE_BKGD = 1,     /* white_bkgd                                                        */
   RF_FLAG_RENDER_DIFFUSE = 2, /* render_diffuse: only the degree-0 SH coefficient of each colour   */
   RF_FLAG_AABB_SAMPLING = 4,  /* optimized_sampling: per-ray [t_enter, t_exit] from the slab test  */
-  RF_FLAG_OCCUPANCY_SKIP = 8  /* use RFGrid.occupancy_dev to skip provably-empty cells (exact)     */
+  RF_FLAG_OCCUPANCY_SKIP = 8, /* use RFGrid.occupancy_dev to skip provably-empty cells (exact)     */
+  RF_FLAG_JITTER_KEYED = 16   /* perturb_sampled_points without a [N,S] tensor: when RFRayBatch.t_rand_dev is NULL the jitter
+                                 of (ray, sample) is a counter-based hash of (jitter_key, first_ray + ray, sample) -- the law of
+                                 torch.rand (uniform on [0,1), independent), evaluated where it is used                    */
 };
 
 /* The dense SH + density voxel grid: VoxelGrid (thre3d_reprs/voxels.py:46-331). */
@@ -90,17 +93,31 @@ typedef struct RFGrid {
                                     (X+1)*(Y+1)*(Z+1) bits, see rf_build_occupancy; may be NULL      */
 } RFGrid;
 
+/* A posed pinhole camera (CameraIntrinsics + CameraPose, utils/imaging_utils.py:17-30) for rays generated in-kernel:
+ * cast_rays (rendering/volumetric/utils/misc.py:12-50) fused into the render.  HOST struct. */
+typedef struct RFCamera {
+  int32_t height, width;
+  float focal;
+  float pose[12]; /* [3,4] row-major = rotation | translation, camera-to-world */
+} RFCamera;
+
 /* Flat rays + sampling parameters: Rays (rendering/volumetric/render_interface.py:13-44),
  * sample_uniform_points_on_rays (rendering/volumetric/sample.py:15-68). */
 typedef struct RFRayBatch {
-  const float* origins_dev;    /* [N, 3]                                                               */
+  const float* origins_dev;    /* [N, 3]   (may be NULL when `camera` is given)                        */
   const float* directions_dev; /* [N, 3], not normalised                                               */
   int64_t num_rays;            /* N                                                                    */
   int32_t num_samples;         /* S >= 1                                                               */
   float near;                  /* CameraBounds.near / far (float32)                                    */
   float far;
   const float* t_vals_dev;     /* [S] = linspace(0, 1, S) (sample.py:46)                               */
-  const float* t_rand_dev;     /* [N, S] jitter in [0,1) (sample.py:63) or NULL = perturb off          */
+  const float* t_rand_dev;     /* [N, S] jitter in [0,1) (sample.py:63) or NULL = perturb off / keyed  */
+  uint64_t jitter_key;         /* RF_FLAG_JITTER_KEYED: key of the counter-based jitter                */
+  int64_t first_ray;           /* global index of ray 0 of this batch: position in the keyed jitter stream, and the
+                                  pixel (row-major) of ray 0 when `camera` generates the rays -- chunks of one frame
+                                  rendered with first_ray = chunk offset give the frame's rays bit for bit      */
+  const RFCamera* camera;      /* optional HOST pointer: rays r = pixel-centre rays of pixels first_ray + r of this
+                                  camera (utils/misc.py:12-50); origins_dev / directions_dev are then ignored   */
 } RFRayBatch;
 
 /* Per-ray outputs: RenderOut (render_interface.py:47-83) + extra {"disparity", "accumulated_weight"}. */
@@ -295,6 +312,55 @@ int rf_l1_loss_grad(const float* colour_dev, const float* target_dev, int64_t nu
  * zero_grad != 0 also clears grad_dev after reading it (optimizer.zero_grad() of the next iteration). */
 int rf_adam_step(float* param_dev, float* grad_dev, float* exp_avg_dev, float* exp_avg_sq_dev, int64_t numel,
                  float lr, float beta1, float beta2, float eps, int32_t step, int32_t zero_grad, void* stream);
+
+/* ---- the training iteration as ONE call -------------------------------------------------------------------------------
+ * modules/trainers.py:278-341 (ray/pixel subset -> specular render -> L1 -> diffuse render -> L1 -> backward of both ->
+ * Adam) enqueued by a single host call: select -> forward (counts records) + loss gradient, twice -> offsets + emit, twice
+ * -> ONE brick pass over both record lists [-> Adam inside its flush].  Nine launches, no host round trip between them; the
+ * caller (a Python trainer, or any host language) pays one FFI crossing per iteration instead of ~20.  Every buffer is
+ * caller-owned scratch that can be reused from step to step. */
+typedef struct RFRaySelection { /* arguments of rf_select_rays_and_pixels */
+  int32_t height, width;
+  float focal;
+  const float* poses_dev;
+  const int64_t* image_ids_dev;
+  int32_t num_batch_images;
+  const float* pixel_table_dev;
+  uint64_t key;
+  int64_t first_index;
+} RFRaySelection;
+
+typedef struct RFPassScratch { /* one per render of the iteration: [0] specular, [1] render_diffuse */
+  RFRenderOut out;           /* all seven per-ray / per-sample buffers, key_hist_dev [8 * nbricks] (zero on entry; left
+                                zero) and brick_size                                                              */
+  float* grad_colour_dev;    /* [N, 3]                                                                           */
+  int32_t* cursor_dev;       /* [8 * nbricks]                                                                    */
+  int64_t* offsets_dev;      /* [8 * nbricks + 1]                                                                */
+  float* records_sorted_dev; /* [N * S, rf_expanded_record_floats(F)] ([1]: rf_expanded_record_floats(3))        */
+  const float* t_rand_dev;   /* [N, S] jitter of this render, or NULL (off, or keyed with RF_FLAG_JITTER_KEYED)  */
+  uint64_t jitter_key;
+} RFPassScratch;
+
+typedef struct RFTrainStep {
+  const RFRaySelection* select; /* non-NULL: the batch is drawn by the fused selection INTO origins / directions / pixels;
+                                   NULL: they are inputs                                                          */
+  float* origins_dev;           /* [N, 3] */
+  float* directions_dev;        /* [N, 3] */
+  float* pixels_dev;            /* [N, 3] target colours */
+  int64_t num_rays;
+  int32_t num_samples;
+  float near, far;
+  const float* t_vals_dev;      /* [S] */
+  uint32_t flags;               /* RF_FLAG_* of both renders (RF_FLAG_RENDER_DIFFUSE is added to the second one here) */
+  RFPassScratch pass[2];
+  float* loss_sums_dev;         /* [4], overwritten: (sum |d|, sum d^2) of the specular render, then of the diffuse render */
+  const RFAdamState* adam;      /* optimizer fused into the brick flush, or NULL: the gradient of L1 + L1 is WRITTEN (not
+                                   added) to grad_first_dev / grad_second_dev (layout of `grid`)                  */
+  float* grad_first_dev;
+  float* grad_second_dev;
+} RFTrainStep;
+
+int rf_train_step(const RFGrid* grid, const RFTrainStep* step, void* stream);
 
 #ifdef __cplusplus
 }

@@ -447,3 +447,30 @@ def keyed_permutation(index: np.ndarray, domain: int, key: int) -> np.ndarray:
         x[todo] = xs
         todo[todo] = xs >= np.uint64(domain)
     return x.astype(np.int64)
+
+
+def keyed_jitter(key: int, first_ray: int, num_rays: int, num_samples: int) -> np.ndarray:
+    """numpy restatement of the kernels' counter-based jitter (RF_FLAG_JITTER_KEYED; jitter_ray_seed / jitter_uniform in
+    csrc/relu_field_kernels.hip): [num_rays, num_samples] float32 in [0, 1) on the 2^-24 lattice -- the table a caller would
+    pass as ``t_rand`` to get the same render.  Not reference behaviour: the reference draws torch.rand(N, S) (sample.py:63);
+    this is the checker of the build's replacement for that draw."""
+    M32 = np.uint64(0xFFFFFFFF)
+
+    def mix32(x):
+        x = x & M32
+        x ^= x >> np.uint64(16)
+        x = (x * np.uint64(0x7FEB352D)) & M32
+        x ^= x >> np.uint64(15)
+        x = (x * np.uint64(0x846CA68B)) & M32
+        x ^= x >> np.uint64(16)
+        return x
+
+    key = int(key) & 0xFFFFFFFFFFFFFFFF
+    klo, khi = np.uint64(key & 0xFFFFFFFF), np.uint64(key >> 32)
+    gray = np.arange(num_rays, dtype=np.uint64) + np.uint64(first_ray)
+    a = mix32((gray & M32) ^ klo)
+    b = mix32(((gray >> np.uint64(32)) + khi) & M32)
+    seed = a ^ ((b * np.uint64(0x9E3779B9) + np.uint64(0x85EBCA6B)) & M32)
+    s = np.arange(num_samples, dtype=np.uint64)
+    h = mix32((seed[:, None] + ((s * np.uint64(0x9E3779B9)) & M32)[None, :]) & M32)
+    return ((h >> np.uint64(8)).astype(np.float32) * np.float32(2.0**-24)).astype(np.float32)

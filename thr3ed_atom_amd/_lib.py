@@ -24,6 +24,7 @@ FLAG_WHITE_BKGD = 1
 FLAG_RENDER_DIFFUSE = 2
 FLAG_AABB_SAMPLING = 4
 FLAG_OCCUPANCY_SKIP = 8
+FLAG_JITTER_KEYED = 16
 
 EXPORTED_SYMBOLS = [
     "rf_abi_version",
@@ -47,6 +48,7 @@ EXPORTED_SYMBOLS = [
     "rf_build_occupancy",
     "rf_l1_loss_grad",
     "rf_adam_step",
+    "rf_train_step",
 ]
 
 
@@ -69,6 +71,10 @@ class RFGrid(C.Structure):
     ]
 
 
+class RFCamera(C.Structure):
+    _fields_ = [("height", C.c_int32), ("width", C.c_int32), ("focal", C.c_float), ("pose", C.c_float * 12)]
+
+
 class RFRayBatch(C.Structure):
     _fields_ = [
         ("origins_dev", C.c_void_p),
@@ -79,6 +85,9 @@ class RFRayBatch(C.Structure):
         ("far", C.c_float),
         ("t_vals_dev", C.c_void_p),
         ("t_rand_dev", C.c_void_p),
+        ("jitter_key", C.c_uint64),
+        ("first_ray", C.c_int64),
+        ("camera", C.POINTER(RFCamera)),
     ]
 
 
@@ -125,6 +134,52 @@ class RFAdamState(C.Structure):
         ("beta2", C.c_float),
         ("eps", C.c_float),
         ("step", C.c_int32),
+    ]
+
+
+class RFRaySelection(C.Structure):
+    _fields_ = [
+        ("height", C.c_int32),
+        ("width", C.c_int32),
+        ("focal", C.c_float),
+        ("poses_dev", C.c_void_p),
+        ("image_ids_dev", C.c_void_p),
+        ("num_batch_images", C.c_int32),
+        ("pixel_table_dev", C.c_void_p),
+        ("key", C.c_uint64),
+        ("first_index", C.c_int64),
+    ]
+
+
+class RFPassScratch(C.Structure):
+    _fields_ = [
+        ("out", RFRenderOut),
+        ("grad_colour_dev", C.c_void_p),
+        ("cursor_dev", C.c_void_p),
+        ("offsets_dev", C.c_void_p),
+        ("records_sorted_dev", C.c_void_p),
+        ("t_rand_dev", C.c_void_p),
+        ("jitter_key", C.c_uint64),
+    ]
+
+
+class RFTrainStep(C.Structure):
+    _fields_ = [
+        ("select", C.POINTER(RFRaySelection)),
+        ("origins_dev", C.c_void_p),
+        ("directions_dev", C.c_void_p),
+        ("pixels_dev", C.c_void_p),
+        ("num_rays", C.c_int64),
+        ("num_samples", C.c_int32),
+        ("near", C.c_float),
+        ("far", C.c_float),
+        ("t_vals_dev", C.c_void_p),
+        ("flags", C.c_uint32),
+        ("pass_", RFPassScratch * 2),
+        ("loss_sums_dev", C.c_void_p),
+        ("adam", C.POINTER(RFAdamState)),
+        ("grad_first_dev", C.c_void_p),
+        ("grad_second_dev", C.c_void_p),
     ]
 
 
@@ -191,6 +246,7 @@ def load() -> C.CDLL:
     lib.rf_scatter_records.argtypes = [C.POINTER(RFGrid), vp, vp, i64, vp, vp, i32, vp, vp, i32, vp]
     lib.rf_brick_accumulate.argtypes = [C.POINTER(RFGrid), i32, C.POINTER(RFBrickList), i32, vp, vp, i32, vp]
     lib.rf_brick_accumulate_adam.argtypes = [C.POINTER(RFGrid), i32, C.POINTER(RFBrickList), i32, C.POINTER(RFAdamState), vp]
+    lib.rf_train_step.argtypes = [C.POINTER(RFGrid), C.POINTER(RFTrainStep), vp]
     lib.rf_grid_query.argtypes = [C.POINTER(RFGrid), vp, i64, vp, vp]
     lib.rf_grid_query_backward.argtypes = [C.POINTER(RFGrid), vp, i64, vp, vp, vp, vp]
     lib.rf_build_occupancy.argtypes = [C.POINTER(RFGrid), f32, vp, vp]

@@ -87,6 +87,15 @@ struct RayArgs {
   float near, far;
   const float* tvals;
   const float* trand;
+  // keyed jitter (RF_FLAG_JITTER_KEYED, trand == NULL): u(ray, sample) = hash of (key, ray0 + ray, sample) -- no [N,S] tensor
+  unsigned long long jkey;
+  long long ray0;  // global index of ray 0 of this batch (jitter stream; pixel index when the camera generates the rays)
+  int jitter;
+  // rays generated in-kernel from a pinhole camera (origins == NULL): ray r = pixel ray0 + r, row-major
+  int cam;
+  int H, W;
+  float focal;
+  float pose[12];  // [3,4] = rotation | translation (camera-to-world)
 };
 
 struct OutArgs {
@@ -197,14 +206,14 @@ __device__ __forceinline__ float sigmoidf_(float x) { return __builtin_amdgcn_rc
 // ---------------------------------------------------------------------------------------------
 __device__ __forceinline__ float z_uniform(float near, float far, float t) { return near * (1.0f - t) + far * t; }
 
-__device__ __forceinline__ float z_sample(const float* __restrict__ tv, const float* __restrict__ tr, int s, int S,
-                                          float near, float far) {
+// jitter u in [0, 1) of sample s, or no jitter at all (have_u = false)
+__device__ __forceinline__ float z_sample(const float* __restrict__ tv, bool have_u, float u, int s, int S, float near, float far) {
   const float zc = z_uniform(near, far, tv[s]);
-  if (tr == nullptr) return zc;
+  if (!have_u) return zc;
   // stratified jitter: lower/upper = neighbouring mid-points (sample.py:57-64)
   const float lo = (s > 0) ? 0.5f * (zc + z_uniform(near, far, tv[s - 1])) : zc;
   const float hi = (s < S - 1) ? 0.5f * (z_uniform(near, far, tv[s + 1]) + zc) : zc;
-  return lo + (hi - lo) * tr[s];
+  return lo + (hi - lo) * u;
 }
 
 // slab test of sample.py:71-184; returns true when the ray hits, writes the (clamped) bounds either way
@@ -349,6 +358,37 @@ __device__ __forceinline__ void sh_basis(float x, float y, float z, float Y[16])
   }
 }
 
+__device__ __forceinline__ uint32_t mix32(uint32_t x) {
+  x ^= x >> 16;
+  x *= 0x7feb352dU;
+  x ^= x >> 15;
+  x *= 0x846ca68bU;
+  x ^= x >> 16;
+  return x;
+}
+
+// Keyed jitter of the stratified sampler (sample.py:57-64 draws torch.rand(N, S)): a counter-based generator instead of a
+// [N, S] tensor.  u = 24 random bits of mix32 over (per-ray seed, sample index); the per-ray seed hashes the 64-bit key with
+// the global ray index.  Restated in oracle/relu_field_oracle.py:keyed_jitter (tests compare the two bit for bit).
+__device__ __forceinline__ uint32_t jitter_ray_seed(unsigned long long key, long long gray) {
+  const uint32_t a = mix32((uint32_t)gray ^ (uint32_t)key);
+  const uint32_t b = mix32((uint32_t)((unsigned long long)gray >> 32) + (uint32_t)(key >> 32));
+  return a ^ (b * 0x9E3779B9u + 0x85EBCA6Bu);
+}
+__device__ __forceinline__ float jitter_uniform(uint32_t ray_seed, int s) {
+  const uint32_t h = mix32(ray_seed + (uint32_t)s * 0x9E3779B9u);
+  return (float)(h >> 8) * 5.9604644775390625e-08f;  // [0, 1) on the 2^-24 lattice
+}
+
+__device__ __forceinline__ void pixel_ray(int i, int j, int H, int W, float focal, const float* R, float d[3]) {
+  // pixel centres; camera looks along -z, y up
+  const float cx = (((float)j + 0.5f) - (float)W * 0.5f) / focal;
+  const float cy = -((((float)i + 0.5f) - (float)H * 0.5f) / focal);
+  const float cz = -1.0f;
+#pragma unroll
+  for (int a = 0; a < 3; ++a) d[a] = (R[a * 3 + 0] * cx + R[a * 3 + 1] * cy) + R[a * 3 + 2] * cz;
+}
+
 // ---------------------------------------------------------------------------------------------
 // per-ray state shared by forward and backward
 // ---------------------------------------------------------------------------------------------
@@ -356,15 +396,27 @@ struct RayState {
   float o[3], d[3];
   float dnorm;
   float near, far;
+  uint32_t jseed;  // keyed jitter: per-ray seed
 };
 
 __device__ __forceinline__ RayState load_ray(const RayArgs& r, const GridArgs& g, long long ray, uint32_t flags) {
   RayState st;
+  if (r.cam) {  // cast_rays (utils/misc.py:12-50) fused: pixel p = ray0 + ray, row-major
+    const long long pidx = r.ray0 + ray;
+    const int i = (int)(pidx / r.W), j = (int)(pidx - (long long)i * r.W);
+    const float R[9] = {r.pose[0], r.pose[1], r.pose[2], r.pose[4], r.pose[5], r.pose[6], r.pose[8], r.pose[9], r.pose[10]};
+    pixel_ray(i, j, r.H, r.W, r.focal, R, st.d);
+    st.o[0] = r.pose[3];
+    st.o[1] = r.pose[7];
+    st.o[2] = r.pose[11];
+  } else {
 #pragma unroll
-  for (int a = 0; a < 3; ++a) {
-    st.o[a] = r.origins[ray * 3 + a];
-    st.d[a] = r.directions[ray * 3 + a];
+    for (int a = 0; a < 3; ++a) {
+      st.o[a] = r.origins[ray * 3 + a];
+      st.d[a] = r.directions[ray * 3 + a];
+    }
   }
+  st.jseed = r.jitter ? jitter_ray_seed(r.jkey, r.ray0 + ray) : 0u;
   st.dnorm = sqrtf((st.d[0] * st.d[0] + st.d[1] * st.d[1]) + st.d[2] * st.d[2]);
   st.near = r.near;
   st.far = r.far;
@@ -402,8 +454,12 @@ __device__ __forceinline__ Sample sample_at(const RayState& st, const RayArgs& r
 
 __device__ __forceinline__ float z_of(const RayState& st, const RayArgs& r, long long ray, int s) {
   const int sc = min(s, r.S - 1);
-  const float* tr = r.trand ? r.trand + ray * (long long)r.S : nullptr;
-  return z_sample(r.tvals, tr, sc, r.S, st.near, st.far);
+  float u = 0.0f;
+  if (r.trand)
+    u = r.trand[ray * (long long)r.S + sc];
+  else if (r.jitter)
+    u = jitter_uniform(st.jseed, sc);
+  return z_sample(r.tvals, r.trand != nullptr || r.jitter, u, sc, r.S, st.near, st.far);
 }
 
 __device__ __forceinline__ Sample make_sample(const RayState& st, const RayArgs& r, const GridArgs& g, long long ray,
@@ -2059,14 +2115,6 @@ struct Pose {
   float t[3];
 };
 
-__device__ __forceinline__ void pixel_ray(int i, int j, int H, int W, float focal, const float* R, float d[3]) {
-  // pixel centres; camera looks along -z, y up
-  const float cx = (((float)j + 0.5f) - (float)W * 0.5f) / focal;
-  const float cy = -((((float)i + 0.5f) - (float)H * 0.5f) / focal);
-  const float cz = -1.0f;
-#pragma unroll
-  for (int a = 0; a < 3; ++a) d[a] = (R[a * 3 + 0] * cx + R[a * 3 + 1] * cy) + R[a * 3 + 2] * cz;
-}
 
 __global__ void cast_rays_kernel(int H, int W, float focal, Pose pose, float* origins, float* dirs) {
   const long long n = (long long)H * W;
@@ -2109,14 +2157,6 @@ __global__ void cast_selected_rays_kernel(int H, int W, float focal, const float
 // The first R values of a random permutation = R distinct uniformly random pixels: the same sampling law as
 // torch.randperm(P)[:R] (utils/misc.py:117-129) without sorting P keys.
 // ---------------------------------------------------------------------------------------------
-__device__ __forceinline__ uint32_t mix32(uint32_t x) {
-  x ^= x >> 16;
-  x *= 0x7feb352dU;
-  x ^= x >> 15;
-  x *= 0x846ca68bU;
-  x ^= x >> 16;
-  return x;
-}
 
 __device__ __forceinline__ unsigned long long keyed_permutation(unsigned long long i, unsigned long long P, int bits,
                                                                 unsigned long long key) {
@@ -2392,11 +2432,17 @@ GridArgs to_args(const RFGrid* g) {
 int check_rays(const RFRayBatch* r) {
   if (!r) return RF_ERR_NULL_POINTER;
   if (r->num_rays < 0 || r->num_samples < 1) return RF_ERR_BAD_SHAPE;
-  if (r->num_rays > 0 && (!r->origins_dev || !r->directions_dev || !r->t_vals_dev)) return RF_ERR_NULL_POINTER;
+  if (r->num_rays > 0 && !r->t_vals_dev) return RF_ERR_NULL_POINTER;
+  if (r->num_rays > 0 && !r->camera && (!r->origins_dev || !r->directions_dev)) return RF_ERR_NULL_POINTER;
+  if (r->camera) {
+    if (r->camera->height < 1 || r->camera->width < 1 || r->first_ray < 0) return RF_ERR_BAD_SHAPE;
+    if (r->first_ray + r->num_rays > (int64_t)r->camera->height * r->camera->width) return RF_ERR_BAD_SHAPE;
+  }
   return RF_OK;
 }
 
-RayArgs to_args(const RFRayBatch* r) {
+RayArgs to_args(const RFRayBatch* r, uint32_t flags = 0);
+RayArgs to_args(const RFRayBatch* r, uint32_t flags) {
   RayArgs a;
   a.origins = r->origins_dev;
   a.directions = r->directions_dev;
@@ -2406,6 +2452,19 @@ RayArgs to_args(const RFRayBatch* r) {
   a.far = r->far;
   a.tvals = r->t_vals_dev;
   a.trand = r->t_rand_dev;
+  a.jkey = r->jitter_key;
+  a.ray0 = r->first_ray;
+  a.jitter = (flags & RF_FLAG_JITTER_KEYED) && !r->t_rand_dev;
+  a.cam = r->camera != nullptr;
+  a.H = a.W = 1;
+  a.focal = 1.0f;
+  for (int i = 0; i < 12; ++i) a.pose[i] = 0.0f;
+  if (r->camera) {
+    a.H = r->camera->height;
+    a.W = r->camera->width;
+    a.focal = r->camera->focal;
+    for (int i = 0; i < 12; ++i) a.pose[i] = r->camera->pose[i];
+  }
   return a;
 }
 
@@ -2576,7 +2635,7 @@ int rf_render_forward(const RFGrid* grid, const RFRayBatch* rays, uint32_t flags
   if ((flags & RF_FLAG_OCCUPANCY_SKIP) && !grid->occupancy_dev) return RF_ERR_NULL_POINTER;
 
   const GridArgs g = to_args(grid);
-  const RayArgs r = to_args(rays);
+  const RayArgs r = to_args(rays, flags);
   OutArgs o = to_args(out);
   if (out->key_hist_dev) {  // count the records of the binned backward per (brick, flags) key
     if (!save) return RF_ERR_NULL_POINTER;
@@ -2613,7 +2672,7 @@ static int backward_impl(const RFGrid* grid, const RFRayBatch* rays, uint32_t fl
   if (rays->num_rays == 0) return RF_OK;
   if (!fwd->sample_cache_dev || !fwd->trans_cache_dev || !fwd->stop_cache_dev) return RF_ERR_NULL_POINTER;
   const GridArgs g = to_args(grid);
-  const RayArgs r = to_args(rays);
+  const RayArgs r = to_args(rays, flags);
   const OutArgs o = to_args(fwd);
   gr.gcolour = grads->grad_colour_dev;
   gr.gdepth = grads->grad_depth_dev;
@@ -2955,6 +3014,66 @@ int rf_adam_step(float* param_dev, float* grad_dev, float* exp_avg_dev, float* e
   }
 #undef RF_ADAM
   return launch_status();
+}
+
+int rf_train_step(const RFGrid* grid, const RFTrainStep* step, void* stream) {
+  if (!grid || !step) return RF_ERR_NULL_POINTER;
+  if (step->num_rays == 0) return RF_OK;
+  if (!step->origins_dev || !step->directions_dev || !step->pixels_dev || !step->loss_sums_dev) return RF_ERR_NULL_POINTER;
+  if (step->num_rays < 0) return RF_ERR_BAD_SHAPE;
+  for (int i = 0; i < 2; ++i) {
+    const RFPassScratch& ps = step->pass[i];
+    if (!ps.grad_colour_dev || !ps.cursor_dev || !ps.offsets_dev || !ps.records_sorted_dev || !ps.out.key_hist_dev) return RF_ERR_NULL_POINTER;
+  }
+  int shift, nb[3];
+  int rc = check_grid(grid);
+  if (rc != RF_OK) return rc;
+  rc = brick_geometry(grid, step->pass[0].out.brick_size, &shift, nb, false);
+  if (rc != RF_OK) return rc;
+  if (step->pass[1].out.brick_size != step->pass[0].out.brick_size) return RF_ERR_BAD_SHAPE;
+  const int nkeys = nb[0] * nb[1] * nb[2] * 8;
+  hipStream_t st = (hipStream_t)stream;
+  if (step->select) {
+    const RFRaySelection* s = step->select;
+    rc = rf_select_rays_and_pixels(s->height, s->width, s->focal, s->poses_dev, s->image_ids_dev, s->num_batch_images, s->pixel_table_dev,
+                                   s->key, s->first_index, step->num_rays, step->origins_dev, step->directions_dev, step->pixels_dev, nullptr, stream);
+    if (rc != RF_OK) return rc;
+  }
+  if (hipMemsetAsync(step->loss_sums_dev, 0, 4 * sizeof(float), st) != hipSuccess) return RF_ERR_LAUNCH;
+  RFRayBatch rays[2];
+  uint32_t flags[2];
+  RFRenderGrads grads[2];
+  for (int i = 0; i < 2; ++i) {
+    const RFPassScratch& ps = step->pass[i];
+    rays[i] = RFRayBatch{};
+    rays[i].origins_dev = step->origins_dev;
+    rays[i].directions_dev = step->directions_dev;
+    rays[i].num_rays = step->num_rays;
+    rays[i].num_samples = step->num_samples;
+    rays[i].near = step->near;
+    rays[i].far = step->far;
+    rays[i].t_vals_dev = step->t_vals_dev;
+    rays[i].t_rand_dev = ps.t_rand_dev;
+    rays[i].jitter_key = ps.jitter_key;
+    flags[i] = (step->flags & ~(uint32_t)RF_FLAG_RENDER_DIFFUSE) | (i == 1 ? (uint32_t)RF_FLAG_RENDER_DIFFUSE : 0u);
+    rc = rf_render_forward(grid, &rays[i], flags[i], &ps.out, stream);
+    if (rc != RF_OK) return rc;
+    rc = rf_l1_loss_grad(ps.out.colour_dev, step->pixels_dev, step->num_rays, 1.0f, ps.grad_colour_dev, step->loss_sums_dev + 2 * i, stream);
+    if (rc != RF_OK) return rc;
+    grads[i] = RFRenderGrads{ps.grad_colour_dev, nullptr, nullptr};
+  }
+  RFBrickList lists[2];
+  for (int i = 0; i < 2; ++i) {
+    const RFPassScratch& ps = step->pass[i];
+    rc = rf_bin_offsets(ps.out.key_hist_dev, nkeys, ps.offsets_dev, ps.cursor_dev, stream);
+    if (rc != RF_OK) return rc;
+    rc = rf_render_backward_emit_direct(grid, &rays[i], flags[i], &ps.out, &grads[i], ps.out.brick_size, ps.cursor_dev, ps.records_sorted_dev,
+                                        ps.out.key_hist_dev, stream);
+    if (rc != RF_OK) return rc;
+    lists[i] = RFBrickList{ps.records_sorted_dev, ps.offsets_dev, i};
+  }
+  if (step->adam) return rf_brick_accumulate_adam(grid, step->pass[0].out.brick_size, lists, 2, step->adam, stream);
+  return rf_brick_accumulate(grid, step->pass[0].out.brick_size, lists, 2, step->grad_first_dev, step->grad_second_dev, 0, stream);
 }
 
 }  // extern "C"

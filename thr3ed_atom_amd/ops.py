@@ -9,7 +9,7 @@ the boundary as raw device pointers; PyTorch is only the allocator and the strea
 Nothing here computes on the CPU and nothing falls back: CPU tensors or a missing library raise.
 """
 import ctypes as C
-from typing import Dict, Optional, Tuple
+from typing import Dict, NamedTuple, Optional, Tuple
 
 import numpy as np
 import torch
@@ -107,7 +107,25 @@ def _ptr(t: Optional[Tensor]):
     return None if t is None else t.data_ptr()
 
 
-def _ray_batch(origins: Tensor, directions: Tensor, num_samples: int, near: float, far: float, t_rand: Optional[Tensor]):
+class KeyedJitter(NamedTuple):
+    """Stands in for a ``t_rand`` tensor: the jitter of (ray r, sample s) is a counter-based hash of
+    (key, first_ray + r, s) evaluated inside the kernels (RF_FLAG_JITTER_KEYED) -- no [N, S] tensor exists."""
+
+    key: int
+    first_ray: int = 0
+
+
+def draw_jitter_key() -> int:
+    """A 64-bit key from torch's CPU generator (so torch.manual_seed makes jittered renders reproducible)."""
+    return int(torch.randint(-(2**63), 2**63 - 1, (1,), dtype=torch.int64).item()) & 0xFFFFFFFFFFFFFFFF
+
+
+def _jitter_flags(flags: int, t_rand) -> int:
+    return int(flags) | (_lib.FLAG_JITTER_KEYED if isinstance(t_rand, KeyedJitter) else 0)
+
+
+def _ray_batch(origins: Tensor, directions: Tensor, num_samples: int, near: float, far: float, t_rand):
+    """``t_rand``: None (no jitter), a [N, S] tensor, or a KeyedJitter."""
     rb = _lib.RFRayBatch()
     rb.origins_dev = origins.data_ptr()
     rb.directions_dev = directions.data_ptr()
@@ -117,7 +135,11 @@ def _ray_batch(origins: Tensor, directions: Tensor, num_samples: int, near: floa
     rb.far = far
     tv = t_vals_for(num_samples, origins.device)
     rb.t_vals_dev = tv.data_ptr()
-    rb.t_rand_dev = _ptr(t_rand)
+    if isinstance(t_rand, KeyedJitter):
+        rb.t_rand_dev = None
+        rb.jitter_key, rb.first_ray = int(t_rand.key) & 0xFFFFFFFFFFFFFFFF, int(t_rand.first_ray)
+    else:
+        rb.t_rand_dev = _ptr(t_rand)
     return rb, tv
 
 
@@ -150,7 +172,7 @@ def render_forward_raw(grid: VoxelGrid, origins: Tensor, directions: Tensor, t_r
         if key_hist is not None:
             out.key_hist_dev, out.brick_size = key_hist.data_ptr(), int(brick_size)
     with _span(f"render_forward[{_variant(grid, flags)}{',save' if save else ''}]", dev):
-        rc = lib.rf_render_forward(C.byref(rf_grid), C.byref(rb), int(flags), C.byref(out), _stream(dev))
+        rc = lib.rf_render_forward(C.byref(rf_grid), C.byref(rb), _jitter_flags(flags, t_rand), C.byref(out), _stream(dev))
     _lib.check(rc, "rf_render_forward")
     return colour, depth, acc, disparity, caches
 
@@ -171,7 +193,7 @@ def render_backward_raw(grid: VoxelGrid, origins: Tensor, directions: Tensor, t_
     fwd.sample_cache_dev, fwd.trans_cache_dev, fwd.stop_cache_dev = cache.data_ptr(), tcache.data_ptr(), stop.data_ptr()
     with _span(f"render_backward[{_variant(grid, flags)}]", dev):
         rc = lib.rf_render_backward(
-            C.byref(rf_grid), C.byref(rb), int(flags), C.byref(fwd), C.byref(grads), grad_first.data_ptr(), _ptr(grad_second), _stream(dev)
+            C.byref(rf_grid), C.byref(rb), _jitter_flags(flags, t_rand), C.byref(fwd), C.byref(grads), grad_first.data_ptr(), _ptr(grad_second), _stream(dev)
         )
     _lib.check(rc, "rf_render_backward")
 
@@ -200,7 +222,7 @@ def render_backward_emit_raw(grid: VoxelGrid, origins: Tensor, directions: Tenso
     fwd.sample_cache_dev, fwd.trans_cache_dev, fwd.stop_cache_dev = cache.data_ptr(), tcache.data_ptr(), stop.data_ptr()
     with _span(f"render_backward_emit[{_variant(grid, flags)}]", dev):
         rc = lib.rf_render_backward_emit(
-            C.byref(rf_grid), C.byref(rb), int(flags), C.byref(fwd), C.byref(grads), int(brick_size), keys.data_ptr(), records.data_ptr(),
+            C.byref(rf_grid), C.byref(rb), _jitter_flags(flags, t_rand), C.byref(fwd), C.byref(grads), int(brick_size), keys.data_ptr(), records.data_ptr(),
             _ptr(ray_basis), _ptr(hist), _stream(dev),
         )
     _lib.check(rc, "rf_render_backward_emit")
@@ -223,7 +245,7 @@ def render_backward_emit_direct_raw(grid: VoxelGrid, origins: Tensor, directions
     fwd.sample_cache_dev, fwd.trans_cache_dev, fwd.stop_cache_dev = cache.data_ptr(), tcache.data_ptr(), stop.data_ptr()
     with _span(f"render_backward_emit_direct[{_variant(grid, flags)}]", dev):
         rc = lib.rf_render_backward_emit_direct(
-            C.byref(rf_grid), C.byref(rb), int(flags), C.byref(fwd), C.byref(grads), int(brick_size), cursor.data_ptr(),
+            C.byref(rf_grid), C.byref(rb), _jitter_flags(flags, t_rand), C.byref(fwd), C.byref(grads), int(brick_size), cursor.data_ptr(),
             records_sorted.data_ptr(), _ptr(hist_clear), _stream(dev),
         )
     _lib.check(rc, "rf_render_backward_emit_direct")
@@ -328,15 +350,18 @@ class _ReluFieldRender(torch.autograd.Function):
         origins = origins.detach().to(torch.float32).contiguous()
         directions = directions.detach().to(torch.float32).contiguous()
         n = origins.shape[0]
+        keyed = t_rand if isinstance(t_rand, KeyedJitter) else None
+        if keyed is not None:
+            t_rand = None
         if t_rand is not None:
             _require_hip(t_rand, "t_rand")
             t_rand = t_rand.detach().to(torch.float32).contiguous()
             if tuple(t_rand.shape) != (n, num_samples):
                 raise ValueError(f"t_rand must be [{n}, {num_samples}], got {tuple(t_rand.shape)}")
         colour, depth, acc, disparity, caches = render_forward_raw(
-            grid, origins, directions, t_rand, int(num_samples), float(near), float(far), int(flags), bool(need_grad)
+            grid, origins, directions, keyed if keyed is not None else t_rand, int(num_samples), float(near), float(far), int(flags), bool(need_grad)
         )
-        ctx.grid, ctx.flags = grid, int(flags)
+        ctx.grid, ctx.flags, ctx.keyed = grid, int(flags), keyed
         ctx.num_samples, ctx.near, ctx.far = int(num_samples), float(near), float(far)
         ctx.has_rand = t_rand is not None
         ctx.has_second = second is not None
@@ -358,7 +383,7 @@ class _ReluFieldRender(torch.autograd.Function):
         first = saved.pop(0)
         second = saved.pop(0) if ctx.has_second else None
         origins, directions, cache, tcache, stop = saved[:5]
-        t_rand = saved[5] if ctx.has_rand else None
+        t_rand = saved[5] if ctx.has_rand else ctx.keyed
         grid: VoxelGrid = ctx.grid
         cur_first, cur_second = grid.kernel_tensors()
         if cur_first.data_ptr() != first.data_ptr() or (second is not None and cur_second.data_ptr() != second.data_ptr()):
@@ -452,14 +477,15 @@ def relu_field_render(
     num_samples: int,
     near: float,
     far: float,
-    t_rand: Optional[Tensor] = None,
+    t_rand=None,
     white_bkgd: bool = False,
     render_diffuse: bool = False,
     optimized_sampling: bool = False,
     use_occupancy: bool = False,
 ) -> Tuple[Tensor, Tensor, Tensor, Tensor]:
     """colour [N,3], depth [N,1], accumulated weight [N,1], disparity [N,1] for flat rays [N,3].
-    Differentiable w.r.t. ``grid.densities`` and ``grid.features`` only (like every reference use)."""
+    Differentiable w.r.t. ``grid.densities`` and ``grid.features`` only (like every reference use).
+    ``t_rand``: None (no jitter), a [N, S] tensor of jitter values, or a ``KeyedJitter``."""
     if origins.dim() != 2 or origins.shape != directions.shape or origins.shape[-1] != 3:
         raise AssertionError("the render op works with FLAT rays [N, 3] only")
     if int(num_samples) < 1:

@@ -19,7 +19,7 @@ from torch.nn import Module
 
 from .camera import CameraBounds
 from .constants import EXTRA_ACCUMULATED_WEIGHTS, EXTRA_DISPARITY
-from .ops import relu_field_render
+from .ops import KeyedJitter, draw_jitter_key, relu_field_render
 from .render_interface import Rays, RenderOut
 from .voxels import VoxelGrid
 
@@ -53,6 +53,10 @@ class SHVoxGridRenderConfig:
     # the reference draws torch.randn for the density noise even when its std is 0 (accumulate.py:59-62),
     # which advances the RNG stream; set True to consume the same numbers and stay stream-compatible
     consume_reference_rng: bool = False
+    # where the jitter of perturb_sampled_points comes from when no t_rand is supplied: "keyed" = a counter-based generator
+    # evaluated inside the kernels (keyed from torch's CPU generator; no [N, S] tensor), "torch" = torch.rand(N, S) on the
+    # rays' device exactly like the reference's sample.py:63
+    jitter: str = "keyed"
 
 
 def _check_supported(cfg: SHVoxGridRenderConfig) -> None:
@@ -70,14 +74,17 @@ def render_sh_voxel_grid(
     rays: Rays,
     render_config: SHVoxGridRenderConfig,
     parallel_points_chunk_size: Optional[int] = None,
-    t_rand: Optional[Tensor] = None,
+    t_rand=None,
+    first_ray: int = 0,
 ) -> RenderOut:
     """Render flat rays [N, 3] through an SH voxel grid with the fused HIP kernels.
 
     ``parallel_points_chunk_size`` is accepted for signature compatibility and ignored: the fused
     kernel never materialises per-point tensors, so there is nothing to chunk.
-    ``t_rand`` [N, S] optionally supplies the stratified-sampling jitter (otherwise drawn with
-    ``torch.rand`` on the rays' device when ``perturb_sampled_points`` is set, like sample.py:63)."""
+    ``t_rand`` optionally supplies the stratified-sampling jitter: a [N, S] tensor, or a ``KeyedJitter``.  Otherwise, when
+    ``perturb_sampled_points`` is set, it comes from ``render_config.jitter``: "keyed" = a counter-based generator inside the
+    kernel (one 64-bit key drawn from torch's CPU generator per call; ``first_ray`` = position of ray 0 in that stream),
+    "torch" = ``torch.rand(N, S)`` on the rays' device like sample.py:63."""
     if not isinstance(voxel_grid, VoxelGrid):
         raise TypeError(f"render_sh_voxel_grid needs a thr3ed_atom_amd VoxelGrid, got {type(voxel_grid)}")
     _check_supported(render_config)
@@ -87,7 +94,12 @@ def render_sh_voxel_grid(
     n = origins.shape[0]
     if render_config.perturb_sampled_points:
         if t_rand is None:
-            t_rand = torch.rand(n, num_samples, dtype=torch.float32, device=origins.device)
+            if render_config.jitter == "torch":
+                t_rand = torch.rand(n, num_samples, dtype=torch.float32, device=origins.device)
+            elif render_config.jitter == "keyed":
+                t_rand = KeyedJitter(draw_jitter_key(), int(first_ray))
+            else:
+                raise ValueError("SHVoxGridRenderConfig.jitter must be 'keyed' or 'torch'")
     else:
         t_rand = None
     if render_config.consume_reference_rng:

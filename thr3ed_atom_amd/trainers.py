@@ -17,6 +17,7 @@ What is done the MI355X way instead of translated:
   * with WORLD_SIZE > 1 every rank draws its own ray batch and the bucket is exchanged once per iteration over RCCL:
     reduce-scatter, Adam on 1/N of the grid per rank, all-gather of the parameters (distributed.py).
 """
+import ctypes as C
 import dataclasses
 import os
 import time
@@ -28,6 +29,7 @@ import torch
 from torch import Tensor
 from torch.nn.functional import l1_loss, mse_loss
 
+from . import _lib, ops
 from . import distributed as rfdist
 from .camera import CameraBounds, CameraIntrinsics, compute_thre3d_grid_sizes, mse2psnr, scale_camera_intrinsics
 from .constants import CAMERA_BOUNDS, CAMERA_INTRINSICS, HEMISPHERICAL_RADIUS
@@ -174,6 +176,7 @@ class TrainStepper:
         self.global_batch = bool(global_batch)
         self.brick_size = int(os.environ.get("RF_BRICK_SIZE", "8"))  # (experiments: 4)
         self._bins = None
+        self._exec = None
         grid = vol_mod.thre3d_repr
         if not isinstance(grid, VoxelGrid):
             raise AssertionError(f"cannot train a {type(grid)}; only a VoxelGrid can be used")
@@ -213,13 +216,7 @@ class TrainStepper:
         hw = intr.height * intr.width
         dev = dataset.pixels.device
         total = min(self.ray_batch_size, image_ids.numel() * hw)
-        lo, hi = 0, total
-        if self.global_batch and self.data_parallel:
-            # equal shares only: every rank scales its L1 gradient by 1 / (3 * own rays) and the ranks are averaged with equal
-            # weight, which is the global-batch mean only when all ranks hold the same number of rays
-            if total % rfdist.world_size() != 0:
-                raise ValueError(f"global_batch: the ray batch ({total}) must be divisible by the world size ({rfdist.world_size()})")
-            lo, hi = rfdist.shard_range(total)
+        lo, hi = self._global_slice(total)
         if self.ray_selection == "keyed":
             key = int(torch.randint(-(2**63), 2**63 - 1, (1,), dtype=torch.int64).item())
             o, d, px = select_rays_and_pixels_hip(intr.height, intr.width, float(intr.focal), dataset.poses, image_ids, dataset.pixels, hi - lo, key, first_index=lo)
@@ -232,6 +229,16 @@ class TrainStepper:
         pixels = dataset.pixels[image_ids[b] * hw + (perm - b * hw)]
         return Rays(origins, directions), pixels
 
+    def _global_slice(self, total: int):
+        """[lo, hi) of the permutation prefix this rank renders (everything unless ``global_batch`` under data parallelism)."""
+        if not (self.global_batch and self.data_parallel):
+            return 0, total
+        # equal shares only: every rank scales its L1 gradient by 1 / (3 * own rays) and the ranks are averaged with equal
+        # weight, which is the global-batch mean only when all ranks hold the same number of rays
+        if total % rfdist.world_size() != 0:
+            raise ValueError(f"global_batch: the ray batch ({total}) must be divisible by the world size ({rfdist.world_size()})")
+        return rfdist.shard_range(total)
+
     def step_on(self, rays: Rays, pixels: Tensor, t_rand=None) -> StepStats:
         """One iteration on the given rays / target pixels.  ``t_rand`` = (jitter of the specular render, jitter of the diffuse
         render), each [N, S] in [0, 1), replaces the draws of ``perturb_sampled_points`` (parity tests)."""
@@ -241,7 +248,12 @@ class TrainStepper:
         if cfg.use_occupancy_mask and not grid.occupancy_current():
             grid.build_occupancy()  # densities changed in the last optimizer step
         if self.fused:
-            stats = self._merged_step_on(rays, pixels, t_rand) if self.merged_bricks else self._fused_step_on(rays, pixels, t_rand)
+            if not self.merged_bricks:
+                stats = self._fused_step_on(rays, pixels, t_rand)
+            elif ops.KERNEL_TIMER is not None:
+                stats = self._merged_step_pieces(rays, pixels, t_rand)
+            else:
+                stats = self._merged_step_on(rays, pixels, t_rand)
             grid.invalidate_occupancy()
             return stats
         if t_rand is not None:
@@ -270,14 +282,136 @@ class TrainStepper:
             if tuple(t.shape) != (n, S):
                 raise ValueError(f"t_rand[{i}] must be [{n}, {S}], got {tuple(t.shape)}")
             return t
-        t = torch.rand(n, S, dtype=torch.float32, device=device) if cfg.perturb_sampled_points else None
+        if not cfg.perturb_sampled_points:
+            t = None
+        elif cfg.jitter == "keyed":  # counter-based jitter inside the kernels, keyed from torch's CPU generator
+            t = ops.KeyedJitter(ops.draw_jitter_key(), 0)
+        elif cfg.jitter == "torch":
+            t = torch.rand(n, S, dtype=torch.float32, device=device)
+        else:
+            raise ValueError("SHVoxGridRenderConfig.jitter must be 'keyed' or 'torch'")
         if cfg.consume_reference_rng:
             torch.randn(n, S, dtype=torch.float32, device=device)
         return t
 
-    def _merged_step_on(self, rays: Rays, pixels: Tensor, t_rand=None) -> StepStats:
+    def _merged_step_on(self, rays: Optional[Rays], pixels: Optional[Tensor], t_rand=None, selection=None) -> StepStats:
         """Both renders forward (each counts its records per key), both adjoints emitted as records at their final positions,
-        ONE brick pass over the two lists; the Adam update inside its flush when ``fuse_optimizer``."""
+        ONE brick pass over the two lists; the Adam update inside its flush when ``fuse_optimizer``.  The whole iteration is
+        enqueued by ONE call into the library (rf_train_step, include/relu_field.h): nine launches, one FFI crossing.
+        ``selection`` = (dataset, image_ids, key, first_index, count) lets the call draw the batch itself."""
+        vol_mod, grid = self.vol_mod, self.vol_mod.thre3d_repr
+        cfg = vol_mod.render_config
+        _check_supported(cfg)
+        S = int(cfg.num_samples_per_ray)
+        if selection is not None:
+            dataset, image_ids, key, first, n = selection
+            dev = dataset.pixels.device
+        else:
+            origins = rays.origins.detach().to(torch.float32).contiguous()
+            directions = rays.directions.detach().to(torch.float32).contiguous()
+            pixels = pixels.detach().to(torch.float32).contiguous()
+            n, dev = origins.shape[0], origins.device
+        ex = self._executor(n, S, dev)
+        st = ex["step"]
+        if selection is not None:
+            intr = dataset.camera_intrinsics
+            ids = image_ids.detach().to(dev, torch.int64).contiguous()
+            sel = ex["select"]
+            sel.height, sel.width, sel.focal = int(intr.height), int(intr.width), float(np.float32(intr.focal))
+            sel.poses_dev, sel.image_ids_dev, sel.num_batch_images = dataset.poses.data_ptr(), ids.data_ptr(), int(ids.numel())
+            sel.pixel_table_dev, sel.key, sel.first_index = dataset.pixels.data_ptr(), int(key) & 0xFFFFFFFFFFFFFFFF, int(first)
+            st.select = C.pointer(sel)
+            st.origins_dev, st.directions_dev, st.pixels_dev = ex["origins"].data_ptr(), ex["directions"].data_ptr(), ex["pixels"].data_ptr()
+            keep = (ids,)
+        else:
+            st.select = None
+            st.origins_dev, st.directions_dev, st.pixels_dev = origins.data_ptr(), directions.data_ptr(), pixels.data_ptr()
+            keep = (origins, directions, pixels)
+        st.near, st.far = float(np.float32(cfg.camera_bounds.near)), float(np.float32(cfg.camera_bounds.far))
+        flags = render_flags(cfg.white_bkgd, False, cfg.optimized_sampling, cfg.use_occupancy_mask)
+        jit = [self._draw_jitter(cfg, n, S, dev, t_rand, i) for i in range(2)]
+        for i in range(2):
+            if isinstance(jit[i], ops.KeyedJitter):
+                flags |= _lib.FLAG_JITTER_KEYED
+                st.pass_[i].jitter_key, st.pass_[i].t_rand_dev = jit[i].key, None
+            else:
+                st.pass_[i].t_rand_dev = None if jit[i] is None else jit[i].data_ptr()
+        st.flags = flags
+        rf_grid = grid.to_rf_grid(use_occupancy=cfg.use_occupancy_mask)
+        opt = self.optimizer
+        if self.fuse_optimizer:
+            opt.step_count += 1
+            ad = ex["adam"]
+            ad.lr, ad.step = float(opt.lr), int(opt.step_count)
+            first, second = grid.kernel_tensors()
+            ad.param_first_dev, ad.param_second_dev = first.data_ptr(), None if second is None else second.data_ptr()
+            st.adam = C.pointer(ad)
+        else:
+            st.adam = None
+            gd, gf = self.flat.views_for_accumulation()
+            st.grad_first_dev, st.grad_second_dev = gd.data_ptr(), None if gf is None else gf.data_ptr()
+        with ops._span("train_step", dev):
+            rc = _lib.load().rf_train_step(C.byref(rf_grid), C.byref(st), torch.cuda.current_stream(dev).cuda_stream)
+        _lib.check(rc, "rf_train_step")
+        del keep, jit
+        if self.fuse_optimizer:
+            self._grad_clean = True  # the bucket is not used at all
+        else:
+            if self.data_parallel and rfdist._collectives_on():
+                rfdist.all_reduce_mean_(self.flat.flat_grad)
+            opt.step()
+            self._grad_clean = False
+        means = ex["sums"] / float(3 * n)
+        return StepStats(means[0], means[2], means[1], means[3])
+
+    def _executor(self, n: int, S: int, device):
+        """Persistent scratch + the ctypes description of one iteration (rebuilt when the batch shape changes)."""
+        ex = self._exec
+        if ex is not None and ex["shape"] == (n, S):
+            return ex
+        grid = self.vol_mod.thre3d_repr
+        nb = brick_counts(grid, self.brick_size)
+        nkeys = nb[0] * nb[1] * nb[2] * 8
+        if nkeys > (1 << 21):
+            raise ValueError("backward='binned' needs at most 2^18 bricks")
+        f32 = dict(dtype=torch.float32, device=device)
+        t = {
+            "origins": torch.empty((n, 3), **f32), "directions": torch.empty((n, 3), **f32), "pixels": torch.empty((n, 3), **f32),
+            "sums": torch.zeros(4, **f32), "t_vals": ops.t_vals_for(S, device),
+        }
+        step, sel, adam = _lib.RFTrainStep(), _lib.RFRaySelection(), _lib.RFAdamState()
+        step.num_rays, step.num_samples, step.t_vals_dev, step.loss_sums_dev = n, S, t["t_vals"].data_ptr(), t["sums"].data_ptr()
+        for i, diffuse in enumerate((False, True)):
+            p = {
+                "colour": torch.empty((n, 3), **f32), "depth": torch.empty(n, **f32), "acc": torch.empty(n, **f32), "disparity": torch.empty(n, **f32),
+                "cache": torch.empty((n, S, 4), **f32), "tcache": torch.empty((n, S), **f32), "stop": torch.empty(n, dtype=torch.int32, device=device),
+                "g_colour": torch.empty((n, 3), **f32),
+                "hist": torch.zeros(nkeys, dtype=torch.int32, device=device), "cursor": torch.empty(nkeys, dtype=torch.int32, device=device),
+                "offsets": torch.empty(nkeys + 1, dtype=torch.int64, device=device),
+                "sorted": torch.empty((n * S, expanded_record_floats(grid, diffuse)), **f32),
+            }
+            t[f"pass{i}"] = p
+            ps = step.pass_[i]
+            o = ps.out
+            o.colour_dev, o.depth_dev, o.acc_dev, o.disparity_dev = p["colour"].data_ptr(), p["depth"].data_ptr(), p["acc"].data_ptr(), p["disparity"].data_ptr()
+            o.sample_cache_dev, o.trans_cache_dev, o.stop_cache_dev = p["cache"].data_ptr(), p["tcache"].data_ptr(), p["stop"].data_ptr()
+            o.key_hist_dev, o.brick_size = p["hist"].data_ptr(), int(self.brick_size)
+            ps.grad_colour_dev, ps.cursor_dev, ps.offsets_dev, ps.records_sorted_dev = p["g_colour"].data_ptr(), p["cursor"].data_ptr(), p["offsets"].data_ptr(), p["sorted"].data_ptr()
+        opt = self.optimizer
+        nd = self.flat.flat_gradient_parts()[0].numel()
+        has_second = self.flat.flat_gradient_parts()[1] is not None
+        adam.exp_avg_first_dev, adam.exp_avg_sq_first_dev = opt.exp_avg[:nd].data_ptr(), opt.exp_avg_sq[:nd].data_ptr()
+        adam.exp_avg_second_dev = opt.exp_avg[nd:].data_ptr() if has_second else None
+        adam.exp_avg_sq_second_dev = opt.exp_avg_sq[nd:].data_ptr() if has_second else None
+        adam.beta1, adam.beta2, adam.eps = opt.betas[0], opt.betas[1], opt.eps
+        self._exec = {"shape": (n, S), "tensors": t, "step": step, "select": sel, "adam": adam, "sums": t["sums"],
+                      "origins": t["origins"], "directions": t["directions"], "pixels": t["pixels"]}
+        return self._exec
+
+    def _merged_step_pieces(self, rays: Rays, pixels: Tensor, t_rand=None) -> StepStats:
+        """The launches of rf_train_step issued one by one from Python (the same kernels in the same order): used when per-kernel
+        HIP events are being recorded (ops.KERNEL_TIMER, bench.py's roofline leg) -- rf_train_step leaves no room for events
+        between its launches."""
         vol_mod, grid = self.vol_mod, self.vol_mod.thre3d_repr
         cfg = vol_mod.render_config
         _check_supported(cfg)
@@ -441,6 +575,18 @@ class TrainStepper:
         return b
 
     def step(self, dataset: PosedImagesInMemory, image_ids: Tensor) -> StepStats:
+        if self.fused and self.merged_bricks and self.ray_selection == "keyed" and ops.KERNEL_TIMER is None:
+            # the library call draws the batch as well (rf_select_rays_and_pixels is its first launch)
+            grid, cfg = self.vol_mod.thre3d_repr, self.vol_mod.render_config
+            if cfg.use_occupancy_mask and not grid.occupancy_current():
+                grid.build_occupancy()
+            intr = dataset.camera_intrinsics
+            total = min(self.ray_batch_size, image_ids.numel() * intr.height * intr.width)
+            lo, hi = self._global_slice(total)
+            key = int(torch.randint(-(2**63), 2**63 - 1, (1,), dtype=torch.int64).item())
+            stats = self._merged_step_on(None, None, selection=(dataset, image_ids, key, lo, hi - lo))
+            grid.invalidate_occupancy()
+            return stats
         rays, pixels = self.select(dataset, image_ids)
         return self.step_on(rays, pixels)
 
