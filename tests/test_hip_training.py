@@ -688,7 +688,7 @@ def test_global_batch_slices_reproduce_the_single_gpu_step(hip_device, monkeypat
         grid = relu_grid(hip_device, T(hash_uniform((G, G, G, 1), 901)), T(hash_uniform((G, G, G, F), 900 + F)), G, storage="split")
         cfg = rf.SHVoxGridRenderConfig(S, data.camera_bounds, perturb_sampled_points=False, white_bkgd=True)
         model = rf.VolumetricModel(grid, rf.render_sh_voxel_grid, cfg, device=hip_device)
-        stepper = TrainStepper(model, R, learning_rate=0.03, global_batch=True, ray_selection=selection)
+        stepper = TrainStepper(model, R, learning_rate=0.03, global_batch=True, ray_selection=selection, fuse_optimizer=False)  # (the gradient bucket is what the ranks would exchange)
         monkeypatch.setattr(rfdist, "world_size", lambda: world)
         monkeypatch.setattr(rfdist, "rank", lambda: rank)
         monkeypatch.setattr(rfdist, "_collectives_on", lambda: False)

@@ -1417,7 +1417,8 @@ __global__ __launch_bounds__(256) void scatter_records_kernel(const short* __res
 // per corner, the record's per-channel values, its packed cell) one batch ahead of the consumers; the two waves
 // alternate batches, so that the global loads of a batch (several microseconds under load) have two accumulation
 // rounds to arrive.  The consumers' loop is then 2 table reads, 2 multiplies and the read-add-write.
-constexpr int kBrickThreads = 256;
+constexpr int kBrickThreads = 512;  // 8 waves: 2 consumers + 2 producers of the table path, 4 more for the phases every thread shares (diffuse records, zero-fill, flush)
+constexpr int kBrickFetchers = 256;  // threads that stage diffuse records (two 16-byte loads per record, 128 records per round)
 constexpr int kBrickBatch = 32;   // records per table (8 staging threads per record)
 constexpr int kMaxRanges = 28;    // 14 (source brick, flag run) ranges per list, two lists
 
@@ -1458,7 +1459,7 @@ __device__ unsigned long long g_brick_prof[8];
 #endif
 
 template <int K, bool ADAM>
-__global__ __launch_bounds__(kBrickThreads, 2) void brick_accumulate_kernel(GridArgs g, BrickArgs a, float* gdens,
+__global__ __launch_bounds__(kBrickThreads, 4) void brick_accumulate_kernel(GridArgs g, BrickArgs a, float* gdens,
                                                                          float* gfeat) {
   constexpr int C = 3 * K + 1;
   constexpr int C4 = (C + 3) / 4 * 4;
@@ -1474,7 +1475,7 @@ __global__ __launch_bounds__(kBrickThreads, 2) void brick_accumulate_kernel(Grid
   constexpr int CELL = GOFF + 2 * C4;             // words: the two packed cells
   constexpr int ROW = (CELL + 2 + 3) / 4 * 4;     // words per step, 16-byte aligned
   extern __shared__ __attribute__((aligned(16))) float acc[];  // node (x, y, z), channel c at x * SX + y * SY + z * CS + c
-  constexpr int TW = (kBrickBatch / 2 + 2) * ROW > kBrickThreads * 4 ? (kBrickBatch / 2 + 2) * ROW : kBrickThreads * 4;  // (also the staging buffers of the diffuse phase)
+  constexpr int TW = (kBrickBatch / 2 + 2) * ROW > kBrickFetchers * 4 ? (kBrickBatch / 2 + 2) * ROW : kBrickFetchers * 4;  // (also the staging buffers of the diffuse phase)
   __shared__ __attribute__((aligned(16))) uint32_t table[2][TW];  // separate object: never aliases acc; + 2 spare steps (prefetch)
   __shared__ long long s_rstart[kMaxRanges];
   __shared__ int s_rlist[kMaxRanges];
@@ -1576,8 +1577,8 @@ __global__ __launch_bounds__(kBrickThreads, 2) void brick_accumulate_kernel(Grid
     // the records are streamed through LDS (the idle table buffers): the whole workgroup fetches 128 records (4 KB) per
     // round with coalesced 16-byte loads, one round ahead of their use; a wave then takes its records from LDS, where
     // a miss costs 65 cycles instead of microseconds
-    constexpr int RPR = kBrickThreads / 2;  // records per round (two float4 per record)
-    static_assert(2 * kBrickThreads * 4 <= (int)(sizeof(table) / sizeof(uint32_t)), "two staging buffers fit the table");
+    constexpr int RPR = kBrickFetchers / 2;  // records per round (two float4 per record)
+    static_assert(2 * kBrickFetchers * 4 <= (int)(sizeof(table) / sizeof(uint32_t)), "two staging buffers fit the table");
     float4* stage = reinterpret_cast<float4*>(&table[0][0]);
     const int nrounds = (total_d + RPR - 1) / RPR;
     int ri = 0;
@@ -1586,12 +1587,14 @@ __global__ __launch_bounds__(kBrickThreads, 2) void brick_accumulate_kernel(Grid
       while (s_dcum[ri + 1] <= v) ++ri;
       return a.lists[1].rec[(s_dstart[ri] + (v - s_dcum[ri])) * 2 + (tid & 1)];
     };
-    float4 inflight = fetch(0);
+    const bool fetcher = tid < kBrickFetchers;
+    float4 inflight = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (fetcher) inflight = fetch(0);
     for (int round = 0; round < nrounds; ++round) {
-      float4* buf = stage + (round & 1) * kBrickThreads;
-      buf[tid] = inflight;
+      float4* buf = stage + (round & 1) * kBrickFetchers;
+      if (fetcher) buf[tid] = inflight;
       __syncthreads();
-      if (round + 1 < nrounds) inflight = fetch(round + 1);
+      if (fetcher && round + 1 < nrounds) inflight = fetch(round + 1);
       const int nrec = min(RPR, total_d - round * RPR);
 #pragma unroll 4
       for (int r = wave * 2 + half; r < nrec; r += 2 * (kBrickThreads / kWave)) {
@@ -1644,7 +1647,7 @@ __global__ __launch_bounds__(kBrickThreads, 2) void brick_accumulate_kernel(Grid
   // ---- producer role (waves 2 and 3): wave 2 prepares the even batches, wave 3 the odd ones, so that the record loads
   // of a batch have two whole accumulation rounds to arrive.  8 lanes per record (lane `part` prepares corner `part`
   // and copies float4 `part` of the record), four records (sj + 8 t) per lane.
-  const bool producer = wave >= 2;
+  const bool producer = wave == 2 || wave == 3;
   const int parity = wave & 1;
   constexpr int TPL = kBrickBatch / 8;  // records per producer lane
   const int sj = lane >> 3, part = lane & 7;
@@ -1830,10 +1833,9 @@ __global__ __launch_bounds__(kBrickThreads, 2) void brick_accumulate_kernel(Grid
       // parameters with ordinary accesses (the next forward pass reads them), moments streamed non-temporally.  The flush is
       // the only phase of the kernel that waits on HBM: a thread issues the 3 x U loads of U quads before it touches the
       // first one (one quad at a time kept ~24 KB per CU in flight and ran at a third of the HBM rate).
-      // A thread issues ALL its loads (3 tensors x up to 14 quads at degree 2 = 168 registers; the accumulation registers are
-      // dead by now and the kernel is LDS-limited to 2 waves per SIMD, i.e. 256 registers per lane) before it touches the
-      // first one.  Element offsets are kept as 32-bit (host-checked) to stay inside that budget.
-      constexpr int U = (QN == 7) ? 12 : 2;
+      // A thread issues ALL its loads (3 tensors x 7 quads at degree 2 = 84 registers) before it touches the first one.
+      // Element offsets are kept as 32-bit (host-checked) to stay inside the 128-register budget of 4 waves per SIMD.
+      constexpr int U = (QN == 7) ? 4 : 1;
       const AdamArgs& ad = a.adam;
       for (int i0 = tid; i0 < nq; i0 += kBrickThreads * U) {
         unsigned int off[U];  // bit 31: rest tensor; 0xffffffff: nothing to do
