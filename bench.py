@@ -4,16 +4,22 @@
     python bench.py --gpus N --steps K --warmup W          (N > 1: launched by torch.distributed.run)
 
 Workload (BASELINE.json: "ray-samples/sec (fwd+bwd) ... 800x800 @ 128^3 grid", configs[2]/[3]):
-one STEP = one training iteration of the posed-image trainer on a 128^3 SH-degree-2 ReLU field --
-random 16384-ray batch out of 8 synthetic 800x800 images (randperm + ray generation), specular render
-fwd, diffuse render fwd, L1 + L1, backward of both, [gradient all-reduce over RCCL when N > 1], Adam --
-with 256 stratified (jittered) samples per ray.  ``value`` = nominal ray-samples/s over the whole job
-= N * 2 renders * 16384 rays * 256 samples * K / time, inputs resident in HBM, nothing skipped.
+one STEP = one training iteration of the posed-image trainer on a 128^3 SH-degree-2 ReLU field -- a random 16384-ray batch
+out of 8 synthetic 800x800 images, specular render fwd, diffuse render fwd, L1 + L1, backward of both, [gradient exchange
+over RCCL when N > 1], Adam -- with 256 stratified (jittered) samples per ray.  ``value`` = nominal ray-samples/s over the
+whole job = N * 2 renders * 16384 rays * 256 samples * K / time, inputs resident in HBM, nothing skipped.
 Weak scaling: every rank draws its own 16384-ray batch.
 
-Also reported in the same JSON line: the forward-only full-frame render of configs[1]
-(``fwd_render``), the HBM roofline of the dominant kernel (``roofline``) and the oracle timed on the
-host cores (``cpu_baseline``).  The oracle is used ONLY in that last leg.
+Also in the same JSON line:
+  roofline      the dominant kernel of the step: HIP events recorded by the library INSIDE the timed region (rf_train_step's
+                timing_events, on the launch stream); ``frac`` = HBM bytes from the PMC counters (profiles/pmc_traffic.json,
+                rocprofv3 --pmc passes of this command) / this run's kernel time / 8 TB/s; ``frac_processed`` = the algorithmic
+                bytes of SURVEY 8d on the units the launch REALLY processes (records emitted, counted on the device) -- never the
+                nominal in-AABB count a kernel legitimately skips most of;
+  fwd_render    configs[1], full 800x800 frame (one launch), on the init field and on a semi-transparent field where every
+                ray traverses the whole volume;
+  highres_render configs[4]; strict_dropin = the torch.autograd.Function path a reference user gets;
+  cpu_baseline  the oracle (checker only) timed on the host cores.
 """
 import argparse
 import json
@@ -40,7 +46,7 @@ RADIUS = 4.0311
 WORLD = 3.0
 
 
-def make_grid(dev, G, sh_degree, seed, sparse=False, storage="reference"):
+def make_grid(dev, G, sh_degree, seed, sparse=False, storage="reference", rho=None):
     gen = torch.Generator(device=dev)
     gen.manual_seed(seed)
     F = 3 * (sh_degree + 1) ** 2
@@ -56,7 +62,7 @@ def make_grid(dev, G, sh_degree, seed, sparse=False, storage="reference"):
         rf.VoxelSize(WORLD / G, WORLD / G, WORLD / G),
         density_preactivation=torch.nn.Identity(),
         density_postactivation=torch.nn.ReLU(),
-        expected_density_scale=rf.compute_expected_density_scale_for_relu_field_grid((WORLD,) * 3),
+        expected_density_scale=rf.compute_expected_density_scale_for_relu_field_grid((WORLD,) * 3) if rho is None else rho,
         tunable=True,
         storage=storage,
     )
@@ -77,9 +83,33 @@ def count_inside(origins, directions, num_samples, aabb):
     return total
 
 
-def cpu_baseline(grid, rays_cpu, pixels_cpu, num_samples, n_rays, threads=0):
-    """The oracle's float32 CPU path (same ATen ops the reference calls) on a bounded sample of the same
-    workload: fwd+bwd of the specular and the diffuse render of ``n_rays`` rays, all host cores."""
+MODEL_ERRORS = []
+
+
+def frac(bytes_, ms, what=""):
+    """fraction of the HBM peak.  A value above 1 cannot be a bandwidth: it means the byte model charges the kernel for work it
+    does not do.  Such a figure is never printed: it is reported as None, shouted on stderr and listed in the JSON line."""
+    f = bytes_ / 1e9 / (ms / 1e3) / HBM_PEAK_GBS
+    if f > 1.0:
+        msg = f"ROOFLINE MODEL ERROR: {what}: {bytes_:.4g} B in {ms:.4f} ms = {f:.3f} of the HBM peak (> 1)"
+        print(msg, file=sys.stderr)
+        MODEL_ERRORS.append(msg)
+        return None
+    return f
+
+
+def load_pmc_table():
+    path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+    try:
+        return json.load(open(path))
+    except Exception:
+        return {}
+
+
+def cpu_baseline(grid, rays_cpu, pixels_cpu, num_samples, n_train, n_fwd, threads=0, reps=3):
+    """The oracle's float32 CPU path (the same ATen ops the reference calls) on bounded samples of the same workloads
+    (SURVEY 8d protocol: 1 warm-up + 3 timed repeats, median): cfg3 = specular+diffuse fwd+bwd of ``n_train`` rays, cfg2 = a
+    forward-only chunk of ``n_fwd`` rays."""
     from oracle import relu_field_oracle as orc  # checker / baseline only
 
     # measured on the MI355X host (256 logical cores): 16 threads 4.2e5, 64 threads 3.8e5, 256 threads 0.5e5
@@ -92,40 +122,78 @@ def cpu_baseline(grid, rays_cpu, pixels_cpu, num_samples, n_rays, threads=0):
     aabb = tuple(tuple(r) for r in grid.aabb)
     rho = grid.expected_density_scale
 
-    def step(n):
+    def train(n):
         o, d, px = rays_cpu[0][:n], rays_cpu[1][:n], pixels_cpu[:n]
         dens.grad = feat.grad = None
         total = 0.0
         for diffuse in (False, True):
             t_rand = torch.rand(n, num_samples)
-            out = orc.render(
-                dens, feat, o, d, aabb, NEAR, FAR, num_samples, rho, "relu", white_bkgd=True,
-                render_diffuse=diffuse, t_rand=t_rand, interp="aten",
-            )
+            out = orc.render(dens, feat, o, d, aabb, NEAR, FAR, num_samples, rho, "relu", white_bkgd=True, render_diffuse=diffuse, t_rand=t_rand, interp="aten")
             total = total + torch.nn.functional.l1_loss(out["colour"], px)
         total.backward()
 
-    step(min(256, n_rays))  # warm-up (thread pool, page-in)
-    reps = 1
-    t0 = time.perf_counter()
-    for _ in range(reps):
-        step(n_rays)
-    dt = (time.perf_counter() - t0) / reps
+    def forward(n):
+        with torch.no_grad():
+            orc.render(dens, feat, rays_cpu[0][:n], rays_cpu[1][:n], aabb, NEAR, FAR, num_samples, rho, "relu", white_bkgd=True,
+                       t_rand=torch.rand(n, num_samples), interp="aten")
+
+    def timed(fn, n):
+        fn(min(256, n))  # warm-up (thread pool, page-in)
+        ts = []
+        for _ in range(reps):
+            t0 = time.perf_counter()
+            fn(n)
+            ts.append(time.perf_counter() - t0)
+        return float(np.median(ts))
+
+    dt_train = timed(train, n_train)
+    dt_fwd = timed(forward, n_fwd) if n_fwd > 0 else None
     return {
-        "value": 2 * n_rays * num_samples / dt,
+        "value": 2 * n_train * num_samples / dt_train,
         "unit": "ray-samples/s",
         "cores": cores,
         "kind": "port",
-        "sample": f"{reps} training-step cores (specular+diffuse fwd+bwd, no optimiser) of {n_rays} rays x {num_samples} samples "
-        f"on the same 128^3 SH-2 grid, oracle with interp='aten' (F.grid_sample), torch {torch.__version__} CPU fp32; {dt:.2f} s/step",
+        "sample": f"median of {reps} repeats after 1 warm-up: training-step core (specular+diffuse fwd+bwd, no optimiser) of {n_train} rays x {num_samples} samples "
+        f"on the same 128^3 SH-2 grid, oracle with interp='aten' (F.grid_sample), torch {torch.__version__} CPU fp32; {dt_train:.2f} s/step",
+        "forward_only": None if dt_fwd is None else {
+            "value": n_fwd * num_samples / dt_fwd,
+            "unit": "ray-samples/s",
+            "sample": f"median of {reps} repeats: forward-only chunk of {n_fwd} rays x {num_samples} samples (configs[1] renders 800x800 = 640000 rays in 32768-ray chunks); {dt_fwd:.2f} s/chunk",
+        },
     }
+
+
+def time_frames(fn, frames):
+    """median of per-frame wall times (sync before and after every frame)"""
+    fn()  # warm-up
+    ts = []
+    for _ in range(frames):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        fn()
+        torch.cuda.synchronize()
+        ts.append(time.perf_counter() - t0)
+    return float(np.median(ts))
+
+
+def kernel_ms(fn, name):
+    """HIP-event time of the launch called ``name`` inside one call of ``fn`` (ops.KernelTimer, events on the launch stream)"""
+    timer = ops.KernelTimer()
+    ops.KERNEL_TIMER = timer
+    try:
+        fn()
+        torch.cuda.synchronize()
+    finally:
+        ops.KERNEL_TIMER = None
+    rec = timer.summary()
+    return rec[name]["total_ms"], rec[name]["launches"]
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
-    ap.add_argument("--warmup", type=int, default=50, help="untimed steps first (clocks and caches take ~50 steps to settle)")
+    ap.add_argument("--warmup", type=int, default=50, help="untimed steps first")
     ap.add_argument("--grid", type=int, default=128)
     ap.add_argument("--sh-degree", type=int, default=2)
     ap.add_argument("--rays", type=int, default=16384, help="ray batch per GPU (reference CLI default)")
@@ -134,19 +202,20 @@ def main():
     ap.add_argument("--images", type=int, default=8)
     ap.add_argument("--render-frames", type=int, default=5, help="full-frame forward renders timed for fwd_render (0 = skip)")
     ap.add_argument("--highres-frames", type=int, default=5, help="frames timed for the 256^3 / 512-sample configs[4] render (0 = skip)")
-    ap.add_argument("--cpu-rays", type=int, default=2048, help="rays of the cpu_baseline sample (0 = skip)")
+    ap.add_argument("--cpu-rays", type=int, default=2048, help="rays of the cpu_baseline training sample (0 = skip the CPU baseline)")
+    ap.add_argument("--cpu-fwd-rays", type=int, default=8192, help="rays of the cpu_baseline forward-only chunk")
+    ap.add_argument("--dropin-steps", type=int, default=20, help="steps timed for the strict drop-in configuration (0 = skip)")
     ap.add_argument("--storage", choices=["split", "bricked", "reference"], default="split",
                     help="HBM layout of the grid: split = MI355X-native (what the trainer uses), reference = the reference's two tensors")
     ap.add_argument("--ray-selection", choices=["keyed", "randperm"], default="keyed",
                     help="how a step picks its 16384 random pixels: keyed = fused keyed-permutation kernel (trainer default), "
                     "randperm = torch.randperm over all 5.12 M pixels like the reference")
     ap.add_argument("--backward", choices=["auto", "atomic", "binned"], default="auto",
-                    help="specular gradient scatter of the train step: float32 atomics, or records binned by brick + atomic-free "
-                    "LDS accumulation (auto = binned where supported and measured faster)")
+                    help="gradient scatter of the train step: float32 atomics, or records binned by brick + atomic-free LDS accumulation")
     ap.add_argument("--deterministic", action="store_true", help="binned backward: stable radix sort instead of the counting sort")
+    ap.add_argument("--no-fuse-optimizer", action="store_true", help="keep the gradient bucket and the separate Adam kernel on one GPU")
     ap.add_argument("--timed-steps", type=int, default=5, help="how many of the --steps record per-kernel HIP events")
-    ap.add_argument("--no-kernel-timer", action="store_true", help="do not record per-kernel HIP events in the timed region (no roofline object)")
-    ap.add_argument("--cpu-threads", type=int, default=0, help="torch CPU threads for cpu_baseline (0 = all host cores)")
+    ap.add_argument("--cpu-threads", type=int, default=0, help="torch CPU threads for cpu_baseline (0 = min(cores, 16))")
     args = ap.parse_args()
 
     rank, local_rank, world = rfdist.init_from_env()
@@ -155,12 +224,17 @@ def main():
     assert torch.cuda.is_available(), "bench.py needs a GPU (the render path has no CPU fallback)"
     dev = torch.device("cuda", local_rank)
     torch.cuda.set_device(dev)
+    backend = torch.distributed.get_backend() if world > 1 else None
+    rccl_world = torch.distributed.get_world_size() if world > 1 else 1
 
     H = W = args.image_size
     focal = 1111.111 * (W / 800.0)
     intr = rf.CameraIntrinsics(H, W, focal)
     S, R, G = args.samples, args.rays, args.grid
+    C = 3 * (args.sh_degree + 1) ** 2 + 1
     bounds = rf.CameraBounds(NEAR, FAR)
+    pmc = load_pmc_table()
+    spec = f"sh{args.sh_degree}"
 
     # ---- synthetic dataset: images of a procedural ground-truth field rendered once (untimed) -------
     gt = make_grid(dev, G, args.sh_degree, seed=7, sparse=True)
@@ -181,38 +255,55 @@ def main():
     fwd_render = None
     if args.render_frames > 0 and rank == 0:
         pose = rf.pose_spherical(30.0, -30.0, RADIUS)
-        model.render(pose, intr)  # warm-up
-        timer = ops.KernelTimer()
-        # every frame is timed on its own (sync before and after) and the MEDIAN is reported: the ROCm runtime now and then
-        # stalls for tens of ms (observed with many outstanding timing events), which would swamp a 4 ms frame
-        frame_s = []
-        for i in range(args.render_frames):
-            ops.KERNEL_TIMER = timer if i == 0 else None  # per-kernel events on one frame only
-            torch.cuda.synchronize()
-            t0 = time.perf_counter()
-            model.render(pose, intr)
-            torch.cuda.synchronize()
-            frame_s.append(time.perf_counter() - t0)
-        dt = float(np.median(frame_s))
-        ops.KERNEL_TIMER = None
         rays = rf.flatten_rays(rf.cast_rays(intr, pose, dev))
         n_in = count_inside(rays.origins, rays.directions, S, grid.aabb)
-        ksum = timer.summary()
-        kname = f"render_forward[sh{args.sh_degree}]"
-        kms = ksum[kname]["total_ms"]  # the one frame with events
-        del timer
-        alg = n_in * 8 * (3 * (args.sh_degree + 1) ** 2 + 1) * 4 + H * W * 48
+        del rays
+        kname = f"render_forward[{spec},frame]"
+        legs = {}
+        # (a) the field the reference initialises (U(-1,1) raw densities x rho = 33): every ray saturates within a few
+        #     samples, so the launch touches a small part of the volume -- fast, but no evidence about HBM;
+        # (b) the same grid with rho = 0.25: sigma * delta << 1, transmittance stays far from 0, EVERY in-box sample with
+        #     positive density fetches its 8 x 28 channels -- rays traverse the whole volume, the HBM-bound regime.
+        for leg, rho in (("init_field", None), ("traversal", 0.25)):
+            g2 = grid if rho is None else make_grid(dev, G, args.sh_degree, seed=42, storage=args.storage, rho=rho)
+            m2 = rf.VolumetricModel(g2, rf.render_sh_voxel_grid, cfg, device=dev)
+            dt = time_frames(lambda: m2.render(pose, intr), args.render_frames)
+            kms, launches = kernel_ms(lambda: m2.render(pose, intr), kname)
+            # units really processed: samples whose features are gathered = in-box, positive density, T != 0; counted by a
+            # save-forward of a ray subset is not possible at frame size, so the record predicate is evaluated on the device
+            # by the training-style forward of a 65536-ray sample of the frame and scaled
+            sub = rf.flatten_rays(rf.cast_rays(intr, pose, dev))[:: (H * W) // 65536][:65536]
+            nb = ops.brick_counts(g2, 8)
+            hist = torch.zeros(nb[0] * nb[1] * nb[2] * 8, dtype=torch.int32, device=dev)
+            flags = ops.render_flags(True, False, False, False)
+            ops.render_forward_raw(g2, sub.origins.contiguous(), sub.directions.contiguous(), ops.KeyedJitter(7, 0), S, NEAR, FAR, flags, save=True, key_hist=hist)
+            gathered = float(hist.sum().item()) / len(sub) * (H * W)
+            inside_sub = count_inside(sub.origins, sub.directions, S, g2.aabb) / len(sub) * (H * W)
+            del hist, sub
+            alg = gathered * 8 * C * 4 + (inside_sub - gathered) * 8 * 4 * 4 + H * W * 12  # features | density only | outputs (rays are generated in-kernel)
+            counter = pmc.get(f"{kname}:{leg}", {}).get("hbm_bytes_per_launch")
+            legs[leg] = {
+                "density_scale": g2.expected_density_scale,
+                "ms_per_frame": dt * 1e3,
+                "ray_samples_per_s": H * W * S / dt,
+                "rays_per_s": H * W / dt,
+                "kernel_ms_per_frame": kms,
+                "render_launches_per_frame": launches,
+                "samples_gathering_features": gathered,
+                "algorithmic_GB_processed": alg / 1e9,
+                "frac_processed": frac(alg, kms, f"fwd_render.{leg} (processed units)"),
+                "counter_GB_per_launch": None if counter is None else counter / 1e9,
+                "frac_hbm": None if counter is None else frac(counter, kms, f"fwd_render.{leg} (counters)"),
+            }
+            if rho is not None:
+                del m2, g2
         fwd_render = {
-            "workload": f"{G}^3 SH-{args.sh_degree} ReLU field, {H}x{W}, {S} samples/ray, jittered, VolumetricModel.render (32768-ray chunks)",
-            "ms_per_frame": dt * 1e3,
-            "ray_samples_per_s": H * W * S / dt,
-            "rays_per_s": H * W / dt,
-            "kernel_ms_per_frame": kms,
+            "workload": f"configs[1]: {G}^3 SH-{args.sh_degree} ReLU field, {H}x{W}, {S} jittered samples/ray, VolumetricModel.render = ONE launch (rays + jitter generated in-kernel)",
             "inside_fraction": n_in / (H * W * S),
-            "algorithmic_GB_per_frame": alg / 1e9,
-            "effective_GBps_kernel": alg / 1e9 / (kms / 1e3),
-            "frac_of_hbm_peak": alg / 1e9 / (kms / 1e3) / HBM_PEAK_GBS,
+            "nominal_GB_per_frame_survey_8d": (n_in * 8 * C * 4 + H * W * 48) / 1e9,
+            **legs,
         }
+        torch.cuda.empty_cache()
 
     # ---- configs[4]: 256^3 grid, 512 samples/ray, sparse scene, exact empty-space skipping (rank 0) ------------
     highres = None
@@ -225,61 +316,98 @@ def main():
         hg.build_occupancy()
         torch.cuda.synchronize()
         t_build = time.perf_counter() - t_build0
-        times = {}
-        for use in (False, True):
-            hmodel.render(pose, intr, use_occupancy_mask=use)  # warm-up
-            torch.cuda.synchronize()
-            frame_s = []
-            for _ in range(args.highres_frames):
-                torch.cuda.synchronize()
-                t0 = time.perf_counter()
-                hmodel.render(pose, intr, use_occupancy_mask=use)
-                torch.cuda.synchronize()
-                frame_s.append(time.perf_counter() - t0)
-            times[use] = float(np.median(frame_s))  # median of per-frame times (see fwd_render)
+        times = {use: time_frames(lambda: hmodel.render(pose, intr, use_occupancy_mask=use), args.highres_frames) for use in (False, True)}
         a = hmodel.render(pose, intr, use_occupancy_mask=False, perturb_sampled_points=False)
         b = hmodel.render(pose, intr, use_occupancy_mask=True, perturb_sampled_points=False)
         occ_bits = int(sum(bin(w & 0xFFFFFFFF).count("1") for w in hg.occupancy.cpu().tolist()))
         highres = {
-            "workload": f"configs[4]: 256^3 SH-{args.sh_degree} sparse ReLU field, {H}x{W}, 512 jittered samples/ray, VolumetricModel.render",
+            "workload": f"configs[4]: 256^3 SH-{args.sh_degree} sparse ReLU field, {H}x{W}, 512 jittered samples/ray, VolumetricModel.render (one launch per frame)",
             "ms_per_frame_no_mask": times[False] * 1e3,
             "ms_per_frame_occupancy_mask": times[True] * 1e3,
             "ray_samples_per_s_occupancy_mask": H * W * 512 / times[True],
             "occupied_cell_fraction": occ_bits / float(257**3),
             "mask_build_ms": t_build * 1e3,
-            "mask_is_exact": bool(torch.equal(a.colour, b.colour) and torch.equal(a.depth, b.depth)),
+            "mask_vs_no_mask_bit_identical": bool(torch.equal(a.colour, b.colour) and torch.equal(a.depth, b.depth)),
+            "oracle_checked_by": "tests/test_hip_baseline_size.py::test_highres_occupancy_render_against_oracle_at_config4_size",
         }
         del hmodel, hg, a, b
         torch.cuda.empty_cache()
 
+    # ---- strict drop-in: reference storage, torch.autograd.Function ops, torch.randperm selection, torch.rand jitter ----
+    dropin = None
+    if args.dropin_steps > 0 and rank == 0 and world == 1:
+        dgrid = make_grid(dev, G, args.sh_degree, seed=42, storage="reference")
+        dcfg = rf.SHVoxGridRenderConfig(S, bounds, perturb_sampled_points=True, white_bkgd=True, jitter="torch")
+        dmodel = rf.VolumetricModel(dgrid, rf.render_sh_voxel_grid, dcfg, device=dev)
+        dstep = TrainStepper(dmodel, R, learning_rate=0.03, fused=False, ray_selection="randperm", backward="atomic", data_parallel=False)
+        torch.manual_seed(99)
+        dbatches = dataset.image_batches(args.images)
+        for _ in range(5):
+            dstep.step(dataset, next(dbatches))
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(args.dropin_steps):
+            dstep.step(dataset, next(dbatches))
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t0) / args.dropin_steps
+        dropin = {
+            "workload": "the same iteration the way a reference user gets it: VoxelGrid in the reference's two tensors, render_sh_voxel_grid as a "
+            "torch.autograd.Function (rf_render_forward / rf_render_backward), torch.randperm over all pixels, torch.rand jitter, L1 via autograd, fused Adam",
+            "ms_per_step": dt * 1e3,
+            "ray_samples_per_s": 2 * R * S / dt,
+            "steps": args.dropin_steps,
+            "warmup": 5,
+        }
+        dstep.flat.detach()
+        del dstep, dmodel, dgrid
+        torch.cuda.empty_cache()
+
     # ---- training steps: the headline ---------------------------------------------------------------
-    stepper = TrainStepper(model, R, learning_rate=0.03, apply_diffuse_render_regularization=True, ray_selection=args.ray_selection, backward=args.backward, deterministic=args.deterministic)
+    stepper = TrainStepper(model, R, learning_rate=0.03, apply_diffuse_render_regularization=True, ray_selection=args.ray_selection, backward=args.backward,
+                           deterministic=args.deterministic, fuse_optimizer=False if args.no_fuse_optimizer else None)
+    executor = stepper.fused and stepper.merged_bricks and args.ray_selection == "keyed"
     torch.manual_seed(1234 + rank)  # every rank draws its own rays
     batches = dataset.image_batches(args.images)
     for _ in range(args.warmup):
         stepper.step(dataset, next(batches))
-    # HIP events are recorded on every `timer_stride`-th timed step only: hundreds of outstanding timing events
-    # make the ROCm runtime stall for tens of ms now and then (measured: 2.0 -> 2.9 ms/step in some runs)
+    # per-kernel HIP events on `--timed-steps` of the timed steps, recorded by the library between its own launches
     timer_stride = max(1, args.steps // max(1, args.timed_steps))
-    n_timed = 0 if args.no_kernel_timer else len(range(0, args.steps, timer_stride))
-    timer = ops.KernelTimer(preallocate=12 * n_timed)
+    timed_idx = [i for i in range(0, args.steps, timer_stride)] if args.timed_steps > 0 else []
+    events = [ops.StepEvents() for _ in timed_idx] if executor else []
+    legacy_timer = ops.KernelTimer(preallocate=14 * len(timed_idx)) if (timed_idx and not executor) else None
+    counts = torch.zeros((max(1, len(timed_idx)), 2), dtype=torch.int64, device=dev)  # records emitted per render on the event steps
     if world > 1:
         torch.distributed.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
+    k = 0
     for i in range(args.steps):
-        ops.KERNEL_TIMER = timer if (not args.no_kernel_timer and i % timer_stride == 0) else None
+        on = k < len(timed_idx) and i == timed_idx[k]
+        if executor:
+            stepper.step_events = events[k] if on else None
+        else:
+            ops.KERNEL_TIMER = legacy_timer if on else None
         stats = stepper.step(dataset, next(batches))
-    host_issue = time.perf_counter() - t0  # time the host needed to enqueue all steps (GPU runs asynchronously)
+        if on:
+            if executor:  # a 16-byte device-side copy; no sync
+                ex = stepper._exec["tensors"]
+                counts[k, 0].copy_(ex["pass0"]["offsets"][-1], non_blocking=True)
+                counts[k, 1].copy_(ex["pass1"]["offsets"][-1], non_blocking=True)
+            k += 1
+    host_issue = time.perf_counter() - t0  # time the host needed to enqueue all steps (the launch queue back-pressures it)
     torch.cuda.synchronize()
     if world > 1:
         torch.distributed.barrier()
     elapsed = time.perf_counter() - t0
     ops.KERNEL_TIMER = None
+    stepper.step_events = None
+    exchange_bytes = 0
     if world > 1:
         te = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         torch.distributed.all_reduce(te, op=torch.distributed.ReduceOp.MAX)
         elapsed = float(te.item())
+        # reduce-scatter + all-gather (or all-reduce) of the flat bucket: 2 (N-1)/N x bucket bytes sent per rank per step
+        exchange_bytes = int(2 * (world - 1) / world * stepper.flat.flat_grad.numel() * 4)
         # every rank leaves the group together, BEFORE rank 0 starts its single-process reporting legs
         torch.distributed.barrier()
         torch.distributed.destroy_process_group()
@@ -289,83 +417,78 @@ def main():
     ms_per_step = elapsed / args.steps * 1e3
     value = world * 2 * R * S * args.steps / elapsed
 
-    # ---- roofline of the dominant kernel (HIP events recorded inside the timed region) ------------
-    ksum = timer.summary()
+    # ---- per-kernel times of the timed region -------------------------------------------------------
+    kernels = {}
+    if executor and events:
+        per = [e.elapsed_ms() for e in events]
+        for name in per[0]:
+            kernels[name] = {"avg_ms": float(np.mean([p[name] for p in per])), "launches": len(per)}
+    elif legacy_timer is not None:
+        for name, rec in legacy_timer.summary().items():
+            kernels[name] = {"avg_ms": rec["avg_ms"], "launches": rec["launches"]}
+    rec_counts = counts.cpu().numpy().astype(np.float64)
+    rec_spec = float(rec_counts[:, 0].mean()) if executor and timed_idx else None
+    rec_diff = float(rec_counts[:, 1].mean()) if executor and timed_idx else None
+    # in-AABB samples of a batch (harness-side, un-jittered positions): density is gathered for these
     rays, pixels = stepper.select(dataset, next(batches))
     n_in = count_inside(rays.origins, rays.directions, S, grid.aabb)
-    C = 3 * (args.sh_degree + 1) ** 2 + 1
-    alg_bytes = {
-        f"render_forward[sh{args.sh_degree},save]": n_in * 8 * C * 4 + R * 48,
-        "render_forward[diffuse,save]": n_in * 8 * 4 * 4 + R * 48,
-        f"render_backward[sh{args.sh_degree}]": n_in * 8 * C * 4 + R * 48,
-        "render_backward[diffuse]": n_in * 8 * 4 * 4 + R * 48,
-        "adam_step": G**3 * C * 4 * 7,
-        # binned specular backward: the brick pass is the kernel that moves the scatter payload (8 corners x C
-        # x 4 B per in-AABB sample) into the gradient tensor; emit / bin / scatter-expand are its front end
-        f"brick_accumulate[sh{args.sh_degree}]": n_in * 8 * C * 4,
-        "brick_accumulate[diffuse]": n_in * 8 * 4 * 4,
-    }
-    kernels = {}
-    for name, rec in ksum.items():
-        b = alg_bytes.get(name)
-        kernels[name] = {"avg_ms": rec["avg_ms"], "launches": rec["launches"]}
-        if b:
-            kernels[name]["algorithmic_GB"] = b / 1e9
-            kernels[name]["effective_GBps"] = b / 1e9 / (rec["avg_ms"] / 1e3)
-    render_kernels = {k: v for k, v in ksum.items() if k in alg_bytes}  # every kernel of the step with a byte model
-    if not render_kernels:
-        print(json.dumps({"ms_per_step": ms_per_step, "value": value, "host_issue_ms_per_step": host_issue / args.steps * 1e3, "note": "kernel timer off"}))
-        return
-    dom = max(render_kernels, key=lambda k: render_kernels[k]["total_ms"])
-    achieved = alg_bytes[dom] / 1e9 / (ksum[dom]["avg_ms"] / 1e3)
-    roofline = {
-        "kernel": dom,
-        "bound": "hbm",
-        "achieved": achieved,
-        "peak": HBM_PEAK_GBS,
-        "unit": "GB/s",
-        "frac": achieved / HBM_PEAK_GBS,
-        "traffic": None,
-        "algorithmic_bytes_per_launch": alg_bytes[dom],
-        "avg_launch_ms": ksum[dom]["avg_ms"],
-        "note": (
-            "streaming kernel: 4 reads + 3 writes of 4 B per parameter (param, grad, exp_avg, exp_avg_sq); algorithmic = real traffic"
-            if dom == "adam_step"
-            else "effective bandwidth: algorithmic gather/scatter bytes (8 corners x C x 4 B per in-AABB sample, SURVEY 8d), "
-            "not credited for cache reuse or skipped zero-weight samples, so it can exceed DRAM traffic"
-        ),
-        "by_kernel": {
-            k: {"avg_launch_ms": ksum[k]["avg_ms"], "achieved": alg_bytes[k] / 1e9 / (ksum[k]["avg_ms"] / 1e3), "frac": alg_bytes[k] / 1e9 / (ksum[k]["avg_ms"] / 1e3) / HBM_PEAK_GBS}
-            for k in render_kernels
-        },
-    }
-    spec = f"sh{args.sh_degree}"
-    pipeline = [k for k in ksum if k in (f"render_backward_emit[{spec}]", f"render_backward_emit_direct[{spec}]", "sort_keys", "expand_records", f"scatter_records[{spec}]", f"brick_accumulate[{spec}]")]
-    if f"brick_accumulate[{spec}]" in ksum:
-        # the whole specular backward (emit -> bin -> scatter-expand -> brick pass) against the same scatter payload
-        # (bin_offsets, 10 us, is shared by both passes and counted once)
-        total_ms = sum(ksum[k]["avg_ms"] for k in pipeline) + ksum.get("bin_offsets", {"avg_ms": 0.0})["avg_ms"]
-        pbytes = alg_bytes[f"brick_accumulate[{spec}]"] + R * 48
-        roofline["pipeline"] = {
-            "kernels": pipeline,
-            "total_ms": total_ms,
-            "algorithmic_bytes": pbytes,
-            "achieved": pbytes / 1e9 / (total_ms / 1e3),
-            "frac": pbytes / 1e9 / (total_ms / 1e3) / HBM_PEAK_GBS,
+    nparam = G**3 * C
+
+    roofline = None
+    if kernels and rec_spec is not None:
+        fused_opt = stepper.fuse_optimizer
+        # algorithmic bytes (SURVEY 8d per-unit figures) on the units each launch really processes:
+        #   forward:  8 corners x C x 4 B per sample whose features are gathered (= the records), 8 x 16 B (the base record) for
+        #             the other in-AABB samples (density only), 20 B of cache per slot written, 48 B per ray
+        #   emit:     20 B cache read + the expanded record written (128 B specular, 32 B diffuse) per record
+        #   bricks:   the scatter payload 8 x C x 4 B per specular record + 8 x 4 x 4 B per diffuse record, plus the optimizer
+        #             traffic when it is fused (3 reads + 3 writes of 4 B per parameter; else the bucket is written once)
+        alg = {
+            "render_forward[spec,save]": rec_spec * 8 * C * 4 + max(n_in - rec_spec, 0) * 8 * 16 + R * S * 20 + R * 48,
+            "render_forward[diffuse,save]": n_in * 8 * 16 + R * S * 20 + R * 48,
+            "render_backward_emit_direct[spec]": rec_spec * (20 + 4 * ops.expanded_record_floats(grid)),
+            "render_backward_emit_direct[diffuse]": rec_diff * (20 + 4 * ops.expanded_record_floats(grid, True)),
+            "brick_accumulate": rec_spec * 8 * C * 4 + rec_diff * 8 * 4 * 4 + nparam * 4 * (6 if fused_opt else 1),
         }
-        roofline["pipeline"]["note"] = "the binned specular backward as a whole (scan -> emit at final positions -> brick pass; its counting runs inside the forward pass) against the scatter payload of SURVEY 8d"
-    prof = os.path.join(ROOT, "profiles", "pmc_traffic.json")
-    if os.path.exists(prof):
-        try:
-            table = json.load(open(prof))
-            roofline["traffic"] = table.get(dom, {}).get("hbm_bytes_per_launch")
-            roofline["traffic_source"] = table.get("_source")
-        except Exception:
-            pass
+        names = {"brick_accumulate": f"brick_accumulate_adam[{spec}]" if fused_opt else f"brick_accumulate[{spec}]"}
+        by_kernel = {}
+        for kname, b in alg.items():
+            ms = kernels[kname]["avg_ms"]
+            counter = pmc.get(names.get(kname, kname), {}).get("hbm_bytes_per_launch")
+            by_kernel[kname] = {
+                "avg_launch_ms": ms,
+                "algorithmic_bytes_processed": b,
+                "frac_processed": frac(b, ms, f"{kname} (processed units)"),
+                "counter_bytes_per_launch": counter,
+                "frac_hbm": None if counter is None else frac(counter, ms, f"{kname} (counters)"),
+            }
+        dom = max(alg, key=lambda kname: kernels[kname]["avg_ms"])
+        d = by_kernel[dom]
+        traffic = d["counter_bytes_per_launch"]
+        achieved_bytes = traffic if traffic is not None else d["algorithmic_bytes_processed"]
+        roofline = {
+            "kernel": names.get(dom, dom),
+            "bound": "hbm",
+            "achieved": achieved_bytes / 1e9 / (d["avg_launch_ms"] / 1e3),
+            "peak": HBM_PEAK_GBS,
+            "unit": "GB/s",
+            "frac": d["frac_hbm"] if d["frac_hbm"] is not None else d["frac_processed"],
+            "frac_basis": "HBM bytes from the PMC counters (profiles/pmc_traffic.json) / this run's launch time" if traffic is not None
+            else "algorithmic bytes on processed units (no counter entry for this kernel in profiles/pmc_traffic.json)",
+            "traffic": traffic,
+            "avg_launch_ms": d["avg_launch_ms"],
+            "frac_processed": d["frac_processed"],
+            "algorithmic_bytes_processed": d["algorithmic_bytes_processed"],
+            "units_processed": {"records_specular": rec_spec, "records_diffuse": rec_diff, "in_aabb_samples": n_in, "nominal_samples": R * S, "parameters": nparam},
+            "note": "brick pass: both renders' gradient records summed per 8^3-node brick in LDS (no float atomics)"
+            + (", Adam applied in the flush (no gradient tensor in HBM)" if fused_opt else "") + "; LDS-latency bound, see DESIGN section 4",
+            "traffic_source": pmc.get("_source"),
+            "by_kernel": by_kernel,
+        }
 
     baseline = None
     if args.cpu_rays > 0:
-        baseline = cpu_baseline(grid, (rays.origins.cpu(), rays.directions.cpu()), pixels.cpu(), S, args.cpu_rays, args.cpu_threads)
+        baseline = cpu_baseline(grid, (rays.origins.cpu(), rays.directions.cpu()), pixels.cpu(), S, args.cpu_rays, args.cpu_fwd_rays, args.cpu_threads)
 
     line = {
         "metric": "ray-samples/sec (fwd+bwd) training step, 800x800 images @ 128^3 SH-2 ReLU field",
@@ -376,7 +499,7 @@ def main():
         "warmup": args.warmup,
         "ms_per_step": ms_per_step,
         "host_issue_ms_per_step": host_issue / args.steps * 1e3,
-        "kernel_timer_steps": n_timed,
+        "kernel_timer_steps": len(timed_idx),
         "higher_is_better": True,
         "scaling": "weak",
         "vs_baseline": None,
@@ -384,7 +507,8 @@ def main():
         "data": "synthetic",
         "config": {
             "workload": f"configs[2]: train step on {G}^3 SH-degree-{args.sh_degree} ReLU field (U(-1,1) init), {args.images} synthetic {H}x{W} images, "
-            f"{R} random distinct pixels/GPU/step out of all {args.images}x{H}x{W} ({args.ray_selection} selection), {S} jittered samples/ray, specular+diffuse fwd+bwd, L1+L1, fused Adam"
+            f"{R} random distinct pixels/GPU/step out of all {args.images}x{H}x{W} ({args.ray_selection} selection), {S} jittered samples/ray, specular+diffuse fwd+bwd, L1+L1, "
+            + ("Adam fused into the brick flush" if stepper.fuse_optimizer else "fused Adam kernel")
             + (", gradient exchange over RCCL: reduce-scatter -> Adam on 1/N of the grid per rank -> all-gather" if world > 1 else ""),
             "rays_per_gpu_per_step": R,
             "samples_per_ray": S,
@@ -393,7 +517,11 @@ def main():
             "grid_storage": args.storage,
             "ray_selection": args.ray_selection,
             "backward": stepper.backward,
+            "merged_brick_pass": bool(stepper.merged_bricks),
+            "fused_optimizer": bool(stepper.fuse_optimizer),
+            "one_call_per_step": bool(executor),
         },
+        "distributed": {"backend": backend, "world_size_seen_by_collectives": rccl_world, "exchange_bytes_sent_per_rank_per_step": exchange_bytes},
         "rays_per_s": world * 2 * R * args.steps / elapsed,
         "final_specular_psnr": stats.psnr()["specular_psnr"],
         "inside_fraction": n_in / (R * S),
@@ -402,6 +530,8 @@ def main():
         "cpu_baseline": baseline,
         "fwd_render": fwd_render,
         "highres_render": highres,
+        "strict_dropin": dropin,
+        "roofline_model_errors": MODEL_ERRORS,
     }
     print(json.dumps(line))
 

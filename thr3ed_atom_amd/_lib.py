@@ -180,7 +180,14 @@ class RFTrainStep(C.Structure):
         ("adam", C.POINTER(RFAdamState)),
         ("grad_first_dev", C.c_void_p),
         ("grad_second_dev", C.c_void_p),
+        ("timing_events", C.POINTER(C.c_void_p)),
     ]
+
+
+TRAIN_STEP_EVENTS = 11
+TRAIN_STEP_EVENT_NAMES = ["select_rays_and_pixels", "render_forward[spec,save]", "l1_loss_grad[spec]", "render_forward[diffuse,save]", "l1_loss_grad[diffuse]",
+                          "bin_offsets[spec]", "render_backward_emit_direct[spec]", "bin_offsets[diffuse]", "render_backward_emit_direct[diffuse]",
+                          "brick_accumulate"]
 
 
 def build(force: bool = False, verbose: bool = False) -> str:

@@ -3035,12 +3035,19 @@ int rf_train_step(const RFGrid* grid, const RFTrainStep* step, void* stream) {
   if (step->pass[1].out.brick_size != step->pass[0].out.brick_size) return RF_ERR_BAD_SHAPE;
   const int nkeys = nb[0] * nb[1] * nb[2] * 8;
   hipStream_t st = (hipStream_t)stream;
+  int ev = 0;
+#define RF_STEP_EVENT()                                                                                      \
+  do {                                                                                                       \
+    if (step->timing_events && hipEventRecord((hipEvent_t)step->timing_events[ev++], st) != hipSuccess) return RF_ERR_LAUNCH; \
+  } while (0)
+  RF_STEP_EVENT();
   if (step->select) {
     const RFRaySelection* s = step->select;
     rc = rf_select_rays_and_pixels(s->height, s->width, s->focal, s->poses_dev, s->image_ids_dev, s->num_batch_images, s->pixel_table_dev,
                                    s->key, s->first_index, step->num_rays, step->origins_dev, step->directions_dev, step->pixels_dev, nullptr, stream);
     if (rc != RF_OK) return rc;
   }
+  RF_STEP_EVENT();
   if (hipMemsetAsync(step->loss_sums_dev, 0, 4 * sizeof(float), st) != hipSuccess) return RF_ERR_LAUNCH;
   RFRayBatch rays[2];
   uint32_t flags[2];
@@ -3060,8 +3067,10 @@ int rf_train_step(const RFGrid* grid, const RFTrainStep* step, void* stream) {
     flags[i] = (step->flags & ~(uint32_t)RF_FLAG_RENDER_DIFFUSE) | (i == 1 ? (uint32_t)RF_FLAG_RENDER_DIFFUSE : 0u);
     rc = rf_render_forward(grid, &rays[i], flags[i], &ps.out, stream);
     if (rc != RF_OK) return rc;
+    RF_STEP_EVENT();
     rc = rf_l1_loss_grad(ps.out.colour_dev, step->pixels_dev, step->num_rays, 1.0f, ps.grad_colour_dev, step->loss_sums_dev + 2 * i, stream);
     if (rc != RF_OK) return rc;
+    RF_STEP_EVENT();
     grads[i] = RFRenderGrads{ps.grad_colour_dev, nullptr, nullptr};
   }
   RFBrickList lists[2];
@@ -3069,13 +3078,21 @@ int rf_train_step(const RFGrid* grid, const RFTrainStep* step, void* stream) {
     const RFPassScratch& ps = step->pass[i];
     rc = rf_bin_offsets(ps.out.key_hist_dev, nkeys, ps.offsets_dev, ps.cursor_dev, stream);
     if (rc != RF_OK) return rc;
+    RF_STEP_EVENT();
     rc = rf_render_backward_emit_direct(grid, &rays[i], flags[i], &ps.out, &grads[i], ps.out.brick_size, ps.cursor_dev, ps.records_sorted_dev,
                                         ps.out.key_hist_dev, stream);
     if (rc != RF_OK) return rc;
+    RF_STEP_EVENT();
     lists[i] = RFBrickList{ps.records_sorted_dev, ps.offsets_dev, i};
   }
-  if (step->adam) return rf_brick_accumulate_adam(grid, step->pass[0].out.brick_size, lists, 2, step->adam, stream);
-  return rf_brick_accumulate(grid, step->pass[0].out.brick_size, lists, 2, step->grad_first_dev, step->grad_second_dev, 0, stream);
+  if (step->adam)
+    rc = rf_brick_accumulate_adam(grid, step->pass[0].out.brick_size, lists, 2, step->adam, stream);
+  else
+    rc = rf_brick_accumulate(grid, step->pass[0].out.brick_size, lists, 2, step->grad_first_dev, step->grad_second_dev, 0, stream);
+  if (rc != RF_OK) return rc;
+  RF_STEP_EVENT();
+#undef RF_STEP_EVENT
+  return RF_OK;
 }
 
 }  // extern "C"

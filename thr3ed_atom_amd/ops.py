@@ -75,6 +75,42 @@ class _NoSpan:
 KERNEL_TIMER: Optional[KernelTimer] = None
 
 
+class StepEvents:
+    """The RF_TRAIN_STEP_EVENTS HIP events rf_train_step records around its launches (RFTrainStep.timing_events): raw
+    hipEvent_t handles created through the HIP runtime (torch.cuda.Event creates its handle lazily and cannot be handed to C).
+    ``elapsed_ms()`` needs the stream to have passed the last event (synchronise first)."""
+
+    _hip = None
+
+    def __init__(self):
+        if StepEvents._hip is None:
+            StepEvents._hip = C.CDLL("libamdhip64.so")
+        hip = StepEvents._hip
+        self.array = (C.c_void_p * _lib.TRAIN_STEP_EVENTS)()
+        for i in range(_lib.TRAIN_STEP_EVENTS):
+            ev = C.c_void_p()
+            if hip.hipEventCreate(C.byref(ev)) != 0:
+                raise RuntimeError("hipEventCreate failed")
+            self.array[i] = ev.value
+
+    def elapsed_ms(self) -> Dict[str, float]:
+        hip = StepEvents._hip
+        out = {}
+        for i, name in enumerate(_lib.TRAIN_STEP_EVENT_NAMES):
+            ms = C.c_float()
+            if hip.hipEventElapsedTime(C.byref(ms), C.c_void_p(self.array[i]), C.c_void_p(self.array[i + 1])) != 0:
+                raise RuntimeError("hipEventElapsedTime failed (events not recorded or not complete)")
+            out[name] = float(ms.value)
+        return out
+
+    def __del__(self):
+        hip = StepEvents._hip
+        if hip is not None:
+            for i in range(len(self.array)):
+                if self.array[i]:
+                    hip.hipEventDestroy(C.c_void_p(self.array[i]))
+
+
 def _span(name: str, device):
     return KERNEL_TIMER.span(name, device) if KERNEL_TIMER is not None else _NoSpan()
 
@@ -175,6 +211,47 @@ def render_forward_raw(grid: VoxelGrid, origins: Tensor, directions: Tensor, t_r
         rc = lib.rf_render_forward(C.byref(rf_grid), C.byref(rb), _jitter_flags(flags, t_rand), C.byref(out), _stream(dev))
     _lib.check(rc, "rf_render_forward")
     return colour, depth, acc, disparity, caches
+
+
+def render_frame_raw(grid: VoxelGrid, height: int, width: int, focal: float, rotation, translation, num_samples: int, near: float, far: float,
+                     flags: int, jitter: Optional[KeyedJitter], first_ray: int = 0, num_rays: Optional[int] = None):
+    """Pixels [first_ray, first_ray + num_rays) (row-major; default: the whole frame) of a posed pinhole camera in ONE launch of
+    rf_render_forward: the rays are generated inside the kernel (RFRayBatch.camera: cast_rays of utils/misc.py:12-50 fused) and
+    the stratified jitter, if any, is the counter-based one keyed by (jitter.key, pixel index) -- no ray tensors, no [N, S]
+    random tensor.  Returns (colour [n,3], depth [n,1], acc [n,1], disparity [n,1]).  Inference only (no cache)."""
+    lib = _lib.load()
+    first, _ = grid.kernel_tensors()
+    dev = first.device
+    _require_hip(first, "grid tensor")
+    n = int(height) * int(width) - int(first_ray) if num_rays is None else int(num_rays)
+    cam = _lib.RFCamera()
+    cam.height, cam.width, cam.focal = int(height), int(width), float(np.float32(focal))
+    rot = torch.as_tensor(rotation).detach().to("cpu", torch.float32).reshape(3, 3)
+    trans = torch.as_tensor(translation).detach().to("cpu", torch.float32).reshape(3)
+    for i in range(3):
+        for j in range(3):
+            cam.pose[4 * i + j] = float(rot[i, j])
+        cam.pose[4 * i + 3] = float(trans[i])
+    rb = _lib.RFRayBatch()
+    rb.num_rays, rb.num_samples, rb.near, rb.far = n, int(num_samples), near, far
+    tv = t_vals_for(num_samples, dev)
+    rb.t_vals_dev = tv.data_ptr()
+    rb.first_ray = int(first_ray)
+    rb.camera = C.pointer(cam)
+    if jitter is not None:
+        rb.jitter_key = int(jitter.key) & 0xFFFFFFFFFFFFFFFF
+        flags = int(flags) | _lib.FLAG_JITTER_KEYED
+    rf_grid = grid.to_rf_grid(use_occupancy=bool(flags & _lib.FLAG_OCCUPANCY_SKIP))
+    colour = torch.empty((n, 3), dtype=torch.float32, device=dev)
+    depth = torch.empty((n, 1), dtype=torch.float32, device=dev)
+    acc = torch.empty((n, 1), dtype=torch.float32, device=dev)
+    disparity = torch.empty((n, 1), dtype=torch.float32, device=dev)
+    out = _lib.RFRenderOut()
+    out.colour_dev, out.depth_dev, out.acc_dev, out.disparity_dev = colour.data_ptr(), depth.data_ptr(), acc.data_ptr(), disparity.data_ptr()
+    with _span(f"render_forward[{_variant(grid, flags)},frame]", dev):
+        rc = lib.rf_render_forward(C.byref(rf_grid), C.byref(rb), int(flags), C.byref(out), _stream(dev))
+    _lib.check(rc, "rf_render_forward")
+    return colour, depth, acc, disparity
 
 
 def render_backward_raw(grid: VoxelGrid, origins: Tensor, directions: Tensor, t_rand: Optional[Tensor], num_samples: int,

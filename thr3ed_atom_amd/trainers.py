@@ -177,6 +177,7 @@ class TrainStepper:
         self.brick_size = int(os.environ.get("RF_BRICK_SIZE", "8"))  # (experiments: 4)
         self._bins = None
         self._exec = None
+        self.step_events = None  # an ops.StepEvents: the next rf_train_step call records its per-launch HIP events there
         grid = vol_mod.thre3d_repr
         if not isinstance(grid, VoxelGrid):
             raise AssertionError(f"cannot train a {type(grid)}; only a VoxelGrid can be used")
@@ -350,6 +351,7 @@ class TrainStepper:
             st.adam = None
             gd, gf = self.flat.views_for_accumulation()
             st.grad_first_dev, st.grad_second_dev = gd.data_ptr(), None if gf is None else gf.data_ptr()
+        st.timing_events = self.step_events.array if self.step_events is not None else None
         with ops._span("train_step", dev):
             rc = _lib.load().rf_train_step(C.byref(rf_grid), C.byref(st), torch.cuda.current_stream(dev).cuda_stream)
         _lib.check(rc, "rf_train_step")

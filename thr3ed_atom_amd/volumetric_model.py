@@ -23,7 +23,7 @@ from .constants import (
 from . import distributed as rfdist
 from .ops import cast_rays_hip
 from .render_interface import Rays, RenderOut, collate_rendered_output, flatten_rays, reshape_rendered_output
-from .renderers import RenderConfig, RenderProcedure
+from .renderers import RenderConfig, RenderProcedure, render_sh_voxel_grid, render_sh_voxel_grid_frame
 
 
 def cast_rays(camera_intrinsics: CameraIntrinsics, pose: CameraPose, device=None) -> Rays:
@@ -114,8 +114,31 @@ class VolumetricModel:
         honoured so that outputs and RNG consumption follow the reference chunk by chunk.
         ``data_parallel=True`` (extension): under torch.distributed the frame's rays are split over the ranks and
         the results gathered; every rank returns the full image."""
+        cfg = self._update_render_config(self._render_config, kwargs)
+        height, width, _ = camera_intrinsics
+        total_rays = int(height) * int(width)
+        if (
+            self._render_procedure is render_sh_voxel_grid
+            and gpu_render
+            and not verbose
+            and (not getattr(cfg, "perturb_sampled_points", False) or getattr(cfg, "jitter", "keyed") == "keyed")
+        ):
+            # the HIP procedure renders a frame (or this rank's share of it) in ONE launch: rays and jitter are generated inside
+            # the kernel, so there is nothing to chunk -- ``parallel_rays_chunk_size`` does not change a single bit of the result
+            lo, hi = (0, total_rays)
+            dp = data_parallel and rfdist.world_size() > 1
+            if dp:
+                lo, hi = rfdist.shard_range(total_rays)
+            with torch.no_grad():
+                out = render_sh_voxel_grid_frame(self._thre3d_repr, camera_intrinsics, camera_pose, cfg, first_ray=lo, num_rays=hi - lo)
+            if dp:
+                keys = sorted(out.extra.keys())
+                packed = torch.cat([out.colour, out.depth] + [out.extra[k] for k in keys], dim=-1)
+                packed = rfdist.all_gather_rows(packed)
+                assert packed.shape[0] == total_rays
+                out = RenderOut(packed[:, :3], packed[:, 3:4], {k: packed[:, 4 + i : 5 + i] for i, k in enumerate(keys)})
+            return reshape_rendered_output(out, camera_intrinsics)
         flat = flatten_rays(cast_rays(camera_intrinsics, camera_pose, self._device))
-        total_rays = len(flat)
         if data_parallel and rfdist.world_size() > 1:
             # rays are independent: every rank renders one contiguous range of the frame against its own replica of
             # the grid; the only exchange is the gather of the [n, 6] per-ray results at the end

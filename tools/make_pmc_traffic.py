@@ -1,0 +1,84 @@
+#!/usr/bin/env python
+"""Build profiles/pmc_traffic.json (HBM bytes per launch, by bench.py kernel name) from rocprofv3 --pmc passes.
+
+    cd /tmp && export TMPDIR=/tmp
+    rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d <out>/fetch -- python bench.py <PROFILE ARGS>
+    rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d <out>/write -- python bench.py <PROFILE ARGS>
+    python tools/make_pmc_traffic.py <out>/fetch <out>/write --gt-frames 8 --frames-per-leg 3 > profiles/pmc_traffic.json
+
+with PROFILE ARGS = --steps 20 --warmup 5 --cpu-rays 0 --dropin-steps 0 --highres-frames 0 --render-frames 1 (separate passes, as the
+microarchitecture guide prescribes: FETCH_SIZE and WRITE_SIZE do not fit one pass).  hbm_bytes = 2 x FETCH_SIZE x 1024 (gfx950 tallies
+a 128-B fill as 64 B; calibrated on the streaming optimizer traffic, see profiles/*_pmc.md) + WRITE_SIZE x 1024.
+The full-frame render launches `render_forward_kernel<9,false,false>` for the dataset images first (--gt-frames launches), then
+--frames-per-leg launches per fwd_render leg in bench.py's order (init_field, traversal); they are told apart by dispatch order."""
+import argparse
+import csv
+import glob
+import json
+import os
+import sys
+from collections import defaultdict
+
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+from summarize_rocprof import short  # noqa: E402
+
+csv.field_size_limit(1 << 30)
+
+BENCH_NAMES = {
+    "render_forward_kernel<9, false, true>": "render_forward[spec,save]",
+    "render_forward_kernel<1, true, true>": "render_forward[diffuse,save]",
+    "render_backward_kernel<9, false, 2>": "render_backward_emit_direct[spec]",
+    "render_backward_kernel<1, true, 2>": "render_backward_emit_direct[diffuse]",
+    "render_backward_kernel<9, false, 0>": "render_backward[sh2]",
+    "render_backward_kernel<1, true, 0>": "render_backward[diffuse]",
+    "brick_accumulate_kernel<9, true>": "brick_accumulate_adam[sh2]",
+    "brick_accumulate_kernel<9, false>": "brick_accumulate[sh2]",
+    "adam_kernel": "adam_step",
+    "bin_offsets_kernel": "bin_offsets",
+}
+
+
+def per_dispatch(root, counter):
+    rows = []
+    for path in glob.glob(os.path.join(root, "**", "*counter_collection.csv"), recursive=True):
+        for r in csv.DictReader(open(path)):
+            if r["Counter_Name"] == counter:
+                rows.append((int(r["Dispatch_Id"]), short(r["Kernel_Name"]), float(r["Counter_Value"])))
+    rows.sort()
+    return rows
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("fetch_dir")
+    ap.add_argument("write_dir")
+    ap.add_argument("--gt-frames", type=int, default=8)
+    ap.add_argument("--frames-per-leg", type=int, default=3)
+    ap.add_argument("--source", default="")
+    args = ap.parse_args()
+    by = {"FETCH_SIZE": defaultdict(list), "WRITE_SIZE": defaultdict(list)}
+    for counter, root in (("FETCH_SIZE", args.fetch_dir), ("WRITE_SIZE", args.write_dir)):
+        for _, name, val in per_dispatch(root, counter):
+            by[counter][name].append(val)
+    out = {"_source": args.source or f"rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) of bench.py; hbm_bytes = FETCH_SIZE*1024*2 (gfx950) + WRITE_SIZE*1024, average per launch"}
+
+    def entry(fetch, write):
+        f = sum(fetch) / max(len(fetch), 1) * 1024 * 2
+        w = sum(write) / max(len(write), 1) * 1024
+        return {"hbm_bytes_per_launch": int(f + w), "fetch_bytes_corrected": int(f), "write_bytes": int(w), "launches": len(fetch)}
+
+    for kname, bname in BENCH_NAMES.items():
+        if by["FETCH_SIZE"].get(kname) and by["WRITE_SIZE"].get(kname):
+            out[bname] = entry(by["FETCH_SIZE"][kname], by["WRITE_SIZE"][kname])
+    frame = "render_forward_kernel<9, false, false>"
+    f, w = by["FETCH_SIZE"].get(frame, []), by["WRITE_SIZE"].get(frame, [])
+    g, n = args.gt_frames, args.frames_per_leg
+    for i, leg in enumerate(("init_field", "traversal")):
+        fs, ws = f[g + i * n : g + (i + 1) * n], w[g + i * n : g + (i + 1) * n]
+        if fs and ws:
+            out[f"render_forward[sh2,frame]:{leg}"] = entry(fs, ws)
+    print(json.dumps(out, indent=1))
+
+
+if __name__ == "__main__":
+    main()
