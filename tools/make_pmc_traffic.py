@@ -60,11 +60,15 @@ def main():
     for counter, root in (("FETCH_SIZE", args.fetch_dir), ("WRITE_SIZE", args.write_dir)):
         for _, name, val in per_dispatch(root, counter):
             by[counter][name].append(val)
-    out = {"_source": args.source or f"rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) of bench.py; hbm_bytes = FETCH_SIZE*1024*2 (gfx950) + WRITE_SIZE*1024, average per launch"}
+    out = {"_source": args.source or f"rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) of bench.py; hbm_bytes = FETCH_SIZE*1024*2 (gfx950) + WRITE_SIZE*1024, median per launch"}
 
-    def entry(fetch, write):
-        f = sum(fetch) / max(len(fetch), 1) * 1024 * 2
-        w = sum(write) / max(len(write), 1) * 1024
+    def median(v):
+        v = sorted(v)
+        return 0.5 * (v[(len(v) - 1) // 2] + v[len(v) // 2]) if v else 0.0
+
+    def entry(fetch, write):  # median per launch: a few launches of the same kernel on other inputs (harness probes) do not skew it
+        f = median(fetch) * 1024 * 2
+        w = median(write) * 1024
         return {"hbm_bytes_per_launch": int(f + w), "fetch_bytes_corrected": int(f), "write_bytes": int(w), "launches": len(fetch)}
 
     for kname, bname in BENCH_NAMES.items():
