@@ -148,6 +148,10 @@ typedef struct RFRenderGrads {
 
 int rf_abi_version(void);
 const char* rf_error_string(int code);
+/* sizeof() of the ABI structs as this library was compiled, so that a binding can verify its own mirrors before the first
+ * call: which = 0 RFGrid, 1 RFRayBatch, 2 RFRenderOut, 3 RFRenderGrads, 4 RFBrickList, 5 RFAdamState, 6 RFCamera,
+ * 7 RFRaySelection, 8 RFPassScratch, 9 RFTrainStep; -1 for any other value. */
+int rf_abi_struct_size(int which);
 
 /* cast_rays (rendering/volumetric/utils/misc.py:12-50) + flatten_rays (:53-57):
  * all H*W pixel-centre rays of one camera, row-major (ray = i*W + j).  rotation/translation are HOST

@@ -1,0 +1,199 @@
+"""thre3d_atom/thre3d_reprs/renderers_hip.py -- the file a maintainer of akanimax/thr3ed_atom adds to use the MI355X library.
+
+It binds `librelu_field_hip.so` (C ABI: include/relu_field.h, RF_ABI_VERSION 3) with ctypes and exposes
+
+    render_sh_voxel_grid_hip(voxel_grid, rays, render_config, parallel_points_chunk_size=None) -> RenderOut
+
+a `RenderProcedure` (thre3d_atom/thre3d_reprs/renderers.py:22-25) that is a drop-in for `render_sh_voxel_grid` (:48-102):
+
+    vol_mod = VolumetricModel(thre3d_repr=voxel_grid, render_procedure=render_sh_voxel_grid_hip, render_config=...)
+
+`voxel_grid` is the REFERENCE's own VoxelGrid (thre3d_reprs/voxels.py) living on a HIP device; `rays`/`RenderOut` are the
+reference's own types.  The render is differentiable w.r.t. `voxel_grid.densities` / `.features` through a
+torch.autograd.Function (forward = rf_render_forward with the per-sample cache, backward = rf_render_backward).
+This file depends on torch, numpy, ctypes and the reference package only -- NOT on the thr3ed_atom_amd Python package.
+
+The one other edit the reference needs: the identity assert of the trainer (modules/trainers.py:116-122) must accept the new
+procedure, e.g. `vol_mod.render_procedure in (render_sh_voxel_grid, render_sh_voxel_grid_hip)`.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+import torch
+
+from thre3d_atom.rendering.volumetric.render_interface import Rays, RenderOut
+from thre3d_atom.utils.constants import EXTRA_ACCUMULATED_WEIGHTS, EXTRA_DISPARITY
+
+RF_ABI_VERSION = 3
+_LIB_PATH = os.environ.get("RELU_FIELD_HIP_LIB", "librelu_field_hip.so")
+
+
+# ---- struct mirrors of include/relu_field.h, field for field ------------------------------------------------------------
+class RFGrid(C.Structure):
+    _fields_ = [("densities_dev", C.c_void_p), ("features_dev", C.c_void_p), ("dims", C.c_int32 * 3), ("num_features", C.c_int32),
+                ("density_stride", C.c_int64), ("feature_stride", C.c_int64), ("aabb_min", C.c_float * 3), ("aabb_max", C.c_float * 3),
+                ("norm_scale", C.c_float * 3), ("norm_bias", C.c_float * 3), ("density_scale", C.c_float), ("density_mode", C.c_int32),
+                ("layout", C.c_int32), ("occupancy_dev", C.c_void_p)]
+
+
+class RFRayBatch(C.Structure):
+    _fields_ = [("origins_dev", C.c_void_p), ("directions_dev", C.c_void_p), ("num_rays", C.c_int64), ("num_samples", C.c_int32),
+                ("near", C.c_float), ("far", C.c_float), ("t_vals_dev", C.c_void_p), ("t_rand_dev", C.c_void_p),
+                ("jitter_key", C.c_uint64), ("first_ray", C.c_int64), ("camera", C.c_void_p)]
+
+
+class RFRenderOut(C.Structure):
+    _fields_ = [("colour_dev", C.c_void_p), ("depth_dev", C.c_void_p), ("acc_dev", C.c_void_p), ("disparity_dev", C.c_void_p),
+                ("sample_cache_dev", C.c_void_p), ("trans_cache_dev", C.c_void_p), ("stop_cache_dev", C.c_void_p),
+                ("key_hist_dev", C.c_void_p), ("brick_size", C.c_int32)]
+
+
+class RFRenderGrads(C.Structure):
+    _fields_ = [("grad_colour_dev", C.c_void_p), ("grad_depth_dev", C.c_void_p), ("grad_acc_dev", C.c_void_p)]
+
+
+RF_FLAG_WHITE_BKGD, RF_FLAG_RENDER_DIFFUSE, RF_FLAG_AABB_SAMPLING = 1, 2, 4
+RF_DENSITY_RELU, RF_DENSITY_SOFTPLUS, RF_DENSITY_ABS, RF_DENSITY_IDENTITY = 0, 1, 2, 3
+RF_LAYOUT_REFERENCE = 0
+
+_lib = None
+
+
+def _library():
+    global _lib
+    if _lib is None:
+        lib = C.CDLL(_LIB_PATH)
+        lib.rf_abi_version.restype = C.c_int
+        lib.rf_error_string.restype = C.c_char_p
+        lib.rf_error_string.argtypes = [C.c_int]
+        lib.rf_render_forward.restype = C.c_int
+        lib.rf_render_forward.argtypes = [C.POINTER(RFGrid), C.POINTER(RFRayBatch), C.c_uint32, C.POINTER(RFRenderOut), C.c_void_p]
+        lib.rf_render_backward.restype = C.c_int
+        lib.rf_render_backward.argtypes = [C.POINTER(RFGrid), C.POINTER(RFRayBatch), C.c_uint32, C.POINTER(RFRenderOut), C.POINTER(RFRenderGrads),
+                                           C.c_void_p, C.c_void_p, C.c_void_p]
+        if lib.rf_abi_version() != RF_ABI_VERSION:
+            raise RuntimeError(f"{_LIB_PATH}: ABI version {lib.rf_abi_version()}, this binding was written for {RF_ABI_VERSION}")
+        _lib = lib
+    return _lib
+
+
+def _check(code, what):
+    if code != 0:
+        raise RuntimeError(f"{what} failed: {_library().rf_error_string(code).decode()} (code {code})")
+
+
+def _is_identity(fn):
+    return fn is None or isinstance(fn, torch.nn.Identity)
+
+
+def _density_mode(voxel_grid):
+    pre, post = voxel_grid._density_preactivation, voxel_grid._density_postactivation
+    if _is_identity(pre) and isinstance(post, torch.nn.ReLU):
+        return RF_DENSITY_RELU
+    if _is_identity(pre) and isinstance(post, torch.nn.Softplus) and post.beta == 1 and post.threshold == 20:
+        return RF_DENSITY_SOFTPLUS
+    if pre is torch.abs and _is_identity(post):
+        return RF_DENSITY_ABS
+    if _is_identity(pre) and _is_identity(post):
+        return RF_DENSITY_IDENTITY
+    raise ValueError(f"unsupported density activations for the HIP renderer: pre={pre}, post={post}")
+
+
+def _describe_grid(voxel_grid, densities, features):
+    """RFGrid of the reference's VoxelGrid: its own two tensors (RF_LAYOUT_REFERENCE), its AABB (voxels.py:187-212) and the
+    float32 (scale, bias) of adjust_dynamic_range(slack=True) (utils/imaging_utils.py:58-63) that _normalize_points applies."""
+    if not (_is_identity(voxel_grid._feature_preactivation) and _is_identity(voxel_grid._feature_postactivation)):
+        raise ValueError("the HIP renderer supports identity feature activations only")
+    if voxel_grid._radiance_transfer_function is not None:
+        raise ValueError("the HIP renderer does not take a radiance transfer function")
+    g = RFGrid()
+    g.densities_dev, g.features_dev = densities.data_ptr(), features.data_ptr()
+    for a, (lo, hi) in enumerate(voxel_grid.aabb):
+        g.dims[a] = int(densities.shape[a])
+        g.aabb_min[a], g.aabb_max[a] = float(np.float32(lo)), float(np.float32(hi))
+        scale = (np.float32(1.0) - np.float32(-1.0)) / (np.float32(hi) - np.float32(lo))
+        g.norm_scale[a] = float(scale)
+        g.norm_bias[a] = float(np.float32(-1.0) - np.float32(lo) * scale)
+    g.num_features, g.density_stride, g.feature_stride = int(features.shape[-1]), 1, int(features.shape[-1])
+    g.density_scale = float(voxel_grid._expected_density_scale)
+    g.density_mode = _density_mode(voxel_grid)
+    g.layout = RF_LAYOUT_REFERENCE
+    g.occupancy_dev = None
+    return g
+
+
+class _RenderFunction(torch.autograd.Function):
+    """forward: rf_render_forward (+ the per-sample cache when a gradient can be asked for); backward: rf_render_backward
+    into zero-filled gradient tensors -- what autograd does for the reference through ~120 ATen ops."""
+
+    @staticmethod
+    def forward(ctx, densities, features, origins, directions, t_vals, t_rand, voxel_grid, num_samples, near, far, flags):
+        lib = _library()
+        dev = origins.device
+        n = origins.shape[0]
+        need_grad = torch.is_grad_enabled() and (densities.requires_grad or features.requires_grad)
+        grid = _describe_grid(voxel_grid, densities, features)
+        rb = RFRayBatch(origins.data_ptr(), directions.data_ptr(), n, num_samples, near, far, t_vals.data_ptr(),
+                        None if t_rand is None else t_rand.data_ptr(), 0, 0, None)
+        colour = torch.empty((n, 3), dtype=torch.float32, device=dev)
+        depth, acc, disparity = (torch.empty((n, 1), dtype=torch.float32, device=dev) for _ in range(3))
+        out = RFRenderOut(colour.data_ptr(), depth.data_ptr(), acc.data_ptr(), disparity.data_ptr(), None, None, None, None, 0)
+        caches = ()
+        if need_grad:
+            caches = (torch.empty((n, num_samples, 4), dtype=torch.float32, device=dev), torch.empty((n, num_samples), dtype=torch.float32, device=dev),
+                      torch.empty((n,), dtype=torch.int32, device=dev))
+            out.sample_cache_dev, out.trans_cache_dev, out.stop_cache_dev = (c.data_ptr() for c in caches)
+        stream = torch.cuda.current_stream(dev).cuda_stream
+        _check(lib.rf_render_forward(C.byref(grid), C.byref(rb), flags, C.byref(out), stream), "rf_render_forward")
+        ctx.voxel_grid, ctx.args, ctx.need_grad, ctx.has_rand = voxel_grid, (num_samples, near, far, flags), need_grad, t_rand is not None
+        ctx.save_for_backward(densities, features, origins, directions, t_vals, *caches, *(() if t_rand is None else (t_rand,)))
+        ctx.mark_non_differentiable(disparity)
+        return colour, depth, acc, disparity
+
+    @staticmethod
+    def backward(ctx, g_colour, g_depth, g_acc, _g_disparity):
+        if not ctx.need_grad:
+            return (None,) * 11
+        lib = _library()
+        saved = ctx.saved_tensors
+        densities, features, origins, directions, t_vals, cache, tcache, stop = saved[:8]
+        t_rand = saved[8] if ctx.has_rand else None
+        num_samples, near, far, flags = ctx.args
+        dev = origins.device
+        grid = _describe_grid(ctx.voxel_grid, densities, features)
+        rb = RFRayBatch(origins.data_ptr(), directions.data_ptr(), origins.shape[0], num_samples, near, far, t_vals.data_ptr(),
+                        None if t_rand is None else t_rand.data_ptr(), 0, 0, None)
+        fwd = RFRenderOut(None, None, None, None, cache.data_ptr(), tcache.data_ptr(), stop.data_ptr(), None, 0)
+        keep = [None if g is None else g.detach().to(torch.float32).contiguous() for g in (g_colour, g_depth, g_acc)]
+        grads = RFRenderGrads(*[None if g is None else g.data_ptr() for g in keep])
+        grad_d, grad_f = torch.zeros_like(densities), torch.zeros_like(features)  # the library accumulates (+=)
+        stream = torch.cuda.current_stream(dev).cuda_stream
+        _check(lib.rf_render_backward(C.byref(grid), C.byref(rb), flags, C.byref(fwd), C.byref(grads), grad_d.data_ptr(), grad_f.data_ptr(), stream),
+               "rf_render_backward")
+        return grad_d, grad_f, None, None, None, None, None, None, None, None, None
+
+
+def render_sh_voxel_grid_hip(voxel_grid, rays: Rays, render_config, parallel_points_chunk_size=None) -> RenderOut:
+    """RenderProcedure: same arguments and results as thre3d_reprs/renderers.py:48-102 (parallel_points_chunk_size is accepted
+    and ignored: the fused kernel materialises nothing per point).  Configurations the kernels do not implement raise."""
+    if render_config.density2occupancy.__name__ != "density2occupancy_pb" or render_config.radiance_hdr_tone_map is not torch.sigmoid:
+        raise ValueError("render_sh_voxel_grid_hip: only density2occupancy_pb / torch.sigmoid are implemented")
+    if render_config.stochastic_density_noise_std != 0.0:
+        raise ValueError("render_sh_voxel_grid_hip: stochastic_density_noise_std must be 0.0")
+    origins = rays.origins.detach().to(torch.float32).contiguous()
+    directions = rays.directions.detach().to(torch.float32).contiguous()
+    assert origins.dim() == 2 and directions.shape == origins.shape, "the render interface only works with FLAT rays"
+    if not origins.is_cuda:
+        raise RuntimeError("render_sh_voxel_grid_hip runs on a HIP device only")
+    densities, features = voxel_grid.densities, voxel_grid.features
+    if not (densities.is_cuda and densities.is_contiguous() and features.is_contiguous() and densities.dtype == features.dtype == torch.float32):
+        raise RuntimeError("the VoxelGrid's tensors must be contiguous float32 on the HIP device")
+    n, s = origins.shape[0], int(render_config.num_samples_per_ray)
+    t_vals = torch.linspace(0.0, 1.0, s, dtype=torch.float32).to(origins.device)  # computed on the host like sample.py:46 on CPU
+    t_rand = torch.rand(n, s, dtype=torch.float32, device=origins.device) if render_config.perturb_sampled_points else None  # sample.py:63
+    flags = (RF_FLAG_WHITE_BKGD if render_config.white_bkgd else 0) | (RF_FLAG_RENDER_DIFFUSE if render_config.render_diffuse else 0) | (
+        RF_FLAG_AABB_SAMPLING if render_config.optimized_sampling else 0)
+    near, far = float(np.float32(render_config.camera_bounds.near)), float(np.float32(render_config.camera_bounds.far))
+    colour, depth, acc, disparity = _RenderFunction.apply(densities, features, origins, directions, t_vals, t_rand, voxel_grid, s, near, far, flags)
+    return RenderOut(colour=colour, depth=depth, extra={EXTRA_DISPARITY: disparity, EXTRA_ACCUMULATED_WEIGHTS: acc})

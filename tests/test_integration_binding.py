@@ -1,0 +1,143 @@
+"""The reference-side binding of INTEGRATION.md (integration/renderers_hip.py): the file a maintainer of the reference would add.
+
+CPU part (here): its struct mirrors have the sizes the library reports, and -- when the reference checkout is present (the build
+container only) -- it imports against the REAL reference package and describes a real reference VoxelGrid.
+GPU part: the binding and the package's own duck-typed procedure render a stand-in module that has exactly the reference
+VoxelGrid's attributes, against the golden vectors G7 (outputs of the reference renderer) including gradients."""
+import ctypes as C
+import importlib.util
+import os
+import sys
+import types
+
+import numpy as np
+import pytest
+import torch
+
+from tests.helpers import REPO_ROOT, hotdog_like_camera, load_golden, procedural_grid
+from thr3ed_atom_amd import _lib
+
+BINDING = os.path.join(REPO_ROOT, "integration", "renderers_hip.py")
+REFERENCE = "/root/reference"
+
+
+def _load_binding(monkeypatch, with_reference: bool):
+    """import integration/renderers_hip.py either against the real reference package or against stand-ins for the three
+    reference names it imports (this package's Rays / RenderOut have the same fields)."""
+    monkeypatch.setenv("RELU_FIELD_HIP_LIB", _lib.LIB_PATH)
+    if with_reference:
+        monkeypatch.syspath_prepend(REFERENCE)
+        if "easydict" not in sys.modules:  # imported by the reference for a type annotation only
+            ed = types.ModuleType("easydict")
+            ed.EasyDict = dict
+            monkeypatch.setitem(sys.modules, "easydict", ed)
+    else:
+        import thr3ed_atom_amd as rf
+        from thr3ed_atom_amd import constants
+
+        names = ["thre3d_atom", "thre3d_atom.rendering", "thre3d_atom.rendering.volumetric", "thre3d_atom.rendering.volumetric.render_interface",
+                 "thre3d_atom.utils", "thre3d_atom.utils.constants"]
+        mods = {n: types.ModuleType(n) for n in names}
+        mods["thre3d_atom.rendering.volumetric.render_interface"].Rays = rf.Rays
+        mods["thre3d_atom.rendering.volumetric.render_interface"].RenderOut = rf.RenderOut
+        mods["thre3d_atom.utils.constants"].EXTRA_DISPARITY = constants.EXTRA_DISPARITY
+        mods["thre3d_atom.utils.constants"].EXTRA_ACCUMULATED_WEIGHTS = constants.EXTRA_ACCUMULATED_WEIGHTS
+        for n, m in mods.items():
+            monkeypatch.setitem(sys.modules, n, m)
+    spec = importlib.util.spec_from_file_location("renderers_hip_under_test", BINDING)
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod
+
+
+def test_binding_struct_mirrors_match_the_library(monkeypatch):
+    if not os.path.exists(_lib.LIB_PATH):
+        _lib.build()
+    rh = _load_binding(monkeypatch, with_reference=False)
+    lib = rh._library()
+    lib.rf_abi_struct_size.argtypes = [C.c_int]
+    for which, mirror in ((0, rh.RFGrid), (1, rh.RFRayBatch), (2, rh.RFRenderOut), (3, rh.RFRenderGrads)):
+        assert lib.rf_abi_struct_size(which) == C.sizeof(mirror) == C.sizeof(_lib.ABI_STRUCTS[which])
+    assert lib.rf_abi_struct_size(99) == -1
+    for which, mirror in enumerate(_lib.ABI_STRUCTS):  # the package's own mirrors (also checked at load time)
+        assert lib.rf_abi_struct_size(which) == C.sizeof(mirror)
+
+
+@pytest.mark.skipif(not os.path.isdir(os.path.join(REFERENCE, "thre3d_atom")), reason="reference checkout not present (GPU box)")
+def test_binding_imports_against_the_real_reference_and_describes_its_grid(monkeypatch):
+    rh = _load_binding(monkeypatch, with_reference=True)
+    from thre3d_atom.thre3d_reprs.voxels import VoxelGrid as RefGrid, VoxelGridLocation as RefLoc, VoxelSize as RefSize
+
+    g = RefGrid(torch.rand(4, 5, 6, 1), torch.rand(4, 5, 6, 27), RefSize(0.1, 0.2, 0.3), RefLoc(0.5, 0.0, -0.25),
+                density_preactivation=torch.nn.Identity(), density_postactivation=torch.nn.ReLU(), expected_density_scale=7.0, tunable=True)
+    d = rh._describe_grid(g, g.densities, g.features)
+    assert list(d.dims) == [4, 5, 6] and d.num_features == 27 and d.layout == 0 and d.density_mode == 0
+    assert abs(d.aabb_min[0] - 0.3) < 1e-6 and abs(d.aabb_max[2] - 0.65) < 1e-6
+    # the package's own duck-typed view describes the same object identically
+    from thr3ed_atom_amd.voxels import as_kernel_grid
+
+    view = as_kernel_grid(g)
+    assert view.grid_dims == (4, 5, 6) and view.density_mode == "relu" and view.sh_degree == 2 and view.storage == "reference"
+    from thr3ed_atom_amd.camera import slack_range_map
+
+    for a in range(3):
+        scale, bias = slack_range_map(tuple(g.aabb[a]))
+        assert d.norm_scale[a] == float(scale) and d.norm_bias[a] == float(bias)
+    with pytest.raises(RuntimeError, match="HIP device"):
+        from thre3d_atom.rendering.volumetric.render_interface import Rays as RefRays
+        from thre3d_atom.thre3d_reprs.renderers import SHVoxGridRenderConfig as RefCfg
+        from thre3d_atom.utils.imaging_utils import CameraBounds as RefBounds
+
+        rh.render_sh_voxel_grid_hip(g, RefRays(torch.zeros(3, 3), torch.ones(3, 3)), RefCfg(8, RefBounds(0.5, 4.0)))
+
+
+class _ReferenceLikeGrid(torch.nn.Module):
+    """A module with exactly the attributes the reference's VoxelGrid has (thre3d_reprs/voxels.py:93-124) and none of this
+    package's: what `VolumetricModel(thre3d_repr=<reference grid>, ...)` hands to a render procedure."""
+
+    def __init__(self, densities, features, voxel_size, location, pre, post, rho):
+        super().__init__()
+        self._densities = torch.nn.Parameter(densities)
+        self._features = torch.nn.Parameter(features)
+        self._density_preactivation, self._density_postactivation = pre, post
+        self._feature_preactivation = self._feature_postactivation = torch.nn.Identity()
+        self._radiance_transfer_function = None
+        self._grid_location, self._voxel_size, self._expected_density_scale, self._tunable = location, voxel_size, rho, True
+        self.width_x, self.depth_y, self.height_z = densities.shape[:3]
+        half = [n * v / 2 for n, v in zip(densities.shape[:3], voxel_size)]
+        self._aabb = tuple((c - h, c + h) for c, h in zip(location, half))
+
+    densities = property(lambda self: self._densities)
+    features = property(lambda self: self._features)
+    aabb = property(lambda self: self._aabb)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("via", ["binding", "package"])
+@pytest.mark.parametrize("variant", ["relu_spec", "relu_diffuse", "relu_opt", "abs_spec", "softplus_spec"])
+def test_reference_like_module_renders_like_the_reference(hip_device, monkeypatch, via, variant):
+    """golden G7 (16^3, SH degree 2): colour / depth / acc and both gradients of L1(colour, target), through
+    (a) integration/renderers_hip.py and (b) thr3ed_atom_amd.render_sh_voxel_grid's duck typing."""
+    import thr3ed_atom_amd as rf
+
+    g7 = load_golden("g7_grid16_render.npz")
+    cam = hotdog_like_camera()
+    dens, feat = procedural_grid((16, 16, 16), 27, 81)
+    acts = {"abs_spec": (torch.abs, torch.nn.Identity()), "softplus_spec": (torch.nn.Identity(), torch.nn.Softplus())}.get(variant, (torch.nn.Identity(), torch.nn.ReLU()))
+    rho = 1.0 if variant == "abs_spec" else float(g7["rho"])
+    grid = _ReferenceLikeGrid(dens.to(hip_device), feat.to(hip_device), (3.0 / 16,) * 3, (0.0, 0.0, 0.0), acts[0], acts[1], rho).to(hip_device)
+    cfg = rf.SHVoxGridRenderConfig(48, rf.CameraBounds(cam["near"], cam["far"]), perturb_sampled_points=False, white_bkgd=True,
+                                   render_diffuse=variant == "relu_diffuse", optimized_sampling=variant == "relu_opt")
+    rays = rf.Rays(torch.from_numpy(g7["origins"]).to(hip_device), torch.from_numpy(g7["directions"]).to(hip_device))
+    if via == "binding":
+        rh = _load_binding(monkeypatch, with_reference=False)
+        out = rh.render_sh_voxel_grid_hip(grid, rays, cfg)
+    else:
+        out = rf.render_sh_voxel_grid(grid, rays, cfg)
+    torch.nn.functional.l1_loss(out.colour, torch.from_numpy(g7["target"]).to(hip_device)).backward()
+    np.testing.assert_allclose(out.colour.detach().cpu().numpy(), g7[f"{variant}_colour"], rtol=0, atol=1e-5)
+    np.testing.assert_allclose(out.extra["accumulated_weight"].detach().cpu().numpy(), g7[f"{variant}_acc"], rtol=0, atol=1e-5)
+    np.testing.assert_allclose(out.depth.detach().cpu().numpy(), g7[f"{variant}_depth"], rtol=0, atol=1e-5)
+    for ours, key in ((grid.densities.grad, f"{variant}_gd"), (grid.features.grad, f"{variant}_gf")):
+        ref = g7[key]
+        np.testing.assert_allclose(ours.cpu().numpy(), ref, rtol=2e-4, atol=2e-6 * np.abs(ref).max())

@@ -12,6 +12,7 @@ from .camera import (  # noqa: F401
     compute_expected_density_scale_for_relu_field_grid,
     compute_thre3d_grid_sizes,
     get_thre360_animation_poses,
+    get_thre360_spiral_animation_poses,
     mse2psnr,
     pose_spherical,
     scale_camera_intrinsics,

@@ -28,6 +28,7 @@ FLAG_JITTER_KEYED = 16
 
 EXPORTED_SYMBOLS = [
     "rf_abi_version",
+    "rf_abi_struct_size",
     "rf_error_string",
     "rf_cast_rays",
     "rf_cast_selected_rays",
@@ -190,6 +191,10 @@ TRAIN_STEP_EVENT_NAMES = ["select_rays_and_pixels", "render_forward[spec,save]",
                           "brick_accumulate"]
 
 
+# order of rf_abi_struct_size(which)
+ABI_STRUCTS = [RFGrid, RFRayBatch, RFRenderOut, RFRenderGrads, RFBrickList, RFAdamState, RFCamera, RFRaySelection, RFPassScratch, RFTrainStep]
+
+
 def build(force: bool = False, verbose: bool = False) -> str:
     """Cross-compile the HIP sources for gfx950 into csrc/librelu_field_hip.so (hipcc needs no GPU)."""
     srcs = [os.path.join(CSRC_DIR, s) for s in SOURCES]
@@ -264,6 +269,10 @@ def load() -> C.CDLL:
             getattr(lib, name).restype = C.c_int
     if lib.rf_abi_version() != ABI_VERSION:
         raise RuntimeError(f"{LIB_PATH}: ABI version {lib.rf_abi_version()} != {ABI_VERSION} (stale build? run __graft_entry__.build())")
+    lib.rf_abi_struct_size.argtypes = [C.c_int]
+    for which, mirror in enumerate(ABI_STRUCTS):
+        if lib.rf_abi_struct_size(which) != C.sizeof(mirror):
+            raise RuntimeError(f"{LIB_PATH}: sizeof({mirror.__name__}) is {lib.rf_abi_struct_size(which)} in the library, {C.sizeof(mirror)} in the binding")
     _LIB = lib
     return lib
 

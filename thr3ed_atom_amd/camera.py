@@ -84,6 +84,15 @@ def get_thre360_animation_poses(hemispherical_radius: float, camera_pitch: float
     return [pose_spherical(yaw, camera_pitch, hemispherical_radius) for yaw in yaws]
 
 
+def get_thre360_spiral_animation_poses(horizontal_radius_range, vertical_camera_height: float, num_rounds: int, num_poses: int):
+    """Spiral path (imaging_utils.py:211-234): the last pose is dropped so that a looped video is smooth."""
+    horizontal_radii = np.linspace(*horizontal_radius_range, num_poses)[:-1]
+    radii = [np.sqrt((h**2) + (vertical_camera_height**2)) for h in horizontal_radii]
+    yaws = np.linspace(0, 360 * num_rounds, num_poses)[:-1]
+    pitches = [math.atan(h / vertical_camera_height) * 180 / math.pi for h in horizontal_radii]
+    return [pose_spherical(yaw, pitch, radius) for yaw, pitch, radius in zip(yaws, pitches, radii)]
+
+
 def mse2psnr(x):
     """PSNR (dB) of a mean squared error on [0, 1] signals; inf for an exact match."""
     if isinstance(x, Tensor):

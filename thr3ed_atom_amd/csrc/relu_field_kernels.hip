@@ -2533,6 +2533,22 @@ int rf_debug_brick_profile(unsigned long long* out_host, int reset) {
 
 int rf_abi_version(void) { return RF_ABI_VERSION; }
 
+int rf_abi_struct_size(int which) {
+  switch (which) {
+    case 0: return (int)sizeof(RFGrid);
+    case 1: return (int)sizeof(RFRayBatch);
+    case 2: return (int)sizeof(RFRenderOut);
+    case 3: return (int)sizeof(RFRenderGrads);
+    case 4: return (int)sizeof(RFBrickList);
+    case 5: return (int)sizeof(RFAdamState);
+    case 6: return (int)sizeof(RFCamera);
+    case 7: return (int)sizeof(RFRaySelection);
+    case 8: return (int)sizeof(RFPassScratch);
+    case 9: return (int)sizeof(RFTrainStep);
+    default: return -1;
+  }
+}
+
 const char* rf_error_string(int code) {
   switch (code) {
     case RF_OK:

@@ -16,7 +16,7 @@ import torch
 from torch import Tensor
 
 from . import _lib
-from .voxels import VoxelGrid
+from .voxels import VoxelGrid, as_kernel_grid
 
 _T_VALS_CACHE: Dict[Tuple[int, str], Tensor] = {}
 
@@ -563,6 +563,7 @@ def relu_field_render(
     """colour [N,3], depth [N,1], accumulated weight [N,1], disparity [N,1] for flat rays [N,3].
     Differentiable w.r.t. ``grid.densities`` and ``grid.features`` only (like every reference use).
     ``t_rand``: None (no jitter), a [N, S] tensor of jitter values, or a ``KeyedJitter``."""
+    grid = as_kernel_grid(grid)
     if origins.dim() != 2 or origins.shape != directions.shape or origins.shape[-1] != 3:
         raise AssertionError("the render op works with FLAT rays [N, 3] only")
     if int(num_samples) < 1:

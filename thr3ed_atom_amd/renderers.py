@@ -21,7 +21,7 @@ from .camera import CameraBounds
 from .constants import EXTRA_ACCUMULATED_WEIGHTS, EXTRA_DISPARITY
 from .ops import KeyedJitter, draw_jitter_key, relu_field_render
 from .render_interface import Rays, RenderOut
-from .voxels import VoxelGrid
+from .voxels import VoxelGrid, as_kernel_grid
 
 RenderConfig = Any
 RenderProcedure = Callable[[Module, Rays, RenderConfig, Optional[int]], RenderOut]
@@ -59,7 +59,9 @@ class SHVoxGridRenderConfig:
     jitter: str = "keyed"
 
 
-def _check_supported(cfg: SHVoxGridRenderConfig) -> None:
+def _check_supported(cfg) -> None:
+    """``cfg``: this package's SHVoxGridRenderConfig or the reference's (same field names; the extension fields of this build
+    default to off when absent)."""
     d2o = cfg.density2occupancy
     if not (d2o is density2occupancy_pb or getattr(d2o, "__name__", "") == "density2occupancy_pb"):
         raise ValueError("render_sh_voxel_grid (HIP): only density2occupancy_pb is supported")
@@ -85,8 +87,9 @@ def render_sh_voxel_grid(
     ``perturb_sampled_points`` is set, it comes from ``render_config.jitter``: "keyed" = a counter-based generator inside the
     kernel (one 64-bit key drawn from torch's CPU generator per call; ``first_ray`` = position of ray 0 in that stream),
     "torch" = ``torch.rand(N, S)`` on the rays' device like sample.py:63."""
-    if not isinstance(voxel_grid, VoxelGrid):
-        raise TypeError(f"render_sh_voxel_grid needs a thr3ed_atom_amd VoxelGrid, got {type(voxel_grid)}")
+    # duck typing, like the reference's plug-in contract (renderers.py:22-25 takes "a Module"): this package's VoxelGrid, or any
+    # module with the reference VoxelGrid's attribute names -- e.g. the reference's own grid object (TypeError otherwise)
+    voxel_grid = as_kernel_grid(voxel_grid)
     _check_supported(render_config)
     origins, directions = rays.origins, rays.directions
     assert origins.dim() == directions.dim() == 2, "the render interface only works with FLAT rays"
@@ -94,15 +97,16 @@ def render_sh_voxel_grid(
     n = origins.shape[0]
     if render_config.perturb_sampled_points:
         if t_rand is None:
-            if render_config.jitter == "torch":
+            jitter = getattr(render_config, "jitter", "keyed")  # (the reference's config class has no such field)
+            if jitter == "torch":
                 t_rand = torch.rand(n, num_samples, dtype=torch.float32, device=origins.device)
-            elif render_config.jitter == "keyed":
+            elif jitter == "keyed":
                 t_rand = KeyedJitter(draw_jitter_key(), int(first_ray))
             else:
                 raise ValueError("SHVoxGridRenderConfig.jitter must be 'keyed' or 'torch'")
     else:
         t_rand = None
-    if render_config.consume_reference_rng:
+    if getattr(render_config, "consume_reference_rng", False):
         torch.randn(n, num_samples, dtype=torch.float32, device=origins.device)
     bounds = render_config.camera_bounds
     colour, depth, acc, disparity = relu_field_render(
@@ -116,7 +120,7 @@ def render_sh_voxel_grid(
         white_bkgd=bool(render_config.white_bkgd),
         render_diffuse=bool(render_config.render_diffuse),
         optimized_sampling=bool(render_config.optimized_sampling),
-        use_occupancy=bool(render_config.use_occupancy_mask),
+        use_occupancy=bool(getattr(render_config, "use_occupancy_mask", False)),
     )
     return RenderOut(colour=colour, depth=depth, extra={EXTRA_DISPARITY: disparity, EXTRA_ACCUMULATED_WEIGHTS: acc})
 
@@ -136,8 +140,7 @@ def render_sh_voxel_grid_frame(
     "keyed" when ``perturb_sampled_points`` is set (a torch.rand table would have to be materialised: use the chunked path)."""
     from .ops import render_flags, render_frame_raw
 
-    if not isinstance(voxel_grid, VoxelGrid):
-        raise TypeError(f"render_sh_voxel_grid_frame needs a thr3ed_atom_amd VoxelGrid, got {type(voxel_grid)}")
+    voxel_grid = as_kernel_grid(voxel_grid)
     _check_supported(render_config)
     jitter = None
     if render_config.perturb_sampled_points:

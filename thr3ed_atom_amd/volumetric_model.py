@@ -172,10 +172,15 @@ def create_volumetric_model_from_saved_model(
     thre3d_repr_creator: Callable[[Dict[str, Any]], Module],
     device: torch.device = torch.device("cpu"),
 ) -> Tuple[VolumetricModel, Dict[str, Any]]:
-    """Load a checkpoint written by ``torch.save(vol_mod.get_save_info(...))`` (reference :177-197).
+    """Load a checkpoint written by ``torch.save(vol_mod.get_save_info(...))`` (reference :177-197) -- by this package OR by
+    the reference itself: the names a reference-written file pickles (``thre3d_atom...render_sh_voxel_grid``,
+    ``SHVoxGridRenderConfig``, ``VoxelSize`` ...) are resolved to their counterparts here (_compat_pickle.py).
     The checkpoint pickles a function object and a class, hence weights_only=False."""
-    data = torch.load(model_path, map_location="cpu", weights_only=False)
+    from . import _compat_pickle
+
+    data = torch.load(model_path, map_location="cpu", weights_only=False, pickle_module=_compat_pickle)
     repr_ = thre3d_repr_creator(data)
-    cfg = data[RENDER_CONFIG_TYPE](**data[RENDER_CONFIG])
+    known = {f.name for f in dataclasses.fields(data[RENDER_CONFIG_TYPE])}
+    cfg = data[RENDER_CONFIG_TYPE](**{k: v for k, v in data[RENDER_CONFIG].items() if k in known})
     model = VolumetricModel(repr_, data[RENDER_PROCEDURE], cfg, device=device)
     return model, data.get(EXTRA_INFO, {})

@@ -121,7 +121,93 @@ def resolve_density_mode(pre: Callable, post: Callable) -> str:
     )
 
 
-class VoxelGrid(Module):
+class KernelGridInterface:
+    """What the render operators need from a grid object -- described to the C ABI (RFGrid) from a handful of attributes:
+    ``kernel_tensors()``, ``grid_dims``, ``_aabb``, ``_expected_density_scale``, ``density_mode``, ``storage``, ``_num_features``.
+    ``VoxelGrid`` (below) provides them from its own state; ``ForeignVoxelGridView`` reads them live from ANY module with the
+    reference VoxelGrid's attribute names (thre3d_atom/thre3d_reprs/voxels.py:47-124,187-212), which is how the reference's own
+    grid object renders through the HIP procedure."""
+
+    _occupancy: Optional[Tensor] = None
+
+    @property
+    def sh_degree(self) -> int:
+        return int(np.sqrt(self._num_features // 3)) - 1
+
+    def to_rf_grid(self, use_occupancy: bool = False) -> "_lib.RFGrid":
+        d, f = self.kernel_tensors()
+        for t in (d, f):
+            if t is None:
+                continue
+            if not t.is_cuda:
+                raise RuntimeError(
+                    "the ReLU-field render path runs on the GPU only: move the VoxelGrid to a HIP device "
+                    "(there is no CPU fallback)"
+                )
+            if not (t.is_contiguous() and t.dtype == torch.float32):
+                raise RuntimeError("grid tensors must be contiguous float32")
+        # the descriptor is rebuilt only when something it describes changed (it is on the per-launch host path)
+        occ_ptr = self._occupancy.data_ptr() if (use_occupancy and self._occupancy is not None) else None
+        mode = self.density_mode
+        key = (d.data_ptr(), None if f is None else f.data_ptr(), occ_ptr, self._aabb, self._expected_density_scale, mode, tuple(d.shape))
+        cached = self.__dict__.get("_rf_grid_cache")
+        if cached is not None and cached[0] == key:
+            return cached[1]
+        g = _lib.RFGrid()
+        g.densities_dev = d.data_ptr()
+        g.features_dev = None if f is None else f.data_ptr()
+        for a in range(3):
+            g.dims[a] = self.grid_dims[a]
+            lo, hi = self._aabb[a]
+            g.aabb_min[a] = float(np.float32(lo))
+            g.aabb_max[a] = float(np.float32(hi))
+            scale, bias = slack_range_map((lo, hi))
+            g.norm_scale[a] = float(scale)
+            g.norm_bias[a] = float(bias)
+        g.num_features = self._num_features
+        g.density_stride = int(d.shape[-1])
+        g.feature_stride = 0 if f is None else int(f.shape[-1])
+        g.layout = _lib.LAYOUTS[self.storage]
+        g.density_scale = float(self._expected_density_scale)
+        g.density_mode = _lib.DENSITY_MODES[mode]
+        g.occupancy_dev = occ_ptr
+        self.__dict__["_rf_grid_cache"] = (key, g)
+        return g
+
+    def build_occupancy(self, threshold: float = 0.0) -> Tensor:
+        """(Re)build the exact empty-cell bit mask used by RF_FLAG_OCCUPANCY_SKIP.  Must be called again
+        whenever the densities change."""
+        X, Y, Z = self.grid_dims
+        ncell = (X + 1) * (Y + 1) * (Z + 1)
+        dev = self.kernel_tensors()[0].device
+        occ = torch.empty((ncell + 31) // 32, dtype=torch.int32, device=dev)
+        grid = self.to_rf_grid()
+        stream = torch.cuda.current_stream(dev).cuda_stream
+        _lib.check(_lib.load().rf_build_occupancy(grid, float(threshold), occ.data_ptr(), stream), "rf_build_occupancy")
+        self._occupancy = occ
+        d = self.kernel_tensors()[0]
+        self._occupancy_stamp = (d.data_ptr(), d._version)
+        return occ
+
+    @property
+    def occupancy(self) -> Optional[Tensor]:
+        return self._occupancy
+
+    def invalidate_occupancy(self) -> None:
+        """The densities were changed behind autograd's back (a fused optimizer kernel writes through raw pointers): the
+        mask has to be rebuilt before its next use."""
+        self._occupancy_stamp = None
+
+    def occupancy_current(self) -> bool:
+        """True when a mask exists AND the density tensor is the one (same storage, same in-place version counter) it was
+        built from.  ``torch.optim`` steps bump the version counter; the fused optimizer calls invalidate_occupancy()."""
+        if self._occupancy is None:
+            return False
+        d = self.kernel_tensors()[0]
+        return self.__dict__.get("_occupancy_stamp") == (d.data_ptr(), d._version)
+
+
+class VoxelGrid(Module, KernelGridInterface):
     def __init__(
         self,
         densities: Tensor,
@@ -311,10 +397,6 @@ class VoxelGrid(Module):
 
         return grid_query(self, points)
 
-    @property
-    def sh_degree(self) -> int:
-        return int(np.sqrt(self._num_features // 3)) - 1
-
     def get_config_dict(self) -> Dict[str, Any]:
         return {
             "grid_location": self._grid_location,
@@ -354,76 +436,87 @@ class VoxelGrid(Module):
             m = m & (points[..., a : a + 1] > lo) & (points[..., a : a + 1] < hi)
         return m
 
-    # ----- description for the C ABI -------------------------------------------------------
-    def to_rf_grid(self, use_occupancy: bool = False) -> "_lib.RFGrid":
-        d, f = self.kernel_tensors()
-        for t in (d, f):
-            if t is None:
-                continue
-            if not t.is_cuda:
-                raise RuntimeError(
-                    "the ReLU-field render path runs on the GPU only: move the VoxelGrid to a HIP device "
-                    "(there is no CPU fallback)"
-                )
-            if not (t.is_contiguous() and t.dtype == torch.float32):
-                raise RuntimeError("grid tensors must be contiguous float32")
-        # the descriptor is rebuilt only when something it describes changed (it is on the per-launch host path)
-        occ_ptr = self._occupancy.data_ptr() if (use_occupancy and self._occupancy is not None) else None
-        key = (d.data_ptr(), None if f is None else f.data_ptr(), occ_ptr, self._aabb, self._expected_density_scale)
-        cached = self.__dict__.get("_rf_grid_cache")
-        if cached is not None and cached[0] == key:
-            return cached[1]
-        g = _lib.RFGrid()
-        g.densities_dev = d.data_ptr()
-        g.features_dev = None if f is None else f.data_ptr()
-        for a in range(3):
-            g.dims[a] = self.grid_dims[a]
-            lo, hi = self._aabb[a]
-            g.aabb_min[a] = float(np.float32(lo))
-            g.aabb_max[a] = float(np.float32(hi))
-            scale, bias = slack_range_map((lo, hi))
-            g.norm_scale[a] = float(scale)
-            g.norm_bias[a] = float(bias)
-        g.num_features = self._num_features
-        g.density_stride = int(d.shape[-1])
-        g.feature_stride = 0 if f is None else int(f.shape[-1])
-        g.layout = _lib.LAYOUTS[self.storage]
-        g.density_scale = float(self._expected_density_scale)
-        g.density_mode = _lib.DENSITY_MODES[self.density_mode]
-        g.occupancy_dev = occ_ptr
-        self.__dict__["_rf_grid_cache"] = (key, g)
-        return g
 
-    def build_occupancy(self, threshold: float = 0.0) -> Tensor:
-        """(Re)build the exact empty-cell bit mask used by RF_FLAG_OCCUPANCY_SKIP.  Must be called again
-        whenever the densities change."""
-        ncell = (self.width_x + 1) * (self.depth_y + 1) * (self.height_z + 1)
-        dev = self.kernel_tensors()[0].device
-        occ = torch.empty((ncell + 31) // 32, dtype=torch.int32, device=dev)
-        grid = self.to_rf_grid()
-        stream = torch.cuda.current_stream(dev).cuda_stream
-        _lib.check(_lib.load().rf_build_occupancy(grid, float(threshold), occ.data_ptr(), stream), "rf_build_occupancy")
-        self._occupancy = occ
-        d = self.kernel_tensors()[0]
-        self._occupancy_stamp = (d.data_ptr(), d._version)
-        return occ
+class ForeignVoxelGridView(KernelGridInterface):
+    """Kernel-side description of a grid module that is NOT this package's VoxelGrid but has the reference VoxelGrid's
+    attribute names (duck typing; thre3d_atom/thre3d_reprs/voxels.py): ``densities`` [X,Y,Z,1] / ``features`` [X,Y,Z,F]
+    (contiguous float32 on a HIP device, the reference's own layout = RF_LAYOUT_REFERENCE), ``aabb``,
+    ``_expected_density_scale``, ``_density_preactivation`` / ``_density_postactivation`` (one of the supported pairs),
+    identity feature activations and no radiance transfer function.  Everything is read from the module at call time, so
+    re-assigned tensors or a changed voxel size are picked up; gradients flow to ``module.densities`` / ``module.features``
+    through autograd like they do with the reference's own procedure."""
+
+    storage = "reference"
+    _grad_bucket = None
+
+    def __init__(self, module):
+        missing = [a for a in ("densities", "features", "aabb", "_expected_density_scale", "_density_preactivation", "_density_postactivation") if not hasattr(module, a)]
+        if missing:
+            raise TypeError(f"render_sh_voxel_grid (HIP) needs a VoxelGrid-like module; {type(module).__name__} lacks {missing}")
+        self.module = module
+        self._occupancy = None
+
+    def _check(self):
+        m = self.module
+        for name in ("_feature_preactivation", "_feature_postactivation"):
+            if not _is_identity(getattr(m, name, None)):
+                raise ValueError("the HIP render path supports identity feature activations only")
+        if getattr(m, "_radiance_transfer_function", None) is not None:
+            raise ValueError("radiance_transfer_function is not used on the SH render path")
+        d, f = m.densities, m.features
+        if d.dim() != 4 or d.shape[-1] != 1 or f.dim() != 4 or f.shape[:3] != d.shape[:3]:
+            raise AssertionError(f"densities [X,Y,Z,1] / features [X,Y,Z,F] expected, got {tuple(d.shape)} / {tuple(f.shape)}")
+
+    def kernel_tensors(self):
+        self._check()
+        return self.module.densities, self.module.features
 
     @property
-    def occupancy(self) -> Optional[Tensor]:
-        return self._occupancy
+    def grid_dims(self):
+        return tuple(int(v) for v in self.module.densities.shape[:3])
 
-    def invalidate_occupancy(self) -> None:
-        """The densities were changed behind autograd's back (a fused optimizer kernel writes through raw pointers): the
-        mask has to be rebuilt before its next use."""
-        self._occupancy_stamp = None
+    @property
+    def _aabb(self):
+        return AxisAlignedBoundingBox(*[(float(lo), float(hi)) for lo, hi in self.module.aabb])
 
-    def occupancy_current(self) -> bool:
-        """True when a mask exists AND the density tensor is the one (same storage, same in-place version counter) it was
-        built from.  ``torch.optim`` steps bump the version counter; the fused optimizer calls invalidate_occupancy()."""
-        if self._occupancy is None:
-            return False
-        d = self.kernel_tensors()[0]
-        return self.__dict__.get("_occupancy_stamp") == (d.data_ptr(), d._version)
+    @property
+    def aabb(self):
+        return self._aabb
+
+    @property
+    def _expected_density_scale(self):
+        return float(self.module._expected_density_scale)
+
+    @property
+    def expected_density_scale(self):
+        return self._expected_density_scale
+
+    @property
+    def density_mode(self):
+        return resolve_density_mode(self.module._density_preactivation, self.module._density_postactivation)
+
+    @property
+    def _num_features(self):
+        return int(self.module.features.shape[-1])
+
+    @property
+    def num_features(self):
+        return self._num_features
+
+
+def as_kernel_grid(module) -> KernelGridInterface:
+    """The object the operators talk to: a VoxelGrid of this package as it is, any other VoxelGrid-like module (the
+    reference's) through a cached ForeignVoxelGridView."""
+    if isinstance(module, KernelGridInterface):
+        return module
+    view = module.__dict__.get("_rf_kernel_view") if hasattr(module, "__dict__") else None
+    if view is None:
+        view = ForeignVoxelGridView(module)
+        try:
+            module.__dict__["_rf_kernel_view"] = view
+        except Exception:  # objects without a writable __dict__: just do not cache
+            pass
+    return view
 
 
 def scale_voxel_grid_with_required_output_size(
