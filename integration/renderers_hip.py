@@ -128,11 +128,10 @@ class _RenderFunction(torch.autograd.Function):
     into zero-filled gradient tensors -- what autograd does for the reference through ~120 ATen ops."""
 
     @staticmethod
-    def forward(ctx, densities, features, origins, directions, t_vals, t_rand, voxel_grid, num_samples, near, far, flags):
+    def forward(ctx, densities, features, origins, directions, t_vals, t_rand, voxel_grid, num_samples, near, far, flags, need_grad):
         lib = _library()
         dev = origins.device
         n = origins.shape[0]
-        need_grad = torch.is_grad_enabled() and (densities.requires_grad or features.requires_grad)
         grid = _describe_grid(voxel_grid, densities, features)
         rb = RFRayBatch(origins.data_ptr(), directions.data_ptr(), n, num_samples, near, far, t_vals.data_ptr(),
                         None if t_rand is None else t_rand.data_ptr(), 0, 0, None)
@@ -154,7 +153,7 @@ class _RenderFunction(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g_colour, g_depth, g_acc, _g_disparity):
         if not ctx.need_grad:
-            return (None,) * 11
+            return (None,) * 12
         lib = _library()
         saved = ctx.saved_tensors
         densities, features, origins, directions, t_vals, cache, tcache, stop = saved[:8]
@@ -171,7 +170,7 @@ class _RenderFunction(torch.autograd.Function):
         stream = torch.cuda.current_stream(dev).cuda_stream
         _check(lib.rf_render_backward(C.byref(grid), C.byref(rb), flags, C.byref(fwd), C.byref(grads), grad_d.data_ptr(), grad_f.data_ptr(), stream),
                "rf_render_backward")
-        return grad_d, grad_f, None, None, None, None, None, None, None, None, None
+        return grad_d, grad_f, None, None, None, None, None, None, None, None, None, None
 
 
 def render_sh_voxel_grid_hip(voxel_grid, rays: Rays, render_config, parallel_points_chunk_size=None) -> RenderOut:
@@ -195,5 +194,7 @@ def render_sh_voxel_grid_hip(voxel_grid, rays: Rays, render_config, parallel_poi
     flags = (RF_FLAG_WHITE_BKGD if render_config.white_bkgd else 0) | (RF_FLAG_RENDER_DIFFUSE if render_config.render_diffuse else 0) | (
         RF_FLAG_AABB_SAMPLING if render_config.optimized_sampling else 0)
     near, far = float(np.float32(render_config.camera_bounds.near)), float(np.float32(render_config.camera_bounds.far))
-    colour, depth, acc, disparity = _RenderFunction.apply(densities, features, origins, directions, t_vals, t_rand, voxel_grid, s, near, far, flags)
+    # (grad mode is off inside Function.forward: whether the per-sample cache is needed is decided here)
+    need_grad = torch.is_grad_enabled() and (densities.requires_grad or features.requires_grad)
+    colour, depth, acc, disparity = _RenderFunction.apply(densities, features, origins, directions, t_vals, t_rand, voxel_grid, s, near, far, flags, need_grad)
     return RenderOut(colour=colour, depth=depth, extra={EXTRA_DISPARITY: disparity, EXTRA_ACCUMULATED_WEIGHTS: acc})
