@@ -315,6 +315,8 @@ __device__ __forceinline__ Corners corners_of(uint32_t packed, const float wts[6
   return c;
 }
 
+__device__ __forceinline__ float density_post(float pre, int mode);
+
 // density: post( interp( pre(D * rho) ) )  (voxels.py:292-309)
 __device__ __forceinline__ float interp_density(const Corners& c, const GridArgs& g, float& pre_out) {
   float acc = 0.0f;
@@ -632,6 +634,39 @@ __device__ __forceinline__ int brick_key(const int i0[3], const GridArgs& g, int
   return (((b3[0] * nby + b3[1]) * nbz + b3[2]) << 3) | flags3;
 }
 
+// Parameter interval of a ray inside the box (same slab test as the AABB sampler, reciprocal-based: only used with a generous
+// margin, never for sample positions).  A chunk of 64 samples that lies outside it by that margin contributes exactly
+// nothing -- sigma = 0 -> alpha = 0 -> w = 0, T unchanged, no gradient -- and is skipped without evaluating a single sample.
+struct BoxSpan {
+  float t_in, t_out, zpad, margin;
+  bool hits;
+};
+
+__device__ __forceinline__ BoxSpan box_span(const RayState& st, const RayArgs& r, const GridArgs& g) {
+  BoxSpan b;
+  b.t_in = -kInfinity;
+  b.t_out = kInfinity;
+#pragma unroll
+  for (int a = 0; a < 3; ++a) {
+    const float inv = __builtin_amdgcn_rcpf(st.d[a] + kZeroPlus);
+    const float ta = (g.amin[a] - st.o[a]) * inv, tb = (g.amax[a] - st.o[a]) * inv;
+    b.t_in = fmaxf(b.t_in, fminf(ta, tb));
+    b.t_out = fminf(b.t_out, fmaxf(ta, tb));
+  }
+  b.margin = 1e-3f * (1.0f + fabsf(b.t_in) + fabsf(b.t_out));
+  b.hits = b.t_out >= b.t_in - b.margin;
+  b.zpad = fabsf(st.far - st.near) / (float)(r.S > 1 ? r.S - 1 : 1);  // jitter stays within one stratum
+  return b;
+}
+
+// wave-uniform: no sample of chunk `chunk` can be inside the box
+__device__ __forceinline__ bool chunk_outside_box(const BoxSpan& b, const RayState& st, const RayArgs& r, int chunk) {
+  const int s_first = chunk * kWave, s_last = min(r.S - 1, chunk * kWave + kWave - 1);
+  const float za = z_uniform(st.near, st.far, r.tvals[s_first]), zb = z_uniform(st.near, st.far, r.tvals[s_last]);
+  const float zlo = fminf(za, zb) - b.zpad, zhi = fmaxf(za, zb) + b.zpad;
+  return !b.hits || zhi < b.t_in - b.margin || zlo > b.t_out + b.margin;
+}
+
 // =============================================================================================
 // forward
 // =============================================================================================
@@ -669,20 +704,7 @@ __global__ __launch_bounds__(kBlock) void render_forward_kernel(GridArgs g, RayA
   float part_acc = 0.f, part_depth = 0.f;
   int processed = 0;
 
-  // Parameter interval of the ray inside the box (same slab test as the AABB sampler).  A chunk whose samples all
-  // lie outside it by a safe margin contributes exactly nothing (sigma = 0 -> alpha = 0 -> T unchanged) and is
-  // skipped without evaluating a single sample.
-  float t_in = -kInfinity, t_out = kInfinity;
-  bool hits_box = true;
-#pragma unroll
-  for (int a = 0; a < 3; ++a) {  // reciprocal-based: only used with a generous margin, never for sample positions
-    const float inv = __builtin_amdgcn_rcpf(st.d[a] + kZeroPlus);
-    const float ta = (g.amin[a] - st.o[a]) * inv, tb = (g.amax[a] - st.o[a]) * inv;
-    t_in = fmaxf(t_in, fminf(ta, tb));
-    t_out = fminf(t_out, fmaxf(ta, tb));
-  }
-  hits_box = t_out >= t_in - 1e-3f * (1.0f + fabsf(t_in) + fabsf(t_out));
-  const float zpad = fabsf(st.far - st.near) / (float)(r.S > 1 ? r.S - 1 : 1);  // jitter stays within one stratum
+  const BoxSpan span = box_span(st, r, g);
 
   // z of the current chunk is computed one iteration ahead, so that the last lane can take its "next sample" from
   // lane 0 of the following chunk: one z evaluation per sample instead of two
@@ -693,11 +715,7 @@ __global__ __launch_bounds__(kBlock) void render_forward_kernel(GridArgs g, RayA
   for (int chunk = 0; chunk < nchunks; ++chunk) {
     const int s = chunk * kWave + lane;
     {
-      const int s_first = chunk * kWave, s_last = min(r.S - 1, chunk * kWave + kWave - 1);
-      const float za = z_uniform(st.near, st.far, r.tvals[s_first]), zb = z_uniform(st.near, st.far, r.tvals[s_last]);
-      const float zlo = fminf(za, zb) - zpad, zhi = fmaxf(za, zb) + zpad;
-      const float margin = 1e-3f * (1.0f + fabsf(t_in) + fabsf(t_out));
-      const bool empty = !hits_box || zhi < t_in - margin || zlo > t_out + margin;
+      const bool empty = chunk_outside_box(span, st, r, chunk);
       if (empty) {  // wave-uniform
         processed = min(r.S, (chunk + 1) * kWave);
         if constexpr (SAVE) {
@@ -725,10 +743,33 @@ __global__ __launch_bounds__(kBlock) void render_forward_kernel(GridArgs g, RayA
     Corners cn;
     float wts[6] = {sm.cell.w0[0], sm.cell.w1[0], sm.cell.w0[1], sm.cell.w1[1], sm.cell.w0[2], sm.cell.w1[2]};
     const uint32_t packed = pack_cell(sm.cell);
+    // Degree-0 / render_diffuse passes on split storage: the 16-byte base record of a corner holds the density AND the three
+    // degree-0 coefficients, so P0's one gather per corner already has everything -- colour is interpolated right here
+    // (ATen's corner order) and the work list + second gather of P1 are skipped.
+    const bool fast_base = L::kCorner && g.layout == RF_LAYOUT_SPLIT;  // wave-uniform
+    float fast_rgb[3] = {0.f, 0.f, 0.f};
     if (live) {
       cn = corners_of(packed, wts, g);
-      float pre;
-      sigma = interp_density(cn, g, pre);
+      if (fast_base) {
+        float acc = 0.0f, cr = 0.0f, cg = 0.0f, cb = 0.0f;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+          const f4u t = *reinterpret_cast<const f4u*>(g.dens + cn.lin[k] * g.dstride);
+          float v = t.v[0] * g.rho;
+          if (g.mode == RF_DENSITY_ABS) v = fabsf(v);
+          acc = acc + v * cn.w[k];
+          cr = cr + t.v[1] * cn.w[k];
+          cg = cg + t.v[2] * cn.w[k];
+          cb = cb + t.v[3] * cn.w[k];
+        }
+        sigma = density_post(acc, g.mode);
+        fast_rgb[0] = kC0 * cr;
+        fast_rgb[1] = kC0 * cg;
+        fast_rgb[2] = kC0 * cb;
+      } else {
+        float pre;
+        sigma = interp_density(cn, g, pre);
+      }
     }
     const float alpha = 1.0f - exp_fast(-(sigma * sm.delta));  // density2occupancy_pb, accumulate.py:24-28
     const float one_minus = 1.0f - alpha;
@@ -742,8 +783,8 @@ __global__ __launch_bounds__(kBlock) void render_forward_kernel(GridArgs g, RayA
     // a sample needs its colour only if it can contribute: inside, T != 0 and (under ReLU) sigma != 0
     const bool need = live && (T != 0.0f) && !(g.mode == RF_DENSITY_RELU && sigma == 0.0f);
     const unsigned long long mask = __ballot(need);
-    const int count = __popcll(mask);
-    if (need) {
+    const int count = fast_base ? 0 : __popcll(mask);
+    if (need && !fast_base) {
       const int slot = __popcll(mask & ((1ull << lane) - 1ull));
       uint32_t* e = my_entry + slot * kEntryFwd;
       // corner k = dx + 2 dy + 4 dz (corners_of): lin[1] / lin[2] / lin[4] are the x / y / z upper neighbours
@@ -849,7 +890,9 @@ __global__ __launch_bounds__(kBlock) void render_forward_kernel(GridArgs g, RayA
     wave_lds_fence();
 
     // ---------------- P2: lanes = samples ----------------
-    const float raw_r = my_rgb[lane * 4 + 0], raw_g = my_rgb[lane * 4 + 1], raw_b = my_rgb[lane * 4 + 2];
+    const float raw_r = fast_base ? (need ? fast_rgb[0] : 0.0f) : my_rgb[lane * 4 + 0];
+    const float raw_g = fast_base ? (need ? fast_rgb[1] : 0.0f) : my_rgb[lane * 4 + 1];
+    const float raw_b = fast_base ? (need ? fast_rgb[2] : 0.0f) : my_rgb[lane * 4 + 2];
     if (need) {
       part_c[0] += w * sigmoidf_(raw_r);
       part_c[1] += w * sigmoidf_(raw_g);
@@ -1034,9 +1077,24 @@ __global__ __launch_bounds__(kBlock) void render_backward_kernel(GridArgs g, Ray
   const int processed = fwd.stop[ray];
   const int nchunks = (processed + kWave - 1) / kWave;
   float suffix = 0.0f;  // sum of w_j e_j over all samples beyond the current chunk
+  const BoxSpan span = box_span(st, r, g);
+  float Yd[16];  // direct emit: the signed SH basis of this ray, multiplied into every record
+  if constexpr (EMIT == 2) {
+    if constexpr (!DIFFUSE && K > 1)
+      sh_basis<K>(st.d[0] / st.dnorm, st.d[1] / st.dnorm, st.d[2] / st.dnorm, Yd);
+    else
+      Yd[0] = kC0;
+  }
 
   for (int chunk = nchunks - 1; chunk >= 0; --chunk) {
     const int s = chunk * kWave + lane;
+    // the forward pass skipped chunks outside the box (all weights exactly 0, nothing counted): so does the adjoint
+    if (chunk_outside_box(span, st, r, chunk)) {
+      if constexpr (EMIT == 1) {  // every slot still gets its "no record" key
+        if (s < r.S) gr.keys[ray * (long long)r.S + s] = kNoBrick;
+      }
+      continue;
+    }
     Sample sm = make_sample(st, r, g, ray, s);
     const bool have = sm.valid && s < processed;
     float raw[3] = {0.f, 0.f, 0.f};
@@ -1089,11 +1147,6 @@ __global__ __launch_bounds__(kBlock) void render_backward_kernel(GridArgs g, Ray
         constexpr int KE = DIFFUSE ? 1 : K;  // diffuse lists carry the base channels only
         constexpr int CE = 3 * KE + 1;
         constexpr int QE = record_quads(KE);
-        float Yd[16];
-        if constexpr (KE > 1)
-          sh_basis<K>(st.d[0] / st.dnorm, st.d[1] / st.dnorm, st.d[2] / st.dnorm, Yd);
-        else
-          Yd[0] = kC0;
         const float graw[4] = {g_raw[0], g_raw[1], g_raw[2], g_pre * g.rho};  // colour 3 = density
         float4* dst = gr.sorted + (long long)pos * QE;
         dst[0] = make_float4(sm.cell.idx[0], sm.cell.idx[1], sm.cell.idx[2], 0.0f);
@@ -1405,18 +1458,18 @@ __global__ __launch_bounds__(256) void scatter_records_kernel(const short* __res
   }
 }
 
-// One workgroup (4 waves) per NODE brick: it owns B^3 nodes exclusively, so the result is written with plain stores.
-// Race-free accumulation without LDS atomics (tools/lds_microbench*.hip: ds_add_f32 retires 0.33 lane/clk/CU, a plain
-// read-add-write chain is bound by the 65-cycle LDS latency): waves 0 and 1 each own HALF the channels of every node
-// and walk ALL records that touch the brick; a lane owns (corner, channel pair) and adds with one 8-byte
-// read-add-write (8 corners x 7 pairs = 56 lanes at degree 2) -- the LDS pipe, not the VALU, bounds this kernel, and
-// 8-byte accesses halve the LDS instructions per record.
+// One workgroup (8 waves) per NODE brick: it owns B^3 nodes exclusively, so the result is written with plain stores.
+// Race-free accumulation without LDS float atomics (tools/lds_microbench*.hip: ds_add_f32 retires 0.33 lane/clk/CU, a plain
+// read-add-write chain is bound by the 65-cycle LDS latency): consumer waves 0..3 each own FOUR channel pairs of every node
+// and walk ALL records that touch the brick; a lane owns (record of the step, corner, channel pair) and adds with one 8-byte
+// read-add-write (2 records x 8 corners x 4 pairs = 64 lanes).
 // Records are sorted by key = cell-brick * 8 + flags, so the records of a source brick that reach into this brick
 // (flags superset of the offset) are a handful of contiguous ranges: no record is read that does not contribute.
-// Waves 2 and 3 are producers: per batch of 32 records, 8 lanes per record build a table row (corner address + weight
+// Waves 4 and 5 are producers: per batch of 32 records, 8 lanes per record build a table row (corner address + weight
 // per corner, the record's per-channel values, its packed cell) one batch ahead of the consumers; the two waves
 // alternate batches, so that the global loads of a batch (several microseconds under load) have two accumulation
 // rounds to arrive.  The consumers' loop is then 2 table reads, 2 multiplies and the read-add-write.
+// Waves 6 and 7 only take part in the phases every thread shares (diffuse records, zero-fill, flush).
 constexpr int kBrickThreads = 512;  // 8 waves: 2 consumers + 2 producers of the table path, 4 more for the phases every thread shares (diffuse records, zero-fill, flush)
 constexpr int kBrickFetchers = 256;  // threads that stage diffuse records (two 16-byte loads per record, 128 records per round)
 constexpr int kBrickBatch = 32;   // records per table (8 staging threads per record)
@@ -1430,7 +1483,12 @@ __host__ __device__ inline int brick_row_stride(int B, int C) {
   const int row = B * brick_node_stride(C);
   return row + ((48 - row % 64) + 64) % 64;
 }
-__host__ __device__ inline int brick_slab_stride(int B, int C) { return B * brick_row_stride(B, C); }
+// ... and slabs (x) so that the slab stride is 8 mod 64 words: the 8 corners of a record, 8 words (4 channel pairs) each in a
+// consumer wave, then tile the 64 banks exactly -- 0 / 28 / 48 / 12 for dx = 0 and 8 / 36 / 56 / 20 for dx = 1
+__host__ __device__ inline int brick_slab_stride(int B, int C) {
+  const int slab = B * brick_row_stride(B, C);
+  return slab + ((8 - slab % 64) + 64) % 64;
+}
 __host__ __device__ inline int brick_acc_words(int B, int C) { return B * brick_slab_stride(B, C) + 64; }  // + trash row
 
 // packed lower nodes (one byte per axis): do the two cells have a node in common?
@@ -1466,8 +1524,7 @@ __global__ __launch_bounds__(kBrickThreads, 4) void brick_accumulate_kernel(Grid
   constexpr int Q = record_quads(K);
   static_assert(Q <= 8 || K == 16, "8 staging threads per record");
   constexpr int CS = C4;                       // node stride in the accumulator
-  constexpr int PW = (CS / 2 + 1) / 2;         // channel pairs owned by each of the two accumulating waves (7 at degree 2)
-  static_assert(PW <= 8 || K == 16, "a lane owns (corner, pair): 8 corners x up to 8 pairs");
+  static_assert(CS / 2 <= 16, "four consumer waves own four channel pairs each");
   // table of a batch: one entry per STEP = the pair of records (j, j + 16), interleaved so that a consumer lane fetches
   // both records' data with one 16-byte read: 8 x (addrA, wA, addrB, wB), then CS/2 x (gA.x, gA.y, gB.x, gB.y), then
   // the two packed cells
@@ -1644,10 +1701,10 @@ __global__ __launch_bounds__(kBrickThreads, 4) void brick_accumulate_kernel(Grid
   const int nbatches = (total + kBrickBatch - 1) / kBrickBatch;
   constexpr int H = kBrickBatch / 2;
 
-  // ---- producer role (waves 2 and 3): wave 2 prepares the even batches, wave 3 the odd ones, so that the record loads
+  // ---- producer role (waves 4 and 5): wave 4 prepares the even batches, wave 5 the odd ones, so that the record loads
   // of a batch have two whole accumulation rounds to arrive.  8 lanes per record (lane `part` prepares corner `part`
   // and copies float4 `part` of the record), four records (sj + 8 t) per lane.
-  const bool producer = wave == 2 || wave == 3;
+  const bool producer = wave == 4 || wave == 5;
   const int parity = wave & 1;
   constexpr int TPL = kBrickBatch / 8;  // records per producer lane
   const int sj = lane >> 3, part = lane & 7;
@@ -1723,16 +1780,20 @@ __global__ __launch_bounds__(kBrickThreads, 4) void brick_accumulate_kernel(Grid
     }
   };
 
-  // ---- consumer role (waves 0 and 1): lane = corner q x channel pair; this lane's two channels start at `ch`
-  const int q = lane >> 3;
-  const int ch = 2 * (wave * PW + (lane & 7));
-  const bool acc_active = wave < 2 && (lane & 7) < PW && ch < CS;
+  // ---- consumer role (waves 0..3, one per SIMD): a wave owns FOUR channel pairs of every node (pairs 4 w .. 4 w + 3; 14 pairs
+  // at degree 2, so wave 3 owns two) and walks ALL records of the batch.  32 lanes = 8 corners x 4 pairs serve one record, so
+  // the two records (j, j + 16) of a step share ONE read-add-write instruction -- lanes 0..31 record A, lanes 32..63 record B.
+  // (Two consumer waves with 7 pairs each needed two read-add-writes per step; the chain per step, not the LDS bandwidth, is what
+  // bounds this phase.)  Disjoint channel ownership across waves => no races between waves; the two records of a step race
+  // only when their cells share a node, and are then issued one half-wave after the other.
+  const int half = lane >> 5;
+  const int q = (lane >> 2) & 7;
+  const int pair = 4 * wave + (lane & 3);
+  const int ch = 2 * pair;
+  const bool acc_active = wave < 4 && ch < CS;
 
-  // -- accumulate batch b from its table
-  // records j and j + 16 of a batch (usually samples of different rays) are handled together: when their cells share
-  // no node (lower nodes >= 2 apart on some axis) the two read-add-writes are independent and overlap, otherwise
-  // they are issued one after the other.  The table entries of step j + 1 are fetched before the read-add-write of
-  // step j, so that only the accumulator latency is on the critical path.
+  // -- accumulate batch b from its table.  The table entries of step j + 1 are fetched before the read-add-write of step j,
+  // so that only the accumulator latency is on the critical path.
   auto accumulate = [&](int b) {
     const uint32_t* tb = table[b & 1];
     const int base = b * kBrickBatch;
@@ -1746,39 +1807,40 @@ __global__ __launch_bounds__(kBrickThreads, 4) void brick_accumulate_kernel(Grid
     if (!acc_active) return;
     const int steps = min(nb, H);  // records >= nb are padded (zero weight, trash address, far-away cell)
     const uint32_t* row = tb;
-    const int aoff = 4 * q, goff = GOFF + 2 * ch;  // this lane's (addrA, wA, addrB, wB) and (gA.x, gA.y, gB.x, gB.y)
-    // One step = the pair of records (j, j + 16).  Ordering inside a step matters: the accumulator reads are issued FIRST,
-    // then the table entries of the next step (which the following step needs only after ITS accumulator reads), so that
-    // the wait for the accumulators leaves the prefetch in flight.
-    uint4 aw = *reinterpret_cast<const uint4*>(row + aoff);
-    float4 gg = *reinterpret_cast<const float4*>(row + goff);
+    const int aoff = 4 * q + 2 * half, goff = GOFF + 4 * pair + 2 * half;  // this lane's (addr, w) and (g.x, g.y) of ITS record
+    uint2 aw = *reinterpret_cast<const uint2*>(row + aoff);
+    float2 gg = *reinterpret_cast<const float2*>(row + goff);
 #pragma unroll 2
     for (int j = 0; j < steps; ++j) {
       row += ROW;  // (the table has spare steps behind the last one)
-      const float wA = __uint_as_float(aw.y), wB = __uint_as_float(aw.w);
-      float2* dA = reinterpret_cast<float2*>(&acc[aw.x + ch]);
-      float2* dB = reinterpret_cast<float2*>(&acc[aw.z + ch]);
-      if ((shared_mask >> j) & 1u) {  // rare: the two cells share nodes -> one after the other
-        float2 vA = *dA;
-        vA.x = vA.x + wA * gg.x;
-        vA.y = vA.y + wA * gg.y;
-        *dA = vA;
-        float2 vB = *dB;
-        vB.x = vB.x + wB * gg.z;
-        vB.y = vB.y + wB * gg.w;
-        *dB = vB;
-        aw = *reinterpret_cast<const uint4*>(row + aoff);
-        gg = *reinterpret_cast<const float4*>(row + goff);
+      const float w = __uint_as_float(aw.y);
+      float2* d = reinterpret_cast<float2*>(&acc[aw.x + ch]);
+      const float gx = w * gg.x, gy = w * gg.y;
+      if ((shared_mask >> j) & 1u) {  // rare: the two cells share nodes -> record A's half-wave first, then record B's
+        if (half == 0) {
+          float2 v = *d;
+          v.x = v.x + gx;
+          v.y = v.y + gy;
+          *d = v;
+        }
+        // (per-thread the two blocks look identical: without this fence the compiler merges them into one unconditional
+        // read-add-write and the half-waves race again)
+        wave_lds_fence();
+        if (half == 1) {
+          float2 v = *d;
+          v.x = v.x + gx;
+          v.y = v.y + gy;
+          *d = v;
+        }
+        aw = *reinterpret_cast<const uint2*>(row + aoff);
+        gg = *reinterpret_cast<const float2*>(row + goff);
       } else {
-        float2 vA = *dA, vB = *dB;
-        const uint4 aw_n = *reinterpret_cast<const uint4*>(row + aoff);
-        const float4 gg_n = *reinterpret_cast<const float4*>(row + goff);
-        vA.x = vA.x + wA * gg.x;
-        vA.y = vA.y + wA * gg.y;
-        vB.x = vB.x + wB * gg.z;
-        vB.y = vB.y + wB * gg.w;
-        *dA = vA;
-        *dB = vB;
+        float2 v = *d;
+        const uint2 aw_n = *reinterpret_cast<const uint2*>(row + aoff);
+        const float2 gg_n = *reinterpret_cast<const float2*>(row + goff);
+        v.x = v.x + gx;
+        v.y = v.y + gy;
+        *d = v;
         aw = aw_n;
         gg = gg_n;
       }
@@ -1807,7 +1869,14 @@ __global__ __launch_bounds__(kBrickThreads, 4) void brick_accumulate_kernel(Grid
     } else {
       accumulate(b);
     }
+#ifdef RF_BRICK_PROFILE
+    unsigned long long tb0_ = 0;
+    if (threadIdx.x == 0) tb0_ = __builtin_readcyclecounter();
+#endif
     __syncthreads();
+#ifdef RF_BRICK_PROFILE
+    if (threadIdx.x == 0) atomicAdd(&g_brick_prof[5], __builtin_readcyclecounter() - tb0_);  // consumer wave 0 waiting at the batch barrier
+#endif
   }
 
   RF_PROF_MARK(3);  // table path: producer / consumer batches
