@@ -153,7 +153,7 @@ def test_highres_occupancy_render_against_oracle_at_config4_size(hip_device):
                        white_bkgd=True, t_rand=t_rand.cpu().double())
     band = (ref["depth"].detach().double() - ref64["depth"]).abs() + 1e-5
     assert bool(((out.depth.detach().cpu().double() - ref64["depth"]).abs() <= band).all())
-    assert float(out.colour.min()) < 0.9  # the blob is visible
+    assert float(out.colour.detach().min()) < 0.9  # the blob is visible
     for ours, r in ((gd, cd.grad), (gf, cf.grad)):
         r = r.numpy()
         assert np.abs(r).max() > 0
