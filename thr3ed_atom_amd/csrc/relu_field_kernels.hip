@@ -25,6 +25,7 @@
 
 #include <atomic>
 #include <cstdlib>
+#include <type_traits>
 
 #include "relu_field.h"
 
@@ -1465,12 +1466,11 @@ __global__ __launch_bounds__(256) void scatter_records_kernel(const short* __res
 // read-add-write (2 records x 8 corners x 4 pairs = 64 lanes).
 // Records are sorted by key = cell-brick * 8 + flags, so the records of a source brick that reach into this brick
 // (flags superset of the offset) are a handful of contiguous ranges: no record is read that does not contribute.
-// Waves 4 and 5 are producers: per batch of 32 records, 8 lanes per record build a table row (corner address + weight
-// per corner, the record's per-channel values, its packed cell) one batch ahead of the consumers; the two waves
-// alternate batches, so that the global loads of a batch (several microseconds under load) have two accumulation
-// rounds to arrive.  The consumers' loop is then 2 table reads, 2 multiplies and the read-add-write.
-// Waves 6 and 7 only take part in the phases every thread shares (diffuse records, zero-fill, flush).
-constexpr int kBrickThreads = 512;  // 8 waves: 2 consumers + 2 producers of the table path, 4 more for the phases every thread shares (diffuse records, zero-fill, flush)
+// Waves 4..7 are producers: per batch of 32 records, 8 lanes per record build a table row (corner address + weight
+// per corner, the record's per-channel values, its packed cell) one batch ahead of the consumers; two pairs of waves
+// alternate batches and keep the global loads of FOUR batches in flight (several microseconds of latency under load).
+// The consumers' loop is then 2 table reads, 2 multiplies and the read-add-write.
+constexpr int kBrickThreads = 512;  // 8 waves: 4 consumers + 4 producers of the table path; every phase is bound by per-workgroup latency and LDS admits 2 workgroups per CU
 constexpr int kBrickFetchers = 256;  // threads that stage diffuse records (two 16-byte loads per record, 128 records per round)
 constexpr int kBrickBatch = 32;   // records per table (8 staging threads per record)
 constexpr int kMaxRanges = 28;    // 14 (source brick, flag run) ranges per list, two lists
@@ -1644,14 +1644,21 @@ __global__ __launch_bounds__(kBrickThreads, 4) void brick_accumulate_kernel(Grid
       while (s_dcum[ri + 1] <= v) ++ri;
       return a.lists[1].rec[(s_dstart[ri] + (v - s_dcum[ri])) * 2 + (tid & 1)];
     };
+    // three rounds of loads in flight per fetcher thread (one round kept 4 KB per workgroup in flight: latency-bound)
     const bool fetcher = tid < kBrickFetchers;
-    float4 inflight = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (fetcher) inflight = fetch(0);
+    float4 f0 = make_float4(0.f, 0.f, 0.f, 0.f), f1 = f0, f2 = f0;
+    if (fetcher) {
+      f0 = fetch(0);
+      if (nrounds > 1) f1 = fetch(1);
+      if (nrounds > 2) f2 = fetch(2);
+    }
     for (int round = 0; round < nrounds; ++round) {
       float4* buf = stage + (round & 1) * kBrickFetchers;
-      if (fetcher) buf[tid] = inflight;
+      if (fetcher) buf[tid] = f0;
       __syncthreads();
-      if (fetcher && round + 1 < nrounds) inflight = fetch(round + 1);
+      f0 = f1;
+      f1 = f2;
+      if (fetcher && round + 3 < nrounds) f2 = fetch(round + 3);
       const int nrec = min(RPR, total_d - round * RPR);
 #pragma unroll 4
       for (int r = wave * 2 + half; r < nrec; r += 2 * (kBrickThreads / kWave)) {
@@ -1701,23 +1708,27 @@ __global__ __launch_bounds__(kBrickThreads, 4) void brick_accumulate_kernel(Grid
   const int nbatches = (total + kBrickBatch - 1) / kBrickBatch;
   constexpr int H = kBrickBatch / 2;
 
-  // ---- producer role (waves 4 and 5): wave 4 prepares the even batches, wave 5 the odd ones, so that the record loads
-  // of a batch have two whole accumulation rounds to arrive.  8 lanes per record (lane `part` prepares corner `part`
-  // and copies float4 `part` of the record), four records (sj + 8 t) per lane.
-  const bool producer = wave == 4 || wave == 5;
+  // ---- producer role (waves 4..7): waves 4 and 6 prepare the even batches, waves 5 and 7 the odd ones (each pair splits the 32
+  // records of its batch).  8 lanes per record (lane `part` prepares corner `part` and copies float4 `part` of the record), two
+  // records (sj + 8 t) per lane and batch.  The record loads of a batch are issued FOUR batches before the table is built from
+  // them (two register sets per wave): the table path is bound by the latency of these loads -- several microseconds while other
+  // workgroups stream their optimizer flush -- and with a distance of two batches only ~16 KB per CU were in flight.
+  const bool producer = wave >= 4;
   const int parity = wave & 1;
-  constexpr int TPL = kBrickBatch / 8;  // records per producer lane
+  const int thalf = (wave >> 1) & 1;            // which half of the batch's records this producer wave stages
+  constexpr int TPL = kBrickBatch / 8 / 2;      // records per producer lane and batch
   const int sj = lane >> 3, part = lane & 7;
   const int pdx = (part >> 2) & 1, pdy = (part >> 1) & 1, pdz = part & 1;
   const int vpart = (part >= 1 && part < Q) ? part : 0;
   int sri = 0;  // running range index of the record this lane LOCATES (record lane & 31 of a batch; monotonic)
-  float4 ridx[TPL], rval[TPL];
+  float4 ridx[2][TPL], rval[2][TPL];  // [register set = (batch >> 1) & 1]
 #pragma unroll
-  for (int t = 0; t < TPL; ++t) ridx[t] = rval[t] = make_float4(0.f, 0.f, 0.f, 0.f);
+  for (int t = 0; t < TPL; ++t) ridx[0][t] = ridx[1][t] = rval[0][t] = rval[1][t] = make_float4(0.f, 0.f, 0.f, 0.f);
 
   // -- issue the loads of batch bb (unconditional, clamped to the last record: no divergent register merges).  Lane l
   // locates record l & 31 in the range list once; the 8 lanes that stage a record fetch its address by shuffle.
-  auto issue = [&](int bb) {
+  auto issue = [&](int bb, auto slot_tag) {
+    constexpr int SLOT = decltype(slot_tag)::value;
     const int v = min(bb * kBrickBatch + (lane & (kBrickBatch - 1)), total - 1);
     while (s_rcum[sri + 1] <= v) ++sri;
     // (positions, not pointers, go through the shuffle: a pointer rebuilt from integers would be a FLAT access, and FLAT
@@ -1726,20 +1737,21 @@ __global__ __launch_bounds__(kBrickThreads, 4) void brick_accumulate_kernel(Grid
     const int lo = (int)(uint32_t)pos, hi = (int)(uint32_t)((unsigned long long)pos >> 32) | (s_rlist[sri] << 30);
 #pragma unroll
     for (int t = 0; t < TPL; ++t) {
-      const int src = sj + 8 * t;
+      const int src = sj + 8 * (t + TPL * thalf);
       const uint32_t plo = (uint32_t)__shfl(lo, src), phi = (uint32_t)__shfl(hi, src);
       const long long p = (long long)(((unsigned long long)(phi & 0x3fffffffu) << 32) | plo);
       const float4* rec = ((phi >> 30) ? a.lists[1].rec : a.lists[0].rec) + p * Q;
-      ridx[t] = rec[0];
-      rval[t] = rec[vpart];
+      ridx[SLOT][t] = rec[0];
+      rval[SLOT][t] = rec[vpart];
     }
   };
 
   // -- build the table of batch bb from the loads issued for it
-  auto build = [&](int bb) {
+  auto build = [&](int bb, auto slot_tag) {
+    constexpr int SLOT = decltype(slot_tag)::value;
 #pragma unroll
     for (int t = 0; t < TPL; ++t) {
-      const int rj = sj + 8 * t;
+      const int rj = sj + 8 * (t + TPL * thalf);
       const int half = rj / H;  // record A or B of step rj % H
       uint32_t* row = table[bb & 1] + (rj & (H - 1)) * ROW;
       uint32_t addr = (uint32_t)TRASH;
@@ -1747,7 +1759,7 @@ __global__ __launch_bounds__(kBrickThreads, 4) void brick_accumulate_kernel(Grid
       float wc = 0.0f;
       float4 val = make_float4(0.f, 0.f, 0.f, 0.f);
       if (bb * kBrickBatch + rj < total) {
-        const float idx[3] = {ridx[t].x, ridx[t].y, ridx[t].z};
+        const float idx[3] = {ridx[SLOT][t].x, ridx[SLOT][t].y, ridx[SLOT][t].z};
         const int org[3] = {X0, Y0, Z0};
         const int dim[3] = {g.X, g.Y, g.Z};
         const int dd[3] = {pdx, pdy, pdz};
@@ -1755,7 +1767,7 @@ __global__ __launch_bounds__(kBrickThreads, 4) void brick_accumulate_kernel(Grid
         bool owned = true;
         float w3[3];
         // (the 4th word of the index quad is 0; reading it keeps all four load registers reserved until here)
-        cell = __float_as_uint(ridx[t].w);
+        cell = __float_as_uint(ridx[SLOT][t].w);
 #pragma unroll
         for (int ax = 0; ax < 3; ++ax) {
           const float fl = floorf(idx[ax]);
@@ -1768,7 +1780,7 @@ __global__ __launch_bounds__(kBrickThreads, 4) void brick_accumulate_kernel(Grid
           addr = (uint32_t)(n3[0] * SX + n3[1] * SY + n3[2] * CS);
           wc = (w3[0] * w3[1]) * w3[2];
         }
-        val = rval[t];
+        val = rval[SLOT][t];
       }
       *reinterpret_cast<uint2*>(row + 4 * part + 2 * half) = make_uint2(addr, __float_as_uint(wc));
       if (part >= 1 && part < Q) {  // channels 4 (part - 1) .. + 3 = channel pairs 2 (part - 1) and 2 (part - 1) + 1
@@ -1792,8 +1804,12 @@ __global__ __launch_bounds__(kBrickThreads, 4) void brick_accumulate_kernel(Grid
   const int ch = 2 * pair;
   const bool acc_active = wave < 4 && ch < CS;
 
-  // -- accumulate batch b from its table.  The table entries of step j + 1 are fetched before the read-add-write of step j,
-  // so that only the accumulator latency is on the critical path.
+  // -- accumulate batch b from its table.  The table entries of step j + 1 are fetched before the read-add-write of step j.
+  // Measured by ablation (tools/brick_phase_profile.py, RF_BRICK_STAGGER bits): of the ~57 K cycles a brick spends here, ~15 K are
+  // the batch barriers alone, ~41 K this loop (~200 cycles per step), the producers fit inside it (32 K on their own) and the
+  // record loads cost nothing extra.  Keeping two steps in flight (records j, j+8, j+16, j+24) did NOT help (0.495 -> 0.528 ms):
+  // the LDS pipe is shared with the other workgroup's float64 atomics and flush reads, so more LDS requests in flight only
+  // queue up.
   auto accumulate = [&](int b) {
     const uint32_t* tb = table[b & 1];
     const int base = b * kBrickBatch;
@@ -1850,33 +1866,45 @@ __global__ __launch_bounds__(kBrickThreads, 4) void brick_accumulate_kernel(Grid
   // producers run one batch ahead of the consumers (tables are double buffered); the loads of a producer wave's next
   // batch (two batches later) are issued as soon as it has built the current one
   RF_PROF_MARK(2);  // zero-fill + initial values
+  RF_PROF_MARK(2);  // zero-fill + initial values
+  using Slot0 = std::integral_constant<int, 0>;
+  using Slot1 = std::integral_constant<int, 1>;
+  // batch bb lives in register set (bb >> 1) & 1 of the producer waves of its parity
   if (total > 0 && producer) {
     if (parity == 0) {
-      issue(0);
-      build(0);
-      if (nbatches > 2) issue(2);
-    } else if (nbatches > 1) {
-      issue(1);
+      issue(0, Slot0{});
+      build(0, Slot0{});
+      if (nbatches > 2) issue(2, Slot1{});
+      if (nbatches > 4) issue(4, Slot0{});
+    } else {
+      if (nbatches > 1) issue(1, Slot0{});
+      if (nbatches > 3) issue(3, Slot1{});
     }
   }
   __syncthreads();
-  for (int b = 0; b < nbatches; ++b) {
+  // one iteration: the consumers drain table b; the producers of batch b + 1 build its table from the register set the loads
+  // went to four batches ago and re-fill that set with batch b + 5
+  auto iteration = [&](int b, auto slot_tag) {
+#ifdef RF_BRICK_PROFILE
+    const bool no_consume = a.stagger & 0x100000, no_build = a.stagger & 0x200000, no_issue = a.stagger & 0x400000;
+#else
+    constexpr bool no_consume = false, no_build = false, no_issue = false;
+#endif
     if (producer) {
       if (b + 1 < nbatches && ((b + 1) & 1) == parity) {
-        build(b + 1);
-        if (b + 3 < nbatches) issue(b + 3);
+        if (!no_build) build(b + 1, slot_tag);
+        if (b + 5 < nbatches && !no_issue) issue(b + 5, slot_tag);
       }
-    } else {
+    } else if (!no_consume) {
       accumulate(b);
     }
-#ifdef RF_BRICK_PROFILE
-    unsigned long long tb0_ = 0;
-    if (threadIdx.x == 0) tb0_ = __builtin_readcyclecounter();
-#endif
     __syncthreads();
-#ifdef RF_BRICK_PROFILE
-    if (threadIdx.x == 0) atomicAdd(&g_brick_prof[5], __builtin_readcyclecounter() - tb0_);  // consumer wave 0 waiting at the batch barrier
-#endif
+  };
+  for (int b0 = 0; b0 < nbatches; b0 += 4) {  // ((b + 1) >> 1) & 1 for b = b0 .. b0 + 3 with b0 % 4 == 0: 0, 1, 1, 0
+    iteration(b0, Slot0{});
+    if (b0 + 1 < nbatches) iteration(b0 + 1, Slot1{});
+    if (b0 + 2 < nbatches) iteration(b0 + 2, Slot1{});
+    if (b0 + 3 < nbatches) iteration(b0 + 3, Slot0{});
   }
 
   RF_PROF_MARK(3);  // table path: producer / consumer batches

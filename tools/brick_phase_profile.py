@@ -57,4 +57,6 @@ tot = sum(out[i] for i in range(5))
 for i, nm in enumerate(names):
     print(f"{nm:34s} {out[i] / nb:10.0f} ticks per brick   {100.0 * out[i] / max(tot, 1):5.1f} %")
 print(f"{'  of the table path: consumer wave 0 waiting at batch barriers':34s} {out[5] / nb:10.0f} ticks per brick")
+print(f"{'  of the table path: producer wave 4 building (every other batch)':34s} {out[6] / nb:10.0f} ticks per brick")
+print(f"{'  of the table path: consumer wave 0 accumulating':34s} {out[7] / nb:10.0f} ticks per brick")
 print(f"{'sum':34s} {tot / nb:10.0f} ticks per brick (s_memtime ticks = 100 MHz constant clock or shader cycles, see DESIGN)")
