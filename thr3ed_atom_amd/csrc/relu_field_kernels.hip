@@ -1613,6 +1613,62 @@ __global__ __launch_bounds__(kBrickThreads, 4) void brick_accumulate_kernel(Grid
   if (!any && a.accumulate) return;  // nothing reaches this brick
   RF_PROF_MARK(0);  // range set-up
 
+  const int nbatches = (total + kBrickBatch - 1) / kBrickBatch;
+  constexpr int H = kBrickBatch / 2;
+  using Slot0 = std::integral_constant<int, 0>;
+  using Slot1 = std::integral_constant<int, 1>;
+
+  // ---- producer role (waves 4..7): waves 4 and 6 prepare the even batches, waves 5 and 7 the odd ones (each pair splits the 32
+  // records of its batch).  8 lanes per record (lane `part` prepares corner `part` and copies float4 `part` of the record), two
+  // records (sj + 8 t) per lane and batch.  The record loads of a batch are issued FOUR batches before the table is built from
+  // them (two register sets per wave): the table path is bound by the latency of these loads -- several microseconds while other
+  // workgroups stream their optimizer flush -- and with a distance of two batches only ~16 KB per CU were in flight.
+  const bool producer = wave >= 4;
+  const int parity = wave & 1;
+  const int thalf = (wave >> 1) & 1;            // which half of the batch's records this producer wave stages
+  constexpr int TPL = kBrickBatch / 8 / 2;      // records per producer lane and batch
+  const int sj = lane >> 3, part = lane & 7;
+  const int pdx = (part >> 2) & 1, pdy = (part >> 1) & 1, pdz = part & 1;
+  const int vpart = (part >= 1 && part < Q) ? part : 0;
+  int sri = 0;  // running range index of the record this lane LOCATES (record lane & 31 of a batch; monotonic)
+  float4 ridx[2][TPL], rval[2][TPL];  // [register set = (batch >> 1) & 1]
+#pragma unroll
+  for (int t = 0; t < TPL; ++t) ridx[0][t] = ridx[1][t] = rval[0][t] = rval[1][t] = make_float4(0.f, 0.f, 0.f, 0.f);
+
+  // -- issue the loads of batch bb (unconditional, clamped to the last record: no divergent register merges).  Lane l
+  // locates record l & 31 in the range list once; the 8 lanes that stage a record fetch its address by shuffle.
+  auto issue = [&](int bb, auto slot_tag) {
+    constexpr int SLOT = decltype(slot_tag)::value;
+    const int v = min(bb * kBrickBatch + (lane & (kBrickBatch - 1)), total - 1);
+    while (s_rcum[sri + 1] <= v) ++sri;
+    // (positions, not pointers, go through the shuffle: a pointer rebuilt from integers would be a FLAT access, and FLAT
+    // loads in flight force every LDS wait in this kernel to drain completely)
+    const long long pos = s_rstart[sri] + (v - s_rcum[sri]);
+    const int lo = (int)(uint32_t)pos, hi = (int)(uint32_t)((unsigned long long)pos >> 32) | (s_rlist[sri] << 30);
+#pragma unroll
+    for (int t = 0; t < TPL; ++t) {
+      const int src = sj + 8 * (t + TPL * thalf);
+      const uint32_t plo = (uint32_t)__shfl(lo, src), phi = (uint32_t)__shfl(hi, src);
+      const long long p = (long long)(((unsigned long long)(phi & 0x3fffffffu) << 32) | plo);
+      const float4* rec = ((phi >> 30) ? a.lists[1].rec : a.lists[0].rec) + p * Q;
+      ridx[SLOT][t] = rec[0];
+      rval[SLOT][t] = rec[vpart];
+    }
+  };
+
+  // The record loads of the first batches go out NOW, before the diffuse phase, so that the table path does not start with
+  // a bare HBM latency (the producer waves issue no other global loads until then; batch bb lives in register set (bb >> 1) & 1
+  // of the producer waves of its parity).
+  if (total > 0 && producer) {
+    if (parity == 0) {
+      issue(0, Slot0{});
+      if (nbatches > 2) issue(2, Slot1{});
+    } else {
+      if (nbatches > 1) issue(1, Slot0{});
+      if (nbatches > 3) issue(3, Slot1{});
+    }
+  }
+
   // ---- mixed call: the base-channel (render_diffuse) records first, summed with LDS float64 atomics.  A 4-channel record
   // would occupy a quarter of the lanes of the table path below at the price of a full record; ds_add_f64 is fire-and-forget
   // and needs neither ownership nor ordering, so all four waves take two records per instruction (32 lanes = 8 corners x 4
@@ -1705,46 +1761,6 @@ __global__ __launch_bounds__(kBrickThreads, 4) void brick_accumulate_kernel(Grid
     }
   }
 
-  const int nbatches = (total + kBrickBatch - 1) / kBrickBatch;
-  constexpr int H = kBrickBatch / 2;
-
-  // ---- producer role (waves 4..7): waves 4 and 6 prepare the even batches, waves 5 and 7 the odd ones (each pair splits the 32
-  // records of its batch).  8 lanes per record (lane `part` prepares corner `part` and copies float4 `part` of the record), two
-  // records (sj + 8 t) per lane and batch.  The record loads of a batch are issued FOUR batches before the table is built from
-  // them (two register sets per wave): the table path is bound by the latency of these loads -- several microseconds while other
-  // workgroups stream their optimizer flush -- and with a distance of two batches only ~16 KB per CU were in flight.
-  const bool producer = wave >= 4;
-  const int parity = wave & 1;
-  const int thalf = (wave >> 1) & 1;            // which half of the batch's records this producer wave stages
-  constexpr int TPL = kBrickBatch / 8 / 2;      // records per producer lane and batch
-  const int sj = lane >> 3, part = lane & 7;
-  const int pdx = (part >> 2) & 1, pdy = (part >> 1) & 1, pdz = part & 1;
-  const int vpart = (part >= 1 && part < Q) ? part : 0;
-  int sri = 0;  // running range index of the record this lane LOCATES (record lane & 31 of a batch; monotonic)
-  float4 ridx[2][TPL], rval[2][TPL];  // [register set = (batch >> 1) & 1]
-#pragma unroll
-  for (int t = 0; t < TPL; ++t) ridx[0][t] = ridx[1][t] = rval[0][t] = rval[1][t] = make_float4(0.f, 0.f, 0.f, 0.f);
-
-  // -- issue the loads of batch bb (unconditional, clamped to the last record: no divergent register merges).  Lane l
-  // locates record l & 31 in the range list once; the 8 lanes that stage a record fetch its address by shuffle.
-  auto issue = [&](int bb, auto slot_tag) {
-    constexpr int SLOT = decltype(slot_tag)::value;
-    const int v = min(bb * kBrickBatch + (lane & (kBrickBatch - 1)), total - 1);
-    while (s_rcum[sri + 1] <= v) ++sri;
-    // (positions, not pointers, go through the shuffle: a pointer rebuilt from integers would be a FLAT access, and FLAT
-    // loads in flight force every LDS wait in this kernel to drain completely)
-    const long long pos = s_rstart[sri] + (v - s_rcum[sri]);
-    const int lo = (int)(uint32_t)pos, hi = (int)(uint32_t)((unsigned long long)pos >> 32) | (s_rlist[sri] << 30);
-#pragma unroll
-    for (int t = 0; t < TPL; ++t) {
-      const int src = sj + 8 * (t + TPL * thalf);
-      const uint32_t plo = (uint32_t)__shfl(lo, src), phi = (uint32_t)__shfl(hi, src);
-      const long long p = (long long)(((unsigned long long)(phi & 0x3fffffffu) << 32) | plo);
-      const float4* rec = ((phi >> 30) ? a.lists[1].rec : a.lists[0].rec) + p * Q;
-      ridx[SLOT][t] = rec[0];
-      rval[SLOT][t] = rec[vpart];
-    }
-  };
 
   // -- build the table of batch bb from the loads issued for it
   auto build = [&](int bb, auto slot_tag) {
@@ -1867,19 +1883,9 @@ __global__ __launch_bounds__(kBrickThreads, 4) void brick_accumulate_kernel(Grid
   // batch (two batches later) are issued as soon as it has built the current one
   RF_PROF_MARK(2);  // zero-fill + initial values
   RF_PROF_MARK(2);  // zero-fill + initial values
-  using Slot0 = std::integral_constant<int, 0>;
-  using Slot1 = std::integral_constant<int, 1>;
-  // batch bb lives in register set (bb >> 1) & 1 of the producer waves of its parity
-  if (total > 0 && producer) {
-    if (parity == 0) {
-      issue(0, Slot0{});
-      build(0, Slot0{});
-      if (nbatches > 2) issue(2, Slot1{});
-      if (nbatches > 4) issue(4, Slot0{});
-    } else {
-      if (nbatches > 1) issue(1, Slot0{});
-      if (nbatches > 3) issue(3, Slot1{});
-    }
+  if (total > 0 && producer && parity == 0) {
+    build(0, Slot0{});
+    if (nbatches > 4) issue(4, Slot0{});
   }
   __syncthreads();
   // one iteration: the consumers drain table b; the producers of batch b + 1 build its table from the register set the loads
