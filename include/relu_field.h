@@ -364,8 +364,8 @@ typedef struct RFTrainStep {
   float* grad_second_dev;
   void* const* timing_events;   /* optional HOST array of RF_TRAIN_STEP_EVENTS hipEvent_t (created by the caller with timing
                                    enabled): event 0 is recorded on `stream` before the first launch, event k after launch k
-                                   in the order select, forward[0], loss[0], forward[1], loss[1], offsets[0], emit[0],
-                                   offsets[1], emit[1], bricks -- per-kernel durations of the very call that is timed    */
+                                   in the order select, forward[0], loss[0], forward[1], loss[1], offsets (both lists, one launch),
+                                   emit[0], (nothing), emit[1], bricks -- per-kernel durations of the very call that is timed    */
 } RFTrainStep;
 
 #define RF_TRAIN_STEP_EVENTS 11

@@ -187,7 +187,7 @@ class RFTrainStep(C.Structure):
 
 TRAIN_STEP_EVENTS = 11
 TRAIN_STEP_EVENT_NAMES = ["select_rays_and_pixels", "render_forward[spec,save]", "l1_loss_grad[spec]", "render_forward[diffuse,save]", "l1_loss_grad[diffuse]",
-                          "bin_offsets[spec]", "render_backward_emit_direct[spec]", "bin_offsets[diffuse]", "render_backward_emit_direct[diffuse]",
+                          "bin_offsets[both]", "render_backward_emit_direct[spec]", "(none)", "render_backward_emit_direct[diffuse]",
                           "brick_accumulate"]
 
 

@@ -1336,10 +1336,18 @@ __global__ void expand_records_kernel(const float4* __restrict__ rec, const long
 // Counting-sort alternative to torch.sort + expand: hist[k] = records per key (filled by the emit pass) ->
 // offsets[k] = exclusive prefix sum (int64, what rf_brick_accumulate reads), cursor[k] = the same as int32 for the
 // scatter pass; hist is cleared for the next iteration.  One workgroup (at most 32768 keys).
-__global__ __launch_bounds__(1024) void bin_offsets_kernel(const int* __restrict__ hist, int nkeys, long long* __restrict__ offsets,
-                                                           int* __restrict__ cursor) {
+struct BinLists {  // up to two independent lists per launch (blockIdx.y)
+  const int* hist[2];
+  long long* offsets[2];
+  int* cursor[2];
+};
+
+__global__ __launch_bounds__(1024) void bin_offsets_kernel(BinLists lists, int nkeys) {
   // workgroup i owns keys [1024 i, 1024 i + 1024): it sums everything in front of its segment (coalesced, L2-resident)
   // and scans its own segment with wave shuffles -- no dependency between workgroups
+  const int* __restrict__ hist = lists.hist[blockIdx.y];
+  long long* __restrict__ offsets = lists.offsets[blockIdx.y];
+  int* __restrict__ cursor = lists.cursor[blockIdx.y];
   __shared__ int s_front[16], s_own[16];
   const int t = threadIdx.x, lane = t & (kWave - 1), wave = t >> 6;
   const int seg0 = blockIdx.x * 1024;
@@ -2897,12 +2905,25 @@ int rf_expand_records(const RFGrid* grid, const float* records_dev, const int64_
   }
 }
 
-int rf_bin_offsets(const int32_t* hist_dev, int32_t num_keys, int64_t* offsets_dev, int32_t* cursor_dev, void* stream) {
-  if (!hist_dev || !offsets_dev || !cursor_dev) return RF_ERR_NULL_POINTER;
+static int bin_offsets_impl(const int32_t* const hist[2], int64_t* const offsets[2], int32_t* const cursor[2], int nlists, int32_t num_keys,
+                            void* stream) {
   if (num_keys < 1 || num_keys > (1 << 21)) return RF_ERR_BAD_SHAPE;
-  hipLaunchKernelGGL(bin_offsets_kernel, dim3((num_keys + 1023) / 1024), dim3(1024), 0, (hipStream_t)stream, hist_dev, num_keys,
-                     reinterpret_cast<long long*>(offsets_dev), cursor_dev);
+  BinLists l = {};
+  for (int i = 0; i < nlists; ++i) {
+    if (!hist[i] || !offsets[i] || !cursor[i]) return RF_ERR_NULL_POINTER;
+    l.hist[i] = hist[i];
+    l.offsets[i] = reinterpret_cast<long long*>(offsets[i]);
+    l.cursor[i] = cursor[i];
+  }
+  hipLaunchKernelGGL(bin_offsets_kernel, dim3((num_keys + 1023) / 1024, nlists), dim3(1024), 0, (hipStream_t)stream, l, num_keys);
   return launch_status();
+}
+
+int rf_bin_offsets(const int32_t* hist_dev, int32_t num_keys, int64_t* offsets_dev, int32_t* cursor_dev, void* stream) {
+  const int32_t* h[2] = {hist_dev, nullptr};
+  int64_t* o[2] = {offsets_dev, nullptr};
+  int32_t* c[2] = {cursor_dev, nullptr};
+  return bin_offsets_impl(h, o, c, 1, num_keys, stream);
 }
 
 extern "C++" {
@@ -3193,11 +3214,16 @@ int rf_train_step(const RFGrid* grid, const RFTrainStep* step, void* stream) {
     grads[i] = RFRenderGrads{ps.grad_colour_dev, nullptr, nullptr};
   }
   RFBrickList lists[2];
+  {  // the offsets of both lists in one launch
+    const int32_t* h[2] = {step->pass[0].out.key_hist_dev, step->pass[1].out.key_hist_dev};
+    int64_t* o[2] = {step->pass[0].offsets_dev, step->pass[1].offsets_dev};
+    int32_t* c[2] = {step->pass[0].cursor_dev, step->pass[1].cursor_dev};
+    rc = bin_offsets_impl(h, o, c, 2, nkeys, stream);
+    if (rc != RF_OK) return rc;
+  }
   for (int i = 0; i < 2; ++i) {
     const RFPassScratch& ps = step->pass[i];
-    rc = rf_bin_offsets(ps.out.key_hist_dev, nkeys, ps.offsets_dev, ps.cursor_dev, stream);
-    if (rc != RF_OK) return rc;
-    RF_STEP_EVENT();
+    RF_STEP_EVENT();  // (offsets[0] = the launch above, offsets[1] = nothing)
     rc = rf_render_backward_emit_direct(grid, &rays[i], flags[i], &ps.out, &grads[i], ps.out.brick_size, ps.cursor_dev, ps.records_sorted_dev,
                                         ps.out.key_hist_dev, stream);
     if (rc != RF_OK) return rc;
