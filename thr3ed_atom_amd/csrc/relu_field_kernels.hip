@@ -1850,7 +1850,6 @@ __global__ __launch_bounds__(kBrickThreads, 4) void brick_accumulate_kernel(Grid
     const int aoff = 4 * q + 2 * half, goff = GOFF + 4 * pair + 2 * half;  // this lane's (addr, w) and (g.x, g.y) of ITS record
     uint2 aw = *reinterpret_cast<const uint2*>(row + aoff);
     float2 gg = *reinterpret_cast<const float2*>(row + goff);
-#pragma unroll 2
     for (int j = 0; j < steps; ++j) {
       row += ROW;  // (the table has spare steps behind the last one)
       const float w = __uint_as_float(aw.y);
