@@ -954,7 +954,7 @@ struct ScatterLayout {
 // Chunks are walked from the far end so that the suffix sum is an exact running sum.
 // =============================================================================================
 // EMIT: 0 = atomic scatter into the gradient tensors; 1 = per-slot keys + 32-byte records (binned backward, sort or
-// scatter binning); 2 = expanded records written straight to their final position (the forward pass counted them)
+// scatter binning).  (Expanded records written straight to their final positions: render_emit_direct_kernel below.)
 template <int K, bool DIFFUSE, int EMIT>
 __global__ __launch_bounds__(kBlock) void render_backward_kernel(GridArgs g, RayArgs r, OutArgs fwd, GradArgs gr,
                                                                  uint32_t flags) {
@@ -965,12 +965,6 @@ __global__ __launch_bounds__(kBlock) void render_backward_kernel(GridArgs g, Ray
   const int lane = threadIdx.x & (kWave - 1);
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const long long ray = (long long)blockIdx.x * kWavesPerBlock + wave;
-  if (EMIT == 2) {
-    // the forward pass's counters have been turned into offsets: clear them for the next iteration (every thread of the
-    // grid takes part, including the waves without a ray)
-    if (gr.hist_clear)
-      for (long long k = (long long)blockIdx.x * blockDim.x + threadIdx.x; k < gr.nkeys; k += (long long)gridDim.x * blockDim.x) gr.hist_clear[k] = 0;
-  }
   if (ray >= r.n) return;
 
   const RayState st = load_ray(r, g, ray, flags);
@@ -1001,7 +995,7 @@ __global__ __launch_bounds__(kBlock) void render_backward_kernel(GridArgs g, Ray
       wave_lds_fence();
     }
   }
-  if (no_upstream && EMIT != 2) return;  // (direct mode: the counted samples of this ray still need their -- zero -- records)
+  if (no_upstream) return;
 
   // Scatter layout (measured on MI355X, tools/atomic_microbench.hip): float32 atomics retire at a fixed rate of
   // ~21 G 64-byte-sector requests/s however many dwords a request carries, so one instruction should cover as
@@ -1079,13 +1073,6 @@ __global__ __launch_bounds__(kBlock) void render_backward_kernel(GridArgs g, Ray
   const int nchunks = (processed + kWave - 1) / kWave;
   float suffix = 0.0f;  // sum of w_j e_j over all samples beyond the current chunk
   const BoxSpan span = box_span(st, r, g);
-  float Yd[16];  // direct emit: the signed SH basis of this ray, multiplied into every record
-  if constexpr (EMIT == 2) {
-    if constexpr (!DIFFUSE && K > 1)
-      sh_basis<K>(st.d[0] / st.dnorm, st.d[1] / st.dnorm, st.d[2] / st.dnorm, Yd);
-    else
-      Yd[0] = kC0;
-  }
 
   for (int chunk = nchunks - 1; chunk >= 0; --chunk) {
     const int s = chunk * kWave + lane;
@@ -1139,35 +1126,6 @@ __global__ __launch_bounds__(kBlock) void render_backward_kernel(GridArgs g, Ray
 
     const bool live = have && sm.inside;
     const bool need = live && (g_pre != 0.f || g_raw[0] != 0.f || g_raw[1] != 0.f || g_raw[2] != 0.f);
-    if constexpr (EMIT == 2) {
-      // every sample the forward pass counted gets its expanded record (zeros when its gradient happens to vanish) at
-      // the next position of its key class; `need` samples are always among the counted ones
-      const int key = counted ? brick_key(sm.cell.i0, g, gr.brick_shift, gr.nby, gr.nbz) : -1;
-      const int pos = add_key_runs<true>(gr.cursor, key, lane);
-      if (counted) {
-        constexpr int KE = DIFFUSE ? 1 : K;  // diffuse lists carry the base channels only
-        constexpr int CE = 3 * KE + 1;
-        constexpr int QE = record_quads(KE);
-        const float graw[4] = {g_raw[0], g_raw[1], g_raw[2], g_pre * g.rho};  // colour 3 = density
-        float4* dst = gr.sorted + (long long)pos * QE;
-        dst[0] = make_float4(sm.cell.idx[0], sm.cell.idx[1], sm.cell.idx[2], 0.0f);
-#pragma unroll
-        for (int part = 1; part < QE; ++part) {
-          float v[4];
-#pragma unroll
-          for (int x = 0; x < 4; ++x) {
-            const int ch = 4 * (part - 1) + x;
-            int colour, basis_k;
-            lds_channel_meaning<KE>(ch < CE ? ch : 0, colour, basis_k);
-            float gv = graw[colour];
-            if (ch > 0) gv = gv * Yd[basis_k];
-            v[x] = (ch < CE) ? gv : 0.0f;
-          }
-          dst[part] = make_float4(v[0], v[1], v[2], v[3]);
-        }
-      }
-      continue;
-    }
     if constexpr (EMIT == 1) {
       short key_of_lane = kNoBrick;
       if (sm.valid) {
@@ -1239,6 +1197,157 @@ __global__ __launch_bounds__(kBlock) void render_backward_kernel(GridArgs g, Ray
       }
     }
     wave_lds_fence();
+  }
+}
+
+// =============================================================================================
+// direct emit (training step): the adjoint of a render as EXPANDED records at their final positions
+//
+// Every sample the forward pass counted (flag in the sign bit of its cached transmittance) writes index quad + dL/d(interpolated
+// channel) for all channels (SH basis of the ray multiplied in) at the next free position of its (brick, flags) key class.
+// The per-chunk dependency chain -- cache load (HBM) -> key -> returning cursor atomic (L2) -> record stores -- is what bounds this
+// kernel, not arithmetic or bandwidth (0.3 of the HBM peak by counters), so a ray's chunks are processed FOUR at a time: all
+// cache loads first, then all cursor atomics back to back (their results are not touched yet), then the gradients far-to-near
+// with the running suffix sum.  Measured on the bench step (specular / diffuse render): 0.098 / 0.073 ms; by ablation the geometry
+// and gradient arithmetic alone take 0.036 / 0.034 ms, the cache loads ~0.03, the cursor atomics ~0.025, the record stores
+// ~0.035 / 0.017 on top -- the components still add up rather than overlap (one chunk at a time: 0.107 / 0.069 ms).
+// =============================================================================================
+template <int K, bool DIFFUSE>
+__global__ __launch_bounds__(kBlock) void render_emit_direct_kernel(GridArgs g, RayArgs r, OutArgs fwd, GradArgs gr, uint32_t flags) {
+  const int lane = threadIdx.x & (kWave - 1);
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const long long ray = (long long)blockIdx.x * kWavesPerBlock + wave;
+  // the forward pass's counters have been turned into offsets: clear them for the next iteration (every thread of the grid
+  // takes part, including the waves without a ray)
+  if (gr.hist_clear)
+    for (long long k = (long long)blockIdx.x * blockDim.x + threadIdx.x; k < gr.nkeys; k += (long long)gridDim.x * blockDim.x) gr.hist_clear[k] = 0;
+  if (ray >= r.n) return;
+
+  const RayState st = load_ray(r, g, ray, flags);
+  const float white = (flags & RF_FLAG_WHITE_BKGD) ? 1.0f : 0.0f;
+  float gC[3] = {0.f, 0.f, 0.f};
+  if (gr.gcolour) {
+    gC[0] = gr.gcolour[ray * 3 + 0];
+    gC[1] = gr.gcolour[ray * 3 + 1];
+    gC[2] = gr.gcolour[ray * 3 + 2];
+  }
+  const float gD = gr.gdepth ? gr.gdepth[ray] : 0.0f;
+  const float gA = gr.gacc ? gr.gacc[ray] : 0.0f;
+  constexpr int KE = DIFFUSE ? 1 : K;  // diffuse lists carry the base channels only
+  constexpr int CE = 3 * KE + 1;
+  constexpr int QE = record_quads(KE);
+  float Yd[16];  // the signed SH basis of this ray, multiplied into every record
+  if constexpr (KE > 1)
+    sh_basis<K>(st.d[0] / st.dnorm, st.d[1] / st.dnorm, st.d[2] / st.dnorm, Yd);
+  else
+    Yd[0] = kC0;
+
+  const int processed = fwd.stop[ray];
+  const int nchunks = (processed + kWave - 1) / kWave;
+  const BoxSpan span = box_span(st, r, g);
+  float suffix = 0.0f;  // sum of w_j e_j over all samples beyond the current chunk
+  constexpr int G = 4;  // chunks in flight
+
+  for (int c0 = nchunks - 1; c0 >= 0; c0 -= G) {
+    float4 cv[G];
+    float Tc[G], zz[G], dl[G], ix[G][3];
+    int base_[G], hl_[G];
+    bool act[G], counted[G];
+    // -- A1: the cache loads of the group (chunks c0, c0 - 1, ...; chunks outside the box carry nothing, like in the forward pass)
+#pragma unroll
+    for (int u = 0; u < G; ++u) {
+      const int chunk = c0 - u;
+      act[u] = chunk >= 0 && !chunk_outside_box(span, st, r, chunk);  // wave-uniform
+      const int s = chunk * kWave + lane;
+      cv[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+      Tc[u] = 0.0f;
+      if (act[u] && s < processed) {
+        const long long idx = ray * (long long)r.S + s;
+        cv[u] = reinterpret_cast<const float4*>(fwd.cache)[idx];
+        Tc[u] = fwd.tcache[idx];
+      }
+    }
+    // -- A2: geometry, keys and the cursor atomics of the group, back to back
+#pragma unroll
+    for (int u = 0; u < G; ++u) {
+      base_[u] = hl_[u] = 0;
+      counted[u] = false;
+      zz[u] = dl[u] = ix[u][0] = ix[u][1] = ix[u][2] = 0.0f;
+      if (!act[u]) continue;
+      const int s = (c0 - u) * kWave + lane;
+      const Sample sm = make_sample(st, r, g, ray, s);
+      zz[u] = sm.z;
+      dl[u] = sm.delta;
+      ix[u][0] = sm.cell.idx[0];
+      ix[u][1] = sm.cell.idx[1];
+      ix[u][2] = sm.cell.idx[2];
+      counted[u] = sm.valid && s < processed && (__float_as_uint(Tc[u]) >> 31);
+      const int key = counted[u] ? brick_key(sm.cell.i0, g, gr.brick_shift, gr.nby, gr.nbz) : -1;
+      // one atomic per RUN of equal keys (add_key_runs, split: the returned base is only combined in phase B)
+      const bool active = key >= 0;
+      const int prev = __shfl_up(key, 1);
+      const bool head = active && (lane == 0 || prev != key);
+      const unsigned long long heads = __ballot(head);
+      const unsigned long long ends = __ballot(head || !active);
+      const unsigned long long above = (lane == 63) ? 0ull : (ends & ~((2ull << lane) - 1ull));
+      const int run = (above ? __builtin_ctzll(above) : 64) - lane;
+      const unsigned long long below = heads & ((lane == 63) ? ~0ull : ((2ull << lane) - 1ull));
+      hl_[u] = below ? 63 - __builtin_clzll(below) : 0;
+      if (head) base_[u] = atomicAdd(&gr.cursor[key], run);
+    }
+    // -- B: gradients, far to near
+#pragma unroll
+    for (int u = 0; u < G; ++u) {
+      if (!act[u]) continue;
+      const int s = (c0 - u) * kWave + lane;
+      const bool have = s < r.S && s < processed;
+      const float sigma = cv[u].w;
+      const float T = fabsf(Tc[u]);
+      const float alpha = 1.0f - exp_fast(-(sigma * dl[u]));
+      const float w = alpha * T;
+      const float Tn = T * (1.0f - alpha);
+      const float raw[3] = {cv[u].x, cv[u].y, cv[u].z};
+      float c[3], e = gD * zz[u] + gA;
+#pragma unroll
+      for (int ch = 0; ch < 3; ++ch) {
+        c[ch] = sigmoidf_(raw[ch]);
+        e += gC[ch] * (c[ch] - white);
+      }
+      const float we = have ? w * e : 0.0f;
+      const float incl = wave_incl_rscan_add(we, lane);
+      const float after = (incl - we) + suffix;  // sum over samples strictly behind this one
+      suffix += __shfl(incl, 0, kWave);
+      const float g_sigma = dl[u] * (Tn * e - after);
+      float g_pre;
+      if (g.mode == RF_DENSITY_RELU)
+        g_pre = (sigma > 0.0f) ? g_sigma : 0.0f;
+      else if (g.mode == RF_DENSITY_SOFTPLUS)
+        g_pre = g_sigma * (1.0f - exp_fast(-sigma));  // softplus'(x) = sigmoid(x) = 1 - exp(-softplus(x))
+      else
+        g_pre = g_sigma;
+      const int pos = __shfl(base_[u], hl_[u]) + (lane - hl_[u]);
+      if (counted[u]) {
+        // (a counted sample is inside the box; its record is written even when its gradient happens to vanish)
+        const float graw[4] = {(w * gC[0]) * (c[0] * (1.0f - c[0])), (w * gC[1]) * (c[1] * (1.0f - c[1])), (w * gC[2]) * (c[2] * (1.0f - c[2])),
+                               g_pre * g.rho};  // colour 3 = density
+        float4* dst = gr.sorted + (long long)pos * QE;
+        dst[0] = make_float4(ix[u][0], ix[u][1], ix[u][2], 0.0f);
+#pragma unroll
+        for (int part = 1; part < QE; ++part) {
+          float v[4];
+#pragma unroll
+          for (int x = 0; x < 4; ++x) {
+            const int ch = 4 * (part - 1) + x;
+            int colour, basis_k;
+            lds_channel_meaning<KE>(ch < CE ? ch : 0, colour, basis_k);
+            float gv = graw[colour];
+            if (ch > 0) gv = gv * Yd[basis_k];
+            v[x] = (ch < CE) ? gv : 0.0f;
+          }
+          dst[part] = make_float4(v[0], v[1], v[2], v[3]);
+        }
+      }
+    }
   }
 }
 
@@ -2610,7 +2719,7 @@ template <int K, bool DIFFUSE>
 void launch_backward(unsigned blocks, hipStream_t st, const GridArgs& g, const RayArgs& r, const OutArgs& o,
                      const GradArgs& gr, uint32_t flags) {
   if (gr.sorted)
-    hipLaunchKernelGGL((render_backward_kernel<K, DIFFUSE, 2>), dim3(blocks), dim3(kBlock), 0, st, g, r, o, gr, flags);
+    hipLaunchKernelGGL((render_emit_direct_kernel<K, DIFFUSE>), dim3(blocks), dim3(kBlock), 0, st, g, r, o, gr, flags);
   else if (gr.keys)
     hipLaunchKernelGGL((render_backward_kernel<K, DIFFUSE, 1>), dim3(blocks), dim3(kBlock), 0, st, g, r, o, gr, flags);
   else
