@@ -27,8 +27,8 @@ csv.field_size_limit(1 << 30)
 BENCH_NAMES = {
     "render_forward_kernel<9, false, true>": "render_forward[spec,save]",
     "render_forward_kernel<1, true, true>": "render_forward[diffuse,save]",
-    "render_backward_kernel<9, false, 2>": "render_backward_emit_direct[spec]",
-    "render_backward_kernel<1, true, 2>": "render_backward_emit_direct[diffuse]",
+    "render_emit_direct_kernel<9, false>": "render_backward_emit_direct[spec]",
+    "render_emit_direct_kernel<1, true>": "render_backward_emit_direct[diffuse]",
     "render_backward_kernel<9, false, 0>": "render_backward[sh2]",
     "render_backward_kernel<1, true, 0>": "render_backward[diffuse]",
     "brick_accumulate_kernel<9, true>": "brick_accumulate_adam[sh2]",
