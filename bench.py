@@ -215,6 +215,8 @@ def main():
                     help="gradient scatter of the train step: float32 atomics, or records binned by brick + atomic-free LDS accumulation")
     ap.add_argument("--deterministic", action="store_true", help="binned backward: stable radix sort instead of the counting sort")
     ap.add_argument("--no-fuse-optimizer", action="store_true", help="keep the gradient bucket and the separate Adam kernel on one GPU")
+    ap.add_argument("--dp-style-step", action="store_true",
+                    help="run the step the way a data-parallel rank computes it (specular brick pass, atomic diffuse backward, separate Adam) on one GPU")
     ap.add_argument("--timed-steps", type=int, default=5, help="how many of the --steps record per-kernel HIP events")
     ap.add_argument("--cpu-threads", type=int, default=0, help="torch CPU threads for cpu_baseline (0 = min(cores, 16))")
     args = ap.parse_args()
@@ -369,7 +371,8 @@ def main():
 
     # ---- training steps: the headline ---------------------------------------------------------------
     stepper = TrainStepper(model, R, learning_rate=0.03, apply_diffuse_render_regularization=True, ray_selection=args.ray_selection, backward=args.backward,
-                           deterministic=args.deterministic, fuse_optimizer=False if args.no_fuse_optimizer else None)
+                           deterministic=args.deterministic, fuse_optimizer=False if (args.no_fuse_optimizer or args.dp_style_step) else None,
+                           merge_bricks=False if args.dp_style_step else None)
     executor = stepper.fused and stepper.merged_bricks and args.ray_selection == "keyed"
     torch.manual_seed(1234 + rank)  # every rank draws its own rays
     batches = dataset.image_batches(args.images)
@@ -489,6 +492,27 @@ def main():
             + (", Adam applied in the flush (no gradient tensor in HBM)" if fused_opt else "") + "; LDS-latency bound, see DESIGN section 4",
             "traffic_source": pmc.get("_source"),
             "by_kernel": by_kernel,
+        }
+
+    if roofline is None and kernels:
+        # the data-parallel-style step (or any non-merged step): per-launch HIP events of ops.KernelTimer; byte figures where the
+        # counter table has the kernel (same kernels as the single-GPU step, plus the specular-only brick pass, the atomic diffuse
+        # backward and the separate optimizer)
+        alias = {f"render_forward[{spec},save]": "render_forward[spec,save]", f"render_backward_emit_direct[{spec}]": "render_backward_emit_direct[spec]"}
+        by_kernel = {}
+        for kname, rec in kernels.items():
+            counter = pmc.get(alias.get(kname, kname), {}).get("hbm_bytes_per_launch")
+            by_kernel[kname] = {"avg_launch_ms": rec["avg_ms"], "counter_bytes_per_launch": counter,
+                                "frac_hbm": None if counter is None else frac(counter, rec["avg_ms"], f"{kname} (counters)")}
+        dom = max(kernels, key=lambda kname: kernels[kname]["avg_ms"] * kernels[kname]["launches"])
+        d = by_kernel[dom]
+        roofline = {
+            "kernel": dom, "bound": "hbm", "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "achieved": None if d["counter_bytes_per_launch"] is None else d["counter_bytes_per_launch"] / 1e9 / (d["avg_launch_ms"] / 1e3),
+            "frac": d["frac_hbm"], "traffic": d["counter_bytes_per_launch"], "avg_launch_ms": d["avg_launch_ms"],
+            "frac_basis": "HBM bytes from the PMC counters (profiles/pmc_traffic.json, single-GPU profile of the same kernels) / this run's launch time",
+            "traffic_source": pmc.get("_source"), "by_kernel": by_kernel,
+            "note": "data-parallel-style step: specular brick pass -> [gradient exchange of `rest` overlapped with] diffuse forward + atomic diffuse backward -> exchange of `base` -> (sharded) Adam",
         }
 
     baseline = None

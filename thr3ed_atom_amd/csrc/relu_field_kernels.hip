@@ -1394,7 +1394,7 @@ struct BrickArgs {
   int nbx, nby, nbz;
   int accumulate;          // 0: grad = brick sum (no zero-fill needed), 1: grad += brick sum
   int fmul;                // reference layout: feature index of degree-0 colour c is c * fmul (base-only lists on an SH grid)
-  int stagger;             // ADAM: number of first-generation workgroups that start with a pseudo-random delay (0 = off)
+  int stagger;             // development builds (RF_BRICK_PROFILE): experiment / ablation switches from $RF_BRICK_STAGGER
   AdamArgs adam;           // only read by the ADAM instantiation
 };
 
@@ -1666,17 +1666,16 @@ __global__ __launch_bounds__(kBrickThreads, 4) void brick_accumulate_kernel(Grid
   const int brick = blockIdx.x;
   const int bz = brick % a.nbz, by = (brick / a.nbz) % a.nby, bx = brick / (a.nbz * a.nby);
   const int X0 = bx << a.shift, Y0 = by << a.shift, Z0 = bz << a.shift;
+#ifdef RF_BRICK_PROFILE
   if constexpr (ADAM) {
-    // De-phase the first generation of workgroups.  Every workgroup alternates between LDS-bound phases (no HBM traffic)
-    // and a flush that streams 344 KB; launched together, the 512 resident workgroups reach their flushes together, HBM
-    // saturates for the flushes and idles in between (measured: the flushes ran at exactly HBM rate, 14 GB/s each).  A
-    // pseudo-random start offset of up to ~40 us spreads the flushes over time; later generations inherit the spread.
+    // (experiment kept for the record: de-phasing the first generation of workgroups with a pseudo-random start delay does NOT
+    // help -- the optimizer flushes of different workgroups are not synchronised to begin with)
     if ((a.stagger & 0xffff) && blockIdx.x < (unsigned)(a.stagger & 0xffff)) {
       const unsigned int h = (blockIdx.x * 2654435761u) >> 28;  // 0..15
       for (unsigned int k = 0; k < h; ++k) __builtin_amdgcn_s_sleep(100);  // ~6400 clk each
     }
   }
-
+#endif
   // ---- which sorted ranges reach into this brick: 14 (offset to the source brick o, run of flag classes f with
   // (f & o) == o) per list, fetched by 14 lanes each and compacted with a wave scan.  Wave 0 does it for the lists that go
   // through the table path, wave 1 for the base-channel list of a mixed call (it has its own, smaller, range table).
@@ -3160,10 +3159,12 @@ static int brick_accumulate_impl(const RFGrid* grid, int32_t brick_size, const R
     a.adam.b2 = adam->beta2;
     a.adam.eps = adam->eps;
     a.adam.bc2_sqrt = (float)sqrt(bc2);
+#ifdef RF_BRICK_PROFILE
     {
       const char* e = getenv("RF_BRICK_STAGGER");
       a.stagger = e ? atoi(e) : 0;
     }
+#endif
     switch (K) {
       case 1:
         return launch_brick<1, true>(g, a, nbricks, nullptr, nullptr, st);

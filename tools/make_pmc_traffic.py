@@ -55,6 +55,7 @@ def main():
     ap.add_argument("--gt-frames", type=int, default=8)
     ap.add_argument("--frames-per-leg", type=int, default=3)
     ap.add_argument("--source", default="")
+    ap.add_argument("--merge-into", default="", help="existing pmc_traffic.json: only ADD the kernels it does not have yet (profiles of another step variant)")
     args = ap.parse_args()
     by = {"FETCH_SIZE": defaultdict(list), "WRITE_SIZE": defaultdict(list)}
     for counter, root in (("FETCH_SIZE", args.fetch_dir), ("WRITE_SIZE", args.write_dir)):
@@ -81,6 +82,13 @@ def main():
         fs, ws = f[g + i * n : g + (i + 1) * n], w[g + i * n : g + (i + 1) * n]
         if fs and ws:
             out[f"render_forward[sh2,frame]:{leg}"] = entry(fs, ws)
+    if args.merge_into:
+        base = json.load(open(args.merge_into))
+        for k, v in out.items():
+            if k not in base and not k.startswith("_") and ":" not in k:
+                v["from"] = args.source
+                base[k] = v
+        out = base
     print(json.dumps(out, indent=1))
 
 
