@@ -126,8 +126,8 @@ typedef struct RFRenderOut {
   float* depth_dev;     /* [N]                                                                         */
   float* acc_dev;       /* [N]                                                                         */
   float* disparity_dev; /* [N]   (NaN where acc == 0, like the reference)                              */
-  /* Optional per-sample cache written by the forward pass and consumed by rf_render_backward
-   * (all three NULL for inference): */
+  /* Optional per-sample cache written by the forward pass and consumed by rf_render_backward* (all three NULL for
+   * inference).  Slots of 64-sample chunks that lie entirely outside the grid's box are left unwritten (and unread). */
   float* sample_cache_dev; /* [N, S, 4] = (raw r, raw g, raw b, sigma)                                 */
   float* trans_cache_dev;  /* [N, S]    = transmittance T_i                                            */
   int32_t* stop_cache_dev; /* [N]       = number of samples the forward pass processed                 */

@@ -718,14 +718,8 @@ __global__ __launch_bounds__(kBlock) void render_forward_kernel(GridArgs g, RayA
     {
       const bool empty = chunk_outside_box(span, st, r, chunk);
       if (empty) {  // wave-uniform
+        // (nothing is cached for such a chunk: the adjoint kernels make the same wave-uniform decision and never read it)
         processed = min(r.S, (chunk + 1) * kWave);
-        if constexpr (SAVE) {
-          if (s < r.S) {
-            const long long idx = ray * (long long)r.S + s;
-            reinterpret_cast<float4*>(out.cache)[idx] = make_float4(0.f, 0.f, 0.f, 0.f);
-            out.tcache[idx] = T_carry;
-          }
-        }
         z_ready = false;
         continue;
       }

@@ -201,7 +201,9 @@ def render_forward_raw(grid: VoxelGrid, origins: Tensor, directions: Tensor, t_r
     caches = None
     if save:
         cache = torch.empty((n, num_samples, 4), dtype=torch.float32, device=dev)
-        tcache = torch.empty((n, num_samples), dtype=torch.float32, device=dev)
+        # (the kernel leaves the slots of chunks outside the box unwritten; callers that inspect the record flags in the sign bits
+        # of this cache -- tests do -- must not see stale negatives there)
+        tcache = (torch.zeros if key_hist is not None else torch.empty)((n, num_samples), dtype=torch.float32, device=dev)
         stop = torch.empty((n,), dtype=torch.int32, device=dev)
         out.sample_cache_dev, out.trans_cache_dev, out.stop_cache_dev = cache.data_ptr(), tcache.data_ptr(), stop.data_ptr()
         caches = (cache, tcache, stop)
