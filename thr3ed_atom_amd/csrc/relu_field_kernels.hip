@@ -1205,6 +1205,8 @@ __global__ __launch_bounds__(kBlock) void render_backward_kernel(GridArgs g, Ray
 // with the running suffix sum.  Measured on the bench step (specular / diffuse render): 0.098 / 0.073 ms; by ablation the geometry
 // and gradient arithmetic alone take 0.036 / 0.034 ms, the cache loads ~0.03, the cursor atomics ~0.025, the record stores
 // ~0.035 / 0.017 on top -- the components still add up rather than overlap (one chunk at a time: 0.107 / 0.069 ms).
+// Also tried: transposing the records through LDS so that a store instruction writes whole contiguous records instead of 64
+// 16-byte pieces of 64 different lines -- slower (0.113 / 0.078 ms): the L2 merges the partial lines at no cost that matters here.
 // =============================================================================================
 template <int K, bool DIFFUSE>
 __global__ __launch_bounds__(kBlock) void render_emit_direct_kernel(GridArgs g, RayArgs r, OutArgs fwd, GradArgs gr, uint32_t flags) {
