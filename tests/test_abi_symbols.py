@@ -98,6 +98,41 @@ def test_node_count_guard_and_fused_optimizer_validation(lib):
     assert lib.rf_brick_accumulate(C.byref(g), 8, lists, 2, 64, 64, 0, None) == -2  # the specular list comes first
 
 
+def test_train_step_and_camera_validation_need_no_gpu(lib):
+    """rf_train_step / RFRayBatch.camera: argument errors are reported as codes before any launch."""
+    import ctypes as C
+
+    g = _lib.RFGrid()
+    g.densities_dev, g.features_dev = 16, 32
+    g.dims[0], g.dims[1], g.dims[2] = 16, 16, 16
+    g.num_features, g.density_stride, g.feature_stride, g.layout = 27, 4, 24, 1
+    st = _lib.RFTrainStep()
+    assert lib.rf_train_step(C.byref(g), None, None) == -1
+    assert lib.rf_train_step(C.byref(g), C.byref(st), None) == 0  # zero rays: nothing to do
+    st.num_rays, st.num_samples = 8, 16
+    assert lib.rf_train_step(C.byref(g), C.byref(st), None) == -1  # ray / pixel / loss buffers missing
+    st.origins_dev = st.directions_dev = st.pixels_dev = st.loss_sums_dev = 64
+    assert lib.rf_train_step(C.byref(g), C.byref(st), None) == -1  # per-render scratch missing
+    for i in range(2):
+        ps = st.pass_[i]
+        ps.grad_colour_dev = ps.cursor_dev = ps.offsets_dev = ps.records_sorted_dev = 64
+        ps.out.key_hist_dev, ps.out.brick_size = 64, 8
+    st.pass_[1].out.brick_size = 4
+    assert lib.rf_train_step(C.byref(g), C.byref(st), None) == -2  # the two lists must use the same bricks
+    st.pass_[0].out.brick_size = st.pass_[1].out.brick_size = 5
+    assert lib.rf_train_step(C.byref(g), C.byref(st), None) == -3  # brick size 4 or 8
+    # camera-generated rays: the pixel range must lie inside the frame
+    cam = _lib.RFCamera()
+    cam.height, cam.width, cam.focal = 10, 12, 20.0
+    r, o = _lib.RFRayBatch(), _lib.RFRenderOut()
+    r.num_rays, r.num_samples, r.t_vals_dev, r.camera, r.first_ray = 100, 8, 64, C.pointer(cam), 30
+    assert lib.rf_render_forward(C.byref(g), C.byref(r), 0, C.byref(o), None) == -2  # 30 + 100 > 120 pixels
+    r.first_ray = 20
+    assert lib.rf_render_forward(C.byref(g), C.byref(r), 0, C.byref(o), None) == -1  # in range; output buffers missing
+    r.camera = None
+    assert lib.rf_render_forward(C.byref(g), C.byref(r), 0, C.byref(o), None) == -1  # neither rays nor a camera
+
+
 def test_product_path_raises_without_gpu_tensors():
     import torch
 

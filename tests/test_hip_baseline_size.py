@@ -177,3 +177,43 @@ def test_full_size_depth_within_float64_anchored_band(hip_device):
         band = (ref32[key].double() - ref64[key]).abs() + 1e-5
         assert bool(((ours.cpu().double() - ref64[key]).abs() <= band).all()), key
     np.testing.assert_allclose(out.colour.cpu().numpy(), ref32["colour"].numpy(), rtol=0, atol=1e-5)
+
+
+def test_one_call_step_equals_the_launch_by_launch_step(hip_device):
+    """rf_train_step (one library call per iteration, the batch drawn by its own first launch) against the same launches issued
+    one by one from Python with the same selection and jitter keys: identical ray batches, losses equal to rounding, parameters
+    equal to the summation order of the float64 LDS atomics (which is not fixed), over several iterations."""
+    from thr3ed_atom_amd import ops
+    from thr3ed_atom_amd.trainers import PosedImagesInMemory
+
+    G, S, n = 32, 48, 999  # (a ray count that fills neither a workgroup nor a wavefront quad)
+    cam = hotdog_like_camera()
+    bounds = rf.CameraBounds(cam["near"], cam["far"])
+    images = T(hash_uniform((3, 3, 40, 40), 55, 0.0, 1.0)).to(hip_device)
+    poses = [rf.pose_spherical(70.0 * k, -30.0, cam["radius"]) for k in range(3)]
+    pose_mat = torch.stack([torch.cat([p.rotation, p.translation], dim=1) for p in poses]).to(hip_device)
+    data = PosedImagesInMemory(images, pose_mat, rf.CameraIntrinsics(40, 40, 55.0), bounds)
+    cfg = rf.SHVoxGridRenderConfig(S, bounds, perturb_sampled_points=True, white_bkgd=True)
+    runs = []
+    for one_call in (True, False):
+        grid, _, _ = _uniform_grid(hip_device, G, 27, 7, "split")
+        stepper = TrainStepper(rf.VolumetricModel(grid, rf.render_sh_voxel_grid, cfg, device=hip_device), n, learning_rate=0.03)
+        assert stepper.merged_bricks and stepper.fuse_optimizer
+        torch.manual_seed(77)
+        losses = []
+        for it in range(5):
+            if one_call:
+                stats = stepper.step(data, torch.arange(3))
+            else:  # the timer switches TrainStepper.step to the launch-by-launch path; same draws from the CPU generator
+                ops.KERNEL_TIMER = ops.KernelTimer()
+                try:
+                    stats = stepper.step(data, torch.arange(3))
+                finally:
+                    ops.KERNEL_TIMER = None
+            losses.append((stats.specular_loss.item(), stats.diffuse_loss.item()))
+        runs.append((losses, stepper.flat.flat_param.clone(), stepper.optimizer.exp_avg_sq.clone(), stepper.optimizer.step_count))
+    np.testing.assert_allclose(np.array(runs[0][0]), np.array(runs[1][0]), rtol=2e-5)
+    assert runs[0][3] == runs[1][3] == 5
+    err = (runs[0][1] - runs[1][1]).abs()
+    assert float((err <= 2e-5).float().mean()) >= 0.999 and float(err.max()) <= 0.03 * 2 * 5 + 1e-6
+    np.testing.assert_allclose(runs[0][2].cpu().numpy(), runs[1][2].cpu().numpy(), rtol=2e-3, atol=1e-7 * float(runs[1][2].abs().max()))
