@@ -842,3 +842,44 @@ def test_fused_binning_beyond_4096_bricks(hip_device):
     np.testing.assert_allclose(gf.cpu().numpy(), ref_f.cpu().numpy(), rtol=3e-4, atol=3e-6 * float(ref_f.abs().max()))
     with pytest.raises(RuntimeError, match="unsupported|not supported|UNSUPPORTED"):
         _binned_gradients(grid, rays, cfg, target, hip_device, diffuse_too=False, binning="sort")
+
+
+def test_psnr_after_equal_steps_with_jitter_through_the_default_fused_path(hip_device):
+    """north_star: PSNR within 0.05 dB of the reference after equal training steps -- here WITH stratified jitter and through
+    the path the trainer and bench.py run by default (rf_train_step: merged brick pass, float64-atomic diffuse sums, Adam in
+    the flush).  Both sides see the same ray batches and the same jitter tables (oracle.keyed_jitter, the numpy restatement
+    of the in-kernel generator); the reference side is the oracle + torch.optim.Adam on the CPU."""
+    G, deg, S, R, steps = 24, 2, 40, 768, 60
+    data, cfg, poses = _make_scene(hip_device, G, deg, 8, 40, S)
+    cfg.perturb_sampled_points = True
+    F = 3 * (deg + 1) ** 2
+    d0, f0 = procedural_grid((G, G, G), F, 78)
+    grid = relu_grid(hip_device, d0, f0, G, storage="split")
+    model = rf.VolumetricModel(grid, rf.render_sh_voxel_grid, cfg, device=hip_device)
+    stepper = TrainStepper(model, R, learning_rate=0.03)
+    assert stepper.merged_bricks and stepper.fuse_optimizer
+    cd, cf = d0.clone().requires_grad_(True), f0.clone().requires_grad_(True)
+    ref_opt = torch.optim.Adam([{"params": [cd, cf], "lr": 0.03}], betas=(0.9, 0.999))
+    aabb = orc.make_aabb((G, G, G), (3.0 / G,) * 3)
+    kw = dict(aabb=aabb, near=cfg.camera_bounds.near, far=cfg.camera_bounds.far, num_samples=S, density_scale=100.0 / 3.0, white_bkgd=True)
+    torch.manual_seed(6)
+    ids = torch.arange(7)  # view 7 is held out
+    for it in range(steps):
+        rays, pixels = stepper.select(data, ids)
+        tables = [T(orc.keyed_jitter(1000 + 2 * it + i, 0, R, S)) for i in range(2)]
+        stats = stepper.step_on(rays, pixels, t_rand=[t.to(hip_device) for t in tables])
+        o, d, px = rays.origins.cpu(), rays.directions.cpu(), pixels.cpu()
+        spec = torch.nn.functional.l1_loss(orc.render(cd, cf, origins=o, directions=d, t_rand=tables[0], **kw)["colour"], px)
+        diff = torch.nn.functional.l1_loss(orc.render(cd, cf, origins=o, directions=d, render_diffuse=True, t_rand=tables[1], **kw)["colour"], px)
+        ref_opt.zero_grad()
+        (spec + diff).backward()
+        ref_opt.step()
+        np.testing.assert_allclose(stats.specular_loss.item(), spec.item(), rtol=1e-3)
+    held = data.images[7].permute(1, 2, 0)
+    ours = model.render(poses[7], data.camera_intrinsics, perturb_sampled_points=False).colour
+    ho, hd = orc.cast_rays(40, 40, data.camera_intrinsics.focal, poses[7].rotation, poses[7].translation)
+    ref = orc.render(cd.detach(), cf.detach(), origins=ho.reshape(-1, 3), directions=hd.reshape(-1, 3), **kw)["colour"].reshape(40, 40, 3)
+    psnr_hip = float(rf.mse2psnr(torch.nn.functional.mse_loss(ours, held)))
+    psnr_ref = float(rf.mse2psnr(torch.nn.functional.mse_loss(ref, held.cpu())))
+    assert psnr_hip > 12.0  # it actually learned something (start is ~7 dB)
+    assert abs(psnr_hip - psnr_ref) <= 0.05, (psnr_hip, psnr_ref)
