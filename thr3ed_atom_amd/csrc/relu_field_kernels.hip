@@ -1370,6 +1370,21 @@ struct BrickList {
 
 // fused optimizer of the brick flush (torch.optim.Adam arithmetic, the same expressions as adam_kernel): the workgroup that
 // owns a brick holds its complete gradient in LDS, so the update is applied there and the gradient never goes to HBM
+// One Adam update (torch.optim.Adam's expressions: exp_avg, exp_avg_sq, denom = sqrt(exp_avg_sq) / sqrt(bias_correction2) + eps,
+// param -= lr / bias_correction1 * exp_avg / denom), shared by rf_adam_step's kernel and the brick pass's optimizer flush so that the
+// two stay bit-identical.  The square root and the reciprocal are the hardware's (v_sqrt_f32 / v_rcp_f32, 1 ulp): the IEEE
+// sequences the compiler emits for sqrtf and '/' cost ~35 instructions per parameter and made the flush instruction-bound
+// (14.8 K of its ~31 K cycles per brick without any memory traffic); 1 ulp of the update is 1e-7 x lr.
+__device__ __forceinline__ void adam_update(float& p, float& m, float& v, float g, float step, float b1, float b2, float eps,
+                                            float inv_bc2_sqrt) {
+  const float mm = m + (g - m) * (1.0f - b1);
+  const float vv = v * b2 + (g * g) * (1.0f - b2);
+  const float denom = __builtin_amdgcn_sqrtf(vv) * inv_bc2_sqrt + eps;
+  p = p - step * (mm * __builtin_amdgcn_rcpf(denom));
+  m = mm;
+  v = vv;
+}
+
 struct AdamArgs {
   float* p1;  // parameters, first / second tensor (the tensors GridArgs describes, writable)
   float* p2;
@@ -1379,7 +1394,7 @@ struct AdamArgs {
   float* v2;
   float step;      // lr / (1 - beta1^t)
   float b1, b2, eps;
-  float bc2_sqrt;  // sqrt(1 - beta2^t)
+  float inv_bc2_sqrt;  // 1 / sqrt(1 - beta2^t)
 };
 
 struct BrickArgs {
@@ -1615,19 +1630,239 @@ __device__ __forceinline__ bool cells_share_nodes(uint32_t ca, uint32_t cb) {
 // every workgroup adds the s_memtime span of each phase to a global table.
 #ifdef RF_BRICK_PROFILE
 __device__ unsigned long long g_brick_prof[8];
+// (the spans are summed in registers and added to the table once, at the end of the kernel: an atomic per mark is a memory
+// operation the next vmcnt wait has to sit out, which tripled the kernel time and mis-attributed it)
 #define RF_PROF_MARK(slot)                                                       \
   do {                                                                           \
+    const unsigned long long now_ = __builtin_readcyclecounter();                \
+    prof_acc_[slot] += now_ - prof_t_;                                           \
+    prof_t_ = now_;                                                              \
+  } while (0)
+#define RF_PROF_START()                                              \
+  unsigned long long prof_acc_[8] = {0, 0, 0, 0, 0, 0, 0, 0};        \
+  unsigned long long prof_t_ = __builtin_readcyclecounter()
+#define RF_PROF_END()                                                            \
+  do {                                                                           \
     if (threadIdx.x == 0) {                                                      \
-      const unsigned long long now_ = __builtin_readcyclecounter();              \
-      atomicAdd(&g_brick_prof[slot], now_ - prof_t_);                            \
-      prof_t_ = now_;                                                            \
+      _Pragma("unroll") for (int s_ = 0; s_ < 8; ++s_)                           \
+        if (prof_acc_[s_]) atomicAdd(&g_brick_prof[s_], prof_acc_[s_]);          \
     }                                                                            \
   } while (0)
-#define RF_PROF_START() unsigned long long prof_t_ = __builtin_readcyclecounter()
 #else
 #define RF_PROF_MARK(slot) do { } while (0)
 #define RF_PROF_START() do { } while (0)
+#define RF_PROF_END() do { } while (0)
 #endif
+
+// Which sorted ranges reach into brick (bx, by, bz): see the kernel.  Called by waves 0 and 1 (wave 1: the base-channel list of a
+// mixed call, which has its own, smaller, range table).
+__device__ __forceinline__ void brick_ranges(const BrickArgs& a, int bx, int by, int bz, int wave, int lane, long long* s_rstart, int* s_rlist,
+                                             int* s_rcum, long long* s_dstart, int* s_dcum) {
+  const bool second = wave == 1;            // the diffuse list of a mixed call
+  const int nl = second ? (a.mixed ? 1 : 0) : (a.mixed ? 1 : a.nlists);
+  const int li = lane / 14, e = lane - li * 14;
+  const bool in_use = lane < 14 * nl;
+  // nibble tables over e: source offset, first and last flag class of the run
+  const int o = (int)((0x76554332211110ull >> (4 * e)) & 7), f0 = (int)((0x76754736275310ull >> (4 * e)) & 7),
+            f1 = (int)((0x77757737375317ull >> (4 * e)) & 7);
+  const int sx = bx - (o & 1), sy = by - ((o >> 1) & 1), sz = bz - (o >> 2);
+  long long rs = 0;
+  int cnt = 0;
+  if (in_use && sx >= 0 && sy >= 0 && sz >= 0) {
+    const long long* off = ((li || second) ? a.lists[1].offsets : a.lists[0].offsets) + ((long long)((sx * a.nby + sy) * a.nbz + sz) << 3);
+    rs = off[f0];
+    cnt = (int)(off[f1 + 1] - rs);
+  }
+  const unsigned long long nonempty = __ballot(cnt > 0);
+  int cum = cnt;  // inclusive prefix sum over the lanes
+#pragma unroll
+  for (int d = 1; d < 32; d <<= 1) {
+    const int up = __shfl_up(cum, d);
+    if (lane >= d) cum += up;
+  }
+  const int slot = __popcll(nonempty & ((1ull << lane) - 1ull));
+  if (!second) {
+    if (cnt > 0) {
+      s_rstart[slot] = rs;
+      s_rlist[slot] = li;
+      s_rcum[slot + 1] = cum;
+    }
+    if (lane == 0) s_rcum[0] = 0;
+    if (lane == 31) s_rcum[kMaxRanges] = cum;  // total (lanes >= 28 carry cnt = 0)
+  } else {
+    if (cnt > 0) {
+      s_dstart[slot] = rs;
+      s_dcum[slot + 1] = cum;
+    }
+    if (lane == 0) s_dcum[0] = 0;
+    if (lane == 31) s_dcum[15] = cum;
+  }
+}
+
+// The last phase of a brick workgroup: the sums of the B^3 owned nodes (LDS accumulators `acc`, node (x, y, z) channel c at
+// x * SX + y * SY + z * CS + c; all zero when `any` is false) go out with plain stores -- or, ADAM, are consumed by the
+// optimizer step on the spot.
+template <int K, bool ADAM>
+__device__ __forceinline__ void brick_flush(const GridArgs& g, const BrickArgs& a, const float* acc, bool any, int X0, int Y0, int Z0,
+                                            float* gdens, float* gfeat) {
+  constexpr int C = 3 * K + 1;
+  constexpr int CS = (C + 3) / 4 * 4;
+  const int B = 1 << a.shift;
+  const int SY = brick_row_stride(B, C), SX = brick_slab_stride(B, C);
+  const int tid = threadIdx.x;
+  // ---- write the brick out: plain stores (exclusive owner), contiguous runs along z
+  const bool split = g.layout == RF_LAYOUT_SPLIT;
+  if (split && (C & 3) == 0 && (g.dstride & 3) == 0 && (C == 4 || (g.fstride & 3) == 0)) {
+    // split layout, whole float4s: base [X,Y,Z,4] = channels 0..3 of a node, rest [X,Y,Z,C-4] = channels 4..C-1
+    constexpr int QN = C / 4;  // float4s per node
+    constexpr int QR = QN > 1 ? QN - 1 : 1;
+    const int nq = B * B * B * QN;
+    // i -> (column (x, y), quad group, z, quad) with the quads of one tensor contiguous along z
+    auto quad_of = [&](int i, int& fx, int& fy, int& fz, int& qd) -> bool {
+      const int col = (i >> a.shift) / QN, r = i - col * (B * QN);  // (division by a constant)
+      const bool first = r < B;  // the B base quads of the column come first
+      fz = first ? r : (r - B) / QR;
+      qd = first ? 0 : 1 + (r - B) - fz * QR;
+      fx = col >> a.shift;
+      fy = col & (B - 1);
+      return i < nq && X0 + fx < g.X && Y0 + fy < g.Y && Z0 + fz < g.Z;
+    };
+    if constexpr (ADAM) {
+      // The optimizer step on the parameters this workgroup holds the complete gradient of (adam_kernel's expressions):
+      // parameters with ordinary accesses (the next forward pass reads them), moments streamed non-temporally.  The flush is
+      // the only phase of the kernel that waits on HBM: a thread issues the 3 x U loads of U quads before it touches the
+      // first one (one quad at a time kept ~24 KB per CU in flight and ran at a third of the HBM rate).
+      // A thread issues ALL its loads (3 tensors x 7 quads at degree 2 = 84 registers) before it touches the first one.
+      // Element offsets are kept as 32-bit (host-checked) to stay inside the 128-register budget of 4 waves per SIMD.
+      constexpr int U = (QN == 7) ? 4 : 1;
+      const AdamArgs& ad = a.adam;
+      for (int i0 = tid; i0 < nq; i0 += kBrickThreads * U) {
+        unsigned int off[U];  // bit 31: rest tensor; 0xffffffff: nothing to do
+        float4 p4[U];
+        vf4 m4[U], v4[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+          int fx, fy, fz, qd;
+          const bool ok = quad_of(i0 + u * kBrickThreads, fx, fy, fz, qd);
+          const unsigned int lin = ok ? node_lin(g, X0 + fx, Y0 + fy, Z0 + fz) : 0u;
+          const unsigned int o = qd == 0 ? lin * (unsigned)g.dstride : (lin * (unsigned)g.fstride + 4u * (unsigned)(qd - 1)) | 0x80000000u;
+          off[u] = ok ? o : 0xffffffffu;
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+          if (off[u] != 0xffffffffu) {
+            const bool rest = off[u] >> 31;
+            const unsigned int o = off[u] & 0x7fffffffu;
+#ifdef RF_BRICK_PROFILE
+            if (a.stagger & 0x10000) { p4[u] = make_float4(0.f, 0.f, 0.f, 0.f); m4[u] = vf4{0.f, 0.f, 0.f, 0.f}; v4[u] = vf4{1.f, 1.f, 1.f, 1.f}; continue; }
+#endif
+            p4[u] = *reinterpret_cast<const float4*>((rest ? ad.p2 : ad.p1) + o);
+            m4[u] = __builtin_nontemporal_load(reinterpret_cast<const vf4*>((rest ? ad.m2 : ad.m1) + o));
+            v4[u] = __builtin_nontemporal_load(reinterpret_cast<const vf4*>((rest ? ad.v2 : ad.v1) + o));
+          }
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+          if (off[u] == 0xffffffffu) continue;
+          const bool rest = off[u] >> 31;
+          const unsigned int o = off[u] & 0x7fffffffu;
+          int fx, fy, fz, qd;
+          quad_of(i0 + u * kBrickThreads, fx, fy, fz, qd);
+          const float4 gq = any ? *reinterpret_cast<const float4*>(&acc[fx * SX + fy * SY + fz * CS + 4 * qd]) : make_float4(0.f, 0.f, 0.f, 0.f);
+          float gg[4] = {gq.x, gq.y, gq.z, gq.w};
+          float pn[4] = {p4[u].x, p4[u].y, p4[u].z, p4[u].w};
+          if (!rest && g.mode == RF_DENSITY_ABS) {  // d|x|/dx of the raw density (the parameter before its update)
+            const float dv = pn[0] * g.rho;
+            gg[0] = (dv > 0.f) ? gg[0] : ((dv < 0.f) ? -gg[0] : 0.0f);
+          }
+          vf4 mn, vn;
+#ifdef RF_BRICK_PROFILE
+          if (a.stagger & 0x40000) {
+#pragma unroll
+            for (int c = 0; c < 4; ++c) { mn[c] = m4[u][c] + gg[c]; vn[c] = v4[u][c]; pn[c] += gg[c]; }
+          } else
+#endif
+#pragma unroll
+          for (int c = 0; c < 4; ++c) {
+            float mm = m4[u][c], vv = v4[u][c];
+            adam_update(pn[c], mm, vv, gg[c], ad.step, ad.b1, ad.b2, ad.eps, ad.inv_bc2_sqrt);
+            mn[c] = mm;
+            vn[c] = vv;
+          }
+#ifdef RF_BRICK_PROFILE
+          if (a.stagger & 0x20000) { if (pn[0] == 123.456f) *reinterpret_cast<float4*>((rest ? ad.p2 : ad.p1) + o) = make_float4(mn[0], vn[1], pn[2], pn[3]); continue; }
+#endif
+          *reinterpret_cast<float4*>((rest ? ad.p2 : ad.p1) + o) = make_float4(pn[0], pn[1], pn[2], pn[3]);
+          __builtin_nontemporal_store(mn, reinterpret_cast<vf4*>((rest ? ad.m2 : ad.m1) + o));
+          __builtin_nontemporal_store(vn, reinterpret_cast<vf4*>((rest ? ad.v2 : ad.v1) + o));
+        }
+      }
+      return;
+    }
+    for (int i = tid; i < nq; i += kBrickThreads) {
+      int fx, fy, fz, qd;
+      if (!quad_of(i, fx, fy, fz, qd)) continue;
+      const long long lin = node_lin(g, X0 + fx, Y0 + fy, Z0 + fz);
+      float4 v = any ? *reinterpret_cast<const float4*>(&acc[fx * SX + fy * SY + fz * CS + 4 * qd]) : make_float4(0.f, 0.f, 0.f, 0.f);
+      if (qd == 0 && g.mode == RF_DENSITY_ABS) {  // d|x|/dx of the raw density, applied once per node
+        const float dv = g.dens[lin * g.dstride] * g.rho;
+        v.x = (dv > 0.f) ? v.x : ((dv < 0.f) ? -v.x : 0.0f);
+      }
+      const long long off = (qd == 0) ? lin * g.dstride : lin * g.fstride + 4 * (qd - 1);
+      if (qd == 0) {
+        float4* dst = reinterpret_cast<float4*>(gdens + off);
+        if (a.accumulate) {
+          const float4 o = *dst;
+          v = make_float4(o.x + v.x, o.y + v.y, o.z + v.z, o.w + v.w);
+        }
+        *dst = v;
+      } else {
+        float4* dst = reinterpret_cast<float4*>(gfeat + off);
+        if (a.accumulate) {
+          const float4 o = *dst;
+          v = make_float4(o.x + v.x, o.y + v.y, o.z + v.z, o.w + v.w);
+        }
+        // non-temporal: nothing reads the `rest` gradients again before the optimizer (or the collective) streams them
+        const vf4 v4 = {v.x, v.y, v.z, v.w};
+        __builtin_nontemporal_store(v4, reinterpret_cast<vf4*>(dst));
+      }
+    }
+    return;
+  }
+  const int n_first = split ? 4 : 1;  // channels of a node that live in the densities/base tensor
+  const int n_second = C - n_first;
+  for (int pass = 0; pass < 2; ++pass) {
+    const int nch = pass == 0 ? n_first : n_second;
+    if (nch == 0) continue;
+    const int run = B * nch;  // floats of one z column in this tensor
+    float* out = pass == 0 ? gdens : gfeat;
+    const long long ostride = pass == 0 ? g.dstride : g.fstride;
+    for (int i = tid; i < B * B * run; i += kBrickThreads) {
+      const int col = i / run, r = i - col * run;
+      const int fz = r / nch, c2 = r - fz * nch;
+      const int fx = col >> a.shift, fy = col & (B - 1);
+      const int X = X0 + fx, Y = Y0 + fy, Z = Z0 + fz;
+      if (X >= g.X || Y >= g.Y || Z >= g.Z) continue;
+      int lds_c;
+      if (split) {
+        lds_c = pass * 4 + c2;
+      } else if (pass == 0) {
+        lds_c = 0;
+      } else {
+        const int col3 = c2 / K, kk = c2 - col3 * K;  // reference order colour * K + k
+        lds_c = (kk == 0) ? 1 + col3 : 4 + col3 * (K - 1) + (kk - 1);
+      }
+      const long long lin = node_lin(g, X, Y, Z);
+      float v = any ? acc[fx * SX + fy * SY + fz * CS + lds_c] : 0.0f;
+      if (lds_c == 0 && g.mode == RF_DENSITY_ABS) {  // d|x|/dx of the raw density, applied once per node
+        const float dv = g.dens[lin * g.dstride] * g.rho;
+        v = (dv > 0.f) ? v : ((dv < 0.f) ? -v : 0.0f);
+      }
+      float* dst = out + lin * ostride + (long long)c2 * (pass == 1 && !split ? a.fmul : 1);
+      *dst = a.accumulate ? (*dst + v) : v;
+    }
+  }
+}
 
 template <int K, bool ADAM>
 __global__ __launch_bounds__(kBrickThreads, 4) void brick_accumulate_kernel(GridArgs g, BrickArgs a, float* gdens,
@@ -1677,47 +1912,7 @@ __global__ __launch_bounds__(kBrickThreads, 4) void brick_accumulate_kernel(Grid
   // through the table path, wave 1 for the base-channel list of a mixed call (it has its own, smaller, range table).
   __shared__ long long s_dstart[14];
   __shared__ int s_dcum[16];  // [15] = total
-  if (wave < 2) {
-    const bool second = wave == 1;            // the diffuse list of a mixed call
-    const int nl = second ? (a.mixed ? 1 : 0) : (a.mixed ? 1 : a.nlists);
-    const int li = lane / 14, e = lane - li * 14;
-    const bool in_use = lane < 14 * nl;
-    // nibble tables over e: source offset, first and last flag class of the run
-    const int o = (int)((0x76554332211110ull >> (4 * e)) & 7), f0 = (int)((0x76754736275310ull >> (4 * e)) & 7),
-              f1 = (int)((0x77757737375317ull >> (4 * e)) & 7);
-    const int sx = bx - (o & 1), sy = by - ((o >> 1) & 1), sz = bz - (o >> 2);
-    long long rs = 0;
-    int cnt = 0;
-    if (in_use && sx >= 0 && sy >= 0 && sz >= 0) {
-      const long long* off = ((li || second) ? a.lists[1].offsets : a.lists[0].offsets) + ((long long)((sx * a.nby + sy) * a.nbz + sz) << 3);
-      rs = off[f0];
-      cnt = (int)(off[f1 + 1] - rs);
-    }
-    const unsigned long long nonempty = __ballot(cnt > 0);
-    int cum = cnt;  // inclusive prefix sum over the lanes
-#pragma unroll
-    for (int d = 1; d < 32; d <<= 1) {
-      const int up = __shfl_up(cum, d);
-      if (lane >= d) cum += up;
-    }
-    const int slot = __popcll(nonempty & ((1ull << lane) - 1ull));
-    if (!second) {
-      if (cnt > 0) {
-        s_rstart[slot] = rs;
-        s_rlist[slot] = li;
-        s_rcum[slot + 1] = cum;
-      }
-      if (lane == 0) s_rcum[0] = 0;
-      if (lane == 31) s_rcum[kMaxRanges] = cum;  // total (lanes >= 28 carry cnt = 0)
-    } else {
-      if (cnt > 0) {
-        s_dstart[slot] = rs;
-        s_dcum[slot + 1] = cum;
-      }
-      if (lane == 0) s_dcum[0] = 0;
-      if (lane == 31) s_dcum[15] = cum;
-    }
-  }
+  if (wave < 2) brick_ranges(a, bx, by, bz, wave, lane, s_rstart, s_rlist, s_rcum, s_dstart, s_dcum);
   __syncthreads();
   const int total = s_rcum[kMaxRanges];
   const int total_d = a.mixed ? s_dcum[15] : 0;
@@ -2025,160 +2220,356 @@ __global__ __launch_bounds__(kBrickThreads, 4) void brick_accumulate_kernel(Grid
   }
 
   RF_PROF_MARK(3);  // table path: producer / consumer batches
-  // ---- write the brick out: plain stores (exclusive owner), contiguous runs along z
-  const bool split = g.layout == RF_LAYOUT_SPLIT;
-  if (split && (C & 3) == 0 && (g.dstride & 3) == 0 && (C == 4 || (g.fstride & 3) == 0)) {
-    // split layout, whole float4s: base [X,Y,Z,4] = channels 0..3 of a node, rest [X,Y,Z,C-4] = channels 4..C-1
-    constexpr int QN = C / 4;  // float4s per node
-    constexpr int QR = QN > 1 ? QN - 1 : 1;
-    const int nq = B * B * B * QN;
-    // i -> (column (x, y), quad group, z, quad) with the quads of one tensor contiguous along z
-    auto quad_of = [&](int i, int& fx, int& fy, int& fz, int& qd) -> bool {
-      const int col = (i >> a.shift) / QN, r = i - col * (B * QN);  // (division by a constant)
-      const bool first = r < B;  // the B base quads of the column come first
-      fz = first ? r : (r - B) / QR;
-      qd = first ? 0 : 1 + (r - B) - fz * QR;
-      fx = col >> a.shift;
-      fy = col & (B - 1);
-      return i < nq && X0 + fx < g.X && Y0 + fy < g.Y && Z0 + fz < g.Z;
+  brick_flush<K, ADAM>(g, a, acc, any, X0, Y0, Z0, gdens, gfeat);
+  RF_PROF_MARK(4);  // flush (stores issued, not necessarily retired)
+  RF_PROF_END();
+}
+
+// ---------------------------------------------------------------------------------------------
+// brick_gather_kernel: the same job as brick_accumulate_kernel -- one workgroup per brick of B^3 owned nodes, the same key ranges,
+// the same flush -- with the sums kept in MFMA accumulators instead of LDS.
+//
+// The gradient of a brick is  acc[node][channel] = sum over records r of  W[node][r] * G[r][channel],  where column r of W holds
+// the 8 trilinear weights of record r (zero for the other nodes) and row r of G the record's per-channel values: a sparse x dense
+// product.  The table path above spends ~200 cycles per pair of records on a read-add-write chain through LDS.  Here the owned
+// nodes are cut into tiles of 16 nodes (2 x 2 x 4), a batch of records (256, staged in LDS) is binned to the tiles it touches
+// (2.8 on average, ballots: no atomics, list order = record order, so the summation order is fixed by the record order), and a
+// wave multiplies the records of a tile four at a time into the tile's 16 x 16 accumulator blocks with v_mfma_f32_16x16x4_f32
+// (f32 in, f32 accumulate = an fmaf chain; 32 cycles per instruction).  A operand = weight of (node of the lane, record k): the
+// product of three table entries the binning pass prepared per record and axis (weight at local node coordinate 0..7, mostly
+// zero); B operand = channel value of record k.  Everything a wave needs per instruction is three 4-byte LDS reads for A and one
+// per 16 channels for B; no LDS writes, no ownership rules, no serialisation of records that share nodes.
+// Each wave owns 4 tiles (B = 8: 32 tiles), i.e. 4 x NT accumulator blocks of 4 registers.
+// The MFMA is used as a scatter-add engine, not to make the pass compute-bound: the kernel stays HBM-bound by its flush
+// (optimizer state) and record reads; this only removes the LDS chain that kept it from that bound.
+// ---------------------------------------------------------------------------------------------
+// LDS reads the compiler cannot re-schedule (brick_gather_kernel's tile loop): the optimizer proves plain LDS loads re-computable and
+// rotates a hand-pipelined loop back into read -> wait -> read -> wait -> multiply.  These are issued where they stand; the value
+// may only be used after lds_wait() was given the same variable.  (LDS returns data in order, so the compiler's own lgkmcnt waits
+// stay conservative in the presence of reads it does not know about.)
+__device__ __forceinline__ uint32_t lds_offset(const void* p) { return (uint32_t)(uintptr_t)p; }
+// (the destination is an in/out operand: the request lands in the variable's own register, and a variable is never copied
+// between its request and its wait -- a copy would read the register before the data arrives)
+template <int OFF>
+__device__ __forceinline__ void lds_request_f32(float& v, uint32_t addr) {
+  asm volatile("ds_read_b32 %0, %1 offset:%2" : "+v"(v) : "v"(addr), "n"(OFF));
+}
+__device__ __forceinline__ void lds_request_u8(uint32_t& v, uint32_t addr) {
+  asm volatile("ds_read_u8 %0, %1" : "+v"(v) : "v"(addr));
+}
+__device__ __forceinline__ void lds_wait(uint32_t& a) { asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a)); }
+__device__ __forceinline__ void lds_wait(uint32_t& a, uint32_t& b) { asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a), "+v"(b)); }
+__device__ __forceinline__ void lds_wait(float& a, float& b, float& c, float& d, float& e, uint32_t& f) {
+  asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a), "+v"(b), "+v"(c), "+v"(d), "+v"(e), "+v"(f));
+}
+
+constexpr int kGatherBatch = 256;  // records per batch (their indices travel as bytes)
+constexpr int kGatherWtab = 24;    // rows of the weight table: 3 axes x local node coordinate 0..7
+// Bank conflicts are what bounds the tile loop (6 LDS reads per instruction): table rows are kGatherBatch + 4 words apart, so that
+// the 2 (x, y) or 4 (z) rows the lanes of one record read, and those of the neighbouring record indices of the same instruction,
+// fall into different banks; records are padded by one quad (36 / 12 words), so that the four records of an instruction do not
+// all start in the same two bank groups.
+constexpr int kGatherRow = kGatherBatch + 4;
+__host__ __device__ constexpr int gather_record_words(int quads) { return quads * 4 + 4; }
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+__host__ __device__ inline int gather_lds_words(int B, int C, int Q) {
+  const int batch = kGatherBatch * gather_record_words(Q) + kGatherBatch * 4 + kGatherRow * kGatherWtab;  // records, their index quads, weight table
+  const int image = brick_acc_words(B, C);
+  return batch > image ? batch : image;
+}
+
+template <int K, bool ADAM>
+__global__ __launch_bounds__(kBrickThreads, 4) void brick_gather_kernel(GridArgs g, BrickArgs a, float* gdens, float* gfeat) {
+  constexpr int C = 3 * K + 1;
+  constexpr int C4 = (C + 3) / 4 * 4;
+  constexpr int Q = record_quads(K);
+  constexpr int QD = record_quads(1);      // quads of a base-channel (render_diffuse) record
+  constexpr int NT = (C4 + 15) / 16;       // 16-channel blocks per tile
+  constexpr int CS = C4;
+  constexpr int NW = kGatherBatch / 64;    // mask words per tile
+  constexpr int PRE = (kGatherBatch * Q + kBrickThreads - 1) / kBrickThreads;  // record quads per thread and batch
+  static_assert(kGatherBatch * QD <= kBrickThreads, "one quad per thread for base-channel batches");
+  extern __shared__ __attribute__((aligned(16))) float acc[];  // first the batch buffers, in the end the accumulator image the flush reads
+  float4* recs = reinterpret_cast<float4*>(acc);               // [kGatherBatch][Q + 1 or QD + 1] quads, record order (padded)
+  float4* q0s = recs + kGatherBatch * (Q + 1);                 // [kGatherBatch] compact copy of the records' index quads
+  float* wtab = acc + kGatherBatch * (Q + 2) * 4;              // [3][8][kGatherRow]: axis, local node coordinate, record
+  __shared__ uint32_t s_tmask[kGatherBatch];                   // record -> bit t: it touches tile t
+  __shared__ unsigned char s_list[32][kGatherBatch + 24];      // tile -> its records (+ padding of the last instructions, + read-ahead slack)
+  __shared__ long long s_rstart[kMaxRanges];
+  __shared__ int s_rlist[kMaxRanges];
+  __shared__ int s_rcum[kMaxRanges + 1];
+  __shared__ long long s_dstart[14];
+  __shared__ int s_dcum[16];
+  const int B = 1 << a.shift;
+  const int SY = brick_row_stride(B, C), SX = brick_slab_stride(B, C);
+
+  RF_PROF_START();
+  const int tid = threadIdx.x;
+  const int lane = tid & (kWave - 1);
+  const int wave = tid >> 6;
+  const int brick = blockIdx.x;
+  const int bz = brick % a.nbz, by = (brick / a.nbz) % a.nby, bx = brick / (a.nbz * a.nby);
+  const int X0 = bx << a.shift, Y0 = by << a.shift, Z0 = bz << a.shift;
+  if (wave < 2) brick_ranges(a, bx, by, bz, wave, lane, s_rstart, s_rlist, s_rcum, s_dstart, s_dcum);
+  __syncthreads();
+  const int total = s_rcum[kMaxRanges];
+  const int total_d = a.mixed ? s_dcum[15] : 0;
+  const bool any = total > 0 || total_d > 0;
+  if (!any && a.accumulate) return;  // nothing reaches this brick
+  RF_PROF_MARK(0);  // range set-up
+
+  // tiles: 2 x 2 x 4 nodes; tile t = (px * npy + py) * npz + pz
+  const int npz = B >> 2, npy = B >> 1;
+  const int ntiles = (B * B * B) >> 4;
+  const int mi = lane & 15;  // node of this lane inside a tile (A operand row / accumulator row group)
+  const int mdx = mi >> 3, mdy = (mi >> 2) & 1, mdz = mi & 3;
+  const int kk = lane >> 4;  // which of the 4 records of an instruction this lane feeds
+  const int jj = lane & 15;  // channel inside a 16-channel block (B operand column / accumulator column)
+
+  f32x4 accr[4][NT];
+#pragma unroll
+  for (int tl = 0; tl < 4; ++tl)
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) accr[tl][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  if (any) {
+    const int nba = (total + kGatherBatch - 1) / kGatherBatch, nbd = (total_d + kGatherBatch - 1) / kGatherBatch;
+    // the weight table starts zero-filled; a record's thread clears the entries of the previous batch before it writes new ones
+    for (int i = tid; i < kGatherRow * kGatherWtab / 4; i += kBrickThreads) reinterpret_cast<float4*>(wtab)[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+    uint32_t wprev = 0x00ffffffu;  // the lower nodes (c + 1, one byte per axis) this thread's record of the previous batch had; 0xff = none
+    // -- bin the batch in LDS and multiply it into the tiles (WIDE: full-width records, else base-channel records)
+    auto process = [&](auto wide_tag, int nrec) {
+      constexpr bool WIDE = decltype(wide_tag)::value;
+      constexpr int RW = gather_record_words(WIDE ? Q : QD);  // words per record in LDS
+      constexpr int NTW = WIDE ? NT : 1;
+      // record pass (one thread per record): its column of the weight table and the set of tiles it touches
+      if (tid < kGatherBatch) {
+        uint32_t tm = 0, wnow = 0x00ffffffu;
+        float* wcol = wtab + tid;
+#pragma unroll
+        for (int ax = 0; ax < 3; ++ax) {  // un-write the previous batch's entries (same thread, same column)
+          const int c1 = (int)((wprev >> (8 * ax)) & 0xffu);  // c + 1
+          if (c1 != 0xff) {
+            if (c1 >= 1) wcol[(ax * 8 + c1 - 1) * kGatherRow] = 0.0f;
+            if (c1 < B) wcol[(ax * 8 + c1) * kGatherRow] = 0.0f;
+          }
+        }
+        if (tid < nrec) {
+          const float4 q0 = q0s[tid];
+          const float idx[3] = {q0.x, q0.y, q0.z};
+          const int org[3] = {X0, Y0, Z0};
+          uint32_t pb[3];
+          wnow = 0;
+#pragma unroll
+          for (int ax = 0; ax < 3; ++ax) {
+            const float fl = floorf(idx[ax]);
+            const int c = (int)fl - org[ax];  // lower node of the cell relative to the brick: -1 .. B - 1
+            const int sh = ax == 2 ? 2 : 1;
+            uint32_t bits = 0;
+            if (c >= 0) {
+              wcol[(ax * 8 + c) * kGatherRow] = (fl + 1.0f) - idx[ax];  // same arithmetic as locate()
+              bits |= 1u << (c >> sh);
+            }
+            if (c + 1 < B) {
+              wcol[(ax * 8 + c + 1) * kGatherRow] = idx[ax] - fl;
+              bits |= 1u << ((c + 1) >> sh);
+            }
+            pb[ax] = bits;
+            wnow |= (uint32_t)(c + 1) << (8 * ax);
+          }
+          uint32_t yz = 0;
+#pragma unroll
+          for (int py = 0; py < 4; ++py)
+            if ((pb[1] >> py) & 1u) yz |= pb[2] << (py * npz);
+#pragma unroll
+          for (int px = 0; px < 4; ++px)
+            if ((pb[0] >> px) & 1u) tm |= yz << (px * npy * npz);
+        }
+        wprev = wnow;
+        s_tmask[tid] = tm;
+      }
+      RF_PROF_MARK(7);  // record pass (thread 0's own work)
+      __syncthreads();
+      RF_PROF_MARK(2);  // ... and its barrier
+      // every wave lists the records of ITS tiles (ballot + prefix count: list order = record order) ...
+      int cnt[4] = {0, 0, 0, 0};
+#ifdef RF_BRICK_PROFILE
+      const bool no_lists = a.stagger & 0x200000, no_tiles = a.stagger & 0x100000;
+#else
+      constexpr bool no_lists = false, no_tiles = false;
+#endif
+      if (!no_lists)
+#pragma unroll
+      for (int wd = 0; wd < NW; ++wd) {
+        const uint32_t tmv = s_tmask[wd * 64 + lane] >> (4 * wave);
+#pragma unroll
+        for (int tl = 0; tl < 4; ++tl) {
+          const bool hit = (tmv >> tl) & 1u;
+          const unsigned long long m = __ballot(hit);
+          const int pos = cnt[tl] + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0));
+          if (hit) s_list[4 * wave + tl][pos] = (unsigned char)(wd * 64 + lane);
+          cnt[tl] += __popcll(m);
+        }
+      }
+#pragma unroll
+      for (int tl = 0; tl < 4; ++tl)
+        if (lane < 8) s_list[4 * wave + tl][cnt[tl] + lane] = 0;  // pad the last instructions with a record that exists
+      // ... and multiplies them into the tiles' accumulators, four records per instruction, two instructions' operands in flight
+#pragma unroll
+      for (int tl = 0; tl < 4; ++tl) {
+        const int t = wave * 4 + tl;
+        const int n = cnt[tl];
+        if (t < ntiles && n > 0 && !no_tiles) {
+          const int pz = t % npz, py = (t / npz) % npy, px = t / (npz * npy);
+          // this lane's three entries of a record's weight-table column, as byte offsets from the record's own
+          const float* wx = wtab + (2 * px + mdx) * kGatherRow;
+          const float* wy = wtab + (8 + 2 * py + mdy) * kGatherRow;
+          const float* wz = wtab + (16 + 4 * pz + mdz) * kGatherRow;
+          const float* gbase = reinterpret_cast<const float*>(recs + 1) + (WIDE ? jj : (jj & 3));  // (base-channel records: lanes 4..15 re-read channels 0..3)
+          // software pipeline: the record index of instruction q + 2 and the operands of instruction q + 1 are requested before
+          // instruction q is issued; an iteration waits once, at its top, for requests that are a whole iteration old
+          const uint32_t a_list = lds_offset(s_list[t]) + kk;
+          const uint32_t a_x = lds_offset(wx), a_y = lds_offset(wy), a_z = lds_offset(wz), a_g = lds_offset(gbase);
+          const int nq = (n + 3) >> 2;
+          // two register sets (A: even instructions, B: odd ones), no rotation copies.  WIDE: channels >= C4 of the second block
+          // read into the next record; those accumulator columns are never stored
+          uint32_t ra = 0, rb = 0;
+          float aw0 = 0.f, aw1 = 0.f, aw2 = 0.f, ag0 = 0.f, ag1 = 0.f, bw0 = 0.f, bw1 = 0.f, bw2 = 0.f, bg0 = 0.f, bg1 = 0.f;
+          auto request_ops = [&](float& w0, float& w1, float& w2, float& g0, float& g1, uint32_t r) {
+            lds_request_f32<0>(w0, a_x + 4 * r);
+            lds_request_f32<0>(w1, a_y + 4 * r);
+            lds_request_f32<0>(w2, a_z + 4 * r);
+            lds_request_f32<0>(g0, a_g + r * (RW * 4));
+            if constexpr (NTW > 1) lds_request_f32<64>(g1, a_g + r * (RW * 4));
+          };
+          auto multiply = [&](float w0, float w1, float w2, float g0, float g1, int q) {
+            const float wv = (w0 * w1) * w2;
+            const float wa = (4 * q + kk < n) ? wv : 0.0f;
+            const float ga = (WIDE || jj < 4) ? g0 : 0.0f;
+            accr[tl][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(wa, ga, accr[tl][0], 0, 0, 0);
+            if constexpr (NTW > 1) accr[tl][NTW - 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(wa, g1, accr[tl][NTW - 1], 0, 0, 0);
+          };
+          lds_request_u8(ra, a_list);      // record index of instruction 0
+          lds_request_u8(rb, a_list + 4);  // ... 1
+          lds_wait(ra, rb);
+          request_ops(aw0, aw1, aw2, ag0, ag1, ra);
+          for (int q = 0; q < nq; q += 2) {
+            lds_wait(aw0, aw1, aw2, ag0, ag1, rb);
+            lds_request_u8(ra, a_list + 4 * q + 8);  // index of instruction q + 2 (the list has slack behind its capacity)
+            request_ops(bw0, bw1, bw2, bg0, bg1, rb);
+            multiply(aw0, aw1, aw2, ag0, ag1, q);
+            if (q + 1 < nq) {
+              lds_wait(bw0, bw1, bw2, bg0, bg1, ra);
+              lds_request_u8(rb, a_list + 4 * q + 12);
+              request_ops(aw0, aw1, aw2, ag0, ag1, ra);
+              multiply(bw0, bw1, bw2, bg0, bg1, q + 1);
+            }
+          }
+          lds_wait(aw0, aw1, aw2, ag0, ag1, ra);  // nothing of this tile stays in flight
+          lds_wait(bw0, bw1, bw2, bg0, bg1, rb);
+        }
+      }
+      RF_PROF_MARK(3);  // lists + tiles (MFMA), thread 0's own work
+      __syncthreads();
+      RF_PROF_MARK(2);
     };
-    if constexpr (ADAM) {
-      // The optimizer step on the parameters this workgroup holds the complete gradient of (adam_kernel's expressions):
-      // parameters with ordinary accesses (the next forward pass reads them), moments streamed non-temporally.  The flush is
-      // the only phase of the kernel that waits on HBM: a thread issues the 3 x U loads of U quads before it touches the
-      // first one (one quad at a time kept ~24 KB per CU in flight and ran at a third of the HBM rate).
-      // A thread issues ALL its loads (3 tensors x 7 quads at degree 2 = 84 registers) before it touches the first one.
-      // Element offsets are kept as 32-bit (host-checked) to stay inside the 128-register budget of 4 waves per SIMD.
-      constexpr int U = (QN == 7) ? 4 : 1;
-      const AdamArgs& ad = a.adam;
-      for (int i0 = tid; i0 < nq; i0 += kBrickThreads * U) {
-        unsigned int off[U];  // bit 31: rest tensor; 0xffffffff: nothing to do
-        float4 p4[U];
-        vf4 m4[U], v4[U];
+    using Wide = std::integral_constant<bool, true>;
+    using Narrow = std::integral_constant<bool, false>;
+
+    // global loads of a batch into registers, issued one batch ahead of their use (always unconditional and clamped, with their
+    // own registers per list kind: a conditionally assigned register is merged with a copy, and the copy waits for the load)
+    int sri = 0, dri = 0;  // running range index of this thread (the records it fetches only move forward), its bounds cached
+    int rlo = 0, rhi = 0, dlo = 0, dhi = 0;  // in quads of the concatenated list
+    const float4* rptr = a.lists[0].rec;     // list base + (start of the range - its position in the concatenation)
+    const float4* dptr = a.lists[1].rec;
+    float4 pre[PRE], pred = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
-        for (int u = 0; u < U; ++u) {
-          int fx, fy, fz, qd;
-          const bool ok = quad_of(i0 + u * kBrickThreads, fx, fy, fz, qd);
-          const unsigned int lin = ok ? node_lin(g, X0 + fx, Y0 + fy, Z0 + fz) : 0u;
-          const unsigned int o = qd == 0 ? lin * (unsigned)g.dstride : (lin * (unsigned)g.fstride + 4u * (unsigned)(qd - 1)) | 0x80000000u;
-          off[u] = ok ? o : 0xffffffffu;
+    for (int u = 0; u < PRE; ++u) pre[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+    auto fetch_wide = [&](int s) {
+      const int nq = min(kGatherBatch, total - s * kGatherBatch) * Q;
+#pragma unroll
+      for (int u = 0; u < PRE; ++u) {
+        const int qi = s * (kGatherBatch * Q) + min(tid + u * kBrickThreads, nq - 1);  // quad of the concatenated list
+        if (qi < rlo || qi >= rhi) {  // rare: the range of the previous quad no longer holds this one
+          const int v = qi / Q;
+          while (s_rcum[sri] > v) --sri;  // (only when the last batch is fetched a second time)
+          while (s_rcum[sri + 1] <= v) ++sri;
+          rlo = s_rcum[sri] * Q;
+          rhi = s_rcum[sri + 1] * Q;
+          rptr = (s_rlist[sri] ? a.lists[1].rec : a.lists[0].rec) + (s_rstart[sri] * Q - rlo);
         }
+        pre[u] = rptr[qi];
+      }
+    };
+    auto fetch_narrow = [&](int sd) {
+      const int nq = min(kGatherBatch, total_d - sd * kGatherBatch) * QD;
+      const int qi = sd * (kGatherBatch * QD) + min(tid, nq - 1);
+      if (qi < dlo || qi >= dhi) {
+        const int v = qi / QD;
+        while (s_dcum[dri] > v) --dri;
+        while (s_dcum[dri + 1] <= v) ++dri;
+        dlo = s_dcum[dri] * QD;
+        dhi = s_dcum[dri + 1] * QD;
+        dptr = a.lists[1].rec + (s_dstart[dri] * QD - dlo);
+      }
+      pred = dptr[qi];
+    };
+    if (nbd > 0) fetch_narrow(0);
+    if (nba > 0) fetch_wide(0);
+    for (int s = 0; s < nba; ++s) {
+      const int nrec = min(kGatherBatch, total - s * kGatherBatch);
 #pragma unroll
-        for (int u = 0; u < U; ++u) {
-          if (off[u] != 0xffffffffu) {
-            const bool rest = off[u] >> 31;
-            const unsigned int o = off[u] & 0x7fffffffu;
-#ifdef RF_BRICK_PROFILE
-            if (a.stagger & 0x10000) { p4[u] = make_float4(0.f, 0.f, 0.f, 0.f); m4[u] = vf4{0.f, 0.f, 0.f, 0.f}; v4[u] = vf4{1.f, 1.f, 1.f, 1.f}; continue; }
-#endif
-            p4[u] = *reinterpret_cast<const float4*>((rest ? ad.p2 : ad.p1) + o);
-            m4[u] = __builtin_nontemporal_load(reinterpret_cast<const vf4*>((rest ? ad.m2 : ad.m1) + o));
-            v4[u] = __builtin_nontemporal_load(reinterpret_cast<const vf4*>((rest ? ad.v2 : ad.v1) + o));
-          }
-        }
-#pragma unroll
-        for (int u = 0; u < U; ++u) {
-          if (off[u] == 0xffffffffu) continue;
-          const bool rest = off[u] >> 31;
-          const unsigned int o = off[u] & 0x7fffffffu;
-          int fx, fy, fz, qd;
-          quad_of(i0 + u * kBrickThreads, fx, fy, fz, qd);
-          const float4 gq = any ? *reinterpret_cast<const float4*>(&acc[fx * SX + fy * SY + fz * CS + 4 * qd]) : make_float4(0.f, 0.f, 0.f, 0.f);
-          float gg[4] = {gq.x, gq.y, gq.z, gq.w};
-          float pn[4] = {p4[u].x, p4[u].y, p4[u].z, p4[u].w};
-          if (!rest && g.mode == RF_DENSITY_ABS) {  // d|x|/dx of the raw density (the parameter before its update)
-            const float dv = pn[0] * g.rho;
-            gg[0] = (dv > 0.f) ? gg[0] : ((dv < 0.f) ? -gg[0] : 0.0f);
-          }
-          vf4 mn, vn;
-#ifdef RF_BRICK_PROFILE
-          if (a.stagger & 0x40000) {
-#pragma unroll
-            for (int c = 0; c < 4; ++c) { mn[c] = m4[u][c] + gg[c]; vn[c] = v4[u][c]; pn[c] += gg[c]; }
-          } else
-#endif
-#pragma unroll
-          for (int c = 0; c < 4; ++c) {
-            const float mm = m4[u][c] + (gg[c] - m4[u][c]) * (1.0f - ad.b1);
-            const float vv = v4[u][c] * ad.b2 + (gg[c] * gg[c]) * (1.0f - ad.b2);
-            pn[c] = pn[c] - ad.step * (mm / (sqrtf(vv) / ad.bc2_sqrt + ad.eps));
-            mn[c] = mm;
-            vn[c] = vv;
-          }
-#ifdef RF_BRICK_PROFILE
-          if (a.stagger & 0x20000) { if (pn[0] == 123.456f) *reinterpret_cast<float4*>((rest ? ad.p2 : ad.p1) + o) = make_float4(mn[0], vn[1], pn[2], pn[3]); continue; }
-#endif
-          *reinterpret_cast<float4*>((rest ? ad.p2 : ad.p1) + o) = make_float4(pn[0], pn[1], pn[2], pn[3]);
-          __builtin_nontemporal_store(mn, reinterpret_cast<vf4*>((rest ? ad.m2 : ad.m1) + o));
-          __builtin_nontemporal_store(vn, reinterpret_cast<vf4*>((rest ? ad.v2 : ad.v1) + o));
+      for (int u = 0; u < PRE; ++u) {
+        const int i = tid + u * kBrickThreads;
+        if (i < nrec * Q) {
+          recs[(i / Q) * (Q + 1) + i % Q] = pre[u];
+          if (i % Q == 0) q0s[i / Q] = pre[u];
         }
       }
-      RF_PROF_MARK(4);  // flush (stores issued, not necessarily retired)
-      return;
+      __syncthreads();
+      RF_PROF_MARK(1);  // waiting for the batch's loads, LDS stores
+      fetch_wide(min(s + 1, nba - 1));  // (the last batch again at the end: cheaper than a conditional)
+      RF_PROF_MARK(6);  // issuing the next batch's loads
+      process(Wide{}, nrec);
     }
-    for (int i = tid; i < nq; i += kBrickThreads) {
-      int fx, fy, fz, qd;
-      if (!quad_of(i, fx, fy, fz, qd)) continue;
-      const long long lin = node_lin(g, X0 + fx, Y0 + fy, Z0 + fz);
-      float4 v = any ? *reinterpret_cast<const float4*>(&acc[fx * SX + fy * SY + fz * CS + 4 * qd]) : make_float4(0.f, 0.f, 0.f, 0.f);
-      if (qd == 0 && g.mode == RF_DENSITY_ABS) {  // d|x|/dx of the raw density, applied once per node
-        const float dv = g.dens[lin * g.dstride] * g.rho;
-        v.x = (dv > 0.f) ? v.x : ((dv < 0.f) ? -v.x : 0.0f);
+    for (int sd = 0; sd < nbd; ++sd) {
+      const int nrec = min(kGatherBatch, total_d - sd * kGatherBatch);
+      if (tid < nrec * QD) {
+        recs[(tid / QD) * (QD + 1) + tid % QD] = pred;
+        if (tid % QD == 0) q0s[tid / QD] = pred;
       }
-      const long long off = (qd == 0) ? lin * g.dstride : lin * g.fstride + 4 * (qd - 1);
-      if (qd == 0) {
-        float4* dst = reinterpret_cast<float4*>(gdens + off);
-        if (a.accumulate) {
-          const float4 o = *dst;
-          v = make_float4(o.x + v.x, o.y + v.y, o.z + v.z, o.w + v.w);
+      __syncthreads();
+      RF_PROF_MARK(1);
+      fetch_narrow(min(sd + 1, nbd - 1));
+      RF_PROF_MARK(6);
+      process(Narrow{}, nrec);
+    }
+    // -- the accumulator image for the flush (the batch buffers are dead).  Accumulator register e of a lane: node row
+    // 4 (lane >> 4) + e of the tile, channel 16 nt + (lane & 15)
+#pragma unroll
+    for (int tl = 0; tl < 4; ++tl) {
+      const int t = wave * 4 + tl;
+      if (t < ntiles) {
+        const int pz = t % npz, py = (t / npz) % npy, px = t / (npz * npy);
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+          const int ch = 16 * nt + jj;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const int i = 4 * kk + e;
+            const int nx = 2 * px + (i >> 3), ny = 2 * py + ((i >> 2) & 1), nz = 4 * pz + (i & 3);
+            if (ch < CS) acc[nx * SX + ny * SY + nz * CS + ch] = accr[tl][nt][e];
+          }
         }
-        *dst = v;
-      } else {
-        float4* dst = reinterpret_cast<float4*>(gfeat + off);
-        if (a.accumulate) {
-          const float4 o = *dst;
-          v = make_float4(o.x + v.x, o.y + v.y, o.z + v.z, o.w + v.w);
-        }
-        // non-temporal: nothing reads the `rest` gradients again before the optimizer (or the collective) streams them
-        const vf4 v4 = {v.x, v.y, v.z, v.w};
-        __builtin_nontemporal_store(v4, reinterpret_cast<vf4*>(dst));
       }
     }
-    return;
+    __syncthreads();
+    RF_PROF_MARK(5);  // accumulator image
   }
-  const int n_first = split ? 4 : 1;  // channels of a node that live in the densities/base tensor
-  const int n_second = C - n_first;
-  for (int pass = 0; pass < 2; ++pass) {
-    const int nch = pass == 0 ? n_first : n_second;
-    if (nch == 0) continue;
-    const int run = B * nch;  // floats of one z column in this tensor
-    float* out = pass == 0 ? gdens : gfeat;
-    const long long ostride = pass == 0 ? g.dstride : g.fstride;
-    for (int i = tid; i < B * B * run; i += kBrickThreads) {
-      const int col = i / run, r = i - col * run;
-      const int fz = r / nch, c2 = r - fz * nch;
-      const int fx = col >> a.shift, fy = col & (B - 1);
-      const int X = X0 + fx, Y = Y0 + fy, Z = Z0 + fz;
-      if (X >= g.X || Y >= g.Y || Z >= g.Z) continue;
-      int lds_c;
-      if (split) {
-        lds_c = pass * 4 + c2;
-      } else if (pass == 0) {
-        lds_c = 0;
-      } else {
-        const int col3 = c2 / K, kk = c2 - col3 * K;  // reference order colour * K + k
-        lds_c = (kk == 0) ? 1 + col3 : 4 + col3 * (K - 1) + (kk - 1);
-      }
-      const long long lin = node_lin(g, X, Y, Z);
-      float v = any ? acc[fx * SX + fy * SY + fz * CS + lds_c] : 0.0f;
-      if (lds_c == 0 && g.mode == RF_DENSITY_ABS) {  // d|x|/dx of the raw density, applied once per node
-        const float dv = g.dens[lin * g.dstride] * g.rho;
-        v = (dv > 0.f) ? v : ((dv < 0.f) ? -v : 0.0f);
-      }
-      float* dst = out + lin * ostride + (long long)c2 * (pass == 1 && !split ? a.fmul : 1);
-      *dst = a.accumulate ? (*dst + v) : v;
-    }
-  }
+  brick_flush<K, ADAM>(g, a, acc, any, X0, Y0, Z0, gdens, gfeat);
+  RF_PROF_MARK(4);  // flush (stores issued, not necessarily retired)
+  RF_PROF_END();
 }
 
 // =============================================================================================
@@ -2482,7 +2873,7 @@ __global__ void build_occupancy_kernel(GridArgs g, float threshold, uint32_t* oc
 template <bool ZERO_GRAD, bool STREAM>
 __global__ void adam_kernel(float* __restrict__ p, float* __restrict__ gradp, float* __restrict__ m,
                             float* __restrict__ v, long long n, float lr, float b1, float b2, float eps, float bc1,
-                            float bc2_sqrt) {
+                            float inv_bc2_sqrt) {
   const long long n4 = n / 4;
   const float step = lr / bc1;
   for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long long)gridDim.x * blockDim.x) {
@@ -2508,9 +2899,7 @@ __global__ void adam_kernel(float* __restrict__ p, float* __restrict__ gradp, fl
     }
 #pragma unroll
     for (int c = 0; c < 4; ++c) {
-      mm.v[c] = mm.v[c] + (gg.v[c] - mm.v[c]) * (1.0f - b1);
-      vv.v[c] = vv.v[c] * b2 + (gg.v[c] * gg.v[c]) * (1.0f - b2);
-      pp.v[c] = pp.v[c] - step * (mm.v[c] / (sqrtf(vv.v[c]) / bc2_sqrt + eps));
+      adam_update(pp.v[c], mm.v[c], vv.v[c], gg.v[c], step, b1, b2, eps, inv_bc2_sqrt);
     }
     if (STREAM) {
       const vf4 p4 = {pp.v[0], pp.v[1], pp.v[2], pp.v[3]}, m4 = {mm.v[0], mm.v[1], mm.v[2], mm.v[3]}, v4 = {vv.v[0], vv.v[1], vv.v[2], vv.v[3]};
@@ -2535,10 +2924,9 @@ __global__ void adam_kernel(float* __restrict__ p, float* __restrict__ gradp, fl
   // tail
   const long long i = n4 * 4 + (long long)blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n) {
-    const float gg = gradp[i];
-    const float mm = m[i] + (gg - m[i]) * (1.0f - b1);
-    const float vv = v[i] * b2 + (gg * gg) * (1.0f - b2);
-    p[i] = p[i] - step * (mm / (sqrtf(vv) / bc2_sqrt + eps));
+    float pp = p[i], mm = m[i], vv = v[i];
+    adam_update(pp, mm, vv, gradp[i], step, b1, b2, eps, inv_bc2_sqrt);
+    p[i] = pp;
     m[i] = mm;
     v[i] = vv;
     if (ZERO_GRAD) gradp[i] = 0.0f;
@@ -3084,6 +3472,24 @@ static int launch_brick(const GridArgs& g, const BrickArgs& a, int nbricks, floa
   hipLaunchKernelGGL((brick_accumulate_kernel<K, ADAM>), dim3(nbricks), dim3(kBrickThreads), lds, st, g, a, gd, gf);
   return launch_status();
 }
+
+template <int K, bool ADAM>
+static int launch_gather(const GridArgs& g, const BrickArgs& a, int nbricks, float* gd, float* gf, hipStream_t st) {
+  const int B = 1 << a.shift;
+  const size_t lds = (size_t)gather_lds_words(B, 3 * K + 1, record_quads(K)) * sizeof(float);
+  if (lds > 150 * 1024) return RF_ERR_UNSUPPORTED;
+  static std::atomic<size_t> configured[64];
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return RF_ERR_LAUNCH;
+  if (lds > configured[dev].load(std::memory_order_relaxed)) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&brick_gather_kernel<K, ADAM>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+      return RF_ERR_LAUNCH;
+    configured[dev].store(lds, std::memory_order_relaxed);
+  }
+  hipLaunchKernelGGL((brick_gather_kernel<K, ADAM>), dim3(nbricks), dim3(kBrickThreads), lds, st, g, a, gd, gf);
+  return launch_status();
+}
 }  // extern "C++"
 
 static int brick_accumulate_impl(const RFGrid* grid, int32_t brick_size, const RFBrickList* lists, int32_t num_lists,
@@ -3123,6 +3529,10 @@ static int brick_accumulate_impl(const RFGrid* grid, int32_t brick_size, const R
   const int nbricks = nb[0] * nb[1] * nb[2];
   hipStream_t st = (hipStream_t)stream;
   const int K = base_only ? 1 : grid->num_features / 3;
+  static const bool gather = [] {  // (development switch while both accumulation paths exist)
+    const char* e = getenv("RF_BRICK_PATH");
+    return !(e && e[0] == 't');  // RF_BRICK_PATH=table
+  }();
   if (adam) {
     // the update needs the complete gradient of every parameter in the owning workgroup: all channels covered by the lists
     // (base-only lists on an SH grid leave the higher-degree channels to someone else), whole float4s, overwrite semantics
@@ -3154,18 +3564,36 @@ static int brick_accumulate_impl(const RFGrid* grid, int32_t brick_size, const R
     a.adam.b1 = adam->beta1;
     a.adam.b2 = adam->beta2;
     a.adam.eps = adam->eps;
-    a.adam.bc2_sqrt = (float)sqrt(bc2);
+    a.adam.inv_bc2_sqrt = (float)(1.0 / sqrt(bc2));
 #ifdef RF_BRICK_PROFILE
     {
       const char* e = getenv("RF_BRICK_STAGGER");
       a.stagger = e ? atoi(e) : 0;
     }
 #endif
+    if (gather) {
+      switch (K) {
+        case 1:
+          return launch_gather<1, true>(g, a, nbricks, nullptr, nullptr, st);
+        default:
+          return launch_gather<9, true>(g, a, nbricks, nullptr, nullptr, st);
+      }
+    }
     switch (K) {
       case 1:
         return launch_brick<1, true>(g, a, nbricks, nullptr, nullptr, st);
       default:
         return launch_brick<9, true>(g, a, nbricks, nullptr, nullptr, st);
+    }
+  }
+  if (gather) {
+    switch (K) {
+      case 1:
+        return launch_gather<1, false>(g, a, nbricks, grad_densities_dev, grad_features_dev, st);
+      case 4:
+        return launch_gather<4, false>(g, a, nbricks, grad_densities_dev, grad_features_dev, st);
+      default:
+        return launch_gather<9, false>(g, a, nbricks, grad_densities_dev, grad_features_dev, st);
     }
   }
   switch (K) {
@@ -3253,7 +3681,7 @@ int rf_adam_step(float* param_dev, float* grad_dev, float* exp_avg_dev, float* e
   hipStream_t st = (hipStream_t)stream;
 #define RF_ADAM(Z, S)                                                                                                    \
   hipLaunchKernelGGL((adam_kernel<Z, S>), grid, block, 0, st, param_dev, grad_dev, exp_avg_dev, exp_avg_sq_dev,          \
-                     (long long)numel, lr, beta1, beta2, eps, (float)bc1, (float)sqrt(bc2))
+                     (long long)numel, lr, beta1, beta2, eps, (float)bc1, (float)(1.0 / sqrt(bc2)))
   if (zero_grad) {
     if (aligned) RF_ADAM(true, true); else RF_ADAM(true, false);
   } else {
