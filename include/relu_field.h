@@ -200,7 +200,7 @@ int rf_render_backward(const RFGrid* grid, const RFRayBatch* rays, uint32_t flag
 /* ---- binned backward: the same adjoint as rf_render_backward without float atomics ----------------------------------
  * The atomic scatter of rf_render_backward is bound by the memory-side atomic unit.  The binned variant turns every
  * contributing sample into a RECORD, puts the records in (brick, flags) order and lets one workgroup per brick sum them
- * in LDS under exclusive ownership:
+ * on chip under exclusive ownership:
  *
  *   key  = brick * 8 + flags;  brick = id ((bx * NBY + by) * NBZ + bz) of the brick (brick_size^3 nodes, brick_size in
  *          {4, 8}) holding the LOWER node of the sample's cell;  flag bit a = the cell's upper node on axis a belongs to
@@ -222,12 +222,13 @@ int rf_render_backward(const RFGrid* grid, const RFRayBatch* rays, uint32_t flag
  *   B and C use 16-bit keys: at most 4096 bricks.  The order inside a key class depends on atomic timing in A and B.
  *
  * rf_brick_accumulate: one workgroup per brick OWNS the brick's nodes: it reads exactly the key classes that touch them
- * (its own and, per flags, up to 7 lower neighbours'), sums them in LDS with plain read-add-writes (wavefronts own disjoint
- * channels: no races, no LDS atomics) and writes the brick with plain coalesced stores: accumulate = 0 OVERWRITES every
+ * (its own and, per flags, up to 7 lower neighbours'), sums them in MFMA accumulators (node sums = trilinear weights x the
+ * records' channel values, four records per v_mfma_f32_16x16x4_f32: exact float32 fma chains, no atomics of any kind,
+ * summation order fixed by the record order) and writes the brick with plain coalesced stores: accumulate = 0 OVERWRITES every
  * element of the gradient tensors (no zero-fill needed; diffuse lists: only density + degree-0 gradients), accumulate = 1
  * adds.  Up to two lists per call: two of the same kind, or (specular list, render_diffuse list) in that order = BOTH renders
- * of a training iteration (modules/trainers.py:306-341) in one pass: the 4-channel diffuse records are summed first, with LDS
- * float64 atomics (order-insensitive to ~1e-16; rounded to float32 once), the full records on top of them.  SH degree <= 2. */
+ * of a training iteration (modules/trainers.py:306-341) in one pass (the base-channel records go into the first four channel
+ * columns of the same accumulators).  SH degree <= 2. */
 typedef struct RFBrickList {
   const float* records_sorted_dev; /* [capacity, rf_expanded_record_floats(F)] (diffuse lists: F = 3) */
   const int64_t* offsets_dev;      /* [8 * nbricks + 1] start of each (brick, flags) class            */
@@ -268,9 +269,10 @@ int rf_brick_accumulate(const RFGrid* grid, int32_t brick_size, const RFBrickLis
                         float* grad_densities_dev, float* grad_features_dev, int32_t accumulate, void* stream);
 
 /* The optimizer of the training iteration (torch.optim.Adam(betas, eps), modules/trainers.py:242-250,339-341) fused into the
- * brick pass: the workgroup that owns a brick holds the COMPLETE gradient of its parameters in LDS (when the lists carry
+ * brick pass: the workgroup that owns a brick holds the COMPLETE gradient of its parameters on chip (when the lists carry
  * every render of the iteration), so it applies the Adam update right there -- the gradient tensor never exists in HBM and
- * the separate optimizer pass (7 x 4 B per parameter) becomes 6 x 4 B inside this one.  Same arithmetic as rf_adam_step.
+ * the separate optimizer pass (7 x 4 B per parameter) becomes 6 x 4 B inside this one.  Same arithmetic as rf_adam_step
+ * (hardware square root and reciprocal, 1 ulp).
  * Requirements: RF_LAYOUT_SPLIT / RF_LAYOUT_BRICKED with F in {3, 27} (whole float4s per node), all six pointers 16-byte
  * aligned, param_*_dev the very tensors `grid` describes.  Bricks without records still take their (zero-gradient) step. */
 typedef struct RFAdamState {

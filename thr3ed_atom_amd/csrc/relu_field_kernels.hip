@@ -1351,15 +1351,16 @@ __global__ __launch_bounds__(kBlock) void render_emit_direct_kernel(GridArgs g, 
 // binned backward: the same adjoint without float atomics
 //
 // The atomic scatter above is pinned on the memory-side atomic unit (~21 G sector requests/s).  This path aggregates
-// in LDS first, under EXCLUSIVE ownership so that no atomics are needed at all:
+// on chip first, under EXCLUSIVE ownership so that no atomics are needed at all:
 //   1. render_backward_kernel<.., EMIT=true> writes one 32-byte gradient record per contributing sample and a 16-bit
 //      key per slot: key = brick * 8 + flags, brick = the B^3-NODE brick holding the cell's lower node, flag bit a = the
 //      cell's upper node on axis a lies in the next brick; it also counts the records per key;
 //   2. bin_offsets_kernel + scatter_records_kernel (counting sort, atomic cursors) -- or torch.sort +
 //      expand_records_kernel (stable, fixed summation order) -- put the EXPANDED records (index + per-channel values, SH
 //      basis multiplied in) in key order;
-//   3. brick_accumulate_kernel: one workgroup per brick reads the <= 14 key ranges that touch its nodes, sums them in LDS
-//      with plain read-add-writes (waves own disjoint channels) and writes the brick with plain stores.
+//   3. brick_gather_kernel: one workgroup per brick reads the <= 14 key ranges that touch its nodes, sums them in MFMA
+//      accumulators (weights x per-channel values, four records per instruction) and writes the brick with plain stores -- or
+//      applies the optimizer step right there.
 // History and measurements: DESIGN.md section 4.
 // =============================================================================================
 struct BrickList {
@@ -1587,44 +1588,27 @@ __global__ __launch_bounds__(256) void scatter_records_kernel(const short* __res
   }
 }
 
-// One workgroup (8 waves) per NODE brick: it owns B^3 nodes exclusively, so the result is written with plain stores.
-// Race-free accumulation without LDS float atomics (tools/lds_microbench*.hip: ds_add_f32 retires 0.33 lane/clk/CU, a plain
-// read-add-write chain is bound by the 65-cycle LDS latency): consumer waves 0..3 each own FOUR channel pairs of every node
-// and walk ALL records that touch the brick; a lane owns (record of the step, corner, channel pair) and adds with one 8-byte
-// read-add-write (2 records x 8 corners x 4 pairs = 64 lanes).
-// Records are sorted by key = cell-brick * 8 + flags, so the records of a source brick that reach into this brick
-// (flags superset of the offset) are a handful of contiguous ranges: no record is read that does not contribute.
-// Waves 4..7 are producers: per batch of 32 records, 8 lanes per record build a table row (corner address + weight
-// per corner, the record's per-channel values, its packed cell) one batch ahead of the consumers; two pairs of waves
-// alternate batches and keep the global loads of FOUR batches in flight (several microseconds of latency under load).
-// The consumers' loop is then 2 table reads, 2 multiplies and the read-add-write.
-constexpr int kBrickThreads = 512;  // 8 waves: 4 consumers + 4 producers of the table path; every phase is bound by per-workgroup latency and LDS admits 2 workgroups per CU
-constexpr int kBrickFetchers = 256;  // threads that stage diffuse records (two 16-byte loads per record, 128 records per round)
-constexpr int kBrickBatch = 32;   // records per table (8 staging threads per record)
-constexpr int kMaxRanges = 28;    // 14 (source brick, flag run) ranges per list, two lists
+// One workgroup (8 waves) per NODE brick: it owns B^3 nodes exclusively, so the result is written with plain stores (or consumed
+// by the optimizer on the spot).  Records are sorted by key = cell-brick * 8 + flags, so the records of a source brick that reach
+// into this brick (flags superset of the offset) are a handful of contiguous ranges: no record is read that does not contribute.
+// The kernel is brick_gather_kernel below.  Its round-1 / early round-2 predecessor summed in LDS with read-add-writes under wave
+// ownership of channel pairs (LDS float atomics retire 0.33 lane/clk/CU, tools/lds_microbench*.hip): ~200 cycles per pair of records
+// on the read-add-write chain plus float64 LDS atomics for the base-channel records, 0.489 ms on the bench step against 0.394 now.
+constexpr int kBrickThreads = 512;  // 8 waves; LDS admits 2 workgroups per CU
+constexpr int kMaxRanges = 28;      // 14 (source brick, flag run) ranges per list, two lists
 
-// accumulator geometry: node stride CS = channels rounded up to a multiple of 4 (8-byte read-add-writes, float4 flush);
-// rows (z runs) are padded so that the row stride is 48 mod 64 words: the four corners (dy, dz) of a 32-lane group then
-// start at banks 0 / 28 / 48 / 12 of the 64 banks an 8-byte access sees -- 14-word spans that overlap in 2 banks only
+// geometry of the accumulator image the flush reads: node stride CS = channels rounded up to a multiple of 4 (float4 flush);
+// rows (z runs) and slabs (x) are padded to odd multiples of 16 / 8 words (bank spread of the image writes and the flush reads)
 __host__ __device__ inline int brick_node_stride(int C) { return (C + 3) / 4 * 4; }
 __host__ __device__ inline int brick_row_stride(int B, int C) {
   const int row = B * brick_node_stride(C);
   return row + ((48 - row % 64) + 64) % 64;
 }
-// ... and slabs (x) so that the slab stride is 8 mod 64 words: the 8 corners of a record, 8 words (4 channel pairs) each in a
-// consumer wave, then tile the 64 banks exactly -- 0 / 28 / 48 / 12 for dx = 0 and 8 / 36 / 56 / 20 for dx = 1
 __host__ __device__ inline int brick_slab_stride(int B, int C) {
   const int slab = B * brick_row_stride(B, C);
   return slab + ((8 - slab % 64) + 64) % 64;
 }
 __host__ __device__ inline int brick_acc_words(int B, int C) { return B * brick_slab_stride(B, C) + 64; }  // + trash row
-
-// packed lower nodes (one byte per axis): do the two cells have a node in common?
-__device__ __forceinline__ bool cells_share_nodes(uint32_t ca, uint32_t cb) {
-  const int dx = (int)(ca & 0xffu) - (int)(cb & 0xffu), dy = (int)((ca >> 8) & 0xffu) - (int)((cb >> 8) & 0xffu),
-            dz = (int)((ca >> 16) & 0xffu) - (int)((cb >> 16) & 0xffu);
-  return (unsigned)(dx + 1) <= 2u && (unsigned)(dy + 1) <= 2u && (unsigned)(dz + 1) <= 2u;
-}
 
 // Phase timing of the brick pass (development builds only: -DRF_BRICK_PROFILE; tools/brick_phase_profile.py): thread 0 of
 // every workgroup adds the s_memtime span of each phase to a global table.
@@ -1864,374 +1848,12 @@ __device__ __forceinline__ void brick_flush(const GridArgs& g, const BrickArgs& 
   }
 }
 
-template <int K, bool ADAM>
-__global__ __launch_bounds__(kBrickThreads, 4) void brick_accumulate_kernel(GridArgs g, BrickArgs a, float* gdens,
-                                                                         float* gfeat) {
-  constexpr int C = 3 * K + 1;
-  constexpr int C4 = (C + 3) / 4 * 4;
-  constexpr int Q = record_quads(K);
-  static_assert(Q <= 8 || K == 16, "8 staging threads per record");
-  constexpr int CS = C4;                       // node stride in the accumulator
-  static_assert(CS / 2 <= 16, "four consumer waves own four channel pairs each");
-  // table of a batch: one entry per STEP = the pair of records (j, j + 16), interleaved so that a consumer lane fetches
-  // both records' data with one 16-byte read: 8 x (addrA, wA, addrB, wB), then CS/2 x (gA.x, gA.y, gB.x, gB.y), then
-  // the two packed cells
-  constexpr int GOFF = 32;                        // words: start of the channel values of a step
-  constexpr int CELL = GOFF + 2 * C4;             // words: the two packed cells
-  constexpr int ROW = (CELL + 2 + 3) / 4 * 4;     // words per step, 16-byte aligned
-  extern __shared__ __attribute__((aligned(16))) float acc[];  // node (x, y, z), channel c at x * SX + y * SY + z * CS + c
-  constexpr int TW = (kBrickBatch / 2 + 2) * ROW > kBrickFetchers * 4 ? (kBrickBatch / 2 + 2) * ROW : kBrickFetchers * 4;  // (also the staging buffers of the diffuse phase)
-  __shared__ __attribute__((aligned(16))) uint32_t table[2][TW];  // separate object: never aliases acc; + 2 spare steps (prefetch)
-  __shared__ long long s_rstart[kMaxRanges];
-  __shared__ int s_rlist[kMaxRanges];
-  __shared__ int s_rcum[kMaxRanges + 1];  // cumulative record counts of the non-empty ranges
-  const int B = 1 << a.shift;
-  const int SY = brick_row_stride(B, C), SX = brick_slab_stride(B, C);
-  const int TRASH = B * SX;  // contributions to nodes this brick does not own land here and are never written out
-  const int acc_words = TRASH + 64;
-
-  RF_PROF_START();
-  const int tid = threadIdx.x;
-  const int lane = tid & (kWave - 1);
-  const int wave = tid >> 6;
-  const int brick = blockIdx.x;
-  const int bz = brick % a.nbz, by = (brick / a.nbz) % a.nby, bx = brick / (a.nbz * a.nby);
-  const int X0 = bx << a.shift, Y0 = by << a.shift, Z0 = bz << a.shift;
-#ifdef RF_BRICK_PROFILE
-  if constexpr (ADAM) {
-    // (experiment kept for the record: de-phasing the first generation of workgroups with a pseudo-random start delay does NOT
-    // help -- the optimizer flushes of different workgroups are not synchronised to begin with)
-    if ((a.stagger & 0xffff) && blockIdx.x < (unsigned)(a.stagger & 0xffff)) {
-      const unsigned int h = (blockIdx.x * 2654435761u) >> 28;  // 0..15
-      for (unsigned int k = 0; k < h; ++k) __builtin_amdgcn_s_sleep(100);  // ~6400 clk each
-    }
-  }
-#endif
-  // ---- which sorted ranges reach into this brick: 14 (offset to the source brick o, run of flag classes f with
-  // (f & o) == o) per list, fetched by 14 lanes each and compacted with a wave scan.  Wave 0 does it for the lists that go
-  // through the table path, wave 1 for the base-channel list of a mixed call (it has its own, smaller, range table).
-  __shared__ long long s_dstart[14];
-  __shared__ int s_dcum[16];  // [15] = total
-  if (wave < 2) brick_ranges(a, bx, by, bz, wave, lane, s_rstart, s_rlist, s_rcum, s_dstart, s_dcum);
-  __syncthreads();
-  const int total = s_rcum[kMaxRanges];
-  const int total_d = a.mixed ? s_dcum[15] : 0;
-  const bool any = total > 0 || total_d > 0;
-  if (!any && a.accumulate) return;  // nothing reaches this brick
-  RF_PROF_MARK(0);  // range set-up
-
-  const int nbatches = (total + kBrickBatch - 1) / kBrickBatch;
-  constexpr int H = kBrickBatch / 2;
-  using Slot0 = std::integral_constant<int, 0>;
-  using Slot1 = std::integral_constant<int, 1>;
-
-  // ---- producer role (waves 4..7): waves 4 and 6 prepare the even batches, waves 5 and 7 the odd ones (each pair splits the 32
-  // records of its batch).  8 lanes per record (lane `part` prepares corner `part` and copies float4 `part` of the record), two
-  // records (sj + 8 t) per lane and batch.  The record loads of a batch are issued FOUR batches before the table is built from
-  // them (two register sets per wave): the table path is bound by the latency of these loads -- several microseconds while other
-  // workgroups stream their optimizer flush -- and with a distance of two batches only ~16 KB per CU were in flight.
-  const bool producer = wave >= 4;
-  const int parity = wave & 1;
-  const int thalf = (wave >> 1) & 1;            // which half of the batch's records this producer wave stages
-  constexpr int TPL = kBrickBatch / 8 / 2;      // records per producer lane and batch
-  const int sj = lane >> 3, part = lane & 7;
-  const int pdx = (part >> 2) & 1, pdy = (part >> 1) & 1, pdz = part & 1;
-  const int vpart = (part >= 1 && part < Q) ? part : 0;
-  int sri = 0;  // running range index of the record this lane LOCATES (record lane & 31 of a batch; monotonic)
-  float4 ridx[2][TPL], rval[2][TPL];  // [register set = (batch >> 1) & 1]
-#pragma unroll
-  for (int t = 0; t < TPL; ++t) ridx[0][t] = ridx[1][t] = rval[0][t] = rval[1][t] = make_float4(0.f, 0.f, 0.f, 0.f);
-
-  // -- issue the loads of batch bb (unconditional, clamped to the last record: no divergent register merges).  Lane l
-  // locates record l & 31 in the range list once; the 8 lanes that stage a record fetch its address by shuffle.
-  auto issue = [&](int bb, auto slot_tag) {
-    constexpr int SLOT = decltype(slot_tag)::value;
-    const int v = min(bb * kBrickBatch + (lane & (kBrickBatch - 1)), total - 1);
-    while (s_rcum[sri + 1] <= v) ++sri;
-    // (positions, not pointers, go through the shuffle: a pointer rebuilt from integers would be a FLAT access, and FLAT
-    // loads in flight force every LDS wait in this kernel to drain completely)
-    const long long pos = s_rstart[sri] + (v - s_rcum[sri]);
-    const int lo = (int)(uint32_t)pos, hi = (int)(uint32_t)((unsigned long long)pos >> 32) | (s_rlist[sri] << 30);
-#pragma unroll
-    for (int t = 0; t < TPL; ++t) {
-      const int src = sj + 8 * (t + TPL * thalf);
-      const uint32_t plo = (uint32_t)__shfl(lo, src), phi = (uint32_t)__shfl(hi, src);
-      const long long p = (long long)(((unsigned long long)(phi & 0x3fffffffu) << 32) | plo);
-      const float4* rec = ((phi >> 30) ? a.lists[1].rec : a.lists[0].rec) + p * Q;
-      ridx[SLOT][t] = rec[0];
-      rval[SLOT][t] = rec[vpart];
-    }
-  };
-
-  // The record loads of the first batches go out NOW, before the diffuse phase, so that the table path does not start with
-  // a bare HBM latency (the producer waves issue no other global loads until then; batch bb lives in register set (bb >> 1) & 1
-  // of the producer waves of its parity).
-  if (total > 0 && producer) {
-    if (parity == 0) {
-      issue(0, Slot0{});
-      if (nbatches > 2) issue(2, Slot1{});
-    } else {
-      if (nbatches > 1) issue(1, Slot0{});
-      if (nbatches > 3) issue(3, Slot1{});
-    }
-  }
-
-  // ---- mixed call: the base-channel (render_diffuse) records first, summed with LDS float64 atomics.  A 4-channel record
-  // would occupy a quarter of the lanes of the table path below at the price of a full record; ds_add_f64 is fire-and-forget
-  // and needs neither ownership nor ordering, so all four waves take two records per instruction (32 lanes = 8 corners x 4
-  // channels each).  Measured (tools/lds_microbench4.hip): 21 clk per record per CU, ds_add_f32 would take 30x longer.  The
-  // float64 sums (order-insensitive to ~1e-16) are rounded to float32 once and become the INITIAL value of the float32
-  // accumulators of the table path.  The doubles live in the first 16 KB of `acc`.
-  double dsum[8];
-#pragma unroll
-  for (int j = 0; j < 8; ++j) dsum[j] = 0.0;
-  const int nd4 = B * B * B * 4;
-  if (total_d > 0) {
-    double* dacc = reinterpret_cast<double*>(acc);
-    for (int i = tid; i < nd4; i += kBrickThreads) dacc[i] = 0.0;
-    __syncthreads();
-    const int half = lane >> 5, qd = (lane >> 2) & 7, cd = lane & 3;
-    const int dd[3] = {(qd >> 2) & 1, (qd >> 1) & 1, qd & 1};
-    const int org[3] = {X0, Y0, Z0};
-    const int dim[3] = {g.X, g.Y, g.Z};
-    // the records are streamed through LDS (the idle table buffers): the whole workgroup fetches 128 records (4 KB) per
-    // round with coalesced 16-byte loads, one round ahead of their use; a wave then takes its records from LDS, where
-    // a miss costs 65 cycles instead of microseconds
-    constexpr int RPR = kBrickFetchers / 2;  // records per round (two float4 per record)
-    static_assert(2 * kBrickFetchers * 4 <= (int)(sizeof(table) / sizeof(uint32_t)), "two staging buffers fit the table");
-    float4* stage = reinterpret_cast<float4*>(&table[0][0]);
-    const int nrounds = (total_d + RPR - 1) / RPR;
-    int ri = 0;
-    auto fetch = [&](int round) -> float4 {
-      const int v = min(round * RPR + (tid >> 1), total_d - 1);  // clamped: unconditional loads
-      while (s_dcum[ri + 1] <= v) ++ri;
-      return a.lists[1].rec[(s_dstart[ri] + (v - s_dcum[ri])) * 2 + (tid & 1)];
-    };
-    // three rounds of loads in flight per fetcher thread (one round kept 4 KB per workgroup in flight: latency-bound)
-    const bool fetcher = tid < kBrickFetchers;
-    float4 f0 = make_float4(0.f, 0.f, 0.f, 0.f), f1 = f0, f2 = f0;
-    if (fetcher) {
-      f0 = fetch(0);
-      if (nrounds > 1) f1 = fetch(1);
-      if (nrounds > 2) f2 = fetch(2);
-    }
-    for (int round = 0; round < nrounds; ++round) {
-      float4* buf = stage + (round & 1) * kBrickFetchers;
-      if (fetcher) buf[tid] = f0;
-      __syncthreads();
-      f0 = f1;
-      f1 = f2;
-      if (fetcher && round + 3 < nrounds) f2 = fetch(round + 3);
-      const int nrec = min(RPR, total_d - round * RPR);
-#pragma unroll 4
-      for (int r = wave * 2 + half; r < nrec; r += 2 * (kBrickThreads / kWave)) {
-        const float4 ridx = buf[2 * r];
-        const float val = reinterpret_cast<const float*>(buf + 2 * r + 1)[cd];
-        const float idx[3] = {ridx.x, ridx.y, ridx.z};
-        int n3[3];
-        float w3[3];
-        bool owned = true;
-#pragma unroll
-        for (int ax = 0; ax < 3; ++ax) {
-          const float fl = floorf(idx[ax]);
-          w3[ax] = dd[ax] ? (idx[ax] - fl) : ((fl + 1.0f) - idx[ax]);  // same arithmetic as locate()
-          n3[ax] = (int)fl - org[ax] + dd[ax];
-          owned = owned && n3[ax] >= 0 && n3[ax] < B && org[ax] + n3[ax] < dim[ax];
-        }
-        if (owned) {
-          const float wc = (w3[0] * w3[1]) * w3[2];
-          atomicAdd(&dacc[(((n3[0] << a.shift) + n3[1]) << a.shift) * 4 + n3[2] * 4 + cd], (double)(wc * val));
-        }
-      }
-    }
-    __syncthreads();
-#pragma unroll
-    for (int j = 0; j < 8; ++j)
-      if (tid + j * kBrickThreads < nd4) dsum[j] = dacc[tid + j * kBrickThreads];
-    __syncthreads();
-  }
-  RF_PROF_MARK(1);  // diffuse records (float64 atomics)
-  if (any) {
-    float4* acc4 = reinterpret_cast<float4*>(acc);
-    for (int i = tid; i < acc_words / 4; i += kBrickThreads) acc4[i] = make_float4(0.f, 0.f, 0.f, 0.f);
-  }
-  if (total_d > 0) {
-    __syncthreads();
-#pragma unroll
-    for (int j = 0; j < 8; ++j) {
-      const int e = tid + j * kBrickThreads;
-      if (e < nd4) {
-        const int node = e >> 2;
-        const int nz = node & (B - 1), ny = (node >> a.shift) & (B - 1), nx = node >> (2 * a.shift);
-        acc[nx * SX + ny * SY + nz * CS + (e & 3)] = (float)dsum[j];
-      }
-    }
-  }
-
-
-  // -- build the table of batch bb from the loads issued for it
-  auto build = [&](int bb, auto slot_tag) {
-    constexpr int SLOT = decltype(slot_tag)::value;
-#pragma unroll
-    for (int t = 0; t < TPL; ++t) {
-      const int rj = sj + 8 * (t + TPL * thalf);
-      const int half = rj / H;  // record A or B of step rj % H
-      uint32_t* row = table[bb & 1] + (rj & (H - 1)) * ROW;
-      uint32_t addr = (uint32_t)TRASH;
-      uint32_t cell = 0x00f0f0f0u + (uint32_t)(rj & 7) * 0x00040404u;  // padded rows: far from every real cell
-      float wc = 0.0f;
-      float4 val = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (bb * kBrickBatch + rj < total) {
-        const float idx[3] = {ridx[SLOT][t].x, ridx[SLOT][t].y, ridx[SLOT][t].z};
-        const int org[3] = {X0, Y0, Z0};
-        const int dim[3] = {g.X, g.Y, g.Z};
-        const int dd[3] = {pdx, pdy, pdz};
-        int n3[3];
-        bool owned = true;
-        float w3[3];
-        // (the 4th word of the index quad is 0; reading it keeps all four load registers reserved until here)
-        cell = __float_as_uint(ridx[SLOT][t].w);
-#pragma unroll
-        for (int ax = 0; ax < 3; ++ax) {
-          const float fl = floorf(idx[ax]);
-          cell |= (uint32_t)((int)fl - org[ax] + 1) << (8 * ax);       // lower node relative to the brick: 0..B
-          w3[ax] = dd[ax] ? (idx[ax] - fl) : ((fl + 1.0f) - idx[ax]);  // same arithmetic as locate()
-          n3[ax] = (int)fl - org[ax] + dd[ax];
-          owned = owned && n3[ax] >= 0 && n3[ax] < B && org[ax] + n3[ax] < dim[ax];
-        }
-        if (owned) {
-          addr = (uint32_t)(n3[0] * SX + n3[1] * SY + n3[2] * CS);
-          wc = (w3[0] * w3[1]) * w3[2];
-        }
-        val = rval[SLOT][t];
-      }
-      *reinterpret_cast<uint2*>(row + 4 * part + 2 * half) = make_uint2(addr, __float_as_uint(wc));
-      if (part >= 1 && part < Q) {  // channels 4 (part - 1) .. + 3 = channel pairs 2 (part - 1) and 2 (part - 1) + 1
-        float* gp = reinterpret_cast<float*>(row) + GOFF + 8 * (part - 1) + 2 * half;
-        *reinterpret_cast<float2*>(gp) = make_float2(val.x, val.y);
-        *reinterpret_cast<float2*>(gp + 4) = make_float2(val.z, val.w);
-      }
-      if (part == 0) row[CELL + half] = cell;
-    }
-  };
-
-  // ---- consumer role (waves 0..3, one per SIMD): a wave owns FOUR channel pairs of every node (pairs 4 w .. 4 w + 3; 14 pairs
-  // at degree 2, so wave 3 owns two) and walks ALL records of the batch.  32 lanes = 8 corners x 4 pairs serve one record, so
-  // the two records (j, j + 16) of a step share ONE read-add-write instruction -- lanes 0..31 record A, lanes 32..63 record B.
-  // (Two consumer waves with 7 pairs each needed two read-add-writes per step; the chain per step, not the LDS bandwidth, is what
-  // bounds this phase.)  Disjoint channel ownership across waves => no races between waves; the two records of a step race
-  // only when their cells share a node, and are then issued one half-wave after the other.
-  const int half = lane >> 5;
-  const int q = (lane >> 2) & 7;
-  const int pair = 4 * wave + (lane & 3);
-  const int ch = 2 * pair;
-  const bool acc_active = wave < 4 && ch < CS;
-
-  // -- accumulate batch b from its table.  The table entries of step j + 1 are fetched before the read-add-write of step j.
-  // Measured by ablation (tools/brick_phase_profile.py, RF_BRICK_STAGGER bits): of the ~57 K cycles a brick spends here, ~15 K are
-  // the batch barriers alone, ~41 K this loop (~200 cycles per step), the producers fit inside it (32 K on their own) and the
-  // record loads cost nothing extra.  Keeping two steps in flight (records j, j+8, j+16, j+24) did NOT help (0.495 -> 0.528 ms):
-  // the LDS pipe is shared with the other workgroup's float64 atomics and flush reads, so more LDS requests in flight only
-  // queue up.
-  auto accumulate = [&](int b) {
-    const uint32_t* tb = table[b & 1];
-    const int base = b * kBrickBatch;
-    const int nb = min(kBrickBatch, total - base);
-    uint32_t shared_mask;  // bit j: the cells of records j and j + H have a node in common
-    {
-      const int l = lane & (H - 1);
-      const uint2 cells = *reinterpret_cast<const uint2*>(tb + l * ROW + CELL);
-      shared_mask = (uint32_t)__ballot(cells_share_nodes(cells.x, cells.y));
-    }
-    if (!acc_active) return;
-    const int steps = min(nb, H);  // records >= nb are padded (zero weight, trash address, far-away cell)
-    const uint32_t* row = tb;
-    const int aoff = 4 * q + 2 * half, goff = GOFF + 4 * pair + 2 * half;  // this lane's (addr, w) and (g.x, g.y) of ITS record
-    uint2 aw = *reinterpret_cast<const uint2*>(row + aoff);
-    float2 gg = *reinterpret_cast<const float2*>(row + goff);
-    for (int j = 0; j < steps; ++j) {
-      row += ROW;  // (the table has spare steps behind the last one)
-      const float w = __uint_as_float(aw.y);
-      float2* d = reinterpret_cast<float2*>(&acc[aw.x + ch]);
-      const float gx = w * gg.x, gy = w * gg.y;
-      if ((shared_mask >> j) & 1u) {  // rare: the two cells share nodes -> record A's half-wave first, then record B's
-        if (half == 0) {
-          float2 v = *d;
-          v.x = v.x + gx;
-          v.y = v.y + gy;
-          *d = v;
-        }
-        // (per-thread the two blocks look identical: without this fence the compiler merges them into one unconditional
-        // read-add-write and the half-waves race again)
-        wave_lds_fence();
-        if (half == 1) {
-          float2 v = *d;
-          v.x = v.x + gx;
-          v.y = v.y + gy;
-          *d = v;
-        }
-        aw = *reinterpret_cast<const uint2*>(row + aoff);
-        gg = *reinterpret_cast<const float2*>(row + goff);
-      } else {
-        float2 v = *d;
-        const uint2 aw_n = *reinterpret_cast<const uint2*>(row + aoff);
-        const float2 gg_n = *reinterpret_cast<const float2*>(row + goff);
-        v.x = v.x + gx;
-        v.y = v.y + gy;
-        *d = v;
-        aw = aw_n;
-        gg = gg_n;
-      }
-    }
-  };
-
-  // producers run one batch ahead of the consumers (tables are double buffered); the loads of a producer wave's next
-  // batch (two batches later) are issued as soon as it has built the current one
-  RF_PROF_MARK(2);  // zero-fill + initial values
-  RF_PROF_MARK(2);  // zero-fill + initial values
-  if (total > 0 && producer && parity == 0) {
-    build(0, Slot0{});
-    if (nbatches > 4) issue(4, Slot0{});
-  }
-  __syncthreads();
-  // one iteration: the consumers drain table b; the producers of batch b + 1 build its table from the register set the loads
-  // went to four batches ago and re-fill that set with batch b + 5
-  auto iteration = [&](int b, auto slot_tag) {
-#ifdef RF_BRICK_PROFILE
-    const bool no_consume = a.stagger & 0x100000, no_build = a.stagger & 0x200000, no_issue = a.stagger & 0x400000;
-#else
-    constexpr bool no_consume = false, no_build = false, no_issue = false;
-#endif
-    if (producer) {
-      if (b + 1 < nbatches && ((b + 1) & 1) == parity) {
-        if (!no_build) build(b + 1, slot_tag);
-        if (b + 5 < nbatches && !no_issue) issue(b + 5, slot_tag);
-      }
-    } else if (!no_consume) {
-      accumulate(b);
-    }
-    __syncthreads();
-  };
-  for (int b0 = 0; b0 < nbatches; b0 += 4) {  // ((b + 1) >> 1) & 1 for b = b0 .. b0 + 3 with b0 % 4 == 0: 0, 1, 1, 0
-    iteration(b0, Slot0{});
-    if (b0 + 1 < nbatches) iteration(b0 + 1, Slot1{});
-    if (b0 + 2 < nbatches) iteration(b0 + 2, Slot1{});
-    if (b0 + 3 < nbatches) iteration(b0 + 3, Slot0{});
-  }
-
-  RF_PROF_MARK(3);  // table path: producer / consumer batches
-  brick_flush<K, ADAM>(g, a, acc, any, X0, Y0, Z0, gdens, gfeat);
-  RF_PROF_MARK(4);  // flush (stores issued, not necessarily retired)
-  RF_PROF_END();
-}
-
 // ---------------------------------------------------------------------------------------------
-// brick_gather_kernel: the same job as brick_accumulate_kernel -- one workgroup per brick of B^3 owned nodes, the same key ranges,
-// the same flush -- with the sums kept in MFMA accumulators instead of LDS.
+// brick_gather_kernel: one workgroup per brick of B^3 owned nodes; the sums live in MFMA accumulators.
 //
 // The gradient of a brick is  acc[node][channel] = sum over records r of  W[node][r] * G[r][channel],  where column r of W holds
 // the 8 trilinear weights of record r (zero for the other nodes) and row r of G the record's per-channel values: a sparse x dense
-// product.  The table path above spends ~200 cycles per pair of records on a read-add-write chain through LDS.  Here the owned
+// product.  (Summing in LDS with read-add-writes cost ~200 cycles per pair of records on the dependent chain.)  The owned
 // nodes are cut into tiles of 16 nodes (2 x 2 x 4), a batch of records (256, staged in LDS) is binned to the tiles it touches
 // (2.8 on average, ballots: no atomics, list order = record order, so the summation order is fixed by the record order), and a
 // wave multiplies the records of a tile four at a time into the tile's 16 x 16 accumulator blocks with v_mfma_f32_16x16x4_f32
@@ -2242,6 +1864,11 @@ __global__ __launch_bounds__(kBrickThreads, 4) void brick_accumulate_kernel(Grid
 // Each wave owns 4 tiles (B = 8: 32 tiles), i.e. 4 x NT accumulator blocks of 4 registers.
 // The MFMA is used as a scatter-add engine, not to make the pass compute-bound: the kernel stays HBM-bound by its flush
 // (optimizer state) and record reads; this only removes the LDS chain that kept it from that bound.
+// Phase times per brick on the bench step (development build, ~1.65 GHz under this load; 5 batches): flush 26 K cycles (9 K of them
+// instructions), lists 8 K + tile loops 15 K (+ 6 K of barrier imbalance behind them), waiting for the first batch's loads 12 K,
+// issuing loads 6 K, record pass 5 K, range set-up 3.5 K, image 4 K.  Tried and dropped: PERSISTENT workgroups that request the
+// next brick's first batch before flushing (0.394 -> 0.53 ms: vmcnt counts loads and stores in issue order, so the next brick's
+// first wait also sits out the completion of the whole flush's stores); 7 instead of 4 quads in flight in the flush (spills).
 // ---------------------------------------------------------------------------------------------
 // LDS reads the compiler cannot re-schedule (brick_gather_kernel's tile loop): the optimizer proves plain LDS loads re-computable and
 // rotates a hand-pipelined loop back into read -> wait -> read -> wait -> multiply.  These are issued where they stand; the value
@@ -3455,25 +3082,6 @@ int32_t rf_expanded_record_floats(int32_t num_features) { return 4 * record_quad
 
 extern "C++" {
 template <int K, bool ADAM>
-static int launch_brick(const GridArgs& g, const BrickArgs& a, int nbricks, float* gd, float* gf, hipStream_t st) {
-  const int B = 1 << a.shift;
-  const size_t lds = (size_t)brick_acc_words(B, 3 * K + 1) * sizeof(float);
-  if (lds > 150 * 1024) return RF_ERR_UNSUPPORTED;  // 160 KB per CU minus the kernel's static staging buffers
-  // raise the dynamic-LDS limit of this instantiation when a larger one is needed (a per-device function attribute)
-  static std::atomic<size_t> configured[64];
-  int dev = 0;
-  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return RF_ERR_LAUNCH;
-  if (lds > configured[dev].load(std::memory_order_relaxed)) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&brick_accumulate_kernel<K, ADAM>),
-                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
-      return RF_ERR_LAUNCH;
-    configured[dev].store(lds, std::memory_order_relaxed);
-  }
-  hipLaunchKernelGGL((brick_accumulate_kernel<K, ADAM>), dim3(nbricks), dim3(kBrickThreads), lds, st, g, a, gd, gf);
-  return launch_status();
-}
-
-template <int K, bool ADAM>
 static int launch_gather(const GridArgs& g, const BrickArgs& a, int nbricks, float* gd, float* gf, hipStream_t st) {
   const int B = 1 << a.shift;
   const size_t lds = (size_t)gather_lds_words(B, 3 * K + 1, record_quads(K)) * sizeof(float);
@@ -3515,7 +3123,7 @@ static int brick_accumulate_impl(const RFGrid* grid, int32_t brick_size, const R
     a.lists[i].offsets = reinterpret_cast<const long long*>(lists[i].offsets_dev);
     a.lists[i].diffuse = lists[i].render_diffuse || grid->num_features == 3;
   }
-  // two lists: either the same kind (both through the table path) or (specular, diffuse) = a mixed call
+  // two lists: either the same kind (one concatenated full-width list) or (specular, diffuse) = a mixed call
   a.mixed = num_lists == 2 && !a.lists[0].diffuse && a.lists[1].diffuse;
   if (num_lists == 2 && a.lists[0].diffuse && !a.lists[1].diffuse) return RF_ERR_BAD_SHAPE;  // the specular list comes first
   const int base_only = a.lists[0].diffuse;  // 4 accumulator channels per node, written to the base channels only
@@ -3529,10 +3137,6 @@ static int brick_accumulate_impl(const RFGrid* grid, int32_t brick_size, const R
   const int nbricks = nb[0] * nb[1] * nb[2];
   hipStream_t st = (hipStream_t)stream;
   const int K = base_only ? 1 : grid->num_features / 3;
-  static const bool gather = [] {  // (development switch while both accumulation paths exist)
-    const char* e = getenv("RF_BRICK_PATH");
-    return !(e && e[0] == 't');  // RF_BRICK_PATH=table
-  }();
   if (adam) {
     // the update needs the complete gradient of every parameter in the owning workgroup: all channels covered by the lists
     // (base-only lists on an SH grid leave the higher-degree channels to someone else), whole float4s, overwrite semantics
@@ -3571,38 +3175,20 @@ static int brick_accumulate_impl(const RFGrid* grid, int32_t brick_size, const R
       a.stagger = e ? atoi(e) : 0;
     }
 #endif
-    if (gather) {
-      switch (K) {
-        case 1:
-          return launch_gather<1, true>(g, a, nbricks, nullptr, nullptr, st);
-        default:
-          return launch_gather<9, true>(g, a, nbricks, nullptr, nullptr, st);
-      }
-    }
     switch (K) {
       case 1:
-        return launch_brick<1, true>(g, a, nbricks, nullptr, nullptr, st);
+        return launch_gather<1, true>(g, a, nbricks, nullptr, nullptr, st);
       default:
-        return launch_brick<9, true>(g, a, nbricks, nullptr, nullptr, st);
-    }
-  }
-  if (gather) {
-    switch (K) {
-      case 1:
-        return launch_gather<1, false>(g, a, nbricks, grad_densities_dev, grad_features_dev, st);
-      case 4:
-        return launch_gather<4, false>(g, a, nbricks, grad_densities_dev, grad_features_dev, st);
-      default:
-        return launch_gather<9, false>(g, a, nbricks, grad_densities_dev, grad_features_dev, st);
+        return launch_gather<9, true>(g, a, nbricks, nullptr, nullptr, st);
     }
   }
   switch (K) {
     case 1:
-      return launch_brick<1, false>(g, a, nbricks, grad_densities_dev, grad_features_dev, st);
+      return launch_gather<1, false>(g, a, nbricks, grad_densities_dev, grad_features_dev, st);
     case 4:
-      return launch_brick<4, false>(g, a, nbricks, grad_densities_dev, grad_features_dev, st);
+      return launch_gather<4, false>(g, a, nbricks, grad_densities_dev, grad_features_dev, st);
     default:
-      return launch_brick<9, false>(g, a, nbricks, grad_densities_dev, grad_features_dev, st);
+      return launch_gather<9, false>(g, a, nbricks, grad_densities_dev, grad_features_dev, st);
   }
 }
 

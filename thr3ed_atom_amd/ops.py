@@ -507,7 +507,7 @@ class _ReluFieldRender(torch.autograd.Function):
             ret_d, ret_f = gd, gf
         if ctx.key_hist is not None:
             # binned adjoint: the forward pass counted the records per (brick, flags) key; offsets -> records written at their
-            # final positions -> one workgroup per brick sums them in LDS and ADDS the brick to the gradient tensors
+            # final positions -> one workgroup per brick sums them and ADDS the brick to the gradient tensors
             hist, dev = ctx.key_hist, origins.device
             diffuse = bool(ctx.flags & _lib.FLAG_RENDER_DIFFUSE)
             offsets = torch.empty(hist.numel() + 1, dtype=torch.int64, device=dev)

@@ -13,7 +13,7 @@ What is done the MI355X way instead of translated:
   * rays are generated only for the selected pixels (rf_cast_selected_rays) instead of casting
     8 x H x W rays and discarding all but 16384 of them every iteration;
   * gradients accumulate in one flat bucket and Adam is one fused kernel (optim.py); the specular backward of the
-    fused step bins per-sample gradient records by 8^3-node brick and sums every brick in LDS without atomics;
+    fused step bins per-sample gradient records by 8^3-node brick and sums every brick on chip (MFMA accumulators) without atomics;
   * with WORLD_SIZE > 1 every rank draws its own ray batch and the bucket is exchanged once per iteration over RCCL:
     reduce-scatter, Adam on 1/N of the grid per rank, all-gather of the parameters (distributed.py).
 """
@@ -159,7 +159,7 @@ class TrainStepper:
         self.fused = bool(fused)
         self._grad_clean = True  # FlatGrid starts zero-filled
         # backward="binned" (fused steps only, SH degree <= 2, at most 4096 bricks): the specular pass writes per-sample
-        # gradient records, bins them by (8^3-node brick, boundary flags) and sums each brick in LDS without atomics
+        # gradient records, bins them by (8^3-node brick, boundary flags) and sums each brick on chip without atomics
         # (DESIGN.md section 4); the diffuse pass stays on the atomic scatter.  deterministic=True sends both passes
         # through the bricks and bins with a stable radix sort instead of the counting sort: no atomics anywhere, fixed
         # float32 summation order, run-to-run bit-identical gradients (slower).
@@ -194,7 +194,7 @@ class TrainStepper:
             backward = "binned" if (self.fused and grid.sh_degree == 2 and nb[0] * nb[1] * nb[2] * 8 <= (1 << 21)) else "atomic"
         self.backward = backward
         # merge_bricks (binned, non-deterministic steps with the diffuse regulariser): BOTH renders emit their records first and
-        # ONE brick pass sums them -- the 4-channel diffuse records with LDS float64 atomics, the specular records on top -- so
+        # ONE brick pass sums them (the 4-channel diffuse records in the first channel columns of the same accumulators), so
         # the atomic diffuse scatter (0.28 ms at 0.13 of the HBM roofline in round 1) disappears.  Default: on, except under
         # data parallelism, where the order "specular bricks -> exchange of the `rest` gradients overlapped with the diffuse
         # pass" is kept.
@@ -493,7 +493,7 @@ class TrainStepper:
             )
             g_colour = l1_loss_grad_hip(colour, pixels, sums[2 * i : 2 * i + 2])
             if use_bricks:
-                # per-sample gradient records -> binned by (8^3-node brick, boundary flags) -> every brick summed in LDS
+                # per-sample gradient records -> binned by (8^3-node brick, boundary flags) -> every brick summed on chip
                 # without atomics and written with plain stores.  The specular pass overwrites the whole bucket (no
                 # zero-fill).  The diffuse pass (4 base channels = one 16-byte sector per corner) is as fast or faster
                 # through the atomic scatter (measured: 0.26 vs 0.26 ms on a random field, 0.13 vs 0.19 ms once the field
@@ -552,7 +552,7 @@ class TrainStepper:
             if num_bricks * 8 > (1 << 21):
                 raise ValueError("backward='binned' needs at most 2^18 bricks")
             if grid.sh_degree > 2:
-                raise ValueError("backward='binned' supports SH degree <= 2 (the brick accumulators must fit the 160 KB LDS)")
+                raise ValueError("backward='binned' supports SH degree <= 2 (the brick's accumulator image must fit the LDS)")
             b = {
                 "shape": (n, S),
                 "num_bricks": num_bricks,

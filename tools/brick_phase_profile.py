@@ -51,16 +51,9 @@ lib.rf_debug_brick_profile(out, 1)
 for _ in range(steps):
     stepper.step(data, next(batches))
 lib.rf_debug_brick_profile(out, 0)
-if os.environ.get("RF_BRICK_PATH", "")[:1] == "t":
-    names = ["range set-up", "diffuse records (f64 atomics)", "zero-fill + init", "table path (spec records)", "flush / optimizer"]
-else:
-    names = ["range set-up", "batch: wait for loads + LDS stores + barrier", "batch: barriers after record pass / tiles", "batch: lists + tiles (MFMA), wave 0", "flush / optimizer", "accumulator image", "batch: issue of the next loads", "batch: record pass, wave 0"]
+names = ["range set-up", "batch: wait for loads + LDS stores + barrier", "batch: barriers after record pass / tiles", "batch: lists + tiles (MFMA), wave 0", "flush / optimizer", "accumulator image", "batch: issue of the next loads", "batch: record pass, wave 0"]
 nb = 4096 * steps
 tot = sum(out[i] for i in range(len(names)))
 for i, nm in enumerate(names):
     print(f"{nm:34s} {out[i] / nb:10.0f} ticks per brick   {100.0 * out[i] / max(tot, 1):5.1f} %")
-if len(names) == 5:
-    print(f"{'  of the table path: consumer wave 0 waiting at batch barriers':34s} {out[5] / nb:10.0f} ticks per brick")
-    print(f"{'  of the table path: producer wave 4 building (every other batch)':34s} {out[6] / nb:10.0f} ticks per brick")
-    print(f"{'  of the table path: consumer wave 0 accumulating':34s} {out[7] / nb:10.0f} ticks per brick")
 print(f"{'sum':34s} {tot / nb:10.0f} ticks per brick (s_memtime ticks = 100 MHz constant clock or shader cycles, see DESIGN)")

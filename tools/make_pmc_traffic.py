@@ -31,8 +31,8 @@ BENCH_NAMES = {
     "render_emit_direct_kernel<1, true>": "render_backward_emit_direct[diffuse]",
     "render_backward_kernel<9, false, 0>": "render_backward[sh2]",
     "render_backward_kernel<1, true, 0>": "render_backward[diffuse]",
-    "brick_accumulate_kernel<9, true>": "brick_accumulate_adam[sh2]",
-    "brick_accumulate_kernel<9, false>": "brick_accumulate[sh2]",
+    "brick_gather_kernel<9, true>": "brick_accumulate_adam[sh2]",
+    "brick_gather_kernel<9, false>": "brick_accumulate[sh2]",
     "adam_kernel": "adam_step",
     "bin_offsets_kernel": "bin_offsets",
 }
