@@ -1716,8 +1716,11 @@ __device__ __forceinline__ void brick_flush(const GridArgs& g, const BrickArgs& 
       // parameters with ordinary accesses (the next forward pass reads them), moments streamed non-temporally.  The flush is
       // the only phase of the kernel that waits on HBM: a thread issues the 3 x U loads of U quads before it touches the
       // first one (one quad at a time kept ~24 KB per CU in flight and ran at a third of the HBM rate).
-      // A thread issues ALL its loads (3 tensors x 7 quads at degree 2 = 84 registers) before it touches the first one.
       // Element offsets are kept as 32-bit (host-checked) to stay inside the 128-register budget of 4 waves per SIMD.
+      // Two rounds (4 + 3 quads per thread).  vmcnt counts loads and stores together and does not order them against each other,
+      // so the second round's wait also sits out the first round's stores; issuing ALL 21 loads before the first store (tried,
+      // with uniform tensor bases + 32-bit byte offsets = saddr addressing) needs 84 data registers, spills 12 of them right
+      // behind their loads and is slower (0.394 -> 0.419 ms).
       constexpr int U = (QN == 7) ? 4 : 1;
       const AdamArgs& ad = a.adam;
       for (int i0 = tid; i0 < nq; i0 += kBrickThreads * U) {
@@ -1868,7 +1871,8 @@ __device__ __forceinline__ void brick_flush(const GridArgs& g, const BrickArgs& 
 // instructions), lists 8 K + tile loops 15 K (+ 6 K of barrier imbalance behind them), waiting for the first batch's loads 12 K,
 // issuing loads 6 K, record pass 5 K, range set-up 3.5 K, image 4 K.  Tried and dropped: PERSISTENT workgroups that request the
 // next brick's first batch before flushing (0.394 -> 0.53 ms: vmcnt counts loads and stores in issue order, so the next brick's
-// first wait also sits out the completion of the whole flush's stores); 7 instead of 4 quads in flight in the flush (spills).
+// first wait also sits out the completion of the whole flush's stores); 7 instead of 4 quads in flight in the flush (spills);
+// an XCD-contiguous brick order (boundary records re-read through one L2: 0.394 -> 0.41 ms).
 // ---------------------------------------------------------------------------------------------
 // LDS reads the compiler cannot re-schedule (brick_gather_kernel's tile loop): the optimizer proves plain LDS loads re-computable and
 // rotates a hand-pipelined loop back into read -> wait -> read -> wait -> multiply.  These are issued where they stand; the value
