@@ -488,8 +488,8 @@ def main():
             "frac_processed": d["frac_processed"],
             "algorithmic_bytes_processed": d["algorithmic_bytes_processed"],
             "units_processed": {"records_specular": rec_spec, "records_diffuse": rec_diff, "in_aabb_samples": n_in, "nominal_samples": R * S, "parameters": nparam},
-            "note": "brick pass: both renders' gradient records summed per 8^3-node brick in LDS (no float atomics)"
-            + (", Adam applied in the flush (no gradient tensor in HBM)" if fused_opt else "") + "; LDS-latency bound, see DESIGN section 4",
+            "note": "brick pass: both renders' gradient records summed per 8^3-node brick in MFMA accumulators (no atomics)"
+            + (", Adam applied in the flush (no gradient tensor in HBM)" if fused_opt else "") + "; two workgroups per CU (LDS), phases of a workgroup serialise: see DESIGN section 4",
             "traffic_source": pmc.get("_source"),
             "by_kernel": by_kernel,
         }

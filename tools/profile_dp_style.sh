@@ -13,6 +13,6 @@ rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/write -- p
 cd $ROOT
 python tools/summarize_rocprof.py $OUT/trace > $OUT/kernel_stats.md
 python tools/summarize_pmc.py $OUT/fetch $OUT/write > $OUT/pmc.md
-python tools/make_pmc_traffic.py $OUT/fetch $OUT/write --merge-into profiles/pmc_traffic.json --source "profiles/r02b_dp_style_pmc.md (bench.py --dp-style-step)" > $OUT/pmc_traffic.json
+python tools/make_pmc_traffic.py $OUT/fetch $OUT/write --merge-into profiles/pmc_traffic.json --source "profiles/r02c_dp_style_pmc.md (bench.py --dp-style-step)" > $OUT/pmc_traffic.json
 find $OUT -name "*.csv" -size +3M -delete
 head -16 $OUT/kernel_stats.md; cat $OUT/pmc.md; python tools/benchsum.py $OUT/trace.json
