@@ -883,3 +883,33 @@ def test_psnr_after_equal_steps_with_jitter_through_the_default_fused_path(hip_d
     psnr_ref = float(rf.mse2psnr(torch.nn.functional.mse_loss(ref, held.cpu())))
     assert psnr_hip > 12.0  # it actually learned something (start is ~7 dB)
     assert abs(psnr_hip - psnr_ref) <= 0.05, (psnr_hip, psnr_ref)
+
+
+@pytest.mark.parametrize("storage,deg", [("split", 2), ("bricked", 0), ("reference", 1)])
+def test_binned_backward_with_records_concentrated_in_few_bricks(hip_device, storage, deg):
+    """4096 rays of a narrow camera through the centre of a 24^3 grid, 256 samples each: tens of thousands of records land in a
+    handful of bricks (dozens of 256-record batches per brick, tile lists hundreds of entries long -- the regime of a trained,
+    sparse field), both renders in one brick pass.  Compared with the atomic adjoint of the autograd op."""
+    G, S = 24, 256
+    F = 3 * (deg + 1) ** 2
+    cam = hotdog_like_camera()
+    grid = relu_grid(hip_device, T(hash_uniform((G, G, G, 1), 41)) + 0.3, T(hash_uniform((G, G, G, F), 42)), G, rho=2.0, storage=storage)
+    pose = rf.pose_spherical(40.0, -25.0, cam["radius"])
+    rays = rf.flatten_rays(rf.cast_rays(rf.CameraIntrinsics(64, 64, 900.0), pose, hip_device))  # field of view ~4 degrees
+    cfg = rf.SHVoxGridRenderConfig(S, rf.CameraBounds(cam["near"], cam["far"]), perturb_sampled_points=False, white_bkgd=True)
+    target = T(hash_uniform((len(rays), 3), 6, 0.0, 1.0)).to(hip_device)
+    total_d = total_f = None
+    for diffuse in (False, True):
+        cfg.render_diffuse = diffuse
+        grid.zero_grad()
+        out = rf.render_sh_voxel_grid(grid, rays, cfg)
+        torch.nn.functional.l1_loss(out.colour, target).backward()
+        ref_d, ref_f = grid.reference_gradients()
+        total_d = ref_d.clone() if total_d is None else total_d + ref_d
+        total_f = ref_f.clone() if total_f is None else total_f + ref_f
+    cfg.render_diffuse = False
+    assert float((total_f != 0).float().mean()) < 0.35  # the rays only see a thin tube of the volume
+    gd, gf = _binned_gradients(grid, rays, cfg, target, hip_device, diffuse_too=True, binning="merged")
+    gd, gf = grid.unpack(gd, gf)
+    np.testing.assert_allclose(gd.cpu().numpy(), total_d.cpu().numpy(), rtol=3e-4, atol=3e-6 * float(total_d.abs().max()))
+    np.testing.assert_allclose(gf.cpu().numpy(), total_f.cpu().numpy(), rtol=3e-4, atol=3e-6 * float(total_f.abs().max()))
