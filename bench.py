@@ -216,7 +216,7 @@ def main():
     ap.add_argument("--deterministic", action="store_true", help="binned backward: stable radix sort instead of the counting sort")
     ap.add_argument("--no-fuse-optimizer", action="store_true", help="keep the gradient bucket and the separate Adam kernel on one GPU")
     ap.add_argument("--dp-style-step", action="store_true",
-                    help="run the step the way a data-parallel rank computes it (specular brick pass, atomic diffuse backward, separate Adam) on one GPU")
+                    help="run the step the way a data-parallel rank computes it (one brick pass per render, separate Adam) on one GPU")
     ap.add_argument("--timed-steps", type=int, default=5, help="how many of the --steps record per-kernel HIP events")
     ap.add_argument("--cpu-threads", type=int, default=0, help="torch CPU threads for cpu_baseline (0 = min(cores, 16))")
     args = ap.parse_args()
@@ -496,9 +496,9 @@ def main():
 
     if roofline is None and kernels:
         # the data-parallel-style step (or any non-merged step): per-launch HIP events of ops.KernelTimer; byte figures where the
-        # counter table has the kernel (same kernels as the single-GPU step, plus the specular-only brick pass, the atomic diffuse
-        # backward and the separate optimizer)
-        alias = {f"render_forward[{spec},save]": "render_forward[spec,save]", f"render_backward_emit_direct[{spec}]": "render_backward_emit_direct[spec]"}
+        # counter table has the kernel (same kernels as the single-GPU step, plus the per-render brick passes and the separate optimizer)
+        alias = {f"render_forward[{spec},save]": "render_forward[spec,save]", f"render_backward_emit_direct[{spec}]": "render_backward_emit_direct[spec]",
+                 "brick_accumulate[diffuse]": "brick_accumulate[base]"}
         by_kernel = {}
         for kname, rec in kernels.items():
             counter = pmc.get(alias.get(kname, kname), {}).get("hbm_bytes_per_launch")
@@ -512,7 +512,7 @@ def main():
             "frac": d["frac_hbm"], "traffic": d["counter_bytes_per_launch"], "avg_launch_ms": d["avg_launch_ms"],
             "frac_basis": "HBM bytes from the PMC counters (profiles/pmc_traffic.json, single-GPU profile of the same kernels) / this run's launch time",
             "traffic_source": pmc.get("_source"), "by_kernel": by_kernel,
-            "note": "data-parallel-style step: specular brick pass -> [gradient exchange of `rest` overlapped with] diffuse forward + atomic diffuse backward -> exchange of `base` -> (sharded) Adam",
+            "note": "data-parallel-style step: specular forward + emit + brick pass -> [gradient exchange of `rest` overlapped with] diffuse forward + emit + base-channel brick pass -> exchange of `base` -> (sharded) Adam",
         }
 
     baseline = None

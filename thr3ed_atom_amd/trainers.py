@@ -158,10 +158,10 @@ class TrainStepper:
         # fused=False goes through torch.autograd like a user of render_rays would.  Same arithmetic either way.
         self.fused = bool(fused)
         self._grad_clean = True  # FlatGrid starts zero-filled
-        # backward="binned" (fused steps only, SH degree <= 2, at most 4096 bricks): the specular pass writes per-sample
-        # gradient records, bins them by (8^3-node brick, boundary flags) and sums each brick on chip without atomics
-        # (DESIGN.md section 4); the diffuse pass stays on the atomic scatter.  deterministic=True sends both passes
-        # through the bricks and bins with a stable radix sort instead of the counting sort: no atomics anywhere, fixed
+        # backward="binned" (fused steps only, SH degree <= 2): both passes write per-sample gradient records, bin them by
+        # (8^3-node brick, boundary flags) and sum each brick on chip without float atomics -- one
+        # brick pass over both record lists on a single GPU (merge_bricks), one per render in the data-parallel order.
+        # deterministic=True bins with a stable radix sort instead of the counting sort: no atomics anywhere, fixed
         # float32 summation order, run-to-run bit-identical gradients (slower).
         # "auto" = binned where it was measured faster (fused step, SH degree 2), else atomic.
         if backward not in ("auto", "atomic", "binned"):
@@ -485,7 +485,7 @@ class TrainStepper:
         for i, diffuse in enumerate((False, True) if self.diffuse else (False,)):
             t_rand = self._draw_jitter(cfg, n, S, origins.device, t_rand_given, i)
             flags = render_flags(cfg.white_bkgd, diffuse, cfg.optimized_sampling, cfg.use_occupancy_mask)
-            use_bricks = binned and (not diffuse or self.deterministic)
+            use_bricks = binned
             fused_binning = use_bricks and not self.deterministic  # the forward pass counts the records per key
             colour, _, _, _, caches = render_forward_raw(
                 grid, origins, directions, t_rand, S, near, far, flags, save=True,
@@ -495,10 +495,10 @@ class TrainStepper:
             if use_bricks:
                 # per-sample gradient records -> binned by (8^3-node brick, boundary flags) -> every brick summed on chip
                 # without atomics and written with plain stores.  The specular pass overwrites the whole bucket (no
-                # zero-fill).  The diffuse pass (4 base channels = one 16-byte sector per corner) is as fast or faster
-                # through the atomic scatter (measured: 0.26 vs 0.26 ms on a random field, 0.13 vs 0.19 ms once the field
-                # is trained), so it goes through the bricks only when a fixed summation order is asked for; it then
-                # carries the base channels only, adds on top and reuses the same scratch buffers (stream order).
+                # zero-fill); the diffuse pass carries the 4 base channels only, adds on top and reuses the same scratch
+                # buffers (stream order).  Measured on the fresh field (bench.py --dp-style-step): emit 0.060 + offsets 0.011 +
+                # bricks 0.146 = 0.22 ms against 0.30 ms for the atomic scatter of the same gradient (a 4-channel brick pass is
+                # all per-brick fixed cost; on a trained, sparse field the two are about even).
                 basis = None if diffuse else bins["ray_basis"]
                 if fused_binning:
                     # counting sort whose counting ran inside the forward pass: offsets, then the backward pass writes
