@@ -211,9 +211,11 @@ __device__ __forceinline__ float z_uniform(float near, float far, float t) { ret
 __device__ __forceinline__ float z_sample(const float* __restrict__ tv, bool have_u, float u, int s, int S, float near, float far) {
   const float zc = z_uniform(near, far, tv[s]);
   if (!have_u) return zc;
-  // stratified jitter: lower/upper = neighbouring mid-points (sample.py:57-64)
-  const float lo = (s > 0) ? 0.5f * (zc + z_uniform(near, far, tv[s - 1])) : zc;
-  const float hi = (s < S - 1) ? 0.5f * (z_uniform(near, far, tv[s + 1]) + zc) : zc;
+  // stratified jitter: lower/upper = neighbouring mid-points (sample.py:57-64).  (The neighbours are loaded unconditionally, with
+  // clamped indices: a load under a lane condition is merged with a copy, and the copy waits for the load on the spot.)
+  const float zm = z_uniform(near, far, tv[s > 0 ? s - 1 : 0]), zp = z_uniform(near, far, tv[s < S - 1 ? s + 1 : S - 1]);
+  const float lo = (s > 0) ? 0.5f * (zc + zm) : zc;
+  const float hi = (s < S - 1) ? 0.5f * (zp + zc) : zc;
   return lo + (hi - lo) * u;
 }
 
@@ -463,6 +465,31 @@ __device__ __forceinline__ float z_of(const RayState& st, const RayArgs& r, long
   else if (r.jitter)
     u = jitter_uniform(st.jseed, sc);
   return z_sample(r.tvals, r.trand != nullptr || r.jitter, u, sc, r.S, st.near, st.far);
+}
+
+// z_of in two halves, for kernels that want every load of several samples in flight before the first one is used:
+// z_requests issues the (unconditional, clamped) reads, z_from does z_of's arithmetic on them -- bit for bit the same value.
+struct ZRequests {
+  float t0, tm, tp, u;
+};
+__device__ __forceinline__ ZRequests z_requests(const RayArgs& r, long long ray, int s) {
+  const int sc = min(s, r.S - 1);
+  ZRequests q;
+  q.t0 = r.tvals[sc];
+  q.tm = r.tvals[sc > 0 ? sc - 1 : 0];
+  q.tp = r.tvals[sc < r.S - 1 ? sc + 1 : r.S - 1];
+  q.u = r.trand ? r.trand[ray * (long long)r.S + sc] : 0.0f;
+  return q;
+}
+__device__ __forceinline__ float z_from(const RayState& st, const RayArgs& r, const ZRequests& q, int s) {
+  const int sc = min(s, r.S - 1);
+  const float zc = z_uniform(st.near, st.far, q.t0);
+  if (!(r.trand != nullptr || r.jitter)) return zc;
+  const float u = r.trand ? q.u : jitter_uniform(st.jseed, sc);
+  const float zm = z_uniform(st.near, st.far, q.tm), zp = z_uniform(st.near, st.far, q.tp);
+  const float lo = (sc > 0) ? 0.5f * (zc + zm) : zc;
+  const float hi = (sc < r.S - 1) ? 0.5f * (zp + zc) : zc;
+  return lo + (hi - lo) * u;
 }
 
 __device__ __forceinline__ Sample make_sample(const RayState& st, const RayArgs& r, const GridArgs& g, long long ray,
@@ -1246,33 +1273,45 @@ __global__ __launch_bounds__(kBlock) void render_emit_direct_kernel(GridArgs g, 
 
   for (int c0 = nchunks - 1; c0 >= 0; c0 -= G) {
     float4 cv[G];
-    float Tc[G], zz[G], dl[G], ix[G][3];
+    float Tc[G], zz[G], zn[G], dl[G], ix[G][3];
     int base_[G], hl_[G];
     bool act[G], counted[G];
-    // -- A1: the cache loads of the group (chunks c0, c0 - 1, ...; chunks outside the box carry nothing, like in the forward pass)
+    // -- A0: which chunks of the group can hold samples inside the box (chunks c0, c0 - 1, ...; wave-uniform table reads)
 #pragma unroll
     for (int u = 0; u < G; ++u) {
       const int chunk = c0 - u;
-      act[u] = chunk >= 0 && !chunk_outside_box(span, st, r, chunk);  // wave-uniform
-      const int s = chunk * kWave + lane;
-      cv[u] = make_float4(0.f, 0.f, 0.f, 0.f);
-      Tc[u] = 0.0f;
-      if (act[u] && s < processed) {
-        const long long idx = ray * (long long)r.S + s;
-        cv[u] = reinterpret_cast<const float4*>(fwd.cache)[idx];
-        Tc[u] = fwd.tcache[idx];
-      }
+      act[u] = chunk >= 0 && !chunk_outside_box(span, st, r, chunk);
+    }
+    // -- A1: every load of the group -- sample caches, t_vals (and the jitter table, if one is used) -- before the first use.
+    // All unconditional, with clamped indices (lanes beyond the processed samples re-read the last one, chunks without samples the
+    // ray's first entry: one line): a load under a condition is followed by a register merge that waits for it, which had
+    // serialised the four chunks' cache loads and the t_vals reads of every sample into as many exposed memory latencies.
+    ZRequests zq[G][2];
+#pragma unroll
+    for (int u = 0; u < G; ++u) {
+      const int s = max(c0 - u, 0) * kWave + lane;
+      const int sc = act[u] ? min(s, processed - 1) : 0;
+      const long long idx = ray * (long long)r.S + sc;
+      cv[u] = reinterpret_cast<const float4*>(fwd.cache)[idx];
+      Tc[u] = fwd.tcache[idx];
+      zq[u][0] = z_requests(r, ray, s);
+      zq[u][1] = z_requests(r, ray, s + 1);
+    }
+#pragma unroll
+    for (int u = 0; u < G; ++u) {
+      const int s = max(c0 - u, 0) * kWave + lane;
+      zz[u] = z_from(st, r, zq[u][0], s);
+      zn[u] = z_from(st, r, zq[u][1], s + 1);
     }
     // -- A2: geometry, keys and the cursor atomics of the group, back to back
 #pragma unroll
     for (int u = 0; u < G; ++u) {
       base_[u] = hl_[u] = 0;
       counted[u] = false;
-      zz[u] = dl[u] = ix[u][0] = ix[u][1] = ix[u][2] = 0.0f;
+      dl[u] = ix[u][0] = ix[u][1] = ix[u][2] = 0.0f;
       if (!act[u]) continue;
       const int s = (c0 - u) * kWave + lane;
-      const Sample sm = make_sample(st, r, g, ray, s);
-      zz[u] = sm.z;
+      const Sample sm = sample_at(st, r, g, s, zz[u], zn[u]);
       dl[u] = sm.delta;
       ix[u][0] = sm.cell.idx[0];
       ix[u][1] = sm.cell.idx[1];
