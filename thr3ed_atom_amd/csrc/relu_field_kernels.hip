@@ -468,24 +468,24 @@ __device__ __forceinline__ float z_of(const RayState& st, const RayArgs& r, long
 }
 
 // z_of in two halves, for kernels that want every load of several samples in flight before the first one is used:
-// z_requests issues the (unconditional, clamped) reads, z_from does z_of's arithmetic on them -- bit for bit the same value.
+// z_requests issues the (unconditional, clamped) t_vals reads, z_from does z_of's arithmetic on them -- bit for bit the same value.
 struct ZRequests {
-  float t0, tm, tp, u;
+  float t0, tm, tp;
 };
-__device__ __forceinline__ ZRequests z_requests(const RayArgs& r, long long ray, int s) {
+__device__ __forceinline__ ZRequests z_requests(const RayArgs& r, int s) {
   const int sc = min(s, r.S - 1);
   ZRequests q;
   q.t0 = r.tvals[sc];
   q.tm = r.tvals[sc > 0 ? sc - 1 : 0];
   q.tp = r.tvals[sc < r.S - 1 ? sc + 1 : r.S - 1];
-  q.u = r.trand ? r.trand[ray * (long long)r.S + sc] : 0.0f;
   return q;
 }
-__device__ __forceinline__ float z_from(const RayState& st, const RayArgs& r, const ZRequests& q, int s) {
+// (a jitter TABLE, if one is used instead of the keyed generator, is read here, synchronously)
+__device__ __forceinline__ float z_from(const RayState& st, const RayArgs& r, const ZRequests& q, long long ray, int s) {
   const int sc = min(s, r.S - 1);
   const float zc = z_uniform(st.near, st.far, q.t0);
   if (!(r.trand != nullptr || r.jitter)) return zc;
-  const float u = r.trand ? q.u : jitter_uniform(st.jseed, sc);
+  const float u = r.trand ? r.trand[ray * (long long)r.S + sc] : jitter_uniform(st.jseed, sc);
   const float zm = z_uniform(st.near, st.far, q.tm), zp = z_uniform(st.near, st.far, q.tp);
   const float lo = (sc > 0) ? 0.5f * (zc + zm) : zc;
   const float hi = (sc < r.S - 1) ? 0.5f * (zp + zc) : zc;
@@ -740,20 +740,30 @@ __global__ __launch_bounds__(kBlock) void render_forward_kernel(GridArgs g, RayA
   bool z_ready = false;
 
   const int nchunks = (r.S + kWave - 1) / kWave;
+  // Which chunks cannot hold a sample inside the box: lane c decides for chunk c, all table reads in flight at once (a ray
+  // of more than 64 chunks falls back to one decision per iteration).  The t_vals reads of a chunk's samples are requested
+  // one iteration before they are needed: per chunk these small dependent loads were 2-3 exposed cache latencies in front of
+  // the corner gather.
+  const unsigned long long empty_mask = __ballot(lane < nchunks && chunk_outside_box(span, st, r, min(lane, nchunks - 1)));
+  ZRequests zq_ahead = z_requests(r, lane + kWave);  // samples of chunk 1
+  bool zq_valid = true;
   for (int chunk = 0; chunk < nchunks; ++chunk) {
     const int s = chunk * kWave + lane;
     {
-      const bool empty = chunk_outside_box(span, st, r, chunk);
+      const bool empty = chunk < kWave ? (bool)((empty_mask >> chunk) & 1ull) : chunk_outside_box(span, st, r, chunk);
       if (empty) {  // wave-uniform
         // (nothing is cached for such a chunk: the adjoint kernels make the same wave-uniform decision and never read it)
         processed = min(r.S, (chunk + 1) * kWave);
         z_ready = false;
+        zq_valid = false;
         continue;
       }
     }
     // ---------------- P0: lanes = samples ----------------
     if (!z_ready) z_cur = z_of(st, r, ray, s);
-    const float z_nxt = z_of(st, r, ray, s + kWave);  // the following chunk (clamped to the last sample)
+    const float z_nxt = zq_valid ? z_from(st, r, zq_ahead, ray, s + kWave) : z_of(st, r, ray, s + kWave);  // the following chunk (clamped to the last sample)
+    zq_ahead = z_requests(r, s + 2 * kWave);
+    zq_valid = true;
     const float z_up = dpp_move<kDppWaveShl1, 0xf>(0.0f, z_cur);  // lane i <- lane i+1
     const float z_next = (lane == kWave - 1) ? read_lane(z_nxt, 0) : z_up;
     Sample sm = sample_at(st, r, g, s, z_cur, z_next);
@@ -1294,14 +1304,14 @@ __global__ __launch_bounds__(kBlock) void render_emit_direct_kernel(GridArgs g, 
       const long long idx = ray * (long long)r.S + sc;
       cv[u] = reinterpret_cast<const float4*>(fwd.cache)[idx];
       Tc[u] = fwd.tcache[idx];
-      zq[u][0] = z_requests(r, ray, s);
-      zq[u][1] = z_requests(r, ray, s + 1);
+      zq[u][0] = z_requests(r, s);
+      zq[u][1] = z_requests(r, s + 1);
     }
 #pragma unroll
     for (int u = 0; u < G; ++u) {
       const int s = max(c0 - u, 0) * kWave + lane;
-      zz[u] = z_from(st, r, zq[u][0], s);
-      zn[u] = z_from(st, r, zq[u][1], s + 1);
+      zz[u] = z_from(st, r, zq[u][0], ray, s);
+      zn[u] = z_from(st, r, zq[u][1], ray, s + 1);
     }
     // -- A2: geometry, keys and the cursor atomics of the group, back to back
 #pragma unroll
