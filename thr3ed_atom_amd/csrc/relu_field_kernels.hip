@@ -1278,6 +1278,8 @@ __global__ __launch_bounds__(kBlock) void render_emit_direct_kernel(GridArgs g, 
   const int processed = fwd.stop[ray];
   const int nchunks = (processed + kWave - 1) / kWave;
   const BoxSpan span = box_span(st, r, g);
+  // lane c decides for chunk c whether it can hold a sample inside the box: all table reads in flight at once
+  const unsigned long long empty_mask = __ballot(lane < nchunks && chunk_outside_box(span, st, r, min(lane, max(nchunks - 1, 0))));
   float suffix = 0.0f;  // sum of w_j e_j over all samples beyond the current chunk
   constexpr int G = 4;  // chunks in flight
 
@@ -1286,11 +1288,11 @@ __global__ __launch_bounds__(kBlock) void render_emit_direct_kernel(GridArgs g, 
     float Tc[G], zz[G], zn[G], dl[G], ix[G][3];
     int base_[G], hl_[G];
     bool act[G], counted[G];
-    // -- A0: which chunks of the group can hold samples inside the box (chunks c0, c0 - 1, ...; wave-uniform table reads)
+    // -- A0: which chunks of the group can hold samples inside the box (chunks c0, c0 - 1, ...)
 #pragma unroll
     for (int u = 0; u < G; ++u) {
       const int chunk = c0 - u;
-      act[u] = chunk >= 0 && !chunk_outside_box(span, st, r, chunk);
+      act[u] = chunk >= 0 && !(chunk < kWave ? (bool)((empty_mask >> chunk) & 1ull) : chunk_outside_box(span, st, r, chunk));
     }
     // -- A1: every load of the group -- sample caches, t_vals (and the jitter table, if one is used) -- before the first use.
     // All unconditional, with clamped indices (lanes beyond the processed samples re-read the last one, chunks without samples the
