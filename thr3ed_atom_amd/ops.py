@@ -8,6 +8,7 @@ the boundary as raw device pointers; PyTorch is only the allocator and the strea
 
 Nothing here computes on the CPU and nothing falls back: CPU tensors or a missing library raise.
 """
+import os
 import ctypes as C
 from typing import Dict, NamedTuple, Optional, Tuple
 
@@ -422,8 +423,10 @@ def brick_accumulate_adam_raw(grid: VoxelGrid, brick_size: int, lists, exp_avg, 
 
 # How the autograd op computes its adjoint: "atomic" = rf_render_backward (float32 atomic scatter, any configuration), "binned" =
 # counting in the forward pass -> rf_render_backward_emit_direct -> rf_brick_accumulate (no float atomics; SH degree <= 2),
-# "auto" = binned for specular renders of SH degree 2 with at least 2^20 samples (where the atomic scatter is pinned on the
-# memory-side atomic unit: 0.97 vs 0.40 ms for 16384 x 256 samples at 128^3), atomic otherwise.
+# "auto" = binned for renders (specular and render_diffuse) of SH-degree-2 grids with at least 2^20 samples (where the atomic
+# scatter is pinned on the memory-side atomic unit: 0.97 vs 0.40 ms for the specular adjoint of 16384 x 256 samples at 128^3; the
+# reference-storage iteration of bench.py's strict drop-in leg: 2.79 -> 1.99 ms with the diffuse adjoint binned as well), atomic
+# otherwise.
 AUTOGRAD_BACKWARD = "auto"
 AUTOGRAD_BRICK_SIZE = 8
 
@@ -436,7 +439,7 @@ def _autograd_uses_bricks(grid, flags: int, n: int, num_samples: int) -> bool:
         return False
     if AUTOGRAD_BACKWARD == "binned":
         return True
-    return grid.sh_degree == 2 and not (flags & _lib.FLAG_RENDER_DIFFUSE) and n * num_samples >= (1 << 20)
+    return grid.sh_degree == 2 and n * num_samples >= (1 << 20)
 
 
 class _ReluFieldRender(torch.autograd.Function):
