@@ -1240,8 +1240,12 @@ __global__ __launch_bounds__(kBlock) void render_backward_kernel(GridArgs g, Ray
 // kernel, not arithmetic or bandwidth (0.3 of the HBM peak by counters), so a ray's chunks are processed FOUR at a time: all
 // cache loads first, then all cursor atomics back to back (their results are not touched yet), then the gradients far-to-near
 // with the running suffix sum.  Measured on the bench step (specular / diffuse render): 0.098 / 0.073 ms; by ablation the geometry
-// and gradient arithmetic alone take 0.036 / 0.034 ms, the cache loads ~0.03, the cursor atomics ~0.025, the record stores
-// ~0.035 / 0.017 on top -- the components still add up rather than overlap (one chunk at a time: 0.107 / 0.069 ms).
+// and gradient arithmetic alone took 0.036 / 0.034 ms, the cache loads ~0.03, the cursor atomics ~0.025, the record stores
+// ~0.035 / 0.017 on top -- the components added up rather than overlapped (one chunk at a time: 0.107 / 0.069 ms).  The reason
+// showed in the ISA: the cache loads sat under `s < processed` and the t_vals reads of every sample under `s > 0` / `s < S - 1`,
+// and the compiler follows a load under a lane condition with a register merge that waits for it -- a dozen exposed memory
+// latencies per group.  With every load of a group unconditional (clamped indices) and issued before the first use:
+// 0.090 / 0.046 ms.  ~2500 instructions per ray remain: issue-bound.
 // Also tried: transposing the records through LDS so that a store instruction writes whole contiguous records instead of 64
 // 16-byte pieces of 64 different lines -- slower (0.113 / 0.078 ms): the L2 merges the partial lines at no cost that matters here.
 // =============================================================================================
