@@ -306,6 +306,14 @@ int rf_grid_query_backward(const RFGrid* grid, const float* points_dev, int64_t 
  * ReLU the skip is bit-exact.  occupancy_dev holds ceil((X+1)(Y+1)(Z+1)/32) words. */
 int rf_build_occupancy(const RFGrid* grid, float threshold, uint32_t* occupancy_dev, void* stream);
 
+/* Stage transition of the trainer: scale_voxel_grid_with_required_output_size (thre3d_reprs/voxels.py:334-373), i.e.
+ * F.interpolate(mode="trilinear", align_corners=False) of the whole [F+1]-channel volume, from `src` into the tensors `dst`
+ * describes (any dims, any layout on either side, same num_features; dst's tensors are overwritten; dst's AABB / activation
+ * fields are not used).  ATen's index and weight arithmetic and the summation order of its channels-last CPU kernel (8-wide
+ * vector body, scalar tail): bit-identical to what the reference's function returns on the CPU.  (Added to ABI version 3
+ * compatibly: no existing struct or signature changed.) */
+int rf_upsample_grid(const RFGrid* src, const RFGrid* dst, void* stream);
+
 /* The loss of the training iteration (modules/trainers.py:311-317, 329-336) in one launch:
  * grad_colour_dev [N,3] = scale * d(mean |colour - target|)/d colour = scale * sign(colour - target) / (3N);
  * sums_dev[0] += sum |colour - target|, sums_dev[1] += sum (colour - target)^2  (L1 loss and MSE/PSNR for

@@ -59,6 +59,16 @@ def test_argument_validation_needs_no_gpu(lib):
     r.num_samples = 8
     assert lib.rf_render_forward(C.byref(g), C.byref(r), 0, C.byref(o), None) == 0  # zero rays: no-op
     assert lib.rf_cast_rays(4, 4, 1.0, None, None, None, None, None) == -1
+    # rf_upsample_grid: null / mismatching / aliased grids
+    assert lib.rf_upsample_grid(None, C.byref(g), None) == -1
+    h = _lib.RFGrid()
+    h.densities_dev, h.features_dev = 4096, 8192
+    h.dims[0], h.dims[1], h.dims[2] = 8, 8, 8
+    h.num_features, h.density_stride, h.feature_stride = 3, 1, 3
+    assert lib.rf_upsample_grid(C.byref(g), C.byref(h), None) == -2  # 27 vs 3 features
+    h.num_features, h.feature_stride = 27, 27
+    h.densities_dev = 16
+    assert lib.rf_upsample_grid(C.byref(g), C.byref(h), None) == -2  # destination aliases the source
 
 
 def test_node_count_guard_and_fused_optimizer_validation(lib):

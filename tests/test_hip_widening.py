@@ -24,8 +24,7 @@ def T(a):
 @pytest.mark.parametrize("storage", ["reference", "split", "bricked"])
 def test_grid_upscaling_matches_the_reference_golden(hip_device, storage):
     """scale_voxel_grid_with_required_output_size (reference voxels.py:334-373) on the GPU == the reference's own output for
-    the anisotropic 5x6x7 -> 10x12x14 case (golden G3).  ROCm's upsample_trilinear3d is not bit-equal to the CPU kernel
-    (it accumulates the 8 corners in a different order): tolerance 2e-6 on values in [-1, 1]."""
+    the anisotropic 5x6x7 -> 10x12x14 case (golden G3), BIT FOR BIT: rf_upsample_grid follows ATen's CPU arithmetic."""
     g = load_golden("g3_voxel_grid.npz")
     d5, f5 = procedural_grid((5, 6, 7), 27, 31)
     voxel = tuple(float(v) for v in g["aniso_voxel"])
@@ -34,12 +33,29 @@ def test_grid_upscaling_matches_the_reference_golden(hip_device, storage):
                         tunable=True, storage=storage)
     up = rf.scale_voxel_grid_with_required_output_size(grid, (10, 12, 14))
     assert up.grid_dims == (10, 12, 14) and up.storage == storage and up.density_mode == "relu"
-    np.testing.assert_allclose(up.features.detach().cpu().numpy(), g["aniso_up_features"], rtol=0, atol=2e-6)
-    np.testing.assert_allclose(up.densities.detach().cpu().numpy(), g["aniso_up_densities"], rtol=0, atol=2e-6)
+    assert np.array_equal(up.features.detach().cpu().numpy(), g["aniso_up_features"])
+    assert np.array_equal(up.densities.detach().cpu().numpy(), g["aniso_up_densities"])
     np.testing.assert_allclose(np.array(up.voxel_size), g["aniso_up_voxel"], rtol=1e-12)
     # the world extent is unchanged
     for a, b in zip(up.aabb, grid.aabb):
         np.testing.assert_allclose(a, b, rtol=1e-12, atol=1e-12)
+
+
+@pytest.mark.parametrize("src_storage,dst_dims,deg", [("split", (13, 9, 17), 2), ("bricked", (16, 16, 16), 1), ("reference", (7, 20, 5), 0),
+                                                       ("bricked", (4, 3, 2), 2), ("split", (6, 7, 8), 3)])
+def test_grid_resampling_equals_torch_cpu_interpolate(hip_device, src_storage, dst_dims, deg):
+    """Non-integer ratios, down-sampling, every SH degree and storage: rf_upsample_grid == F.interpolate(mode='trilinear',
+    align_corners=False) of the unified volume on the CPU (what the reference's function computes), bit for bit."""
+    F = 3 * (deg + 1) ** 2
+    d, f = procedural_grid((6, 7, 8), F, 5 + deg)
+    grid = rf.VoxelGrid(d.to(hip_device), f.to(hip_device), rf.VoxelSize(0.5, 0.4, 0.3), density_preactivation=torch.nn.Identity(),
+                        density_postactivation=torch.nn.ReLU(), expected_density_scale=3.0, tunable=False, storage=src_storage)
+    up = rf.scale_voxel_grid_with_required_output_size(grid, dst_dims)
+    unified = torch.cat([f, d], dim=-1)
+    ref = torch.nn.functional.interpolate(unified.permute(3, 0, 1, 2)[None], size=dst_dims, mode="trilinear", align_corners=False)[0].permute(1, 2, 3, 0)
+    assert torch.equal(up.features.detach().cpu(), ref[..., :-1])
+    assert torch.equal(up.densities.detach().cpu(), ref[..., -1:])
+    assert up.grid_dims == tuple(dst_dims) and up.storage == src_storage
 
 
 def _run(args, timeout=600):

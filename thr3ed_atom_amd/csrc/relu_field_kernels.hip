@@ -2259,6 +2259,95 @@ __global__ __launch_bounds__(kBrickThreads, 4) void brick_gather_kernel(GridArgs
 }
 
 // =============================================================================================
+// stage transition: scale_voxel_grid_with_required_output_size (thre3d_reprs/voxels.py:334-373) = F.interpolate(mode="trilinear",
+// align_corners=False) of the [F+1]-channel volume.  One thread per (destination node, channel), channel fastest; source and
+// destination in any storage (the value lands in the destination's layout directly: no unified tensor, no permutes).  ATen's
+// arithmetic (UpSampleKernel.cpp / UpSample.h): scale = in / out in float, src = fma(scale, dst + 0.5, -0.5) clamped at 0,
+// i0 = min(floor(src), in - 1), i1 = i0 + (i0 < in - 1), lambda = clamp(src - i0, 0, 1); the 8 corners weighted by the products of
+// the per-axis weights and summed in the order of ATen's channels-last CPU kernel (see below).
+// =============================================================================================
+__device__ __forceinline__ long long channel_offset(const GridArgs& g, unsigned int lin, int ch, int K, bool& in_first) {
+  // ch: 0 = density, 1..3 = degree-0 coefficient of r, g, b, then colour-major higher degrees (the order of a node's accumulators)
+  if (g.layout == RF_LAYOUT_REFERENCE) {
+    in_first = ch == 0;
+    if (ch == 0) return (long long)lin * g.dstride;
+    if (ch < 4) return (long long)lin * g.fstride + (long long)(ch - 1) * K;
+    const int j = ch - 4, colour = j / (K - 1), kk = 1 + j - colour * (K - 1);
+    return (long long)lin * g.fstride + (long long)colour * K + kk;
+  }
+  in_first = ch < 4;
+  return ch < 4 ? (long long)lin * g.dstride + ch : (long long)lin * g.fstride + (ch - 4);
+}
+
+struct UpsampleAxis {
+  int i0, i1;
+  float w0, w1;
+};
+__device__ __forceinline__ UpsampleAxis upsample_axis(int dst, int in_size, float scale) {
+  float src = fmaf(scale, (float)dst + 0.5f, -0.5f);  // (contracted in ATen's build)
+  src = src < 0.0f ? 0.0f : src;
+  UpsampleAxis a;
+  a.i0 = min((int)floorf(src), in_size - 1);
+  a.i1 = a.i0 + (a.i0 < in_size - 1 ? 1 : 0);
+  const float lambda = fminf(fmaxf(src - (float)a.i0, 0.0f), 1.0f);
+  a.w0 = 1.0f - lambda;
+  a.w1 = lambda;
+  return a;
+}
+
+__global__ void upsample_grid_kernel(GridArgs src, GridArgs dst, float* dst_first, float* dst_second, long long total) {
+  const int C = dst.F + 1, K = dst.F / 3;
+  const float sx = (float)src.X / (float)dst.X, sy = (float)src.Y / (float)dst.Y, sz = (float)src.Z / (float)dst.Z;
+  for (long long it = (long long)blockIdx.x * blockDim.x + threadIdx.x; it < total; it += (long long)gridDim.x * blockDim.x) {
+    const int ch = (int)(it % C);
+    long long node = it / C;
+    const int z = (int)(node % dst.Z);
+    node /= dst.Z;
+    const int y = (int)(node % dst.Y), x = (int)(node / dst.Y);
+    const UpsampleAxis ax = upsample_axis(x, src.X, sx), ay = upsample_axis(y, src.Y, sy), az = upsample_axis(z, src.Z, sz);
+    auto at = [&](int xi, int yi, int zi) -> float {
+      bool first;
+      const long long off = channel_offset(src, node_lin(src, xi, yi, zi), ch, K, first);
+      return (first ? src.dens : src.feat)[off];
+    };
+    // corner k = (dx, dy, dz) with z fastest, weight = (wx * wy) * wz
+    float val[8], wgt[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      const int dx = k >> 2, dy = (k >> 1) & 1, dz = k & 1;
+      val[k] = at(dx ? ax.i1 : ax.i0, dy ? ay.i1 : ay.i0, dz ? az.i1 : az.i0);
+      wgt[k] = ((dx ? ax.w1 : ax.w0) * (dy ? ay.w1 : ay.w0)) * (dz ? az.w1 : az.w0);
+    }
+    // The reference hands F.interpolate a channels-last volume (features in the reference order, density last), and ATen's
+    // channels-last CPU kernel sums the 8 weighted corners right to left in its 8-wide vector body and left to right in the
+    // scalar tail of the last C mod 8 channels, every step contracted to a fused multiply-add.  Both orders are reproduced per
+    // channel, so that the result equals the reference's own output bit for bit (golden G3).
+    int uc;  // index of this channel in the reference's unified [features, density] order
+    if (ch == 0) {
+      uc = dst.F;
+    } else if (ch < 4) {
+      uc = (ch - 1) * K;
+    } else {
+      const int j = ch - 4, colour = j / (K - 1);
+      uc = colour * K + 1 + (j - colour * (K - 1));
+    }
+    float v;
+    if (uc < (C & ~7)) {
+      v = fmaf(val[7], wgt[7], val[6] * wgt[6]);
+#pragma unroll
+      for (int k = 5; k >= 0; --k) v = fmaf(val[k], wgt[k], v);
+    } else {
+      v = fmaf(val[0], wgt[0], val[1] * wgt[1]);
+#pragma unroll
+      for (int k = 2; k < 8; ++k) v = fmaf(val[k], wgt[k], v);
+    }
+    bool first;
+    const long long off = channel_offset(dst, node_lin(dst, x, y, z), ch, K, first);
+    (first ? dst_first : dst_second)[off] = v;
+  }
+}
+
+// =============================================================================================
 // standalone point query: VoxelGrid.forward (thre3d_reprs/voxels.py:276-331) and its adjoint.
 // One thread per (point, output channel); channel c < F is feature c in the reference order (colour*K + k),
 // channel F is the activated density.  Any point is allowed (zeros padding outside the grid, no AABB mask --
@@ -3299,6 +3388,20 @@ int rf_build_occupancy(const RFGrid* grid, float threshold, uint32_t* occupancy_
   const long long nwords = (ncell + 31) / 32;
   hipLaunchKernelGGL(build_occupancy_kernel, dim3(grid_1d(ncell, 256, 256LL * 32)), dim3(256), 0, (hipStream_t)stream, g,
                      threshold, occupancy_dev, nwords);
+  return launch_status();
+}
+
+int rf_upsample_grid(const RFGrid* src, const RFGrid* dst, void* stream) {
+  int rc = check_grid(src);
+  if (rc != RF_OK) return rc;
+  rc = check_grid(dst);
+  if (rc != RF_OK) return rc;
+  if (src->num_features != dst->num_features) return RF_ERR_BAD_SHAPE;
+  if (src->densities_dev == dst->densities_dev || (dst->features_dev && src->features_dev == dst->features_dev)) return RF_ERR_BAD_SHAPE;
+  const GridArgs gs = to_args(src), gd = to_args(dst);
+  const long long total = (long long)gd.X * gd.Y * gd.Z * (gd.F + 1);
+  hipLaunchKernelGGL(upsample_grid_kernel, dim3(grid_1d(total, 256, 256LL * 64)), dim3(256), 0, (hipStream_t)stream, gs, gd,
+                     const_cast<float*>(dst->densities_dev), const_cast<float*>(dst->features_dev), total);
   return launch_status();
 }
 

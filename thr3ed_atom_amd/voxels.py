@@ -523,8 +523,29 @@ def scale_voxel_grid_with_required_output_size(
     voxel_grid: VoxelGrid, output_size: Tuple[int, int, int], mode: str = "trilinear"
 ) -> VoxelGrid:
     """Trilinear (align_corners=False) resampling of the whole [F+1]-channel volume, the voxel size
-    shrinking so that the world extent is unchanged (reference voxels.py:334-373).  One-off per training
-    stage; stays a PyTorch-ROCm op."""
+    shrinking so that the world extent is unchanged (reference voxels.py:334-373).  On the GPU: rf_upsample_grid
+    (ATen's index / weight arithmetic, bit-identical to torch's CPU result) straight from the source storage into the
+    new grid's storage -- no unified [X,Y,Z,F+1] tensor, no permutes.  CPU grids and other modes: F.interpolate."""
+    old = voxel_grid.voxel_size
+    new_voxel = VoxelSize(
+        (old.x_size * voxel_grid.width_x) / output_size[0],
+        (old.y_size * voxel_grid.depth_y) / output_size[1],
+        (old.z_size * voxel_grid.height_z) / output_size[2],
+    )
+    first = voxel_grid.kernel_tensors()[0]
+    if mode == "trilinear" and first.is_cuda:
+        out = tuple(int(v) for v in output_size)
+        new_grid = VoxelGrid(
+            densities=torch.empty((*out, 1), dtype=torch.float32, device=first.device),
+            features=torch.empty((*out, voxel_grid._num_features), dtype=torch.float32, device=first.device),
+            voxel_size=new_voxel,
+            **voxel_grid.get_config_dict(),
+            storage=voxel_grid.storage,
+        )
+        stream = torch.cuda.current_stream(first.device).cuda_stream
+        with torch.no_grad():
+            _lib.check(_lib.load().rf_upsample_grid(voxel_grid.to_rf_grid(), new_grid.to_rf_grid(), stream), "rf_upsample_grid")
+        return new_grid
     unified = torch.cat([voxel_grid.features, voxel_grid.densities], dim=-1).detach()
     new = torch.nn.functional.interpolate(
         unified.permute(3, 0, 1, 2)[None],
@@ -534,12 +555,6 @@ def scale_voxel_grid_with_required_output_size(
         recompute_scale_factor=False,
     )[0].permute(1, 2, 3, 0)
     assert tuple(new.shape[:-1]) == tuple(output_size)
-    old = voxel_grid.voxel_size
-    new_voxel = VoxelSize(
-        (old.x_size * voxel_grid.width_x) / output_size[0],
-        (old.y_size * voxel_grid.depth_y) / output_size[1],
-        (old.z_size * voxel_grid.height_z) / output_size[2],
-    )
     return VoxelGrid(
         densities=new[..., -1:].contiguous(),
         features=new[..., :-1].contiguous(),
