@@ -410,6 +410,54 @@ def trilinear_upsample(volume: Tensor, output_size) -> Tensor:
     return up.permute(1, 2, 3, 0)
 
 
+def trilinear_upsample_recipe(volume, output_size, vector_width: int = 8):
+    """The arithmetic behind ``trilinear_upsample`` spelled out in numpy (what rf_upsample_grid implements), pinned by the tests
+    to F.interpolate on the CPU and to golden G3 bit for bit.  The reference hands ATen a CHANNELS-LAST volume
+    (``unified.permute(3, 0, 1, 2)[None]``, voxels.py:352-361), so aten/src/ATen/native/cpu/UpSampleKernel.cpp
+    (cpu_upsample_linear_channels_last, 3-d loop) applies:
+      scale = float(in) / float(out);  src = fma(scale, dst + 0.5, -0.5) clamped at 0 (area_pixel_compute_source_index,
+      contracted);  i0 = min(floor(src), in - 1);  i1 = i0 + (i0 < in - 1);  lambda1 = clamp(src - i0, 0, 1);  lambda0 = 1 - lambda1;
+      corner weights w_dhw = (lambda_d * lambda_h) * lambda_w;
+      the first C - C % 8 channels (8-wide vector body: interpolate(t, w, args...) = t * w + interpolate(args...)) are summed from
+      the LAST corner to the first, the remaining channels (scalar tail) from the first to the last, every step a fused
+      multiply-add (the innermost product of each chain is rounded on its own)."""
+    v = np.asarray(volume, dtype=np.float32)
+    f32 = np.float32
+
+    def fma(a, b, c):  # exact: the product of two float32 values fits a float64
+        return (np.asarray(a, np.float64) * np.asarray(b, np.float64) + np.asarray(c, np.float64)).astype(np.float32)
+
+    def mul(a, b):
+        return (a * b).astype(np.float32)
+
+    def axis(out, size):
+        scale = f32(size) / f32(out)
+        dst = np.arange(out, dtype=np.float32)
+        src = fma(scale, (dst + f32(0.5)).astype(np.float32), f32(-0.5))
+        src = np.where(src < 0, f32(0), src).astype(np.float32)
+        i0 = np.minimum(np.floor(src).astype(np.int64), size - 1)
+        i1 = i0 + (i0 < size - 1)
+        lam = np.clip((src - i0.astype(np.float32)).astype(np.float32), 0, 1).astype(np.float32)
+        return (i0, (f32(1) - lam).astype(np.float32)), (i1, lam)
+
+    ax, ay, az = (axis(o, n) for o, n in zip(output_size, v.shape[:3]))
+    vals, wts = [], []
+    for dx in (0, 1):
+        for dy in (0, 1):
+            for dz in (0, 1):
+                (ix, wx), (iy, wy), (iz, wz) = ax[dx], ay[dy], az[dz]
+                vals.append(v[ix[:, None, None], iy[None, :, None], iz[None, None, :]])
+                wts.append(mul(mul(wx[:, None, None], wy[None, :, None]), wz[None, None, :])[..., None])
+    body = fma(vals[7], wts[7], mul(vals[6], wts[6]))
+    for k in range(5, -1, -1):
+        body = fma(vals[k], wts[k], body)
+    tail = fma(vals[0], wts[0], mul(vals[1], wts[1]))
+    for k in range(2, 8):
+        tail = fma(vals[k], wts[k], tail)
+    nv = v.shape[-1] - v.shape[-1] % vector_width
+    return np.concatenate([body[..., :nv], tail[..., nv:]], axis=-1)
+
+
 # --------------------------------------------------------------------------------------------
 # checker for the build's own batch selection (rf_select_rays_and_pixels) -- not reference behaviour
 # --------------------------------------------------------------------------------------------

@@ -84,6 +84,15 @@ def test_g3_cube16_and_upsample():
     up = orc.trilinear_upsample(torch.cat([f5, d5], dim=-1), (10, 12, 14))
     assert torch.equal(up[..., :-1], T(g["aniso_up_features"]))
     assert torch.equal(up[..., -1:], T(g["aniso_up_densities"]))
+    # the arithmetic spelled out (what rf_upsample_grid implements): golden G3 bit for bit, and F.interpolate for non-integer
+    # ratios / down-sampling / channel counts with and without a scalar tail
+    rec = orc.trilinear_upsample_recipe(torch.cat([f5, d5], dim=-1).numpy(), (10, 12, 14))
+    assert np.array_equal(rec[..., :-1], g["aniso_up_features"]) and np.array_equal(rec[..., -1:], g["aniso_up_densities"])
+    for size, channels, out in (((6, 7, 8), 28, (13, 9, 17)), ((6, 7, 8), 4, (7, 20, 5)), ((5, 4, 3), 13, (3, 9, 4)), ((4, 4, 4), 16, (9, 9, 9))):
+        vol = T(hash_uniform((*size, channels), 1234 + channels))
+        # (the width of ATen's vector body is a property of the host's CPU capability: 8 floats with AVX2, 16 with AVX-512)
+        live = orc.trilinear_upsample(vol, out).numpy()
+        assert any(np.array_equal(orc.trilinear_upsample_recipe(vol.numpy(), out, vector_width=vw), live) for vw in (8, 16)), (size, channels, out)
 
 
 @pytest.mark.parametrize("deg", [0, 1, 2, 3])
