@@ -164,6 +164,40 @@ def cpu_baseline(grid, rays_cpu, pixels_cpu, num_samples, n_train, n_fwd, thread
     }
 
 
+def cfg1_leg(dev, cores, reps=3):
+    """configs[0] in full on both sides (the reference's own CPU-runnable case): 64^3 SH-degree-0 U(-1,1) field, one
+    64x64 frame (f = 88.9), 32 samples per ray, pose_spherical(30, -30, 4.0311), jitter off."""
+    from oracle import relu_field_oracle as orc  # checker / baseline only
+
+    G, S1, H = 64, 32, 64
+    g1 = make_grid(dev, G, 0, seed=1)
+    cfg1 = rf.SHVoxGridRenderConfig(S1, rf.CameraBounds(NEAR, FAR), perturb_sampled_points=False, white_bkgd=True)
+    model = rf.VolumetricModel(g1, rf.render_sh_voxel_grid, cfg1, device=dev)
+    intr, pose = rf.CameraIntrinsics(H, H, 88.9), rf.pose_spherical(30.0, -30.0, RADIUS)
+    gpu_s = time_frames(lambda: model.render(pose, intr), 5)
+    gpu = model.render(pose, intr).colour.cpu()
+    torch.set_num_threads(cores)
+    dens, feat = g1.densities.detach().cpu(), g1.features.detach().cpu()
+    o, d = orc.cast_rays(H, H, 88.9, pose.rotation.cpu(), pose.translation.cpu())
+    aabb = tuple(tuple(r) for r in g1.aabb)
+
+    def cpu():
+        with torch.no_grad():
+            return orc.render(dens, feat, o.reshape(-1, 3), d.reshape(-1, 3), aabb, NEAR, FAR, S1, g1.expected_density_scale, "relu", white_bkgd=True, interp="aten")["colour"]
+
+    ref = cpu()  # warm-up + the check
+    ts = []
+    for _ in range(reps):
+        t0 = time.perf_counter()
+        cpu()
+        ts.append(time.perf_counter() - t0)
+    cpu_s = float(np.median(ts))
+    n = H * H * S1
+    return {"workload": "configs[0]: 64^3 SH-0 field, 64x64 frame, 32 samples/ray, jitter off", "ray_samples": n,
+            "cpu_ms": cpu_s * 1e3, "cpu_ray_samples_per_s": n / cpu_s, "gpu_ms_incl_launch_and_sync": gpu_s * 1e3,
+            "gpu_ray_samples_per_s": n / gpu_s, "max_abs_colour_difference_gpu_vs_cpu": float((gpu.reshape(-1, 3) - ref).abs().max())}
+
+
 def time_frames(fn, frames):
     """median of per-frame wall times (sync before and after every frame)"""
     fn()  # warm-up
@@ -518,6 +552,7 @@ def main():
     baseline = None
     if args.cpu_rays > 0:
         baseline = cpu_baseline(grid, (rays.origins.cpu(), rays.directions.cpu()), pixels.cpu(), S, args.cpu_rays, args.cpu_fwd_rays, args.cpu_threads)
+        baseline["cfg1_full_frame"] = cfg1_leg(dev, baseline["cores"])
 
     line = {
         "metric": "ray-samples/sec (fwd+bwd) training step, 800x800 images @ 128^3 SH-2 ReLU field",
