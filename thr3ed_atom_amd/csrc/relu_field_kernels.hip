@@ -2712,8 +2712,16 @@ __global__ void adam_kernel(float* __restrict__ p, float* __restrict__ gradp, fl
 // mean-L1 loss of a rendered batch + its gradient (modules/trainers.py:311-317, 329-336), one launch instead of
 // the ~10 elementwise/reduction kernels autograd runs for l1_loss + mse_loss + their backward
 // =============================================================================================
-__global__ void l1_loss_grad_kernel(const float* __restrict__ colour, const float* __restrict__ target, long long n3,
-                                    float gscale, float* __restrict__ grad, float* __restrict__ sums) {
+struct L1Sets {  // up to two (render, gradient, sums) sets against the same targets in one launch (blockIdx.y)
+  const float* colour[2];
+  float* grad[2];
+  float* sums[2];
+};
+
+__global__ void l1_loss_grad_kernel(L1Sets sets, const float* __restrict__ target, long long n3, float gscale) {
+  const float* __restrict__ colour = sets.colour[blockIdx.y];
+  float* __restrict__ grad = sets.grad[blockIdx.y];
+  float* __restrict__ sums = sets.sums[blockIdx.y];
   float abs_sum = 0.0f, sq_sum = 0.0f;
   for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n3; i += (long long)gridDim.x * blockDim.x) {
     const float d = colour[i] - target[i];
@@ -3405,15 +3413,23 @@ int rf_upsample_grid(const RFGrid* src, const RFGrid* dst, void* stream) {
   return launch_status();
 }
 
+static int l1_loss_grad_impl(const L1Sets& sets, int nsets, const float* target_dev, int64_t num_rays, float scale, void* stream) {
+  const long long n3 = (long long)num_rays * 3;
+  hipLaunchKernelGGL(l1_loss_grad_kernel, dim3(grid_1d(n3, kBlock * 8, 32), nsets), dim3(kBlock), 0, (hipStream_t)stream, sets,
+                     target_dev, n3, scale / (float)n3);
+  return launch_status();
+}
+
 int rf_l1_loss_grad(const float* colour_dev, const float* target_dev, int64_t num_rays, float scale,
                     float* grad_colour_dev, float* sums_dev, void* stream) {
   if (num_rays == 0) return RF_OK;
   if (!colour_dev || !target_dev || !grad_colour_dev || !sums_dev) return RF_ERR_NULL_POINTER;
   if (num_rays < 0) return RF_ERR_BAD_SHAPE;
-  const long long n3 = (long long)num_rays * 3;
-  hipLaunchKernelGGL(l1_loss_grad_kernel, dim3(grid_1d(n3, kBlock * 8, 32)), dim3(kBlock), 0, (hipStream_t)stream, colour_dev,
-                     target_dev, n3, scale / (float)n3, grad_colour_dev, sums_dev);
-  return launch_status();
+  L1Sets sets = {};
+  sets.colour[0] = colour_dev;
+  sets.grad[0] = grad_colour_dev;
+  sets.sums[0] = sums_dev;
+  return l1_loss_grad_impl(sets, 1, target_dev, num_rays, scale, stream);
 }
 
 int rf_adam_step(float* param_dev, float* grad_dev, float* exp_avg_dev, float* exp_avg_sq_dev, int64_t numel,
@@ -3489,8 +3505,16 @@ int rf_train_step(const RFGrid* grid, const RFTrainStep* step, void* stream) {
     rc = rf_render_forward(grid, &rays[i], flags[i], &ps.out, stream);
     if (rc != RF_OK) return rc;
     RF_STEP_EVENT();
-    rc = rf_l1_loss_grad(ps.out.colour_dev, step->pixels_dev, step->num_rays, 1.0f, ps.grad_colour_dev, step->loss_sums_dev + 2 * i, stream);
-    if (rc != RF_OK) return rc;
+    if (i == 1) {  // the losses of both renders in one launch
+      L1Sets sets = {};
+      for (int k = 0; k < 2; ++k) {
+        sets.colour[k] = step->pass[k].out.colour_dev;
+        sets.grad[k] = step->pass[k].grad_colour_dev;
+        sets.sums[k] = step->loss_sums_dev + 2 * k;
+      }
+      rc = l1_loss_grad_impl(sets, 2, step->pixels_dev, step->num_rays, 1.0f, stream);
+      if (rc != RF_OK) return rc;
+    }
     RF_STEP_EVENT();
     grads[i] = RFRenderGrads{ps.grad_colour_dev, nullptr, nullptr};
   }
