@@ -2561,7 +2561,8 @@ __device__ __forceinline__ unsigned long long keyed_permutation(unsigned long lo
 __global__ void select_rays_and_pixels_kernel(int H, int W, float focal, const float* poses, const int64_t* image_ids,
                                               int num_batch_images, const float* pixel_table, unsigned long long key,
                                               int bits, long long first, long long n, float* origins, float* dirs,
-                                              float* pixels, int64_t* pixel_index) {
+                                              float* pixels, int64_t* pixel_index, float* zero4) {
+  if (zero4 && blockIdx.x == 0 && threadIdx.x < 4) zero4[threadIdx.x] = 0.0f;  // (rf_train_step: the loss sums of the iteration)
   const long long hw = (long long)H * W;
   const unsigned long long P = (unsigned long long)num_batch_images * hw;
   for (long long q = (long long)blockIdx.x * blockDim.x + threadIdx.x; q < n; q += (long long)gridDim.x * blockDim.x) {
@@ -2976,10 +2977,10 @@ int rf_cast_selected_rays(int32_t height, int32_t width, float focal, const floa
   return launch_status();
 }
 
-int rf_select_rays_and_pixels(int32_t height, int32_t width, float focal, const float* poses_dev,
-                              const int64_t* image_ids_dev, int32_t num_batch_images, const float* pixel_table_dev,
-                              uint64_t key, int64_t first_index, int64_t num_rays, float* origins_dev,
-                              float* directions_dev, float* pixels_dev, int64_t* pixel_index_dev, void* stream) {
+static int select_impl(int32_t height, int32_t width, float focal, const float* poses_dev, const int64_t* image_ids_dev,
+                       int32_t num_batch_images, const float* pixel_table_dev, uint64_t key, int64_t first_index, int64_t num_rays,
+                       float* origins_dev, float* directions_dev, float* pixels_dev, int64_t* pixel_index_dev, float* zero4_dev,
+                       void* stream) {
   if (num_rays == 0) return RF_OK;
   if (!poses_dev || !pixel_table_dev || !origins_dev || !directions_dev || !pixels_dev) return RF_ERR_NULL_POINTER;
   if (height < 1 || width < 1 || num_batch_images < 1 || num_rays < 0 || first_index < 0) return RF_ERR_BAD_SHAPE;
@@ -2991,8 +2992,16 @@ int rf_select_rays_and_pixels(int32_t height, int32_t width, float focal, const 
   hipLaunchKernelGGL(select_rays_and_pixels_kernel, dim3(grid_1d(num_rays, 256)), dim3(256), 0, (hipStream_t)stream,
                      height, width, focal, poses_dev, image_ids_dev, num_batch_images, pixel_table_dev,
                      (unsigned long long)key, bits, (long long)first_index, (long long)num_rays, origins_dev, directions_dev,
-                     pixels_dev, pixel_index_dev);
+                     pixels_dev, pixel_index_dev, zero4_dev);
   return launch_status();
+}
+
+int rf_select_rays_and_pixels(int32_t height, int32_t width, float focal, const float* poses_dev,
+                              const int64_t* image_ids_dev, int32_t num_batch_images, const float* pixel_table_dev,
+                              uint64_t key, int64_t first_index, int64_t num_rays, float* origins_dev,
+                              float* directions_dev, float* pixels_dev, int64_t* pixel_index_dev, void* stream) {
+  return select_impl(height, width, focal, poses_dev, image_ids_dev, num_batch_images, pixel_table_dev, key, first_index, num_rays,
+                     origins_dev, directions_dev, pixels_dev, pixel_index_dev, nullptr, stream);
 }
 
 int rf_ray_aabb_bounds(const float* origins_dev, const float* directions_dev, int64_t num_rays, float near, float far,
@@ -3480,12 +3489,14 @@ int rf_train_step(const RFGrid* grid, const RFTrainStep* step, void* stream) {
   RF_STEP_EVENT();
   if (step->select) {
     const RFRaySelection* s = step->select;
-    rc = rf_select_rays_and_pixels(s->height, s->width, s->focal, s->poses_dev, s->image_ids_dev, s->num_batch_images, s->pixel_table_dev,
-                                   s->key, s->first_index, step->num_rays, step->origins_dev, step->directions_dev, step->pixels_dev, nullptr, stream);
+    rc = select_impl(s->height, s->width, s->focal, s->poses_dev, s->image_ids_dev, s->num_batch_images, s->pixel_table_dev, s->key,
+                     s->first_index, step->num_rays, step->origins_dev, step->directions_dev, step->pixels_dev, nullptr,
+                     step->loss_sums_dev /* cleared by the same launch */, stream);
     if (rc != RF_OK) return rc;
+  } else if (hipMemsetAsync(step->loss_sums_dev, 0, 4 * sizeof(float), st) != hipSuccess) {
+    return RF_ERR_LAUNCH;
   }
   RF_STEP_EVENT();
-  if (hipMemsetAsync(step->loss_sums_dev, 0, 4 * sizeof(float), st) != hipSuccess) return RF_ERR_LAUNCH;
   RFRayBatch rays[2];
   uint32_t flags[2];
   RFRenderGrads grads[2];
