@@ -329,8 +329,8 @@ int rf_adam_step(float* param_dev, float* grad_dev, float* exp_avg_dev, float* e
 
 /* ---- the training iteration as ONE call -------------------------------------------------------------------------------
  * modules/trainers.py:278-341 (ray/pixel subset -> specular render -> L1 -> diffuse render -> L1 -> backward of both ->
- * Adam) enqueued by a single host call: select -> forward (counts records), twice -> loss gradients -> offsets -> emit, twice
- * -> ONE brick pass over both record lists [-> Adam inside its flush].  Eight launches, no host round trip between them; the
+ * Adam) enqueued by a single host call: select -> forward (counts records), twice -> loss gradients + offsets -> emit, twice
+ * -> ONE brick pass over both record lists [-> Adam inside its flush].  Seven launches, no host round trip between them; the
  * caller (a Python trainer, or any host language) pays one FFI crossing per iteration instead of ~20.  Every buffer is
  * caller-owned scratch that can be reused from step to step. */
 typedef struct RFRaySelection { /* arguments of rf_select_rays_and_pixels */
@@ -374,8 +374,9 @@ typedef struct RFTrainStep {
   float* grad_second_dev;
   void* const* timing_events;   /* optional HOST array of RF_TRAIN_STEP_EVENTS hipEvent_t (created by the caller with timing
                                    enabled): event 0 is recorded on `stream` before the first launch, event k after launch k
-                                   in the order select, forward[0], (nothing), forward[1], loss (both renders, one launch), offsets (both lists, one launch),
-                                   emit[0], (nothing), emit[1], bricks -- per-kernel durations of the very call that is timed    */
+                                   in the order select, forward[0], (nothing), forward[1], losses of both renders + offsets of
+                                   both lists (one launch), (nothing), emit[0], (nothing), emit[1], bricks -- per-kernel durations
+                                   of the very call that is timed                                                              */
 } RFTrainStep;
 
 #define RF_TRAIN_STEP_EVENTS 11

@@ -187,9 +187,9 @@ class RFTrainStep(C.Structure):
 
 
 TRAIN_STEP_EVENTS = 11
-TRAIN_STEP_EVENT_NAMES = ["select_rays_and_pixels", "render_forward[spec,save]", "(no launch: loss slot of the first render)", "render_forward[diffuse,save]", "l1_loss_grad[both]",
-                          "bin_offsets[both]", "render_backward_emit_direct[spec]", "(no launch: offsets slot of the second list)", "render_backward_emit_direct[diffuse]",
-                          "brick_accumulate"]
+TRAIN_STEP_EVENT_NAMES = ["select_rays_and_pixels", "render_forward[spec,save]", "(no launch: loss slot of the first render)", "render_forward[diffuse,save]",
+                          "l1_loss_grad+bin_offsets[both]", "(no launch: offsets slot)", "render_backward_emit_direct[spec]",
+                          "(no launch: offsets slot of the second list)", "render_backward_emit_direct[diffuse]", "brick_accumulate"]
 
 
 # order of rf_abi_struct_size(which)

@@ -1518,15 +1518,15 @@ struct BinLists {  // up to two independent lists per launch (blockIdx.y)
   int* cursor[2];
 };
 
-__global__ __launch_bounds__(1024) void bin_offsets_kernel(BinLists lists, int nkeys) {
+__device__ __forceinline__ void bin_offsets_body(const BinLists& lists, int nkeys, int list, int block) {
   // workgroup i owns keys [1024 i, 1024 i + 1024): it sums everything in front of its segment (coalesced, L2-resident)
   // and scans its own segment with wave shuffles -- no dependency between workgroups
-  const int* __restrict__ hist = lists.hist[blockIdx.y];
-  long long* __restrict__ offsets = lists.offsets[blockIdx.y];
-  int* __restrict__ cursor = lists.cursor[blockIdx.y];
+  const int* __restrict__ hist = lists.hist[list];
+  long long* __restrict__ offsets = lists.offsets[list];
+  int* __restrict__ cursor = lists.cursor[list];
   __shared__ int s_front[16], s_own[16];
   const int t = threadIdx.x, lane = t & (kWave - 1), wave = t >> 6;
-  const int seg0 = blockIdx.x * 1024;
+  const int seg0 = block * 1024;
   int front = 0;
   for (int k = t; k < seg0; k += 1024) front += hist[k];
 #pragma unroll
@@ -1558,6 +1558,8 @@ __global__ __launch_bounds__(1024) void bin_offsets_kernel(BinLists lists, int n
   }
   if (t == 0 && seg0 + 1024 >= nkeys) offsets[nkeys] = base + own;
 }
+
+__global__ __launch_bounds__(1024) void bin_offsets_kernel(BinLists lists, int nkeys) { bin_offsets_body(lists, nkeys, blockIdx.y, blockIdx.x); }
 
 // Every keyed slot takes the next free position of its key class (run-aggregated atomic cursor) and its expanded record
 // is written there.  One wave per 256 consecutive slots (4 chunks of 64 whose atomics are in flight together): active
@@ -2719,19 +2721,20 @@ struct L1Sets {  // up to two (render, gradient, sums) sets against the same tar
   float* sums[2];
 };
 
-__global__ void l1_loss_grad_kernel(L1Sets sets, const float* __restrict__ target, long long n3, float gscale) {
-  const float* __restrict__ colour = sets.colour[blockIdx.y];
-  float* __restrict__ grad = sets.grad[blockIdx.y];
-  float* __restrict__ sums = sets.sums[blockIdx.y];
+__device__ __forceinline__ void l1_loss_grad_body(const L1Sets& sets, const float* __restrict__ target, long long n3, float gscale, int set,
+                                                  int block, int nblocks) {
+  const float* __restrict__ colour = sets.colour[set];
+  float* __restrict__ grad = sets.grad[set];
+  float* __restrict__ sums = sets.sums[set];
   float abs_sum = 0.0f, sq_sum = 0.0f;
-  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n3; i += (long long)gridDim.x * blockDim.x) {
+  for (long long i = (long long)block * blockDim.x + threadIdx.x; i < n3; i += (long long)nblocks * blockDim.x) {
     const float d = colour[i] - target[i];
     abs_sum += fabsf(d);
     sq_sum += d * d;
     grad[i] = (d > 0.0f) ? gscale : ((d < 0.0f) ? -gscale : 0.0f);  // sign(d) * scale / numel
   }
   // wave reduce -> block reduce through LDS -> ONE pair of atomics per block (same-address atomics serialise)
-  __shared__ float s_part[2][kBlock / kWave];
+  __shared__ float s_part[2][16];  // (up to 1024 threads)
   abs_sum = wave_sum(abs_sum);
   sq_sum = wave_sum(sq_sum);
   const int wave = threadIdx.x >> 6;
@@ -2748,6 +2751,21 @@ __global__ void l1_loss_grad_kernel(L1Sets sets, const float* __restrict__ targe
     }
     unsafeAtomicAdd(sums + 0, a);
     unsafeAtomicAdd(sums + 1, b);
+  }
+}
+
+__global__ void l1_loss_grad_kernel(L1Sets sets, const float* __restrict__ target, long long n3, float gscale) {
+  l1_loss_grad_body(sets, target, n3, gscale, blockIdx.y, blockIdx.x, gridDim.x);
+}
+
+// rf_train_step: the losses of both renders AND the offsets of both record lists -- everything between the forward passes and the
+// adjoints -- in one launch (1024-thread workgroups; blockIdx.y 0, 1: loss of render 0, 1; 2, 3: offsets of list 0, 1)
+__global__ __launch_bounds__(1024) void loss_and_offsets_kernel(L1Sets sets, const float* __restrict__ target, long long n3, float gscale,
+                                                                int loss_blocks, BinLists lists, int nkeys, int offset_blocks) {
+  if (blockIdx.y < 2) {
+    if ((int)blockIdx.x < loss_blocks) l1_loss_grad_body(sets, target, n3, gscale, blockIdx.y, blockIdx.x, loss_blocks);
+  } else if ((int)blockIdx.x < offset_blocks) {
+    bin_offsets_body(lists, nkeys, blockIdx.y - 2, blockIdx.x);
   }
 }
 
@@ -3516,27 +3534,29 @@ int rf_train_step(const RFGrid* grid, const RFTrainStep* step, void* stream) {
     rc = rf_render_forward(grid, &rays[i], flags[i], &ps.out, stream);
     if (rc != RF_OK) return rc;
     RF_STEP_EVENT();
-    if (i == 1) {  // the losses of both renders in one launch
+    if (i == 1) {  // the losses of both renders and the offsets of both record lists in one launch
       L1Sets sets = {};
+      BinLists bl = {};
       for (int k = 0; k < 2; ++k) {
         sets.colour[k] = step->pass[k].out.colour_dev;
         sets.grad[k] = step->pass[k].grad_colour_dev;
         sets.sums[k] = step->loss_sums_dev + 2 * k;
+        bl.hist[k] = step->pass[k].out.key_hist_dev;
+        bl.offsets[k] = reinterpret_cast<long long*>(step->pass[k].offsets_dev);
+        bl.cursor[k] = step->pass[k].cursor_dev;
       }
-      rc = l1_loss_grad_impl(sets, 2, step->pixels_dev, step->num_rays, 1.0f, stream);
+      if (nkeys > (1 << 21)) return RF_ERR_BAD_SHAPE;
+      const long long n3 = (long long)step->num_rays * 3;
+      const int loss_blocks = (int)grid_1d(n3, 1024 * 2, 64), offset_blocks = (nkeys + 1023) / 1024;
+      hipLaunchKernelGGL(loss_and_offsets_kernel, dim3(loss_blocks > offset_blocks ? loss_blocks : offset_blocks, 4), dim3(1024), 0, st, sets,
+                         step->pixels_dev, n3, 1.0f / (float)n3, loss_blocks, bl, nkeys, offset_blocks);
+      rc = launch_status();
       if (rc != RF_OK) return rc;
     }
     RF_STEP_EVENT();
     grads[i] = RFRenderGrads{ps.grad_colour_dev, nullptr, nullptr};
   }
   RFBrickList lists[2];
-  {  // the offsets of both lists in one launch
-    const int32_t* h[2] = {step->pass[0].out.key_hist_dev, step->pass[1].out.key_hist_dev};
-    int64_t* o[2] = {step->pass[0].offsets_dev, step->pass[1].offsets_dev};
-    int32_t* c[2] = {step->pass[0].cursor_dev, step->pass[1].cursor_dev};
-    rc = bin_offsets_impl(h, o, c, 2, nkeys, stream);
-    if (rc != RF_OK) return rc;
-  }
   for (int i = 0; i < 2; ++i) {
     const RFPassScratch& ps = step->pass[i];
     RF_STEP_EVENT();  // (offsets[0] = the launch above, offsets[1] = nothing)

@@ -36,6 +36,7 @@ BENCH_NAMES = {
     "brick_gather_kernel<1, false>": "brick_accumulate[base]",
     "adam_kernel": "adam_step",
     "bin_offsets_kernel": "bin_offsets",
+    "loss_and_offsets_kernel": "l1_loss_grad+bin_offsets[both]",
 }
 
 
