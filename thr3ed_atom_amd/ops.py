@@ -8,7 +8,6 @@ the boundary as raw device pointers; PyTorch is only the allocator and the strea
 
 Nothing here computes on the CPU and nothing falls back: CPU tensors or a missing library raise.
 """
-import os
 import ctypes as C
 from typing import Dict, NamedTuple, Optional, Tuple
 
