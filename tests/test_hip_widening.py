@@ -124,3 +124,32 @@ def test_test_set_psnr_loop_against_the_oracle(hip_device):
         mse = torch.nn.functional.mse_loss(col.reshape(hw, hw, 3), images[k].permute(1, 2, 0))
         psnrs.append(float(-10.0 * torch.log10(mse)))
     assert abs(ours - float(np.mean(psnrs))) < 1e-3, (ours, psnrs)
+
+
+def test_bench_line_contract(hip_device):
+    """bench.py the way the driver runs it (fewer steps): ONE JSON line with the contract's keys, the roofline object priced on
+    counter bytes (a fraction in (0, 1]), the CPU baseline measured by the oracle, nothing above the HBM peak anywhere."""
+    import json
+
+    r = _run([os.path.join(REPO_ROOT, "bench.py"), "--gpus", "1", "--steps", "3", "--warmup", "2", "--cpu-rays", "256", "--cpu-fwd-rays", "512",
+              "--render-frames", "1", "--highres-frames", "0", "--dropin-steps", "2"], timeout=900)
+    lines = [ln for ln in r.stdout.strip().splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    line = json.loads(lines[0])
+    for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data",
+                "config", "roofline", "cpu_baseline"):
+        assert key in line, key
+    assert line["n_gpus"] == 1 and line["steps"] == 3 and line["warmup"] == 2 and line["higher_is_better"] is True
+    assert line["unit"] == "ray-samples/s" and line["dtype"] == "f32" and line["data"] == "synthetic" and line["vs_baseline"] is None
+    assert "workload" in line["config"] and "model" not in line["config"]
+    np.testing.assert_allclose(line["value"], 2 * 16384 * 256 / (line["ms_per_step"] * 1e-3), rtol=1e-6)
+    roof = line["roofline"]
+    assert roof["bound"] == "hbm" and roof["unit"] == "GB/s" and roof["peak"] == 8000.0
+    assert 0.0 < roof["frac"] <= 1.0 and abs(roof["frac"] - roof["achieved"] / roof["peak"]) < 1e-9 and roof["traffic"] > 0
+    for rec in roof["by_kernel"].values():
+        assert rec.get("frac_hbm") is None or 0.0 < rec["frac_hbm"] <= 1.0
+    assert line["roofline_model_errors"] == []
+    cpu = line["cpu_baseline"]
+    assert cpu["kind"] == "port" and cpu["unit"] == "ray-samples/s" and cpu["value"] > 0 and cpu["cores"] >= 1 and "sample" in cpu
+    assert cpu["cfg1_full_frame"]["max_abs_colour_difference_gpu_vs_cpu"] <= 1e-5
+    assert line["fwd_render"]["init_field"]["render_launches_per_frame"] == 1
