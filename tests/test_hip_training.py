@@ -915,3 +915,54 @@ def test_binned_backward_with_records_concentrated_in_few_bricks(hip_device, sto
     gd, gf = grid.unpack(gd, gf)
     np.testing.assert_allclose(gd.cpu().numpy(), total_d.cpu().numpy(), rtol=3e-4, atol=3e-6 * float(total_d.abs().max()))
     np.testing.assert_allclose(gf.cpu().numpy(), total_f.cpu().numpy(), rtol=3e-4, atol=3e-6 * float(total_f.abs().max()))
+
+
+@pytest.mark.parametrize("storage,deg", [("split", 2), ("reference", 1), ("bricked", 0)])
+def test_brick_pass_over_two_lists_of_the_same_kind(hip_device, storage, deg):
+    """rf_brick_accumulate with TWO full-width lists in one call (the ranges of both lists concatenated per brick) == the two
+    lists accumulated one after the other == the atomic adjoint of both ray sets."""
+    from thr3ed_atom_amd import ops as O
+
+    G, S = 20, 48
+    F = 3 * (deg + 1) ** 2
+    cam = hotdog_like_camera()
+    grid = relu_grid(hip_device, T(hash_uniform((G, G, G, 1), 61)), T(hash_uniform((G, G, G, F), 62)), G, storage=storage)
+    cfg = rf.SHVoxGridRenderConfig(S, rf.CameraBounds(cam["near"], cam["far"]), perturb_sampled_points=False, white_bkgd=True)
+    first, second = grid.kernel_tensors()
+    nb = O.brick_counts(grid, 8)
+    nkeys = nb[0] * nb[1] * nb[2] * 8
+    near, far = float(np.float32(cam["near"])), float(np.float32(cam["far"]))
+    lists, total_d, total_f = [], None, None
+    for k, (yaw, hw) in enumerate(((30.0, 24), (200.0, 31))):
+        rays = rf.flatten_rays(rf.cast_rays(rf.CameraIntrinsics(hw, hw, 33.0), rf.pose_spherical(yaw, -30.0, cam["radius"]), hip_device))
+        target = T(hash_uniform((len(rays), 3), 70 + k, 0.0, 1.0)).to(hip_device)
+        grid.zero_grad()
+        torch.nn.functional.l1_loss(rf.render_sh_voxel_grid(grid, rays, cfg).colour, target).backward()
+        ref_d, ref_f = grid.reference_gradients()
+        total_d = ref_d.clone() if total_d is None else total_d + ref_d
+        total_f = ref_f.clone() if total_f is None else total_f + ref_f
+        o, d, n = rays.origins.contiguous(), rays.directions.contiguous(), len(rays)
+        flags = O.render_flags(True, False, False, False)
+        hist = torch.zeros(nkeys, dtype=torch.int32, device=hip_device)
+        colour, _, _, _, caches = O.render_forward_raw(grid, o, d, None, S, near, far, flags, save=True, key_hist=hist, brick_size=8)
+        sums = torch.zeros(2, device=hip_device)
+        g_colour = O.l1_loss_grad_hip(colour, target, sums)
+        srt = torch.empty((n * S, O.expanded_record_floats(grid, False)), device=hip_device)
+        offsets = torch.empty(nkeys + 1, dtype=torch.int64, device=hip_device)
+        cursor = torch.empty(nkeys, dtype=torch.int32, device=hip_device)
+        O.bin_offsets(hist, offsets, cursor)
+        O.render_backward_emit_direct_raw(grid, o, d, None, S, near, far, flags, caches, g_colour, None, None, 8, cursor, srt, hist_clear=hist)
+        lists.append((srt, offsets, False))
+    gd = torch.full_like(first, 5.0)
+    gf = None if second is None else torch.full_like(second, -5.0)
+    O.brick_accumulate_raw(grid, 8, lists, gd, gf, accumulate=False)
+    both_d, both_f = grid.unpack(gd, gf)
+    np.testing.assert_allclose(both_d.cpu().numpy(), total_d.cpu().numpy(), rtol=3e-4, atol=3e-6 * float(total_d.abs().max()))
+    np.testing.assert_allclose(both_f.cpu().numpy(), total_f.cpu().numpy(), rtol=3e-4, atol=3e-6 * float(total_f.abs().max()))
+    gd2 = torch.zeros_like(first)
+    gf2 = None if second is None else torch.zeros_like(second)
+    for one in lists:
+        O.brick_accumulate_raw(grid, 8, [one], gd2, gf2, accumulate=True)
+    one_d, one_f = grid.unpack(gd2, gf2)
+    np.testing.assert_allclose(both_d.cpu().numpy(), one_d.cpu().numpy(), rtol=1e-5, atol=1e-7 * float(total_d.abs().max()))
+    np.testing.assert_allclose(both_f.cpu().numpy(), one_f.cpu().numpy(), rtol=1e-5, atol=1e-7 * float(total_f.abs().max()))
