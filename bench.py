@@ -536,6 +536,8 @@ def main():
         by_kernel = {}
         for kname, rec in kernels.items():
             counter = pmc.get(alias.get(kname, kname), {}).get("hbm_bytes_per_launch")
+            if counter is not None and kname == "adam_step" and world > 1 and stepper.shard_optimizer:
+                counter = counter / world  # ZeRO stage 1: a rank updates 1/N of the parameters (the table holds the full pass)
             by_kernel[kname] = {"avg_launch_ms": rec["avg_ms"], "counter_bytes_per_launch": counter,
                                 "frac_hbm": None if counter is None else frac(counter, rec["avg_ms"], f"{kname} (counters)")}
         dom = max(kernels, key=lambda kname: kernels[kname]["avg_ms"] * kernels[kname]["launches"])
