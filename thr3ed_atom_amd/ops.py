@@ -497,21 +497,27 @@ class _ReluFieldRender(torch.autograd.Function):
         def prep(g):
             return None if g is None else g.detach().to(torch.float32).contiguous()
 
-        # gradient buffers: a caller-provided flat bucket when there is one (optim.FlatGrid), else fresh zero-filled
-        # tensors.  The kernel accumulates with atomics.
+        # gradient buffers: a caller-provided flat bucket when there is one (optim.FlatGrid), else fresh tensors
         bucket = getattr(grid, "_grad_bucket", None)
+        binned = ctx.key_hist is not None
+        diffuse = bool(ctx.flags & _lib.FLAG_RENDER_DIFFUSE)
+        overwrite = False
         if bucket is not None and bucket.matches(first, second):
             gd, gf = bucket.views_for_accumulation()
             ret_d, ret_f = bucket.autograd_return()
         else:
-            gd = torch.zeros_like(first)
-            gf = None if second is None else torch.zeros_like(second)
+            # fresh tensors.  The brick pass can OVERWRITE them (every element a full-width list covers; the density and degree-0
+            # elements for a render_diffuse list): no zero-fill and no read-add-write of 235 MB for a specular render
+            overwrite = binned
+            covers_all = binned and (not diffuse or grid.sh_degree == 0)  # (a render_diffuse list leaves the higher degrees alone)
+            fresh = torch.empty_like if covers_all else torch.zeros_like
+            gd = fresh(first)
+            gf = None if second is None else fresh(second)
             ret_d, ret_f = gd, gf
         if ctx.key_hist is not None:
             # binned adjoint: the forward pass counted the records per (brick, flags) key; offsets -> records written at their
             # final positions -> one workgroup per brick sums them and ADDS the brick to the gradient tensors
             hist, dev = ctx.key_hist, origins.device
-            diffuse = bool(ctx.flags & _lib.FLAG_RENDER_DIFFUSE)
             offsets = torch.empty(hist.numel() + 1, dtype=torch.int64, device=dev)
             cursor = torch.empty(hist.numel(), dtype=torch.int32, device=dev)
             records = torch.empty((origins.shape[0] * ctx.num_samples, expanded_record_floats(grid, diffuse)), dtype=torch.float32, device=dev)
@@ -520,7 +526,7 @@ class _ReluFieldRender(torch.autograd.Function):
                 grid, origins, directions, t_rand, ctx.num_samples, ctx.near, ctx.far, ctx.flags, (cache, tcache, stop),
                 prep(g_colour), prep(g_depth), prep(g_acc), AUTOGRAD_BRICK_SIZE, cursor, records, hist_clear=None,
             )
-            brick_accumulate_raw(grid, AUTOGRAD_BRICK_SIZE, [(records, offsets, diffuse)], gd, gf, accumulate=True)
+            brick_accumulate_raw(grid, AUTOGRAD_BRICK_SIZE, [(records, offsets, diffuse)], gd, gf, accumulate=not overwrite)
             ctx.key_hist = None  # (a second backward through the same graph would find the counters consumed)
         else:
             render_backward_raw(
