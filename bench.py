@@ -99,12 +99,43 @@ def frac(bytes_, ms, what=""):
     return f
 
 
+KERNEL_SOURCE = os.path.join(ROOT, "thr3ed_atom_amd", "csrc", "relu_field_kernels.hip")
+
+
+def kernel_source_sha256():
+    import hashlib
+
+    return hashlib.sha256(open(KERNEL_SOURCE, "rb").read()).hexdigest()
+
+
 def load_pmc_table():
+    """profiles/pmc_traffic.json (tools/make_pmc_traffic.py) is tied to the kernel source it was measured on by a sha256 of
+    relu_field_kernels.hip: a table measured on other kernels is STALE -- its byte counts are not used for any fraction (the line
+    says ``traffic_stale: true`` and falls back to the algorithmic bytes on processed units)."""
     path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
     try:
-        return json.load(open(path))
+        table = json.load(open(path))
     except Exception:
-        return {}
+        return {}, True
+    stale = table.get("_kernel_source_sha256") != kernel_source_sha256()
+    return ({} if stale else table), stale
+
+
+def respawn_under_torchrun(gpus: int):
+    """``python bench.py --gpus N`` with N > 1 and no torchrun environment: re-exec this command as N ranks (one per GPU, RCCL)
+    under torch.distributed.run on 127.0.0.1.  Never silently runs fewer ranks than asked for."""
+    import socket
+
+    if torch.cuda.device_count() < gpus:
+        raise SystemExit(f"--gpus {gpus} but only {torch.cuda.device_count()} HIP device(s) are visible")
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={gpus}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    sys.stdout.flush()
+    os.execv(sys.executable, cmd)
 
 
 def cpu_baseline(grid, rays_cpu, pixels_cpu, num_samples, n_train, n_fwd, threads=0, reps=3):
@@ -149,6 +180,20 @@ def cpu_baseline(grid, rays_cpu, pixels_cpu, num_samples, n_train, n_fwd, thread
 
     dt_train = timed(train, n_train)
     dt_fwd = timed(forward, n_fwd) if n_fwd > 0 else None
+    # SURVEY 8d asks for torch.set_num_threads(os.cpu_count()); on a many-core host that is SLOWER for these ATen ops (thread
+    # hand-off dominates), so it is reported beside the default figure, on a smaller sample (one repeat after the warm-up)
+    all_cores = None
+    ncpu = os.cpu_count() or 1
+    if threads <= 0 and ncpu > cores:
+        torch.set_num_threads(ncpu)
+        n_all = max(64, n_train // 8)
+        train(min(64, n_all))
+        t0 = time.perf_counter()
+        train(n_all)
+        dt_all = time.perf_counter() - t0
+        all_cores = {"value": 2 * n_all * num_samples / dt_all, "unit": "ray-samples/s", "cores": ncpu,
+                     "sample": f"one repeat of the same training-step core on {n_all} rays with torch.set_num_threads(os.cpu_count() = {ncpu}); {dt_all:.2f} s"}
+        torch.set_num_threads(cores)
     return {
         "value": 2 * n_train * num_samples / dt_train,
         "unit": "ray-samples/s",
@@ -156,6 +201,7 @@ def cpu_baseline(grid, rays_cpu, pixels_cpu, num_samples, n_train, n_fwd, thread
         "kind": "port",
         "sample": f"median of {reps} repeats after 1 warm-up: training-step core (specular+diffuse fwd+bwd, no optimiser) of {n_train} rays x {num_samples} samples "
         f"on the same 128^3 SH-2 grid, oracle with interp='aten' (F.grid_sample), torch {torch.__version__} CPU fp32; {dt_train:.2f} s/step",
+        "all_host_cores": all_cores,
         "forward_only": None if dt_fwd is None else {
             "value": n_fwd * num_samples / dt_fwd,
             "unit": "ray-samples/s",
@@ -238,7 +284,7 @@ def main():
     ap.add_argument("--render-frames", type=int, default=5, help="full-frame forward renders timed for fwd_render (0 = skip)")
     ap.add_argument("--highres-frames", type=int, default=5, help="frames timed for the 256^3 / 512-sample configs[4] render (0 = skip)")
     ap.add_argument("--cpu-rays", type=int, default=2048, help="rays of the cpu_baseline training sample (0 = skip the CPU baseline)")
-    ap.add_argument("--cpu-fwd-rays", type=int, default=8192, help="rays of the cpu_baseline forward-only chunk")
+    ap.add_argument("--cpu-fwd-rays", type=int, default=32768, help="rays of the cpu_baseline forward-only chunk (SURVEY 8d: one parallel_rays_chunk_size chunk)")
     ap.add_argument("--dropin-steps", type=int, default=20, help="steps timed for the strict drop-in configuration (0 = skip)")
     ap.add_argument("--storage", choices=["split", "bricked", "reference"], default="split",
                     help="HBM layout of the grid: split = MI355X-native (what the trainer uses), reference = the reference's two tensors")
@@ -255,9 +301,11 @@ def main():
     ap.add_argument("--cpu-threads", type=int, default=0, help="torch CPU threads for cpu_baseline (0 = min(cores, 16))")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ and "RANK" not in os.environ:
+        respawn_under_torchrun(args.gpus)  # does not return
     rank, local_rank, world = rfdist.init_from_env()
-    if world != args.gpus and world > 1:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus} (or without it: bench.py spawns the ranks itself)")
     assert torch.cuda.is_available(), "bench.py needs a GPU (the render path has no CPU fallback)"
     dev = torch.device("cuda", local_rank)
     torch.cuda.set_device(dev)
@@ -270,7 +318,7 @@ def main():
     S, R, G = args.samples, args.rays, args.grid
     C = 3 * (args.sh_degree + 1) ** 2 + 1
     bounds = rf.CameraBounds(NEAR, FAR)
-    pmc = load_pmc_table()
+    pmc, pmc_stale = load_pmc_table()
     spec = f"sh{args.sh_degree}"
 
     # ---- synthetic dataset: images of a procedural ground-truth field rendered once (untimed) -------
@@ -515,8 +563,9 @@ def main():
             "peak": HBM_PEAK_GBS,
             "unit": "GB/s",
             "frac": d["frac_hbm"] if d["frac_hbm"] is not None else d["frac_processed"],
-            "frac_basis": "HBM bytes from the PMC counters (profiles/pmc_traffic.json) / this run's launch time" if traffic is not None
-            else "algorithmic bytes on processed units (no counter entry for this kernel in profiles/pmc_traffic.json)",
+            "frac_basis": "HBM bytes from the PMC counters (profiles/pmc_traffic.json, sha256-tied to the kernel source) / this run's launch time" if traffic is not None
+            else ("algorithmic bytes on processed units (profiles/pmc_traffic.json was measured on a different relu_field_kernels.hip: stale, not used)" if pmc_stale
+                  else "algorithmic bytes on processed units (no counter entry for this kernel in profiles/pmc_traffic.json)"),
             "traffic": traffic,
             "avg_launch_ms": d["avg_launch_ms"],
             "frac_processed": d["frac_processed"],
@@ -525,6 +574,7 @@ def main():
             "note": "brick pass: both renders' gradient records summed per 8^3-node brick in MFMA accumulators (no atomics)"
             + (", Adam applied in the flush (no gradient tensor in HBM)" if fused_opt else "") + "; two workgroups per CU (LDS), phases of a workgroup serialise: see DESIGN section 4",
             "traffic_source": pmc.get("_source"),
+            "traffic_stale": bool(pmc_stale),
             "by_kernel": by_kernel,
         }
 
@@ -547,7 +597,7 @@ def main():
             "achieved": None if d["counter_bytes_per_launch"] is None else d["counter_bytes_per_launch"] / 1e9 / (d["avg_launch_ms"] / 1e3),
             "frac": d["frac_hbm"], "traffic": d["counter_bytes_per_launch"], "avg_launch_ms": d["avg_launch_ms"],
             "frac_basis": "HBM bytes from the PMC counters (profiles/pmc_traffic.json, single-GPU profile of the same kernels) / this run's launch time",
-            "traffic_source": pmc.get("_source"), "by_kernel": by_kernel,
+            "traffic_source": pmc.get("_source"), "traffic_stale": bool(pmc_stale), "by_kernel": by_kernel,
             "note": "data-parallel-style step: specular forward + emit + brick pass -> [gradient exchange of `rest` overlapped with] diffuse forward + emit + base-channel brick pass -> exchange of `base` -> (sharded) Adam",
         }
 

@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define RF_ABI_VERSION 3
+#define RF_ABI_VERSION 4
 
 enum {
   RF_OK = 0,
@@ -126,14 +126,17 @@ typedef struct RFRenderOut {
   float* depth_dev;     /* [N]                                                                         */
   float* acc_dev;       /* [N]                                                                         */
   float* disparity_dev; /* [N]   (NaN where acc == 0, like the reference)                              */
-  /* Optional per-sample cache written by the forward pass and consumed by rf_render_backward* (all three NULL for
-   * inference).  Slots of 64-sample chunks that lie entirely outside the grid's box are left unwritten (and unread). */
+  /* Optional per-sample cache written by the forward pass and consumed by rf_render_backward* (all four NULL for
+   * inference).  Only the samples that can carry gradient are cached -- inside the box, T != 0, and sigma != 0 under ReLU
+   * (every other sample contributes exactly nothing to any adjoint) -- COMPACTED per chunk of 64 samples: the j-th such
+   * sample of chunk c of ray r is entry r * S + 64 c + j, and bit l of chunk_mask_dev[r][c] says that sample 64 c + l is
+   * one of them.  Everything else in the two caches is left unwritten (and unread). */
   float* sample_cache_dev; /* [N, S, 4] = (raw r, raw g, raw b, sigma)                                 */
   float* trans_cache_dev;  /* [N, S]    = transmittance T_i                                            */
   int32_t* stop_cache_dev; /* [N]       = number of samples the forward pass processed                 */
-  /* Optional (with the cache): the forward pass also COUNTS, per (brick, flags) key of the binned backward (see
-   * rf_render_backward_emit), the samples that can carry gradient -- T != 0, and sigma != 0 under ReLU -- into
-   * key_hist_dev [8 * nbricks] (added to; clear before the first use) and flags them in the sign bit of trans_cache, so
+  uint64_t* chunk_mask_dev; /* [N, ceil(S / 64)] which samples of each chunk are cached               */
+  /* Optional (with the cache): the forward pass also COUNTS the cached samples per (brick, flags) key of the binned
+   * backward (see rf_render_backward_emit) into key_hist_dev [8 * nbricks] (added to; clear before the first use), so
    * that rf_render_backward_emit_direct can write their records straight to the final positions. */
   int32_t* key_hist_dev;
   int32_t brick_size;      /* 4 or 8 (only read when key_hist_dev != NULL)                             */
@@ -202,20 +205,26 @@ int rf_render_backward(const RFGrid* grid, const RFRayBatch* rays, uint32_t flag
  * contributing sample into a RECORD, puts the records in (brick, flags) order and lets one workgroup per brick sum them
  * on chip under exclusive ownership:
  *
- *   key  = brick * 8 + flags;  brick = id ((bx * NBY + by) * NBZ + bz) of the brick (brick_size^3 nodes, brick_size in
- *          {4, 8}) holding the LOWER node of the sample's cell;  flag bit a = the cell's upper node on axis a belongs to
- *          the next brick (so the record also touches that neighbour's nodes).
- *   expanded record = rf_expanded_record_floats(F) floats: (continuous index x, y, z, 0) followed by dL/d(interpolated
- *          channel) for every channel of a node -- density first, then degree-0 r, g, b, then colour-major higher
- *          degrees -- i.e. the SH basis of the record's ray already multiplied in.  Lists of a render_diffuse pass carry
- *          the 4 base channels only: rf_expanded_record_floats(3) = 8 floats, whatever the grid's degree.
+ *   key  = ((((bx * 2 + f_x) * NBY + by) * NBZ + bz) << 2) | f_y | f_z << 1;  (bx, by, bz) = the brick (brick_size^3 nodes,
+ *          brick_size in {4, 8}) holding the LOWER node of the sample's cell;  f_a = the cell's upper node on axis a belongs
+ *          to the next brick (so the record also touches that neighbour's nodes).  8 * nbricks keys.  The order is x-slab
+ *          major with the x flag directly below the slab index: everything that touches the nodes of the x-slabs [s0, s1)
+ *          of bricks is ONE contiguous key range, [key(s0 - 1, f_x = 1), key(s1, f_x = 0)) -- what a data-parallel rank
+ *          sends the owner of those slabs is a single slice of its sorted list (see rf_brick_accumulate_adam_range).
+ *   record = rf_expanded_record_floats(F) floats, COMPACT:
+ *          F > 3:  (continuous index x, y, z, dL/d density) (dL/d raw r, g, b, v_x) (v_y, v_z, 0, 0) -- 48 B; v = the ray's
+ *                  unit viewing direction.  The per-channel values dL/d raw[colour] * Y_k(v) of a node's 3K + 1 channels are
+ *                  expanded by rf_brick_accumulate in LDS (the reference's evaluate_spherical_harmonics operation order):
+ *                  they never exist in HBM.
+ *          F == 3, and every list of a render_diffuse pass whatever the grid's degree:  (index x, y, z, 0) (dL/d density,
+ *                  dL/d sh0 r, g, b) -- 32 B.
  *   offsets [8 * nbricks + 1] (int64): start of every key class in the record list (last = end).
  *
  * Three front ends produce (records in key order, offsets); rf_brick_accumulate consumes them:
  *   A. fused (default of the trainer): rf_render_forward with RFRenderOut.key_hist_dev COUNTS the records per key ->
  *      rf_bin_offsets -> rf_render_backward_emit_direct writes each record at the next free position of its key.
  *      No per-slot arrays; integer atomics only (counters, cursors); any number of bricks up to 2^18.
- *   B. counting sort after the fact: rf_render_backward_emit (per-slot 16-bit keys + 32-byte records, hist_dev) ->
+ *   B. counting sort after the fact: rf_render_backward_emit (per-slot 16-bit keys + per-slot records, hist_dev) ->
  *      rf_bin_offsets -> rf_scatter_records.
  *   C. deterministic: rf_render_backward_emit -> torch.sort of the keys (stable radix) + searchsorted ->
  *      rf_expand_records.  Fixed float32 summation order: bit-reproducible gradients.
@@ -226,9 +235,9 @@ int rf_render_backward(const RFGrid* grid, const RFRayBatch* rays, uint32_t flag
  * records' channel values, four records per v_mfma_f32_16x16x4_f32: exact float32 fma chains, no atomics of any kind,
  * summation order fixed by the record order) and writes the brick with plain coalesced stores: accumulate = 0 OVERWRITES every
  * element of the gradient tensors (no zero-fill needed; diffuse lists: only density + degree-0 gradients), accumulate = 1
- * adds.  Up to two lists per call: two of the same kind, or (specular list, render_diffuse list) in that order = BOTH renders
- * of a training iteration (modules/trainers.py:306-341) in one pass (the base-channel records go into the first four channel
- * columns of the same accumulators).  SH degree <= 2. */
+ * adds.  Up to 16 lists per call, at most 8 of a kind, the full-width lists first: (specular list, render_diffuse list) = BOTH
+ * renders of a training iteration (modules/trainers.py:306-341) in one pass (the base-channel records go into the first four
+ * channel columns of the same accumulators); under data parallelism one pair per source rank.  SH degree <= 2. */
 typedef struct RFBrickList {
   const float* records_sorted_dev; /* [capacity, rf_expanded_record_floats(F)] (diffuse lists: F = 3) */
   const int64_t* offsets_dev;      /* [8 * nbricks + 1] start of each (brick, flags) class            */
@@ -241,29 +250,26 @@ int32_t rf_expanded_record_floats(int32_t num_features);
  * and an int32 copy cursor_dev [num_keys] for the atomic cursors of A / B */
 int rf_bin_offsets(const int32_t* hist_dev, int32_t num_keys, int64_t* offsets_dev, int32_t* cursor_dev, void* stream);
 
-/* A: every sample counted (and flagged in trans_cache) by the forward call that produced `fwd` writes its expanded
- * record -- zeros if its gradient happens to vanish -- at the next free position of its key; hist_clear_dev
+/* A: every sample counted (= cached) by the forward call that produced `fwd` writes its record -- zeros if its gradient
+ * happens to vanish -- at the next free position of its key; hist_clear_dev
  * [8 * nbricks] (may be NULL) is cleared for the next iteration. */
 int rf_render_backward_emit_direct(const RFGrid* grid, const RFRayBatch* rays, uint32_t flags, const RFRenderOut* fwd,
                                    const RFRenderGrads* grads, int32_t brick_size, int32_t* cursor_dev,
                                    float* records_sorted_dev, int32_t* hist_clear_dev, void* stream);
 
-/* B / C: per contributing sample a 32-byte record records_dev [N*S, 8] = (index x, y, z, dL/d pre-activation density,
- * dL/d raw r, g, b, ray id bits) and, for EVERY slot, keys_dev [N*S] (-1 = no gradient).  ray_basis_dev [N,16] (may be
- * NULL for a diffuse pass) receives the signed SH basis of each ray; hist_dev [8 * nbricks] (may be NULL; zero before the
- * first use) is incremented by the number of records per key (B). */
+/* B / C: per contributing sample its record (format above) at its SLOT: records_dev [N*S, rf_expanded_record_floats(F)]
+ * (render_diffuse passes: F = 3), and, for EVERY slot, keys_dev [N*S] (-1 = no gradient).  hist_dev [8 * nbricks] (may be NULL;
+ * zero before the first use) is incremented by the number of records per key (B). */
 int rf_render_backward_emit(const RFGrid* grid, const RFRayBatch* rays, uint32_t flags, const RFRenderOut* fwd,
                             const RFRenderGrads* grads, int32_t brick_size, int16_t* keys_dev, float* records_dev,
-                            float* ray_basis_dev, int32_t* hist_dev, void* stream);
-/* B: every keyed slot's expanded record goes to the next free position of its key; clears hist_dev (may be NULL) */
+                            int32_t* hist_dev, void* stream);
+/* B: every keyed slot's record goes to the next free position of its key; clears hist_dev (may be NULL) */
 int rf_scatter_records(const RFGrid* grid, const int16_t* keys_dev, const float* records_dev, int64_t capacity,
-                       int32_t* cursor_dev, const float* ray_basis_dev, int32_t render_diffuse, float* records_sorted_dev,
-                       int32_t* hist_dev, int32_t num_keys, void* stream);
-/* C: records_sorted[i] = expanded record of slot perm_dev[i] for *begin_dev (= offsets[0]: unkeyed slots sort in front)
- * <= i < capacity */
+                       int32_t* cursor_dev, int32_t render_diffuse, float* records_sorted_dev, int32_t* hist_dev, int32_t num_keys,
+                       void* stream);
+/* C: records_sorted[i] = record of slot perm_dev[i] for *begin_dev (= offsets[0]: unkeyed slots sort in front) <= i < capacity */
 int rf_expand_records(const RFGrid* grid, const float* records_dev, const int64_t* perm_dev, const int64_t* begin_dev,
-                      int64_t capacity, const float* ray_basis_dev, int32_t render_diffuse, float* records_sorted_dev,
-                      void* stream);
+                      int64_t capacity, int32_t render_diffuse, float* records_sorted_dev, void* stream);
 
 int rf_brick_accumulate(const RFGrid* grid, int32_t brick_size, const RFBrickList* lists, int32_t num_lists,
                         float* grad_densities_dev, float* grad_features_dev, int32_t accumulate, void* stream);
@@ -288,6 +294,17 @@ typedef struct RFAdamState {
 
 int rf_brick_accumulate_adam(const RFGrid* grid, int32_t brick_size, const RFBrickList* lists, int32_t num_lists,
                              const RFAdamState* adam, void* stream);
+
+/* The same pass restricted to the bricks [first_brick, first_brick + num_bricks) (brick id = (bx * NBY + by) * NBZ + bz): the
+ * OWNER-COMPUTES step of data-parallel training.  The reference trains on one device (modules/trainers.py:338-341 is its
+ * loss.backward(); optimizer.step()); with N ranks each rank owns a range of x-slabs of bricks, receives from every rank the
+ * slice of that rank's sorted record lists that touches its slabs (one contiguous key range, see the key order above; the
+ * lists here are then one (specular, render_diffuse) pair per source rank, each with that rank's offsets table and a records
+ * pointer positioned such that records_sorted_dev + offsets[k] * record size is the first record of key k), sums them and
+ * applies Adam to its own parameters only; an all-gather of the parameters follows.  Scale the losses by 1 / N
+ * (RFTrainStep.loss_scale) so that the sum over the ranks' records is the mean gradient. */
+int rf_brick_accumulate_adam_range(const RFGrid* grid, int32_t brick_size, const RFBrickList* lists, int32_t num_lists,
+                                   const RFAdamState* adam, int32_t first_brick, int32_t num_bricks, void* stream);
 
 /* VoxelGrid.forward (thre3d_reprs/voxels.py:276-331) as a standalone point query: points_dev [M,3] (any
  * points: zeros padding outside the grid, no AABB mask) -> out_dev [M, F+1] = (F interpolated features in the
@@ -372,12 +389,20 @@ typedef struct RFTrainStep {
                                    added) to grad_first_dev / grad_second_dev (layout of `grid`)                  */
   float* grad_first_dev;
   float* grad_second_dev;
+  int64_t first_ray;            /* position of ray 0 in the keyed jitter streams (global-batch data parallelism: the rank's
+                                   offset in the batch); 0 otherwise                                                          */
+  uint32_t phases;              /* 0 = the whole iteration; RF_STEP_FRONT: select .. emit only (the caller runs the brick pass
+                                   itself, e.g. rf_brick_accumulate_adam_range after a record exchange); RF_STEP_BRICKS: the
+                                   brick pass over pass[0..1]'s lists only                                                     */
+  float loss_scale;             /* the L1 gradients are scaled by this (0 = 1): 1 / world size under data parallelism          */
   void* const* timing_events;   /* optional HOST array of RF_TRAIN_STEP_EVENTS hipEvent_t (created by the caller with timing
                                    enabled): event 0 is recorded on `stream` before the first launch, event k after launch k
                                    in the order select, forward[0], (nothing), forward[1], losses of both renders + offsets of
                                    both lists (one launch), (nothing), emit[0], (nothing), emit[1], bricks -- per-kernel durations
-                                   of the very call that is timed                                                              */
+                                   of the very call that is timed (only with phases == 0)                                      */
 } RFTrainStep;
+
+enum { RF_STEP_FRONT = 1, RF_STEP_BRICKS = 2 };
 
 #define RF_TRAIN_STEP_EVENTS 11
 

@@ -1,6 +1,6 @@
 """thre3d_atom/thre3d_reprs/renderers_hip.py -- the file a maintainer of akanimax/thr3ed_atom adds to use the MI355X library.
 
-It binds `librelu_field_hip.so` (C ABI: include/relu_field.h, RF_ABI_VERSION 3) with ctypes and exposes
+It binds `librelu_field_hip.so` (C ABI: include/relu_field.h, RF_ABI_VERSION 4) with ctypes and exposes
 
     render_sh_voxel_grid_hip(voxel_grid, rays, render_config, parallel_points_chunk_size=None) -> RenderOut
 
@@ -25,7 +25,7 @@ import torch
 from thre3d_atom.rendering.volumetric.render_interface import Rays, RenderOut
 from thre3d_atom.utils.constants import EXTRA_ACCUMULATED_WEIGHTS, EXTRA_DISPARITY
 
-RF_ABI_VERSION = 3
+RF_ABI_VERSION = 4
 _LIB_PATH = os.environ.get("RELU_FIELD_HIP_LIB", "librelu_field_hip.so")
 
 
@@ -46,7 +46,7 @@ class RFRayBatch(C.Structure):
 class RFRenderOut(C.Structure):
     _fields_ = [("colour_dev", C.c_void_p), ("depth_dev", C.c_void_p), ("acc_dev", C.c_void_p), ("disparity_dev", C.c_void_p),
                 ("sample_cache_dev", C.c_void_p), ("trans_cache_dev", C.c_void_p), ("stop_cache_dev", C.c_void_p),
-                ("key_hist_dev", C.c_void_p), ("brick_size", C.c_int32)]
+                ("chunk_mask_dev", C.c_void_p), ("key_hist_dev", C.c_void_p), ("brick_size", C.c_int32)]
 
 
 class RFRenderGrads(C.Structure):
@@ -137,12 +137,12 @@ class _RenderFunction(torch.autograd.Function):
                         None if t_rand is None else t_rand.data_ptr(), 0, 0, None)
         colour = torch.empty((n, 3), dtype=torch.float32, device=dev)
         depth, acc, disparity = (torch.empty((n, 1), dtype=torch.float32, device=dev) for _ in range(3))
-        out = RFRenderOut(colour.data_ptr(), depth.data_ptr(), acc.data_ptr(), disparity.data_ptr(), None, None, None, None, 0)
+        out = RFRenderOut(colour.data_ptr(), depth.data_ptr(), acc.data_ptr(), disparity.data_ptr(), None, None, None, None, None, 0)
         caches = ()
-        if need_grad:
+        if need_grad:  # per-sample cache of the samples that carry gradient + which ones they are (relu_field.h: RFRenderOut)
             caches = (torch.empty((n, num_samples, 4), dtype=torch.float32, device=dev), torch.empty((n, num_samples), dtype=torch.float32, device=dev),
-                      torch.empty((n,), dtype=torch.int32, device=dev))
-            out.sample_cache_dev, out.trans_cache_dev, out.stop_cache_dev = (c.data_ptr() for c in caches)
+                      torch.empty((n,), dtype=torch.int32, device=dev), torch.empty((n, (num_samples + 63) // 64), dtype=torch.int64, device=dev))
+            out.sample_cache_dev, out.trans_cache_dev, out.stop_cache_dev, out.chunk_mask_dev = (c.data_ptr() for c in caches)
         stream = torch.cuda.current_stream(dev).cuda_stream
         _check(lib.rf_render_forward(C.byref(grid), C.byref(rb), flags, C.byref(out), stream), "rf_render_forward")
         ctx.voxel_grid, ctx.args, ctx.need_grad, ctx.has_rand = voxel_grid, (num_samples, near, far, flags), need_grad, t_rand is not None
@@ -156,14 +156,14 @@ class _RenderFunction(torch.autograd.Function):
             return (None,) * 12
         lib = _library()
         saved = ctx.saved_tensors
-        densities, features, origins, directions, t_vals, cache, tcache, stop = saved[:8]
-        t_rand = saved[8] if ctx.has_rand else None
+        densities, features, origins, directions, t_vals, cache, tcache, stop, cmask = saved[:9]
+        t_rand = saved[9] if ctx.has_rand else None
         num_samples, near, far, flags = ctx.args
         dev = origins.device
         grid = _describe_grid(ctx.voxel_grid, densities, features)
         rb = RFRayBatch(origins.data_ptr(), directions.data_ptr(), origins.shape[0], num_samples, near, far, t_vals.data_ptr(),
                         None if t_rand is None else t_rand.data_ptr(), 0, 0, None)
-        fwd = RFRenderOut(None, None, None, None, cache.data_ptr(), tcache.data_ptr(), stop.data_ptr(), None, 0)
+        fwd = RFRenderOut(None, None, None, None, cache.data_ptr(), tcache.data_ptr(), stop.data_ptr(), cmask.data_ptr(), None, 0)
         keep = [None if g is None else g.detach().to(torch.float32).contiguous() for g in (g_colour, g_depth, g_acc)]
         grads = RFRenderGrads(*[None if g is None else g.data_ptr() for g in keep])
         grad_d, grad_f = torch.zeros_like(densities), torch.zeros_like(features)  # the library accumulates (+=)

@@ -31,7 +31,7 @@ def test_every_declared_symbol_is_exported(lib):
 
 
 def test_abi_version_and_error_strings(lib):
-    assert lib.rf_abi_version() == _lib.ABI_VERSION == 3
+    assert lib.rf_abi_version() == _lib.ABI_VERSION == 4
     assert lib.rf_error_string(0) == b"ok"
     for code in (-1, -2, -3, -4):
         assert lib.rf_error_string(code) not in (b"ok", b"unknown error code")

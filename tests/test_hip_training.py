@@ -426,7 +426,6 @@ def _binned_gradients(grid, rays, cfg, target, device, diffuse_too=True, accumul
     nb = O.brick_counts(grid, brick)
     num_bricks = nb[0] * nb[1] * nb[2]
     boundaries = torch.arange(num_bricks * 8, dtype=torch.int16, device=device)
-    ray_basis = torch.zeros((n, 16), device=device)
     first, second = grid.kernel_tensors()
     # accumulate=False overwrites every element (no zero-fill needed): start from garbage to prove it
     gd = torch.full_like(first, 7.0) if not accumulate else torch.zeros_like(first)
@@ -443,24 +442,24 @@ def _binned_gradients(grid, rays, cfg, target, device, diffuse_too=True, accumul
         colour, _, _, _, caches = O.render_forward_raw(grid, o, d, None, S, near, far, flags, save=True, key_hist=hist if binning == "fused" else None, brick_size=brick)
         g_colour = O.l1_loss_grad_hip(colour, target, sums[2 * i : 2 * i + 2])
         keys = torch.empty(n * S, dtype=torch.int16, device=device)
-        rec = torch.empty((n * S, 8), device=device)
+        rec = torch.empty((n * S, O.expanded_record_floats(grid, is_diffuse)), device=device)
         srt = torch.empty((n * S, O.expanded_record_floats(grid, is_diffuse)), device=device)
         offsets = torch.full((num_bricks * 8 + 1,), n * S, dtype=torch.int64, device=device)
         cursor = torch.empty(num_bricks * 8, dtype=torch.int32, device=device)
         if binning == "fused":  # the forward pass counted; the backward pass writes expanded records at their final positions
             counted = int(hist.sum())
-            assert counted == int((caches[1] < 0).sum())  # one flag per counted sample
+            assert counted == int(np.unpackbits(caches[3].cpu().numpy().view(np.uint8)).sum())  # one mask bit per counted (= cached) sample
             O.bin_offsets(hist, offsets, cursor)
             O.render_backward_emit_direct_raw(grid, o, d, None, S, near, far, flags, caches, g_colour, None, None, brick, cursor, srt, hist_clear=hist)
             assert int(hist.abs().sum()) == 0 and int(offsets[-1]) == counted
             assert torch.equal(cursor.to(torch.int64), offsets[1:])  # every class filled exactly
         else:
-            O.render_backward_emit_raw(grid, o, d, None, S, near, far, flags, caches, g_colour, None, None, brick, keys, rec, None if diffuse else ray_basis, hist)
+            O.render_backward_emit_raw(grid, o, d, None, S, near, far, flags, caches, g_colour, None, None, brick, keys, rec, hist)
             if binning == "count":
-                O.bin_records_by_brick(grid, keys, rec, None if is_diffuse else ray_basis, is_diffuse, hist, cursor, srt, offsets)
+                O.bin_records_by_brick(grid, keys, rec, is_diffuse, hist, cursor, srt, offsets)
                 assert int(hist.abs().sum()) == 0 and int(offsets[-1]) == int((keys >= 0).sum())
             else:
-                O.sort_records_by_brick(grid, keys, rec, None if is_diffuse else ray_basis, is_diffuse, srt, offsets, boundaries)
+                O.sort_records_by_brick(grid, keys, rec, is_diffuse, srt, offsets, boundaries)
         lists.append((srt, offsets, diffuse or cfg.render_diffuse))
         keep.append((keys, rec, caches))
     if merged:

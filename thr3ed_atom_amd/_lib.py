@@ -15,7 +15,7 @@ LIB_PATH = os.environ.get("RF_LIB_PATH") or os.path.join(CSRC_DIR, LIB_NAME)  # 
 SOURCES = ["relu_field_kernels.hip"]
 HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared"]
 
-ABI_VERSION = 3  # RF_ABI_VERSION of include/relu_field.h (3: mixed brick lists, optimizer fused into the brick flush)
+ABI_VERSION = 4  # RF_ABI_VERSION of include/relu_field.h (4: compact records + compacted sample cache, x-slab-major keys, brick ranges)
 
 # enums of relu_field.h
 DENSITY_MODES = {"relu": 0, "softplus": 1, "abs": 2, "identity": 3}
@@ -25,6 +25,8 @@ FLAG_RENDER_DIFFUSE = 2
 FLAG_AABB_SAMPLING = 4
 FLAG_OCCUPANCY_SKIP = 8
 FLAG_JITTER_KEYED = 16
+STEP_FRONT = 1
+STEP_BRICKS = 2
 
 EXPORTED_SYMBOLS = [
     "rf_abi_version",
@@ -44,6 +46,7 @@ EXPORTED_SYMBOLS = [
     "rf_scatter_records",
     "rf_brick_accumulate",
     "rf_brick_accumulate_adam",
+    "rf_brick_accumulate_adam_range",
     "rf_grid_query",
     "rf_grid_query_backward",
     "rf_build_occupancy",
@@ -102,6 +105,7 @@ class RFRenderOut(C.Structure):
         ("sample_cache_dev", C.c_void_p),
         ("trans_cache_dev", C.c_void_p),
         ("stop_cache_dev", C.c_void_p),
+        ("chunk_mask_dev", C.c_void_p),
         ("key_hist_dev", C.c_void_p),
         ("brick_size", C.c_int32),
     ]
@@ -182,6 +186,9 @@ class RFTrainStep(C.Structure):
         ("adam", C.POINTER(RFAdamState)),
         ("grad_first_dev", C.c_void_p),
         ("grad_second_dev", C.c_void_p),
+        ("first_ray", C.c_int64),
+        ("phases", C.c_uint32),
+        ("loss_scale", C.c_float),
         ("timing_events", C.POINTER(C.c_void_p)),
     ]
 
@@ -247,18 +254,19 @@ def load() -> C.CDLL:
         vp,
     ]
     lib.rf_render_backward_emit.argtypes = [
-        C.POINTER(RFGrid), C.POINTER(RFRayBatch), u32, C.POINTER(RFRenderOut), C.POINTER(RFRenderGrads), i32, vp, vp, vp, vp, vp,
+        C.POINTER(RFGrid), C.POINTER(RFRayBatch), u32, C.POINTER(RFRenderOut), C.POINTER(RFRenderGrads), i32, vp, vp, vp, vp,
     ]
-    lib.rf_expand_records.argtypes = [C.POINTER(RFGrid), vp, vp, vp, i64, vp, i32, vp, vp]
+    lib.rf_expand_records.argtypes = [C.POINTER(RFGrid), vp, vp, vp, i64, i32, vp, vp]
     lib.rf_expanded_record_floats.argtypes = [i32]
     lib.rf_expanded_record_floats.restype = i32
     lib.rf_bin_offsets.argtypes = [vp, i32, vp, vp, vp]
     lib.rf_render_backward_emit_direct.argtypes = [
         C.POINTER(RFGrid), C.POINTER(RFRayBatch), u32, C.POINTER(RFRenderOut), C.POINTER(RFRenderGrads), i32, vp, vp, vp, vp,
     ]
-    lib.rf_scatter_records.argtypes = [C.POINTER(RFGrid), vp, vp, i64, vp, vp, i32, vp, vp, i32, vp]
+    lib.rf_scatter_records.argtypes = [C.POINTER(RFGrid), vp, vp, i64, vp, i32, vp, vp, i32, vp]
     lib.rf_brick_accumulate.argtypes = [C.POINTER(RFGrid), i32, C.POINTER(RFBrickList), i32, vp, vp, i32, vp]
     lib.rf_brick_accumulate_adam.argtypes = [C.POINTER(RFGrid), i32, C.POINTER(RFBrickList), i32, C.POINTER(RFAdamState), vp]
+    lib.rf_brick_accumulate_adam_range.argtypes = [C.POINTER(RFGrid), i32, C.POINTER(RFBrickList), i32, C.POINTER(RFAdamState), i32, i32, vp]
     lib.rf_train_step.argtypes = [C.POINTER(RFGrid), C.POINTER(RFTrainStep), vp]
     lib.rf_grid_query.argtypes = [C.POINTER(RFGrid), vp, i64, vp, vp]
     lib.rf_grid_query_backward.argtypes = [C.POINTER(RFGrid), vp, i64, vp, vp, vp, vp]

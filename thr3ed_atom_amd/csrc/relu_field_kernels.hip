@@ -104,9 +104,13 @@ struct OutArgs {
   float* depth;
   float* acc;
   float* disparity;
-  float* cache;   // [N,S,4]
-  float* tcache;  // [N,S]; the sign bit marks the samples counted in `hist` (transmittance itself is >= 0)
-  int* stop;      // [N]
+  // per-sample cache of the samples that can carry gradient (`need`: inside, T != 0, sigma != 0 under ReLU), COMPACTED per chunk of
+  // 64 samples: the j-th such sample of chunk c of ray r sits at slot r * S + 64 c + j, and bit l of cmask[r][c] says that sample
+  // 64 c + l is one of them -- the adjoint kernels read nothing else (every other sample contributes exactly nothing)
+  float* cache;                // [N,S,4] (raw r, g, b, sigma)
+  float* tcache;               // [N,S] transmittance
+  unsigned long long* cmask;   // [N, ceil(S / 64)]
+  int* stop;                   // [N]
   // binned backward, fused binning: the forward pass counts, per (brick, flags) key, the samples that will emit a record
   int* hist;        // [8 * nbricks] or NULL
   int brick_shift;  // log2 of the brick edge (nodes)
@@ -121,8 +125,7 @@ struct GradArgs {
   float* gfeat;
   // emit mode (binned backward): per-sample records instead of a scatter
   short* keys;      // [N*S] brick id of the sample's cell, kNoBrick for samples without gradient
-  float* records;   // [N*S, 8] = (idx_x, idx_y, idx_z, dL/dpre, dL/draw r, g, b, ray id bits); written for keyed samples only
-  float* ray_basis; // [N, 16] signed SH basis of the ray (may be NULL)
+  float* records;   // [N*S, 4 * record_quads] the record of every keyed slot (formats: record_quads), in slot order
   int brick_shift;  // log2 of the brick edge (nodes)
   int nby, nbz;     // bricks along y and z
   int* hist;        // [8 * nbricks] records per key, added to (may be NULL)
@@ -645,21 +648,36 @@ __device__ __forceinline__ void lds_channel_meaning(int c, int& colour, int& bas
   }
 }
 
-// float4s of an expanded record: (index x, y, z, -) followed by the per-channel values in LDS channel order
-__host__ __device__ constexpr int record_quads(int K) { return 1 + (3 * K + 1 + 3) / 4; }
+// float4s of a gradient record of the binned backward:
+//   K == 1 (render_diffuse passes, degree-0 grids): (index x, y, z, -) (d density, d sh0 r, g, b)                       32 B
+//   K  > 1: (index x, y, z, d density) (d raw r, g, b, v_x) (v_y, v_z, -, -), v = the ray's unit viewing direction       48 B
+//           -- the per-channel values d raw[colour] * Y_k(v) are expanded by the brick pass in LDS, never in HBM
+__host__ __device__ constexpr int record_quads(int K) { return K == 1 ? 2 : 3; }
+// channel values of a compact record in LDS channel order (lds_channel_meaning): 0 = density, 1..3 = degree 0, 4 + rr = rest rr
+template <int K>
+__device__ __forceinline__ float record_channel(int ch, float gdens, const float graw[3], const float Y[16]) {
+  if (ch == 0) return gdens;
+  int colour, basis_k;
+  lds_channel_meaning<K>(ch, colour, basis_k);
+  return graw[colour] * Y[basis_k];
+}
 
-// key of a sample's cell in the binned backward = brick of the cell's lower node * 8 + flags; flag bit a = the cell's
-// UPPER node on axis a belongs to the next brick (and exists), i.e. the record also touches nodes of that neighbour
+// key of a sample's cell in the binned backward.  Brick (bx, by, bz) = the brick of the cell's lower node; flag f_a = the cell's
+// UPPER node on axis a belongs to the next brick (and exists), i.e. the record also touches nodes of that neighbour.
+//   key = ((((bx * 2 + f_x) * nby + by) * nbz + bz) << 2) | f_y | f_z << 1
+// x-slab major with the x flag directly below the slab index: everything that touches the nodes of the x-slabs [s0, s1) of bricks --
+// the records of those slabs plus the x-flagged records of slab s0 - 1 -- is ONE contiguous key range.  That is what lets a
+// data-parallel rank send an owner of a slab range its share of a sorted list as a single slice (owner-computes exchange).
 __device__ __forceinline__ int brick_key(const int i0[3], const GridArgs& g, int shift, int nby, int nbz) {
   const int dims3[3] = {g.X, g.Y, g.Z};
-  int b3[3], flags3 = 0;
+  int b3[3], f3[3];
 #pragma unroll
   for (int a = 0; a < 3; ++a) {
     const int lo = max(i0[a], 0), up = i0[a] + 1;
     b3[a] = lo >> shift;
-    if (up < dims3[a] && (up >> shift) != b3[a]) flags3 |= 1 << a;
+    f3[a] = (up < dims3[a] && (up >> shift) != b3[a]) ? 1 : 0;
   }
-  return (((b3[0] * nby + b3[1]) * nbz + b3[2]) << 3) | flags3;
+  return (((((b3[0] << 1) | f3[0]) * nby + b3[1]) * nbz + b3[2]) << 2) | f3[1] | (f3[2] << 1);
 }
 
 // Parameter interval of a ray inside the box (same slab test as the AABB sampler, reciprocal-based: only used with a generous
@@ -740,6 +758,14 @@ __global__ __launch_bounds__(kBlock) void render_forward_kernel(GridArgs g, RayA
   bool z_ready = false;
 
   const int nchunks = (r.S + kWave - 1) / kWave;
+  // SAVE: lane c keeps the mask of the cached samples of chunk 64 g + c of the current group g of 64 chunks
+  unsigned long long my_cmask = 0ull;
+  int cmask_group = 0;
+  auto flush_cmasks = [&](int group) {
+    const int c = group * kWave + lane;
+    if (c < nchunks) out.cmask[ray * (long long)nchunks + c] = my_cmask;
+    my_cmask = 0ull;
+  };
   // Which chunks cannot hold a sample inside the box: lane c decides for chunk c, all table reads in flight at once (a ray
   // of more than 64 chunks falls back to one decision per iteration).  The t_vals reads of a chunk's samples are requested
   // one iteration before they are needed: per chunk these small dependent loads were 2-3 exposed cache latencies in front of
@@ -749,10 +775,16 @@ __global__ __launch_bounds__(kBlock) void render_forward_kernel(GridArgs g, RayA
   bool zq_valid = true;
   for (int chunk = 0; chunk < nchunks; ++chunk) {
     const int s = chunk * kWave + lane;
+    if constexpr (SAVE) {
+      if ((chunk >> 6) != cmask_group) {  // (rays of more than 4096 samples)
+        flush_cmasks(cmask_group);
+        cmask_group = chunk >> 6;
+      }
+    }
     {
       const bool empty = chunk < kWave ? (bool)((empty_mask >> chunk) & 1ull) : chunk_outside_box(span, st, r, chunk);
       if (empty) {  // wave-uniform
-        // (nothing is cached for such a chunk: the adjoint kernels make the same wave-uniform decision and never read it)
+        // (nothing is cached for such a chunk: its mask stays 0)
         processed = min(r.S, (chunk + 1) * kWave);
         z_ready = false;
         zq_valid = false;
@@ -816,8 +848,8 @@ __global__ __launch_bounds__(kBlock) void render_forward_kernel(GridArgs g, RayA
     const bool need = live && (T != 0.0f) && !(g.mode == RF_DENSITY_RELU && sigma == 0.0f);
     const unsigned long long mask = __ballot(need);
     const int count = fast_base ? 0 : __popcll(mask);
+    const int slot = __popcll(mask & ((1ull << lane) - 1ull));
     if (need && !fast_base) {
-      const int slot = __popcll(mask & ((1ull << lane) - 1ull));
       uint32_t* e = my_entry + slot * kEntryFwd;
       // corner k = dx + 2 dy + 4 dz (corners_of): lin[1] / lin[2] / lin[4] are the x / y / z upper neighbours
       // bits 0..2: the step exists; bits 3..5: it is a jump into the next brick (bricked node order)
@@ -935,18 +967,20 @@ __global__ __launch_bounds__(kBlock) void render_forward_kernel(GridArgs g, RayA
       part_depth += w * sm.z;
     }
     if constexpr (SAVE) {
-      if (sm.valid) {
-        const long long idx = ray * (long long)r.S + s;
+      // `need` samples are exactly those that can carry gradient (inside, T != 0, and sigma != 0 under ReLU): only they are
+      // cached -- compacted to the front of the chunk's 64 slots, so that the adjoint reads whole lines of useful entries --
+      // flagged in the chunk's mask, and counted per key for the binned adjoint
+      if (need) {
+        const long long idx = ray * (long long)r.S + chunk * kWave + slot;
         float4 cv;
         cv.x = raw_r;
         cv.y = raw_g;
         cv.z = raw_b;
         cv.w = sigma;
         reinterpret_cast<float4*>(out.cache)[idx] = cv;
-        // `need` samples are exactly those that can carry gradient (T != 0, and sigma != 0 under ReLU): they are counted
-        // per key below, and flagged here so that the backward pass emits exactly the counted ones
-        out.tcache[idx] = (out.hist && need) ? -T : T;
+        out.tcache[idx] = T;
       }
+      my_cmask = (lane == (chunk & (kWave - 1))) ? mask : my_cmask;
       if (out.hist) add_key_runs<false>(out.hist, need ? brick_key(sm.cell.i0, g, out.brick_shift, out.nby, out.nbz) : -1, lane);
     }
     wave_lds_fence();
@@ -966,6 +1000,31 @@ __global__ __launch_bounds__(kBlock) void render_forward_kernel(GridArgs g, RayA
     out.disparity[ray] = 1.0f / ((q != q) ? q : fmaxf(kZeroPlus, q));
     if constexpr (SAVE) out.stop[ray] = processed;
   }
+  if constexpr (SAVE) {
+    flush_cmasks(cmask_group);
+    for (int gq = cmask_group + 1; gq * kWave < nchunks; ++gq) flush_cmasks(gq);  // (chunks never reached: zero masks)
+  }
+}
+
+// The cached samples of a chunk (forward pass, SAVE): lane l of the adjoint handles sample 64 c + l like the forward pass did; its
+// cache entry, if bit l of the chunk's mask is set, is entry rank(l) = popcount(mask below l) of the chunk's slots.  Lanes without
+// an entry load entry 0 of the chunk (a line the wave touches anyway; a load under a lane condition would be followed by a
+// register merge that waits for it) and are zeroed by the caller.
+struct CachedSample {
+  float4 cv;  // raw r, g, b, sigma
+  float T;
+};
+__device__ __forceinline__ long long cached_slot(long long ray, int S, int chunk, unsigned long long cm, int lane) {
+  const bool has = (cm >> lane) & 1ull;
+  const int rank = __popcll(cm & ((1ull << lane) - 1ull));
+  return ray * (long long)S + chunk * kWave + (has ? rank : 0);
+}
+// wave-uniform mask of chunk `chunk` out of the per-lane copies (lane c holds chunk 64 g + c)
+__device__ __forceinline__ unsigned long long chunk_mask_of(unsigned long long lanes_masks, int chunk) {
+  const int c = chunk & (kWave - 1);
+  const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)lanes_masks, c);
+  const uint32_t hi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(lanes_masks >> 32), c);
+  return ((unsigned long long)hi << 32) | lo;
 }
 
 // lanes per corner for the backward scatter: F features + 1 density, rounded up to a power of two
@@ -1013,18 +1072,6 @@ __global__ __launch_bounds__(kBlock) void render_backward_kernel(GridArgs g, Ray
     // every sample slot of the ray gets a key (the sort runs over the dense array)
     const int done = (no_upstream) ? 0 : fwd.stop[ray];
     for (int s2 = ((done + kWave - 1) / kWave) * kWave + lane; s2 < r.S; s2 += kWave) gr.keys[ray * (long long)r.S + s2] = kNoBrick;
-    if (gr.ray_basis) {  // staged through LDS so that the per-lane pick is an LDS read, not a scratch array
-      float Yb[16];
-      sh_basis<K>(st.d[0] / st.dnorm, st.d[1] / st.dnorm, st.d[2] / st.dnorm, Yb);
-      float* ldsY = reinterpret_cast<float*>(s_entry[wave]);
-      if (lane == 0) {
-#pragma unroll
-        for (int k = 0; k < K; ++k) ldsY[k] = Yb[k];
-      }
-      wave_lds_fence();
-      if (lane < 16) gr.ray_basis[ray * 16 + lane] = (lane < K) ? ldsY[lane] : 0.0f;
-      wave_lds_fence();
-    }
   }
   if (no_upstream) return;
 
@@ -1102,33 +1149,42 @@ __global__ __launch_bounds__(kBlock) void render_backward_kernel(GridArgs g, Ray
 
   const int processed = fwd.stop[ray];
   const int nchunks = (processed + kWave - 1) / kWave;
+  const int mask_words = (r.S + kWave - 1) / kWave;
   float suffix = 0.0f;  // sum of w_j e_j over all samples beyond the current chunk
-  const BoxSpan span = box_span(st, r, g);
+  unsigned long long lane_masks = 0ull;
+  int masks_group = -1;
 
   for (int chunk = nchunks - 1; chunk >= 0; --chunk) {
     const int s = chunk * kWave + lane;
-    // the forward pass skipped chunks outside the box (all weights exactly 0, nothing counted): so does the adjoint
-    if (chunk_outside_box(span, st, r, chunk)) {
+    if ((chunk >> 6) != masks_group) {  // the masks of (up to) 64 chunks at a time, one per lane
+      masks_group = chunk >> 6;
+      const int c = masks_group * kWave + lane;
+      lane_masks = fwd.cmask[ray * (long long)mask_words + min(c, mask_words - 1)];
+    }
+    const unsigned long long cm = chunk_mask_of(lane_masks, chunk);
+    // a chunk without cached samples (outside the box, empty space, behind the point where T reached 0) contributes nothing
+    if (cm == 0ull) {
       if constexpr (EMIT == 1) {  // every slot still gets its "no record" key
         if (s < r.S) gr.keys[ray * (long long)r.S + s] = kNoBrick;
       }
       continue;
     }
     Sample sm = make_sample(st, r, g, ray, s);
-    const bool have = sm.valid && s < processed;
+    const bool have = (cm >> lane) & 1ull;
     float raw[3] = {0.f, 0.f, 0.f};
     float sigma = 0.f, T = 0.f;
-    if (have) {
-      const long long idx = ray * (long long)r.S + s;
+    {
+      const long long idx = cached_slot(ray, r.S, chunk, cm, lane);
       const float4 cv = reinterpret_cast<const float4*>(fwd.cache)[idx];
-      raw[0] = cv.x;
-      raw[1] = cv.y;
-      raw[2] = cv.z;
-      sigma = cv.w;
-      T = fwd.tcache[idx];
+      const float Tl = fwd.tcache[idx];
+      if (have) {
+        raw[0] = cv.x;
+        raw[1] = cv.y;
+        raw[2] = cv.z;
+        sigma = cv.w;
+        T = Tl;
+      }
     }
-    const bool counted = have && (__float_as_uint(T) >> 31);  // flagged by a forward pass that counts records per key
-    T = fabsf(T);
     const float alpha = 1.0f - exp_fast(-(sigma * sm.delta));
     const float w = alpha * T;
     const float Tn = T * (1.0f - alpha);
@@ -1164,9 +1220,16 @@ __global__ __launch_bounds__(kBlock) void render_backward_kernel(GridArgs g, Ray
         short key = kNoBrick;
         if (need) {
           key = (short)brick_key(sm.cell.i0, g, gr.brick_shift, gr.nby, gr.nbz);
-          float4* rec = reinterpret_cast<float4*>(gr.records) + slot * 2;
-          rec[0] = make_float4(sm.cell.idx[0], sm.cell.idx[1], sm.cell.idx[2], g_pre);
-          rec[1] = make_float4(g_raw[0], g_raw[1], g_raw[2], __int_as_float((int)ray));
+          constexpr int KE = SL::kCorner ? 1 : K;
+          float4* rec = reinterpret_cast<float4*>(gr.records) + slot * record_quads(KE);
+          if constexpr (KE == 1) {
+            rec[0] = make_float4(sm.cell.idx[0], sm.cell.idx[1], sm.cell.idx[2], 0.0f);
+            rec[1] = make_float4(g_pre * g.rho, g_raw[0] * kC0, g_raw[1] * kC0, g_raw[2] * kC0);
+          } else {
+            rec[0] = make_float4(sm.cell.idx[0], sm.cell.idx[1], sm.cell.idx[2], g_pre * g.rho);
+            rec[1] = make_float4(g_raw[0], g_raw[1], g_raw[2], st.d[0] / st.dnorm);
+            rec[2] = make_float4(st.d[1] / st.dnorm, st.d[2] / st.dnorm, 0.0f, 0.0f);
+          }
         }
         gr.keys[slot] = key;
         key_of_lane = key;
@@ -1271,43 +1334,45 @@ __global__ __launch_bounds__(kBlock) void render_emit_direct_kernel(GridArgs g, 
   const float gD = gr.gdepth ? gr.gdepth[ray] : 0.0f;
   const float gA = gr.gacc ? gr.gacc[ray] : 0.0f;
   constexpr int KE = DIFFUSE ? 1 : K;  // diffuse lists carry the base channels only
-  constexpr int CE = 3 * KE + 1;
   constexpr int QE = record_quads(KE);
-  float Yd[16];  // the signed SH basis of this ray, multiplied into every record
-  if constexpr (KE > 1)
-    sh_basis<K>(st.d[0] / st.dnorm, st.d[1] / st.dnorm, st.d[2] / st.dnorm, Yd);
-  else
-    Yd[0] = kC0;
+  // the unit viewing direction (process.py:53) travels in the record: the brick pass evaluates the SH basis from it
+  const float vdir[3] = {st.d[0] / st.dnorm, st.d[1] / st.dnorm, st.d[2] / st.dnorm};
 
   const int processed = fwd.stop[ray];
   const int nchunks = (processed + kWave - 1) / kWave;
-  const BoxSpan span = box_span(st, r, g);
-  // lane c decides for chunk c whether it can hold a sample inside the box: all table reads in flight at once
-  const unsigned long long empty_mask = __ballot(lane < nchunks && chunk_outside_box(span, st, r, min(lane, max(nchunks - 1, 0))));
+  const int mask_words = (r.S + kWave - 1) / kWave;
   float suffix = 0.0f;  // sum of w_j e_j over all samples beyond the current chunk
   constexpr int G = 4;  // chunks in flight
+  unsigned long long lane_masks = 0ull;
+  int masks_group = -1;
 
   for (int c0 = nchunks - 1; c0 >= 0; c0 -= G) {
     float4 cv[G];
-    float Tc[G], zz[G], zn[G], dl[G], ix[G][3];
-    int base_[G], hl_[G];
-    bool act[G], counted[G];
-    // -- A0: which chunks of the group can hold samples inside the box (chunks c0, c0 - 1, ...)
+    float Tc[G], zz[G], zn[G];
+    unsigned long long cm[G];
+    // -- A0: the masks of the cached samples of chunks c0, c0 - 1, ...: a chunk without any is skipped
 #pragma unroll
     for (int u = 0; u < G; ++u) {
       const int chunk = c0 - u;
-      act[u] = chunk >= 0 && !(chunk < kWave ? (bool)((empty_mask >> chunk) & 1ull) : chunk_outside_box(span, st, r, chunk));
+      cm[u] = 0ull;
+      if (chunk >= 0) {  // wave-uniform
+        if ((chunk >> 6) != masks_group) {
+          masks_group = chunk >> 6;
+          const int c = masks_group * kWave + lane;
+          lane_masks = fwd.cmask[ray * (long long)mask_words + min(c, mask_words - 1)];
+        }
+        cm[u] = chunk_mask_of(lane_masks, chunk);
+      }
     }
     // -- A1: every load of the group -- sample caches, t_vals (and the jitter table, if one is used) -- before the first use.
-    // All unconditional, with clamped indices (lanes beyond the processed samples re-read the last one, chunks without samples the
-    // ray's first entry: one line): a load under a condition is followed by a register merge that waits for it, which had
-    // serialised the four chunks' cache loads and the t_vals reads of every sample into as many exposed memory latencies.
+    // All unconditional, with clamped indices: a load under a condition is followed by a register merge that waits for it, which
+    // had serialised the four chunks' cache loads and the t_vals reads of every sample into as many exposed memory latencies.
     ZRequests zq[G][2];
 #pragma unroll
     for (int u = 0; u < G; ++u) {
-      const int s = max(c0 - u, 0) * kWave + lane;
-      const int sc = act[u] ? min(s, processed - 1) : 0;
-      const long long idx = ray * (long long)r.S + sc;
+      const int chunk = max(c0 - u, 0);
+      const int s = chunk * kWave + lane;
+      const long long idx = cached_slot(ray, r.S, chunk, cm[u], lane);
       cv[u] = reinterpret_cast<const float4*>(fwd.cache)[idx];
       Tc[u] = fwd.tcache[idx];
       zq[u][0] = z_requests(r, s);
@@ -1320,19 +1385,22 @@ __global__ __launch_bounds__(kBlock) void render_emit_direct_kernel(GridArgs g, 
       zn[u] = z_from(st, r, zq[u][1], ray, s + 1);
     }
     // -- A2: geometry, keys and the cursor atomics of the group, back to back
+    float dl[G], ix[G][3];
+    int base_[G], hl_[G];
+    bool counted[G];
 #pragma unroll
     for (int u = 0; u < G; ++u) {
       base_[u] = hl_[u] = 0;
       counted[u] = false;
       dl[u] = ix[u][0] = ix[u][1] = ix[u][2] = 0.0f;
-      if (!act[u]) continue;
+      if (cm[u] == 0ull) continue;
       const int s = (c0 - u) * kWave + lane;
       const Sample sm = sample_at(st, r, g, s, zz[u], zn[u]);
       dl[u] = sm.delta;
       ix[u][0] = sm.cell.idx[0];
       ix[u][1] = sm.cell.idx[1];
       ix[u][2] = sm.cell.idx[2];
-      counted[u] = sm.valid && s < processed && (__float_as_uint(Tc[u]) >> 31);
+      counted[u] = (cm[u] >> lane) & 1ull;
       const int key = counted[u] ? brick_key(sm.cell.i0, g, gr.brick_shift, gr.nby, gr.nbz) : -1;
       // one atomic per RUN of equal keys (add_key_runs, split: the returned base is only combined in phase B)
       const bool active = key >= 0;
@@ -1349,11 +1417,10 @@ __global__ __launch_bounds__(kBlock) void render_emit_direct_kernel(GridArgs g, 
     // -- B: gradients, far to near
 #pragma unroll
     for (int u = 0; u < G; ++u) {
-      if (!act[u]) continue;
-      const int s = (c0 - u) * kWave + lane;
-      const bool have = s < r.S && s < processed;
-      const float sigma = cv[u].w;
-      const float T = fabsf(Tc[u]);
+      if (cm[u] == 0ull) continue;
+      const bool have = counted[u];
+      const float sigma = have ? cv[u].w : 0.0f;
+      const float T = have ? Tc[u] : 0.0f;
       const float alpha = 1.0f - exp_fast(-(sigma * dl[u]));
       const float w = alpha * T;
       const float Tn = T * (1.0f - alpha);
@@ -1377,25 +1444,17 @@ __global__ __launch_bounds__(kBlock) void render_emit_direct_kernel(GridArgs g, 
       else
         g_pre = g_sigma;
       const int pos = __shfl(base_[u], hl_[u]) + (lane - hl_[u]);
-      if (counted[u]) {
+      if (have) {
         // (a counted sample is inside the box; its record is written even when its gradient happens to vanish)
-        const float graw[4] = {(w * gC[0]) * (c[0] * (1.0f - c[0])), (w * gC[1]) * (c[1] * (1.0f - c[1])), (w * gC[2]) * (c[2] * (1.0f - c[2])),
-                               g_pre * g.rho};  // colour 3 = density
+        const float graw[3] = {(w * gC[0]) * (c[0] * (1.0f - c[0])), (w * gC[1]) * (c[1] * (1.0f - c[1])), (w * gC[2]) * (c[2] * (1.0f - c[2]))};
         float4* dst = gr.sorted + (long long)pos * QE;
-        dst[0] = make_float4(ix[u][0], ix[u][1], ix[u][2], 0.0f);
-#pragma unroll
-        for (int part = 1; part < QE; ++part) {
-          float v[4];
-#pragma unroll
-          for (int x = 0; x < 4; ++x) {
-            const int ch = 4 * (part - 1) + x;
-            int colour, basis_k;
-            lds_channel_meaning<KE>(ch < CE ? ch : 0, colour, basis_k);
-            float gv = graw[colour];
-            if (ch > 0) gv = gv * Yd[basis_k];
-            v[x] = (ch < CE) ? gv : 0.0f;
-          }
-          dst[part] = make_float4(v[0], v[1], v[2], v[3]);
+        if constexpr (KE == 1) {  // base-channel record: index quad + (density, degree-0 r, g, b) -- nothing left to expand
+          dst[0] = make_float4(ix[u][0], ix[u][1], ix[u][2], 0.0f);
+          dst[1] = make_float4(g_pre * g.rho, graw[0] * kC0, graw[1] * kC0, graw[2] * kC0);
+        } else {  // compact specular record (48 B): the brick pass multiplies the SH basis of `vdir` in
+          dst[0] = make_float4(ix[u][0], ix[u][1], ix[u][2], g_pre * g.rho);
+          dst[1] = make_float4(graw[0], graw[1], graw[2], vdir[0]);
+          dst[2] = make_float4(vdir[1], vdir[2], 0.0f, 0.0f);
         }
       }
     }
@@ -1418,10 +1477,13 @@ __global__ __launch_bounds__(kBlock) void render_emit_direct_kernel(GridArgs g, 
 //      applies the optimizer step right there.
 // History and measurements: DESIGN.md section 4.
 // =============================================================================================
+constexpr int kMaxListsPerKind = 8;   // lists of one kind per brick pass (data parallel: one per source rank)
+constexpr int kRangeEntries = 15;     // contiguous key ranges of ONE sorted list that reach into a brick (brick_range_entry)
+constexpr int kMaxRangesKind = kRangeEntries * kMaxListsPerKind;
+
 struct BrickList {
-  const float4* rec;         // sorted, expanded records: record_quads(K) float4 each
-  const long long* offsets;  // [8 * nbricks + 1]
-  int diffuse;
+  const float4* rec;         // sorted records: record_quads(K) float4 each
+  const long long* offsets;  // [8 * nbricks + 1] start of every key class in `rec` (absolute positions)
 };
 
 // fused optimizer of the brick flush (torch.optim.Adam arithmetic, the same expressions as adam_kernel): the workgroup that
@@ -1454,11 +1516,12 @@ struct AdamArgs {
 };
 
 struct BrickArgs {
-  BrickList lists[2];
-  int nlists;
-  int mixed;               // lists[0] = full records of a specular pass, lists[1] = base-channel records of a render_diffuse pass
+  BrickList wide[kMaxListsPerKind];    // full-width lists: compact K-records (kernel<K>), or base-channel records (kernel<1>)
+  BrickList narrow[kMaxListsPerKind];  // kernel<K > 1> only: base-channel records of render_diffuse passes, summed into channels 0..3
+  int nwide, nnarrow;
   int shift;               // log2(B)
   int nbx, nby, nbz;
+  int brick_first;         // workgroup i handles brick brick_first + i (data parallel: the rank's own x-slabs)
   int accumulate;          // 0: grad = brick sum (no zero-fill needed), 1: grad += brick sum
   int fmul;                // reference layout: feature index of degree-0 colour c is c * fmul (base-only lists on an SH grid)
   int stagger;             // development builds (RF_BRICK_PROFILE): experiment / ablation switches from $RF_BRICK_STAGGER
@@ -1467,45 +1530,17 @@ struct BrickArgs {
 
 
 
-// Sorted position p (>= *begin: the slots without gradient sort in front) receives the EXPANDED record of slot
-// perm[p]: its continuous index and, for every channel of a node, dL/d(interpolated channel) = dL/draw colour * SH basis
-// of the record's ray (channel 0: dL/dpre * rho).  Everything the brick pass needs per record that does not depend on
-// the corner, computed once here (4 lanes per float4 of output; coalesced 16-byte stores).
-template <int K>
+// Sorted position p (>= *begin: the slots without gradient sort in front) receives the record of slot perm[p] (Q quads each;
+// one thread per quad, coalesced 16-byte stores).
+template <int Q>
 __global__ void expand_records_kernel(const float4* __restrict__ rec, const long long* __restrict__ perm,
-                                      const long long* __restrict__ begin_ptr, long long capacity,
-                                      const float* __restrict__ ray_basis, int diffuse, float rho,
-                                      float4* __restrict__ out) {
-  constexpr int C = 3 * K + 1;
-  constexpr int Q = record_quads(K);
+                                      const long long* __restrict__ begin_ptr, long long capacity, float4* __restrict__ out) {
   const long long begin = *begin_ptr;
   const long long items = (capacity - begin) * Q;
   for (long long it = (long long)blockIdx.x * blockDim.x + threadIdx.x; it < items; it += (long long)gridDim.x * blockDim.x) {
     const long long i = begin + it / Q;
     const int part = (int)(it % Q);
-    const long long src = perm[i];
-    const float4 r0 = rec[2 * src];
-    float4 o;
-    if (part == 0) {
-      o = make_float4(r0.x, r0.y, r0.z, 0.0f);
-    } else {
-      const float4 r1 = rec[2 * src + 1];
-      const float graw[4] = {r1.x, r1.y, r1.z, r0.w * rho};  // colour 3 = density
-      const float* yb = ray_basis + (long long)__float_as_int(r1.w) * 16;
-      float v[4];
-#pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        const int ch = 4 * (part - 1) + e;
-        int colour, basis_k;
-        lds_channel_meaning<K>(ch < C ? ch : 0, colour, basis_k);
-        float gv = graw[colour];
-        if (ch > 0) gv = gv * ((diffuse || basis_k == 0) ? kC0 : yb[basis_k]);
-        if (ch >= C || (diffuse && ch >= 4)) gv = 0.0f;
-        v[e] = gv;
-      }
-      o = make_float4(v[0], v[1], v[2], v[3]);
-    }
-    out[i * Q + part] = o;
+    out[i * Q + part] = rec[perm[i] * Q + part];
   }
 }
 
@@ -1566,13 +1601,10 @@ __global__ __launch_bounds__(1024) void bin_offsets_kernel(BinLists lists, int n
 // slots are compacted into LDS, then groups of Q lanes write the Q quads of a record (coalesced 16-byte stores).  The
 // order inside a class depends on the atomics' timing (unlike the sort path, results are not run-to-run bit-identical).
 // Also clears `hist` for the next iteration.
-template <int K>
+template <int Q>
 __global__ __launch_bounds__(256) void scatter_records_kernel(const short* __restrict__ keys, const float4* __restrict__ rec,
                                                               long long capacity, int* __restrict__ cursor,
-                                                              const float* __restrict__ ray_basis, int diffuse, float rho,
                                                               float4* __restrict__ out, int* __restrict__ hist, int nkeys) {
-  constexpr int C = 3 * K + 1;
-  constexpr int Q = record_quads(K);
   constexpr int NCH = 4;  // chunks per wave
   __shared__ long long s_slot[4][NCH * kWave];
   __shared__ int s_pos[4][NCH * kWave];
@@ -1619,29 +1651,7 @@ __global__ __launch_bounds__(256) void scatter_records_kernel(const short* __res
   const int items = n_act * Q;
   for (int it = lane; it < items; it += kWave) {
     const int e = it / Q, part = it - e * Q;
-    const long long src = s_slot[wave][e];
-    const float4 r0 = rec[2 * src];
-    float4 o;
-    if (part == 0) {
-      o = make_float4(r0.x, r0.y, r0.z, 0.0f);
-    } else {
-      const float4 r1 = rec[2 * src + 1];
-      const float graw[4] = {r1.x, r1.y, r1.z, r0.w * rho};  // colour 3 = density
-      const float* yb = ray_basis + (long long)__float_as_int(r1.w) * 16;
-      float v[4];
-#pragma unroll
-      for (int x = 0; x < 4; ++x) {
-        const int ch = 4 * (part - 1) + x;
-        int colour, basis_k;
-        lds_channel_meaning<K>(ch < C ? ch : 0, colour, basis_k);
-        float gv = graw[colour];
-        if (ch > 0) gv = gv * ((diffuse || basis_k == 0) ? kC0 : yb[basis_k]);
-        if (ch >= C || (diffuse && ch >= 4)) gv = 0.0f;
-        v[x] = gv;
-      }
-      o = make_float4(v[0], v[1], v[2], v[3]);
-    }
-    out[(long long)s_pos[wave][e] * Q + part] = o;
+    out[(long long)s_pos[wave][e] * Q + part] = rec[s_slot[wave][e] * Q + part];
   }
 }
 
@@ -1652,7 +1662,6 @@ __global__ __launch_bounds__(256) void scatter_records_kernel(const short* __res
 // ownership of channel pairs (LDS float atomics retire 0.33 lane/clk/CU, tools/lds_microbench*.hip): ~200 cycles per pair of records
 // on the read-add-write chain plus float64 LDS atomics for the base-channel records, 0.489 ms on the bench step against 0.394 now.
 constexpr int kBrickThreads = 512;  // 8 waves; LDS admits 2 workgroups per CU
-constexpr int kMaxRanges = 28;      // 14 (source brick, flag run) ranges per list, two lists
 
 // geometry of the accumulator image the flush reads: node stride CS = channels rounded up to a multiple of 4 (float4 flush);
 // rows (z runs) and slabs (x) are padded to odd multiples of 16 / 8 words (bank spread of the image writes and the flush reads)
@@ -1695,48 +1704,25 @@ __device__ unsigned long long g_brick_prof[8];
 #define RF_PROF_END() do { } while (0)
 #endif
 
-// Which sorted ranges reach into brick (bx, by, bz): see the kernel.  Called by waves 0 and 1 (wave 1: the base-channel list of a
-// mixed call, which has its own, smaller, range table).
-__device__ __forceinline__ void brick_ranges(const BrickArgs& a, int bx, int by, int bz, int wave, int lane, long long* s_rstart, int* s_rlist,
-                                             int* s_rcum, long long* s_dstart, int* s_dcum) {
-  const bool second = wave == 1;            // the diffuse list of a mixed call
-  const int nl = second ? (a.mixed ? 1 : 0) : (a.mixed ? 1 : a.nlists);
-  const int li = lane / 14, e = lane - li * 14;
-  const bool in_use = lane < 14 * nl;
-  // nibble tables over e: source offset, first and last flag class of the run
-  const int o = (int)((0x76554332211110ull >> (4 * e)) & 7), f0 = (int)((0x76754736275310ull >> (4 * e)) & 7),
-            f1 = (int)((0x77757737375317ull >> (4 * e)) & 7);
-  const int sx = bx - (o & 1), sy = by - ((o >> 1) & 1), sz = bz - (o >> 2);
-  long long rs = 0;
-  int cnt = 0;
-  if (in_use && sx >= 0 && sy >= 0 && sz >= 0) {
-    const long long* off = ((li || second) ? a.lists[1].offsets : a.lists[0].offsets) + ((long long)((sx * a.nby + sy) * a.nbz + sz) << 3);
-    rs = off[f0];
+// Which ranges of a sorted list reach into brick (bx, by, bz).  A record with key (source brick, f_x, f_y, f_z) touches the bricks
+// source + o for every offset o <= f (component-wise), so brick b receives, from the source brick b - o, the classes f >= o.  In the
+// key order of brick_key -- ((2 sx + f_x) * nby + sy) * nbz + sz) * 4 + (f_y | 2 f_z) -- those are, per (o_x, f_x) in
+// {(0,0), (0,1), (1,1)} and per (o_y, o_z): o_yz = (0,0): classes 0..3; (1,0): {1}, {3}; (0,1): 2..3; (1,1): {3} -- 3 x 5 = 15
+// contiguous ranges.  Entry e = 5 e_x + e_yz.
+__device__ __forceinline__ void brick_range_entry(const BrickArgs& a, const long long* __restrict__ offsets, int bx, int by, int bz, int e,
+                                                  int& start, int& cnt) {
+  const int ex = e / 5, eyz = e - ex * 5;
+  const int ox = ex == 2, xf = ex >= 1;
+  const int oy = (0x16 >> eyz) & 1, oz = (0x18 >> eyz) & 1;
+  const int f0 = (0x32310 >> (4 * eyz)) & 7, f1 = (0x33313 >> (4 * eyz)) & 7;
+  const int sx = bx - ox, sy = by - oy, sz = bz - oz;
+  start = 0;
+  cnt = 0;
+  if (sx >= 0 && sy >= 0 && sz >= 0) {
+    const long long* off = offsets + ((long long)((((sx << 1) | xf) * a.nby + sy) * a.nbz + sz) << 2);
+    const long long rs = off[f0];
+    start = (int)rs;
     cnt = (int)(off[f1 + 1] - rs);
-  }
-  const unsigned long long nonempty = __ballot(cnt > 0);
-  int cum = cnt;  // inclusive prefix sum over the lanes
-#pragma unroll
-  for (int d = 1; d < 32; d <<= 1) {
-    const int up = __shfl_up(cum, d);
-    if (lane >= d) cum += up;
-  }
-  const int slot = __popcll(nonempty & ((1ull << lane) - 1ull));
-  if (!second) {
-    if (cnt > 0) {
-      s_rstart[slot] = rs;
-      s_rlist[slot] = li;
-      s_rcum[slot + 1] = cum;
-    }
-    if (lane == 0) s_rcum[0] = 0;
-    if (lane == 31) s_rcum[kMaxRanges] = cum;  // total (lanes >= 28 carry cnt = 0)
-  } else {
-    if (cnt > 0) {
-      s_dstart[slot] = rs;
-      s_dcum[slot + 1] = cum;
-    }
-    if (lane == 0) s_dcum[0] = 0;
-    if (lane == 31) s_dcum[15] = cum;
   }
 }
 
@@ -1955,14 +1941,16 @@ constexpr int kGatherBatch = 256;  // records per batch (their indices travel as
 constexpr int kGatherWtab = 24;    // rows of the weight table: 3 axes x local node coordinate 0..7
 // Bank conflicts are what bounds the tile loop (6 LDS reads per instruction): table rows are kGatherBatch + 4 words apart, so that
 // the 2 (x, y) or 4 (z) rows the lanes of one record read, and those of the neighbouring record indices of the same instruction,
-// fall into different banks; records are padded by one quad (36 / 12 words), so that the four records of an instruction do not
-// all start in the same two bank groups.
+// fall into different banks; record rows are padded by two quads (36 / 12 words), so that the four records of an instruction do
+// not all start in the same two bank groups.
 constexpr int kGatherRow = kGatherBatch + 4;
-__host__ __device__ constexpr int gather_record_words(int quads) { return quads * 4 + 4; }
+// words of a record's row of per-channel values in LDS (C4 = channels rounded up to whole quads)
+__host__ __device__ constexpr int gather_record_words(int C4) { return C4 + 8; }
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
-__host__ __device__ inline int gather_lds_words(int B, int C, int Q) {
-  const int batch = kGatherBatch * gather_record_words(Q) + kGatherBatch * 4 + kGatherRow * kGatherWtab;  // records, their index quads, weight table
+__host__ __device__ inline int gather_lds_words(int B, int C) {
+  const int C4 = (C + 3) / 4 * 4;
+  const int batch = kGatherBatch * gather_record_words(C4) + kGatherRow * kGatherWtab;  // per-channel rows, weight table
   const int image = brick_acc_words(B, C);
   return batch > image ? batch : image;
 }
@@ -1971,24 +1959,21 @@ template <int K, bool ADAM>
 __global__ __launch_bounds__(kBrickThreads, 4) void brick_gather_kernel(GridArgs g, BrickArgs a, float* gdens, float* gfeat) {
   constexpr int C = 3 * K + 1;
   constexpr int C4 = (C + 3) / 4 * 4;
-  constexpr int Q = record_quads(K);
-  constexpr int QD = record_quads(1);      // quads of a base-channel (render_diffuse) record
+  constexpr int QW = record_quads(K);      // quads of a full-width record in HBM
+  constexpr int QN = record_quads(1);      // quads of a base-channel (render_diffuse) record
   constexpr int NT = (C4 + 15) / 16;       // 16-channel blocks per tile
+  static_assert(NT <= 2, "SH degree <= 2 (two 16-channel blocks)");
   constexpr int CS = C4;
   constexpr int NW = kGatherBatch / 64;    // mask words per tile
-  constexpr int PRE = (kGatherBatch * Q + kBrickThreads - 1) / kBrickThreads;  // record quads per thread and batch
-  static_assert(kGatherBatch * QD <= kBrickThreads, "one quad per thread for base-channel batches");
+  static_assert(2 * kGatherBatch == kBrickThreads, "two threads per record of a batch");
   extern __shared__ __attribute__((aligned(16))) float acc[];  // first the batch buffers, in the end the accumulator image the flush reads
-  float4* recs = reinterpret_cast<float4*>(acc);               // [kGatherBatch][Q + 1 or QD + 1] quads, record order (padded)
-  float4* q0s = recs + kGatherBatch * (Q + 1);                 // [kGatherBatch] compact copy of the records' index quads
-  float* wtab = acc + kGatherBatch * (Q + 2) * 4;              // [3][8][kGatherRow]: axis, local node coordinate, record
+  float* rows = acc;                                            // [kGatherBatch][RW] per-channel values of the batch's records
+  float* wtab = acc + kGatherBatch * gather_record_words(C4);   // [3][8][kGatherRow]: axis, local node coordinate, record
   __shared__ uint32_t s_tmask[kGatherBatch];                   // record -> bit t: it touches tile t
   __shared__ unsigned char s_list[32][kGatherBatch + 24];      // tile -> its records (+ padding of the last instructions, + read-ahead slack)
-  __shared__ long long s_rstart[kMaxRanges];
-  __shared__ int s_rlist[kMaxRanges];
-  __shared__ int s_rcum[kMaxRanges + 1];
-  __shared__ long long s_dstart[14];
-  __shared__ int s_dcum[16];
+  __shared__ int s_wstart[kMaxRangesKind], s_wcum[kMaxRangesKind + 1];  // ranges of the full-width lists: first record, running count
+  __shared__ int s_nstart[kMaxRangesKind], s_ncum[kMaxRangesKind + 1];  // ... of the base-channel lists of a mixed call
+  __shared__ int s_part[4];
   const int B = 1 << a.shift;
   const int SY = brick_row_stride(B, C), SX = brick_slab_stride(B, C);
 
@@ -1996,13 +1981,43 @@ __global__ __launch_bounds__(kBrickThreads, 4) void brick_gather_kernel(GridArgs
   const int tid = threadIdx.x;
   const int lane = tid & (kWave - 1);
   const int wave = tid >> 6;
-  const int brick = blockIdx.x;
+  const int brick = a.brick_first + (int)blockIdx.x;
   const int bz = brick % a.nbz, by = (brick / a.nbz) % a.nby, bx = brick / (a.nbz * a.nby);
   const int X0 = bx << a.shift, Y0 = by << a.shift, Z0 = bz << a.shift;
-  if (wave < 2) brick_ranges(a, bx, by, bz, wave, lane, s_rstart, s_rlist, s_rcum, s_dstart, s_dcum);
-  __syncthreads();
-  const int total = s_rcum[kMaxRanges];
-  const int total_d = a.mixed ? s_dcum[15] : 0;
+  // ---- range set-up: waves 0, 1 = the 15 ranges of each full-width list, waves 2, 3 = of each base-channel list; running
+  // counts by wave scan (empty ranges stay in the tables with zero length: the record -> range walk skips them)
+  {
+    const int kind = tid >> 7, i = tid & 127;
+    int start = 0, cnt = 0;
+    if (tid < 256) {
+      const int nl = kind ? a.nnarrow : a.nwide;
+      if (i < kRangeEntries * nl) {
+        const int l = i / kRangeEntries;
+        brick_range_entry(a, kind ? a.narrow[l].offsets : a.wide[l].offsets, bx, by, bz, i - l * kRangeEntries, start, cnt);
+      }
+    }
+    int cum = cnt;
+#pragma unroll
+    for (int d = 1; d < kWave; d <<= 1) {
+      const int up = __shfl_up(cum, d);
+      if (lane >= d) cum += up;
+    }
+    if (wave < 4 && lane == kWave - 1) s_part[wave] = cum;
+    __syncthreads();
+    if (tid < 256) {
+      if (wave & 1) cum += s_part[wave - 1];
+      int* st_ = kind ? s_nstart : s_wstart;
+      int* cu_ = kind ? s_ncum : s_wcum;
+      if (i < kMaxRangesKind) {
+        st_[i] = start;
+        cu_[i + 1] = cum;
+      }
+      if (i == 0) cu_[0] = 0;
+    }
+    __syncthreads();
+  }
+  const int total = s_wcum[kMaxRangesKind];
+  const int total_d = s_ncum[kMaxRangesKind];
   const bool any = total > 0 || total_d > 0;
   if (!any && a.accumulate) return;  // nothing reaches this brick
   RF_PROF_MARK(0);  // range set-up
@@ -2025,16 +2040,21 @@ __global__ __launch_bounds__(kBrickThreads, 4) void brick_gather_kernel(GridArgs
     const int nba = (total + kGatherBatch - 1) / kGatherBatch, nbd = (total_d + kGatherBatch - 1) / kGatherBatch;
     // the weight table starts zero-filled; a record's thread clears the entries of the previous batch before it writes new ones
     for (int i = tid; i < kGatherRow * kGatherWtab / 4; i += kBrickThreads) reinterpret_cast<float4*>(wtab)[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+    __syncthreads();
     uint32_t wprev = 0x00ffffffu;  // the lower nodes (c + 1, one byte per axis) this thread's record of the previous batch had; 0xff = none
-    // -- bin the batch in LDS and multiply it into the tiles (WIDE: full-width records, else base-channel records)
-    auto process = [&](auto wide_tag, int nrec) {
-      constexpr bool WIDE = decltype(wide_tag)::value;
-      constexpr int RW = gather_record_words(WIDE ? Q : QD);  // words per record in LDS
-      constexpr int NTW = WIDE ? NT : 1;
-      // record pass (one thread per record): its column of the weight table and the set of tiles it touches
-      if (tid < kGatherBatch) {
+    const int rec_id = tid & (kGatherBatch - 1);  // this thread's record of every batch; the two threads of a record split its channels
+    const int half = tid >> 8;
+
+    // -- the thread's part of the record pass: the record's column of the weight table and the set of tiles it touches (first
+    // thread of the record), and its row of per-channel values.  A full-width record of an SH grid arrives COMPACT -- d density,
+    // d raw r, g, b and the unit viewing direction -- and is expanded here, d raw[colour] * Y_k(v) in the operation order of the
+    // reference's evaluate_spherical_harmonics, so that the expanded values never exist in HBM.
+    auto stage = [&](auto expand_tag, float4 q0, float4 q1, float4 q2, int nrec) {
+      constexpr bool EXPAND = decltype(expand_tag)::value;
+      constexpr int RW = gather_record_words(EXPAND ? C4 : 4);
+      if (half == 0) {
         uint32_t tm = 0, wnow = 0x00ffffffu;
-        float* wcol = wtab + tid;
+        float* wcol = wtab + rec_id;
 #pragma unroll
         for (int ax = 0; ax < 3; ++ax) {  // un-write the previous batch's entries (same thread, same column)
           const int c1 = (int)((wprev >> (8 * ax)) & 0xffu);  // c + 1
@@ -2043,8 +2063,7 @@ __global__ __launch_bounds__(kBrickThreads, 4) void brick_gather_kernel(GridArgs
             if (c1 < B) wcol[(ax * 8 + c1) * kGatherRow] = 0.0f;
           }
         }
-        if (tid < nrec) {
-          const float4 q0 = q0s[tid];
+        if (rec_id < nrec) {
           const float idx[3] = {q0.x, q0.y, q0.z};
           const int org[3] = {X0, Y0, Z0};
           uint32_t pb[3];
@@ -2075,8 +2094,32 @@ __global__ __launch_bounds__(kBrickThreads, 4) void brick_gather_kernel(GridArgs
             if ((pb[0] >> px) & 1u) tm |= yz << (px * npy * npz);
         }
         wprev = wnow;
-        s_tmask[tid] = tm;
+        s_tmask[rec_id] = tm;
       }
+      float* row = rows + rec_id * RW;
+      if constexpr (EXPAND) {
+        float Y[16];
+        sh_basis<K>(q1.w, q2.x, q2.y, Y);
+        const float graw[3] = {q1.x, q1.y, q1.z};
+        constexpr int NQ = C4 / 4, QH = (NQ + 1) / 2;  // quads of a row; the first thread of the record writes [0, QH)
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) {
+          if ((q < QH) == (half == 0)) {
+            float v[4];
+#pragma unroll
+            for (int x = 0; x < 4; ++x) v[x] = (4 * q + x < C) ? record_channel<K>(4 * q + x, q0.w, graw, Y) : 0.0f;
+            *reinterpret_cast<float4*>(row + 4 * q) = make_float4(v[0], v[1], v[2], v[3]);
+          }
+        }
+      } else {
+        if (half == 0) *reinterpret_cast<float4*>(row) = q1;
+      }
+    };
+    // -- bin the batch to the tiles it touches and multiply it into the tiles' accumulators (WIDE: rows of C4 channels, else 4)
+    auto process = [&](auto wide_tag) {
+      constexpr bool WIDE = decltype(wide_tag)::value;
+      constexpr int RW = gather_record_words(WIDE ? C4 : 4);  // words per row in LDS
+      constexpr int NTW = WIDE ? NT : 1;
       RF_PROF_MARK(7);  // record pass (thread 0's own work)
       __syncthreads();
       RF_PROF_MARK(2);  // ... and its barrier
@@ -2114,14 +2157,14 @@ __global__ __launch_bounds__(kBrickThreads, 4) void brick_gather_kernel(GridArgs
           const float* wx = wtab + (2 * px + mdx) * kGatherRow;
           const float* wy = wtab + (8 + 2 * py + mdy) * kGatherRow;
           const float* wz = wtab + (16 + 4 * pz + mdz) * kGatherRow;
-          const float* gbase = reinterpret_cast<const float*>(recs + 1) + (WIDE ? jj : (jj & 3));  // (base-channel records: lanes 4..15 re-read channels 0..3)
+          const float* gbase = rows + (WIDE ? jj : (jj & 3));  // (base-channel rows: lanes 4..15 re-read channels 0..3)
           // software pipeline: the record index of instruction q + 2 and the operands of instruction q + 1 are requested before
           // instruction q is issued; an iteration waits once, at its top, for requests that are a whole iteration old
           const uint32_t a_list = lds_offset(s_list[t]) + kk;
           const uint32_t a_x = lds_offset(wx), a_y = lds_offset(wy), a_z = lds_offset(wz), a_g = lds_offset(gbase);
           const int nq = (n + 3) >> 2;
           // two register sets (A: even instructions, B: odd ones), no rotation copies.  WIDE: channels >= C4 of the second block
-          // read into the next record; those accumulator columns are never stored
+          // read into the row's padding / the next row; those accumulator columns are never stored
           uint32_t ra = 0, rb = 0;
           float aw0 = 0.f, aw1 = 0.f, aw2 = 0.f, ag0 = 0.f, ag1 = 0.f, bw0 = 0.f, bw1 = 0.f, bw2 = 0.f, bg0 = 0.f, bg1 = 0.f;
           auto request_ops = [&](float& w0, float& w1, float& w2, float& g0, float& g1, uint32_t r) {
@@ -2162,76 +2205,66 @@ __global__ __launch_bounds__(kBrickThreads, 4) void brick_gather_kernel(GridArgs
       __syncthreads();
       RF_PROF_MARK(2);
     };
-    using Wide = std::integral_constant<bool, true>;
-    using Narrow = std::integral_constant<bool, false>;
+    using Yes = std::integral_constant<bool, true>;
+    using No = std::integral_constant<bool, false>;
 
-    // global loads of a batch into registers, issued one batch ahead of their use (always unconditional and clamped, with their
-    // own registers per list kind: a conditionally assigned register is merged with a copy, and the copy waits for the load)
-    int sri = 0, dri = 0;  // running range index of this thread (the records it fetches only move forward), its bounds cached
-    int rlo = 0, rhi = 0, dlo = 0, dhi = 0;  // in quads of the concatenated list
-    const float4* rptr = a.lists[0].rec;     // list base + (start of the range - its position in the concatenation)
-    const float4* dptr = a.lists[1].rec;
-    float4 pre[PRE], pred = make_float4(0.f, 0.f, 0.f, 0.f);
-#pragma unroll
-    for (int u = 0; u < PRE; ++u) pre[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+    // global loads of a batch straight into registers -- every thread the quads of ITS record (the two threads of a record
+    // both: the second copy is an L1 hit) --, issued one batch ahead of their use; always unconditional and clamped, with their
+    // own registers per list kind (a conditionally assigned register is merged with a copy, and the copy waits for the load)
+    int sri = 0, dri = 0;  // running range index of this thread (its records only move forward), the range's bounds cached
+    int rlo = 0, rhi = 0, dlo = 0, dhi = 0;
+    const float4* rptr = a.wide[0].rec;    // list base + (start of the range - its position in the concatenation)
+    const float4* dptr = a.narrow[0].rec;
+    float4 w0 = make_float4(0.f, 0.f, 0.f, 0.f), w1 = w0, w2 = w0, d0 = w0, d1 = w0;
     auto fetch_wide = [&](int s) {
-      const int nq = min(kGatherBatch, total - s * kGatherBatch) * Q;
-#pragma unroll
-      for (int u = 0; u < PRE; ++u) {
-        const int qi = s * (kGatherBatch * Q) + min(tid + u * kBrickThreads, nq - 1);  // quad of the concatenated list
-        if (qi < rlo || qi >= rhi) {  // rare: the range of the previous quad no longer holds this one
-          const int v = qi / Q;
-          while (s_rcum[sri] > v) --sri;  // (only when the last batch is fetched a second time)
-          while (s_rcum[sri + 1] <= v) ++sri;
-          rlo = s_rcum[sri] * Q;
-          rhi = s_rcum[sri + 1] * Q;
-          rptr = (s_rlist[sri] ? a.lists[1].rec : a.lists[0].rec) + (s_rstart[sri] * Q - rlo);
-        }
-        pre[u] = rptr[qi];
+      const int nrec = min(kGatherBatch, total - s * kGatherBatch);
+      const int v = s * kGatherBatch + min(rec_id, nrec - 1);  // record of the concatenated ranges
+      if (v < rlo || v >= rhi) {  // the range of the previous batch's record no longer holds this one
+        while (s_wcum[sri] > v) --sri;  // (only when the last batch is fetched a second time)
+        while (s_wcum[sri + 1] <= v) ++sri;
+        rlo = s_wcum[sri];
+        rhi = s_wcum[sri + 1];
+        rptr = a.wide[sri / kRangeEntries].rec + (long long)(s_wstart[sri] - rlo) * QW;
       }
+      const float4* p = rptr + (long long)v * QW;
+      w0 = p[0];
+      w1 = p[1];
+      if constexpr (QW > 2) w2 = p[2];
     };
     auto fetch_narrow = [&](int sd) {
-      const int nq = min(kGatherBatch, total_d - sd * kGatherBatch) * QD;
-      const int qi = sd * (kGatherBatch * QD) + min(tid, nq - 1);
-      if (qi < dlo || qi >= dhi) {
-        const int v = qi / QD;
-        while (s_dcum[dri] > v) --dri;
-        while (s_dcum[dri + 1] <= v) ++dri;
-        dlo = s_dcum[dri] * QD;
-        dhi = s_dcum[dri + 1] * QD;
-        dptr = a.lists[1].rec + (s_dstart[dri] * QD - dlo);
+      const int nrec = min(kGatherBatch, total_d - sd * kGatherBatch);
+      const int v = sd * kGatherBatch + min(rec_id, nrec - 1);
+      if (v < dlo || v >= dhi) {
+        while (s_ncum[dri] > v) --dri;
+        while (s_ncum[dri + 1] <= v) ++dri;
+        dlo = s_ncum[dri];
+        dhi = s_ncum[dri + 1];
+        dptr = a.narrow[dri / kRangeEntries].rec + (long long)(s_nstart[dri] - dlo) * QN;
       }
-      pred = dptr[qi];
+      const float4* p = dptr + (long long)v * QN;
+      d0 = p[0];
+      d1 = p[1];
     };
     if (nbd > 0) fetch_narrow(0);
     if (nba > 0) fetch_wide(0);
     for (int s = 0; s < nba; ++s) {
       const int nrec = min(kGatherBatch, total - s * kGatherBatch);
-#pragma unroll
-      for (int u = 0; u < PRE; ++u) {
-        const int i = tid + u * kBrickThreads;
-        if (i < nrec * Q) {
-          recs[(i / Q) * (Q + 1) + i % Q] = pre[u];
-          if (i % Q == 0) q0s[i / Q] = pre[u];
-        }
-      }
-      __syncthreads();
-      RF_PROF_MARK(1);  // waiting for the batch's loads, LDS stores
+      if constexpr (K > 1)
+        stage(Yes{}, w0, w1, w2, nrec);
+      else
+        stage(No{}, w0, w1, w2, nrec);
+      RF_PROF_MARK(1);  // waiting for the batch's loads, record pass
       fetch_wide(min(s + 1, nba - 1));  // (the last batch again at the end: cheaper than a conditional)
       RF_PROF_MARK(6);  // issuing the next batch's loads
-      process(Wide{}, nrec);
+      process(Yes{});
     }
     for (int sd = 0; sd < nbd; ++sd) {
       const int nrec = min(kGatherBatch, total_d - sd * kGatherBatch);
-      if (tid < nrec * QD) {
-        recs[(tid / QD) * (QD + 1) + tid % QD] = pred;
-        if (tid % QD == 0) q0s[tid / QD] = pred;
-      }
-      __syncthreads();
+      stage(No{}, d0, d1, d1, nrec);
       RF_PROF_MARK(1);
       fetch_narrow(min(sd + 1, nbd - 1));
       RF_PROF_MARK(6);
-      process(Narrow{}, nrec);
+      process(No{});
     }
     // -- the accumulator image for the flush (the batch buffers are dead).  Accumulator register e of a lane: node row
     // 4 (lane >> 4) + e of the tile, channel 16 nt + (lane & 15)
@@ -2882,6 +2915,7 @@ OutArgs to_args(const RFRenderOut* o) {
   a.disparity = o->disparity_dev;
   a.cache = o->sample_cache_dev;
   a.tcache = o->trans_cache_dev;
+  a.cmask = reinterpret_cast<unsigned long long*>(o->chunk_mask_dev);
   a.stop = o->stop_cache_dev;
   a.hist = nullptr;
   a.brick_shift = 0;
@@ -3061,7 +3095,7 @@ int rf_render_forward(const RFGrid* grid, const RFRayBatch* rays, uint32_t flags
   if (rays->num_rays == 0) return RF_OK;
   if (!out->colour_dev || !out->depth_dev || !out->acc_dev || !out->disparity_dev) return RF_ERR_NULL_POINTER;
   const bool save = out->sample_cache_dev != nullptr;
-  if (save && (!out->trans_cache_dev || !out->stop_cache_dev)) return RF_ERR_NULL_POINTER;
+  if (save && (!out->trans_cache_dev || !out->stop_cache_dev || !out->chunk_mask_dev)) return RF_ERR_NULL_POINTER;
   if ((flags & RF_FLAG_OCCUPANCY_SKIP) && !grid->occupancy_dev) return RF_ERR_NULL_POINTER;
 
   const GridArgs g = to_args(grid);
@@ -3100,7 +3134,7 @@ static int backward_impl(const RFGrid* grid, const RFRayBatch* rays, uint32_t fl
   if (rc != RF_OK) return rc;
   if (!fwd || !grads) return RF_ERR_NULL_POINTER;
   if (rays->num_rays == 0) return RF_OK;
-  if (!fwd->sample_cache_dev || !fwd->trans_cache_dev || !fwd->stop_cache_dev) return RF_ERR_NULL_POINTER;
+  if (!fwd->sample_cache_dev || !fwd->trans_cache_dev || !fwd->stop_cache_dev || !fwd->chunk_mask_dev) return RF_ERR_NULL_POINTER;
   const GridArgs g = to_args(grid);
   const RayArgs r = to_args(rays, flags);
   const OutArgs o = to_args(fwd);
@@ -3135,7 +3169,7 @@ int rf_render_backward(const RFGrid* grid, const RFRayBatch* rays, uint32_t flag
 
 int rf_render_backward_emit(const RFGrid* grid, const RFRayBatch* rays, uint32_t flags, const RFRenderOut* fwd,
                             const RFRenderGrads* grads, int32_t brick_size, int16_t* keys_dev, float* records_dev,
-                            float* ray_basis_dev, int32_t* hist_dev, void* stream) {
+                            int32_t* hist_dev, void* stream) {
   if (!grid) return RF_ERR_NULL_POINTER;
   if (!keys_dev || !records_dev) return RF_ERR_NULL_POINTER;
   int shift, nb[3];
@@ -3144,7 +3178,6 @@ int rf_render_backward_emit(const RFGrid* grid, const RFRayBatch* rays, uint32_t
   GradArgs gr = {};
   gr.keys = keys_dev;
   gr.records = records_dev;
-  gr.ray_basis = ray_basis_dev;
   gr.brick_shift = shift;
   gr.nby = nb[1];
   gr.nbz = nb[2];
@@ -3173,20 +3206,17 @@ int rf_render_backward_emit_direct(const RFGrid* grid, const RFRayBatch* rays, u
 }
 
 extern "C++" {
-template <int K>
-static int launch_expand(const float* records_dev, const int64_t* perm_dev, const int64_t* begin_dev, int64_t capacity,
-                         const float* ray_basis_dev, int diffuse, float rho, float* out, hipStream_t st) {
-  hipLaunchKernelGGL((expand_records_kernel<K>), dim3(grid_1d(capacity * record_quads(K), 256, 256LL * 16)), dim3(256), 0, st,
+template <int Q>
+static int launch_expand(const float* records_dev, const int64_t* perm_dev, const int64_t* begin_dev, int64_t capacity, float* out, hipStream_t st) {
+  hipLaunchKernelGGL((expand_records_kernel<Q>), dim3(grid_1d(capacity * Q, 256, 256LL * 16)), dim3(256), 0, st,
                      reinterpret_cast<const float4*>(records_dev), reinterpret_cast<const long long*>(perm_dev),
-                     reinterpret_cast<const long long*>(begin_dev), (long long)capacity, ray_basis_dev, diffuse, rho,
-                     reinterpret_cast<float4*>(out));
+                     reinterpret_cast<const long long*>(begin_dev), (long long)capacity, reinterpret_cast<float4*>(out));
   return launch_status();
 }
 }  // extern "C++"
 
 int rf_expand_records(const RFGrid* grid, const float* records_dev, const int64_t* perm_dev, const int64_t* begin_dev,
-                      int64_t capacity, const float* ray_basis_dev, int32_t render_diffuse, float* records_sorted_dev,
-                      void* stream) {
+                      int64_t capacity, int32_t render_diffuse, float* records_sorted_dev, void* stream) {
   const int rc = check_grid(grid);
   if (rc != RF_OK) return rc;
   if (capacity == 0) return RF_OK;
@@ -3194,16 +3224,9 @@ int rf_expand_records(const RFGrid* grid, const float* records_dev, const int64_
   if (capacity < 0) return RF_ERR_BAD_SHAPE;
   if (grid->num_features > 27) return RF_ERR_UNSUPPORTED;
   const int diffuse = render_diffuse || grid->num_features == 3;
-  if (!diffuse && !ray_basis_dev) return RF_ERR_NULL_POINTER;
   hipStream_t st = (hipStream_t)stream;
-  switch (diffuse ? 1 : grid->num_features / 3) {  // diffuse lists carry the 4 base channels only
-    case 1:
-      return launch_expand<1>(records_dev, perm_dev, begin_dev, capacity, ray_basis_dev, diffuse, grid->density_scale, records_sorted_dev, st);
-    case 4:
-      return launch_expand<4>(records_dev, perm_dev, begin_dev, capacity, ray_basis_dev, diffuse, grid->density_scale, records_sorted_dev, st);
-    default:
-      return launch_expand<9>(records_dev, perm_dev, begin_dev, capacity, ray_basis_dev, diffuse, grid->density_scale, records_sorted_dev, st);
-  }
+  if (diffuse) return launch_expand<2>(records_dev, perm_dev, begin_dev, capacity, records_sorted_dev, st);  // base-channel records
+  return launch_expand<3>(records_dev, perm_dev, begin_dev, capacity, records_sorted_dev, st);
 }
 
 static int bin_offsets_impl(const int32_t* const hist[2], int64_t* const offsets[2], int32_t* const cursor[2], int nlists, int32_t num_keys,
@@ -3228,20 +3251,18 @@ int rf_bin_offsets(const int32_t* hist_dev, int32_t num_keys, int64_t* offsets_d
 }
 
 extern "C++" {
-template <int K>
-static int launch_scatter(const int16_t* keys_dev, const float* records_dev, int64_t capacity, int32_t* cursor_dev,
-                          const float* ray_basis_dev, int diffuse, float rho, float* out, int32_t* hist_dev, int nkeys,
-                          hipStream_t st) {
-  hipLaunchKernelGGL((scatter_records_kernel<K>), dim3((unsigned)((capacity + 1023) / 1024)), dim3(256), 0, st, keys_dev,
-                     reinterpret_cast<const float4*>(records_dev), (long long)capacity, cursor_dev, ray_basis_dev, diffuse, rho,
-                     reinterpret_cast<float4*>(out), hist_dev, nkeys);
+template <int Q>
+static int launch_scatter(const int16_t* keys_dev, const float* records_dev, int64_t capacity, int32_t* cursor_dev, float* out,
+                          int32_t* hist_dev, int nkeys, hipStream_t st) {
+  hipLaunchKernelGGL((scatter_records_kernel<Q>), dim3((unsigned)((capacity + 1023) / 1024)), dim3(256), 0, st, keys_dev,
+                     reinterpret_cast<const float4*>(records_dev), (long long)capacity, cursor_dev, reinterpret_cast<float4*>(out), hist_dev, nkeys);
   return launch_status();
 }
 }  // extern "C++"
 
 int rf_scatter_records(const RFGrid* grid, const int16_t* keys_dev, const float* records_dev, int64_t capacity,
-                       int32_t* cursor_dev, const float* ray_basis_dev, int32_t render_diffuse, float* records_sorted_dev,
-                       int32_t* hist_dev, int32_t num_keys, void* stream) {
+                       int32_t* cursor_dev, int32_t render_diffuse, float* records_sorted_dev, int32_t* hist_dev, int32_t num_keys,
+                       void* stream) {
   const int rc = check_grid(grid);
   if (rc != RF_OK) return rc;
   if (capacity == 0) return RF_OK;
@@ -3249,16 +3270,9 @@ int rf_scatter_records(const RFGrid* grid, const int16_t* keys_dev, const float*
   if (capacity < 0) return RF_ERR_BAD_SHAPE;
   if (grid->num_features > 27) return RF_ERR_UNSUPPORTED;
   const int diffuse = render_diffuse || grid->num_features == 3;
-  if (!diffuse && !ray_basis_dev) return RF_ERR_NULL_POINTER;
   hipStream_t st = (hipStream_t)stream;
-  switch (diffuse ? 1 : grid->num_features / 3) {  // diffuse lists carry the 4 base channels only
-    case 1:
-      return launch_scatter<1>(keys_dev, records_dev, capacity, cursor_dev, ray_basis_dev, diffuse, grid->density_scale, records_sorted_dev, hist_dev, num_keys, st);
-    case 4:
-      return launch_scatter<4>(keys_dev, records_dev, capacity, cursor_dev, ray_basis_dev, diffuse, grid->density_scale, records_sorted_dev, hist_dev, num_keys, st);
-    default:
-      return launch_scatter<9>(keys_dev, records_dev, capacity, cursor_dev, ray_basis_dev, diffuse, grid->density_scale, records_sorted_dev, hist_dev, num_keys, st);
-  }
+  if (diffuse) return launch_scatter<2>(keys_dev, records_dev, capacity, cursor_dev, records_sorted_dev, hist_dev, num_keys, st);
+  return launch_scatter<3>(keys_dev, records_dev, capacity, cursor_dev, records_sorted_dev, hist_dev, num_keys, st);
 }
 
 int32_t rf_expanded_record_floats(int32_t num_features) { return 4 * record_quads(num_features / 3); }
@@ -3267,7 +3281,7 @@ extern "C++" {
 template <int K, bool ADAM>
 static int launch_gather(const GridArgs& g, const BrickArgs& a, int nbricks, float* gd, float* gf, hipStream_t st) {
   const int B = 1 << a.shift;
-  const size_t lds = (size_t)gather_lds_words(B, 3 * K + 1, record_quads(K)) * sizeof(float);
+  const size_t lds = (size_t)gather_lds_words(B, 3 * K + 1) * sizeof(float);
   if (lds > 150 * 1024) return RF_ERR_UNSUPPORTED;
   static std::atomic<size_t> configured[64];
   int dev = 0;
@@ -3283,9 +3297,32 @@ static int launch_gather(const GridArgs& g, const BrickArgs& a, int nbricks, flo
 }
 }  // extern "C++"
 
+// what the optimizer in the brick flush needs of the grid and the state (checked before anything is launched)
+static int check_fused_adam(const RFGrid* grid, const RFAdamState* adam, int K, bool base_only) {
+  // the update needs the complete gradient of every parameter in the owning workgroup: all channels covered by the lists
+  // (base-only lists on an SH grid leave the higher-degree channels to someone else), whole float4s, overwrite semantics
+  const int C = 3 * K + 1;
+  if (grid->layout == RF_LAYOUT_REFERENCE || (C & 3) || (base_only && grid->num_features != 3)) return RF_ERR_UNSUPPORTED;
+  if ((grid->density_stride & 3) || (C > 4 && (grid->feature_stride & 3))) return RF_ERR_UNSUPPORTED;
+  if (!adam->param_first_dev || !adam->exp_avg_first_dev || !adam->exp_avg_sq_first_dev) return RF_ERR_NULL_POINTER;
+  if (C > 4 && (!adam->param_second_dev || !adam->exp_avg_second_dev || !adam->exp_avg_sq_second_dev)) return RF_ERR_NULL_POINTER;
+  if (adam->param_first_dev != grid->densities_dev || (C > 4 && adam->param_second_dev != grid->features_dev)) return RF_ERR_BAD_SHAPE;
+  if (adam->step < 1) return RF_ERR_BAD_SHAPE;
+  {  // the flush keeps element offsets in 31 bits
+    unsigned long long nodes = 1;
+    for (int ax = 0; ax < 3; ++ax) nodes *= (unsigned long long)((grid->dims[ax] + 7) / 8 * 8);
+    const unsigned long long smax = (unsigned long long)(grid->density_stride > grid->feature_stride ? grid->density_stride : grid->feature_stride);
+    if (nodes * smax >= (1ull << 31)) return RF_ERR_UNSUPPORTED;
+  }
+  const uintptr_t align = (uintptr_t)adam->param_first_dev | (uintptr_t)adam->exp_avg_first_dev | (uintptr_t)adam->exp_avg_sq_first_dev |
+                          (C > 4 ? ((uintptr_t)adam->param_second_dev | (uintptr_t)adam->exp_avg_second_dev | (uintptr_t)adam->exp_avg_sq_second_dev) : 0);
+  if (align & 15u) return RF_ERR_BAD_SHAPE;
+  return RF_OK;
+}
+
 static int brick_accumulate_impl(const RFGrid* grid, int32_t brick_size, const RFBrickList* lists, int32_t num_lists,
                                  float* grad_densities_dev, float* grad_features_dev, int32_t accumulate,
-                                 const RFAdamState* adam, void* stream) {
+                                 const RFAdamState* adam, int32_t first_brick, int32_t num_bricks, void* stream) {
   int rc = check_grid(grid);
   if (rc != RF_OK) return rc;
   if (!lists) return RF_ERR_NULL_POINTER;
@@ -3293,23 +3330,31 @@ static int brick_accumulate_impl(const RFGrid* grid, int32_t brick_size, const R
     if (!grad_densities_dev) return RF_ERR_NULL_POINTER;
     if (!grad_features_dev && !(grid->layout != RF_LAYOUT_REFERENCE && grid->num_features == 3)) return RF_ERR_NULL_POINTER;
   }
-  if (num_lists < 1 || num_lists > 2) return RF_ERR_BAD_SHAPE;
+  if (num_lists < 1 || num_lists > 2 * kMaxListsPerKind) return RF_ERR_BAD_SHAPE;
   if (grid->num_features > 27) return RF_ERR_UNSUPPORTED;  // the accumulators of a brick must fit the LDS (SH degree <= 2)
   int shift, nb[3];
   rc = brick_geometry(grid, brick_size, &shift, nb, false);
   if (rc != RF_OK) return rc;
+  // lists: the full-width ones first, then the base-channel lists of render_diffuse passes (on a degree-0 grid, or when every list
+  // is a render_diffuse list, there is one kind only and the pass runs on the 4 base channels)
   BrickArgs a = {};
-  a.nlists = num_lists;
+  int ndiffuse = 0;
   for (int i = 0; i < num_lists; ++i) {
     if (!lists[i].records_sorted_dev || !lists[i].offsets_dev) return RF_ERR_NULL_POINTER;
-    a.lists[i].rec = reinterpret_cast<const float4*>(lists[i].records_sorted_dev);
-    a.lists[i].offsets = reinterpret_cast<const long long*>(lists[i].offsets_dev);
-    a.lists[i].diffuse = lists[i].render_diffuse || grid->num_features == 3;
+    const bool diffuse = lists[i].render_diffuse || grid->num_features == 3;
+    if (!diffuse && ndiffuse) return RF_ERR_BAD_SHAPE;  // the specular lists come first
+    ndiffuse += diffuse;
   }
-  // two lists: either the same kind (one concatenated full-width list) or (specular, diffuse) = a mixed call
-  a.mixed = num_lists == 2 && !a.lists[0].diffuse && a.lists[1].diffuse;
-  if (num_lists == 2 && a.lists[0].diffuse && !a.lists[1].diffuse) return RF_ERR_BAD_SHAPE;  // the specular list comes first
-  const int base_only = a.lists[0].diffuse;  // 4 accumulator channels per node, written to the base channels only
+  const bool base_only = ndiffuse == num_lists;  // 4 accumulator channels per node, written to the base channels only
+  for (int i = 0; i < num_lists; ++i) {
+    const bool narrow = !base_only && (lists[i].render_diffuse != 0);
+    int& n = narrow ? a.nnarrow : a.nwide;
+    if (n >= kMaxListsPerKind) return RF_ERR_BAD_SHAPE;
+    BrickList& dst = narrow ? a.narrow[n] : a.wide[n];
+    dst.rec = reinterpret_cast<const float4*>(lists[i].records_sorted_dev);
+    dst.offsets = reinterpret_cast<const long long*>(lists[i].offsets_dev);
+    ++n;
+  }
   a.fmul = base_only ? grid->num_features / 3 : 1;
   a.shift = shift;
   a.nbx = nb[0];
@@ -3317,28 +3362,17 @@ static int brick_accumulate_impl(const RFGrid* grid, int32_t brick_size, const R
   a.nbz = nb[2];
   a.accumulate = accumulate;
   const GridArgs g = to_args(grid);
-  const int nbricks = nb[0] * nb[1] * nb[2];
+  const int all_bricks = nb[0] * nb[1] * nb[2];
+  if (first_brick < 0 || num_bricks < 0 || first_brick + num_bricks > all_bricks) return RF_ERR_BAD_SHAPE;
+  const int nbricks = num_bricks > 0 ? num_bricks : all_bricks - first_brick;
+  a.brick_first = first_brick;
+  if (nbricks == 0) return RF_OK;
   hipStream_t st = (hipStream_t)stream;
   const int K = base_only ? 1 : grid->num_features / 3;
   if (adam) {
-    // the update needs the complete gradient of every parameter in the owning workgroup: all channels covered by the lists
-    // (base-only lists on an SH grid leave the higher-degree channels to someone else), whole float4s, overwrite semantics
-    const int C = 3 * K + 1;
-    if (accumulate || grid->layout == RF_LAYOUT_REFERENCE || (C & 3) || (base_only && grid->num_features != 3)) return RF_ERR_UNSUPPORTED;
-    if ((grid->density_stride & 3) || (C > 4 && (grid->feature_stride & 3))) return RF_ERR_UNSUPPORTED;
-    if (!adam->param_first_dev || !adam->exp_avg_first_dev || !adam->exp_avg_sq_first_dev) return RF_ERR_NULL_POINTER;
-    if (C > 4 && (!adam->param_second_dev || !adam->exp_avg_second_dev || !adam->exp_avg_sq_second_dev)) return RF_ERR_NULL_POINTER;
-    if (adam->param_first_dev != grid->densities_dev || (C > 4 && adam->param_second_dev != grid->features_dev)) return RF_ERR_BAD_SHAPE;
-    if (adam->step < 1) return RF_ERR_BAD_SHAPE;
-    {  // the flush keeps element offsets in 31 bits
-      unsigned long long nodes = 1;
-      for (int ax = 0; ax < 3; ++ax) nodes *= (unsigned long long)((grid->dims[ax] + 7) / 8 * 8);
-      const unsigned long long smax = (unsigned long long)(grid->density_stride > grid->feature_stride ? grid->density_stride : grid->feature_stride);
-      if (nodes * smax >= (1ull << 31)) return RF_ERR_UNSUPPORTED;
-    }
-    const uintptr_t align = (uintptr_t)adam->param_first_dev | (uintptr_t)adam->exp_avg_first_dev | (uintptr_t)adam->exp_avg_sq_first_dev |
-                            (C > 4 ? ((uintptr_t)adam->param_second_dev | (uintptr_t)adam->exp_avg_second_dev | (uintptr_t)adam->exp_avg_sq_second_dev) : 0);
-    if (align & 15u) return RF_ERR_BAD_SHAPE;
+    if (accumulate) return RF_ERR_UNSUPPORTED;
+    rc = check_fused_adam(grid, adam, K, base_only);
+    if (rc != RF_OK) return rc;
     const double bc1 = 1.0 - pow((double)adam->beta1, (double)adam->step);
     const double bc2 = 1.0 - pow((double)adam->beta2, (double)adam->step);
     a.adam.p1 = adam->param_first_dev;
@@ -3377,13 +3411,20 @@ static int brick_accumulate_impl(const RFGrid* grid, int32_t brick_size, const R
 
 int rf_brick_accumulate(const RFGrid* grid, int32_t brick_size, const RFBrickList* lists, int32_t num_lists,
                         float* grad_densities_dev, float* grad_features_dev, int32_t accumulate, void* stream) {
-  return brick_accumulate_impl(grid, brick_size, lists, num_lists, grad_densities_dev, grad_features_dev, accumulate, nullptr, stream);
+  return brick_accumulate_impl(grid, brick_size, lists, num_lists, grad_densities_dev, grad_features_dev, accumulate, nullptr, 0, 0, stream);
 }
 
 int rf_brick_accumulate_adam(const RFGrid* grid, int32_t brick_size, const RFBrickList* lists, int32_t num_lists,
                              const RFAdamState* adam, void* stream) {
   if (!adam) return RF_ERR_NULL_POINTER;
-  return brick_accumulate_impl(grid, brick_size, lists, num_lists, nullptr, nullptr, 0, adam, stream);
+  return brick_accumulate_impl(grid, brick_size, lists, num_lists, nullptr, nullptr, 0, adam, 0, 0, stream);
+}
+
+int rf_brick_accumulate_adam_range(const RFGrid* grid, int32_t brick_size, const RFBrickList* lists, int32_t num_lists,
+                                   const RFAdamState* adam, int32_t first_brick, int32_t num_bricks, void* stream) {
+  if (!adam) return RF_ERR_NULL_POINTER;
+  if (num_bricks < 1) return num_bricks == 0 ? RF_OK : RF_ERR_BAD_SHAPE;
+  return brick_accumulate_impl(grid, brick_size, lists, num_lists, nullptr, nullptr, 0, adam, first_brick, num_bricks, stream);
 }
 
 int rf_grid_query(const RFGrid* grid, const float* points_dev, int64_t num_points, float* out_dev, void* stream) {
@@ -3498,26 +3539,27 @@ int rf_train_step(const RFGrid* grid, const RFTrainStep* step, void* stream) {
   if (rc != RF_OK) return rc;
   if (step->pass[1].out.brick_size != step->pass[0].out.brick_size) return RF_ERR_BAD_SHAPE;
   const int nkeys = nb[0] * nb[1] * nb[2] * 8;
+  if (nkeys > (1 << 21)) return RF_ERR_BAD_SHAPE;
+  const bool run_front = step->phases == 0 || (step->phases & RF_STEP_FRONT), run_bricks = step->phases == 0 || (step->phases & RF_STEP_BRICKS);
+  if (run_bricks) {  // everything the last launch would refuse is refused before the first one
+    if (step->adam) {
+      rc = check_fused_adam(grid, step->adam, grid->num_features / 3, false);
+      if (rc != RF_OK) return rc;
+    } else if (!step->grad_first_dev || (!step->grad_second_dev && !(grid->layout != RF_LAYOUT_REFERENCE && grid->num_features == 3))) {
+      return RF_ERR_NULL_POINTER;
+    }
+    if (grid->num_features > 27) return RF_ERR_UNSUPPORTED;
+  }
+  const float loss_scale = step->loss_scale != 0.0f ? step->loss_scale : 1.0f;
   hipStream_t st = (hipStream_t)stream;
   int ev = 0;
 #define RF_STEP_EVENT()                                                                                      \
   do {                                                                                                       \
-    if (step->timing_events && hipEventRecord((hipEvent_t)step->timing_events[ev++], st) != hipSuccess) return RF_ERR_LAUNCH; \
+    if (events && hipEventRecord((hipEvent_t)events[ev++], st) != hipSuccess) return RF_ERR_LAUNCH; \
   } while (0)
-  RF_STEP_EVENT();
-  if (step->select) {
-    const RFRaySelection* s = step->select;
-    rc = select_impl(s->height, s->width, s->focal, s->poses_dev, s->image_ids_dev, s->num_batch_images, s->pixel_table_dev, s->key,
-                     s->first_index, step->num_rays, step->origins_dev, step->directions_dev, step->pixels_dev, nullptr,
-                     step->loss_sums_dev /* cleared by the same launch */, stream);
-    if (rc != RF_OK) return rc;
-  } else if (hipMemsetAsync(step->loss_sums_dev, 0, 4 * sizeof(float), st) != hipSuccess) {
-    return RF_ERR_LAUNCH;
-  }
-  RF_STEP_EVENT();
+  void* const* events = (run_front && run_bricks) ? step->timing_events : nullptr;  // (the per-launch events describe the whole iteration)
   RFRayBatch rays[2];
   uint32_t flags[2];
-  RFRenderGrads grads[2];
   for (int i = 0; i < 2; ++i) {
     const RFPassScratch& ps = step->pass[i];
     rays[i] = RFRayBatch{};
@@ -3530,48 +3572,67 @@ int rf_train_step(const RFGrid* grid, const RFTrainStep* step, void* stream) {
     rays[i].t_vals_dev = step->t_vals_dev;
     rays[i].t_rand_dev = ps.t_rand_dev;
     rays[i].jitter_key = ps.jitter_key;
+    rays[i].first_ray = step->first_ray;
     flags[i] = (step->flags & ~(uint32_t)RF_FLAG_RENDER_DIFFUSE) | (i == 1 ? (uint32_t)RF_FLAG_RENDER_DIFFUSE : 0u);
-    rc = rf_render_forward(grid, &rays[i], flags[i], &ps.out, stream);
-    if (rc != RF_OK) return rc;
+  }
+  if (run_front) {
     RF_STEP_EVENT();
-    if (i == 1) {  // the losses of both renders and the offsets of both record lists in one launch
-      L1Sets sets = {};
-      BinLists bl = {};
-      for (int k = 0; k < 2; ++k) {
-        sets.colour[k] = step->pass[k].out.colour_dev;
-        sets.grad[k] = step->pass[k].grad_colour_dev;
-        sets.sums[k] = step->loss_sums_dev + 2 * k;
-        bl.hist[k] = step->pass[k].out.key_hist_dev;
-        bl.offsets[k] = reinterpret_cast<long long*>(step->pass[k].offsets_dev);
-        bl.cursor[k] = step->pass[k].cursor_dev;
-      }
-      if (nkeys > (1 << 21)) return RF_ERR_BAD_SHAPE;
-      const long long n3 = (long long)step->num_rays * 3;
-      const int loss_blocks = (int)grid_1d(n3, 1024 * 2, 64), offset_blocks = (nkeys + 1023) / 1024;
-      hipLaunchKernelGGL(loss_and_offsets_kernel, dim3(loss_blocks > offset_blocks ? loss_blocks : offset_blocks, 4), dim3(1024), 0, st, sets,
-                         step->pixels_dev, n3, 1.0f / (float)n3, loss_blocks, bl, nkeys, offset_blocks);
-      rc = launch_status();
+    if (step->select) {
+      const RFRaySelection* s = step->select;
+      rc = select_impl(s->height, s->width, s->focal, s->poses_dev, s->image_ids_dev, s->num_batch_images, s->pixel_table_dev, s->key,
+                       s->first_index, step->num_rays, step->origins_dev, step->directions_dev, step->pixels_dev, nullptr,
+                       step->loss_sums_dev /* cleared by the same launch */, stream);
       if (rc != RF_OK) return rc;
+    } else if (hipMemsetAsync(step->loss_sums_dev, 0, 4 * sizeof(float), st) != hipSuccess) {
+      return RF_ERR_LAUNCH;
     }
     RF_STEP_EVENT();
-    grads[i] = RFRenderGrads{ps.grad_colour_dev, nullptr, nullptr};
+    RFRenderGrads grads[2];
+    for (int i = 0; i < 2; ++i) {
+      const RFPassScratch& ps = step->pass[i];
+      rc = rf_render_forward(grid, &rays[i], flags[i], &ps.out, stream);
+      if (rc != RF_OK) return rc;
+      RF_STEP_EVENT();
+      if (i == 1) {  // the losses of both renders and the offsets of both record lists in one launch
+        L1Sets sets = {};
+        BinLists bl = {};
+        for (int k = 0; k < 2; ++k) {
+          sets.colour[k] = step->pass[k].out.colour_dev;
+          sets.grad[k] = step->pass[k].grad_colour_dev;
+          sets.sums[k] = step->loss_sums_dev + 2 * k;
+          bl.hist[k] = step->pass[k].out.key_hist_dev;
+          bl.offsets[k] = reinterpret_cast<long long*>(step->pass[k].offsets_dev);
+          bl.cursor[k] = step->pass[k].cursor_dev;
+        }
+        const long long n3 = (long long)step->num_rays * 3;
+        const int loss_blocks = (int)grid_1d(n3, 1024 * 2, 64), offset_blocks = (nkeys + 1023) / 1024;
+        hipLaunchKernelGGL(loss_and_offsets_kernel, dim3(loss_blocks > offset_blocks ? loss_blocks : offset_blocks, 4), dim3(1024), 0, st, sets,
+                           step->pixels_dev, n3, loss_scale / (float)n3, loss_blocks, bl, nkeys, offset_blocks);
+        rc = launch_status();
+        if (rc != RF_OK) return rc;
+      }
+      RF_STEP_EVENT();
+      grads[i] = RFRenderGrads{ps.grad_colour_dev, nullptr, nullptr};
+    }
+    for (int i = 0; i < 2; ++i) {
+      const RFPassScratch& ps = step->pass[i];
+      RF_STEP_EVENT();  // (offsets[0] = the launch above, offsets[1] = nothing)
+      rc = rf_render_backward_emit_direct(grid, &rays[i], flags[i], &ps.out, &grads[i], ps.out.brick_size, ps.cursor_dev, ps.records_sorted_dev,
+                                          ps.out.key_hist_dev, stream);
+      if (rc != RF_OK) return rc;
+      RF_STEP_EVENT();
+    }
   }
-  RFBrickList lists[2];
-  for (int i = 0; i < 2; ++i) {
-    const RFPassScratch& ps = step->pass[i];
-    RF_STEP_EVENT();  // (offsets[0] = the launch above, offsets[1] = nothing)
-    rc = rf_render_backward_emit_direct(grid, &rays[i], flags[i], &ps.out, &grads[i], ps.out.brick_size, ps.cursor_dev, ps.records_sorted_dev,
-                                        ps.out.key_hist_dev, stream);
+  if (run_bricks) {
+    RFBrickList lists[2];
+    for (int i = 0; i < 2; ++i) lists[i] = RFBrickList{step->pass[i].records_sorted_dev, step->pass[i].offsets_dev, i};
+    if (step->adam)
+      rc = rf_brick_accumulate_adam(grid, step->pass[0].out.brick_size, lists, 2, step->adam, stream);
+    else
+      rc = rf_brick_accumulate(grid, step->pass[0].out.brick_size, lists, 2, step->grad_first_dev, step->grad_second_dev, 0, stream);
     if (rc != RF_OK) return rc;
     RF_STEP_EVENT();
-    lists[i] = RFBrickList{ps.records_sorted_dev, ps.offsets_dev, i};
   }
-  if (step->adam)
-    rc = rf_brick_accumulate_adam(grid, step->pass[0].out.brick_size, lists, 2, step->adam, stream);
-  else
-    rc = rf_brick_accumulate(grid, step->pass[0].out.brick_size, lists, 2, step->grad_first_dev, step->grad_second_dev, 0, stream);
-  if (rc != RF_OK) return rc;
-  RF_STEP_EVENT();
 #undef RF_STEP_EVENT
   return RF_OK;
 }

@@ -182,9 +182,10 @@ def _ray_batch(origins: Tensor, directions: Tensor, num_samples: int, near: floa
 def render_forward_raw(grid: VoxelGrid, origins: Tensor, directions: Tensor, t_rand: Optional[Tensor], num_samples: int,
                        near: float, far: float, flags: int, save: bool, key_hist: Optional[Tensor] = None, brick_size: int = 8):
     """Enqueue rf_render_forward.  Returns (colour [N,3], depth [N,1], acc [N,1], disparity [N,1], caches) where
-    ``caches`` = (sample_cache [N,S,4], trans_cache [N,S], stop [N]) when ``save`` else None.  No autograd.
-    ``key_hist`` (int32 [8 * num_bricks], with ``save``): the pass also counts, per (brick, flags) key, the samples that
-    will emit a record in ``render_backward_emit_direct_raw`` and flags them in the cache."""
+    ``caches`` = (sample_cache [N,S,4], trans_cache [N,S], stop [N], chunk_mask [N, ceil(S/64)] int64) when ``save`` else None:
+    only the samples that can carry gradient are cached, compacted per 64-sample chunk, the mask says which (relu_field.h).
+    No autograd.  ``key_hist`` (int32 [8 * num_bricks], with ``save``): the pass also counts those samples per (brick, flags)
+    key for ``render_backward_emit_direct_raw``."""
     lib = _lib.load()
     for name, t in (("ray origins", origins), ("ray directions", directions)):
         _require_hip(t, name)
@@ -201,12 +202,11 @@ def render_forward_raw(grid: VoxelGrid, origins: Tensor, directions: Tensor, t_r
     caches = None
     if save:
         cache = torch.empty((n, num_samples, 4), dtype=torch.float32, device=dev)
-        # (the kernel leaves the slots of chunks outside the box unwritten; callers that inspect the record flags in the sign bits
-        # of this cache -- tests do -- must not see stale negatives there)
-        tcache = (torch.zeros if key_hist is not None else torch.empty)((n, num_samples), dtype=torch.float32, device=dev)
+        tcache = torch.empty((n, num_samples), dtype=torch.float32, device=dev)
         stop = torch.empty((n,), dtype=torch.int32, device=dev)
-        out.sample_cache_dev, out.trans_cache_dev, out.stop_cache_dev = cache.data_ptr(), tcache.data_ptr(), stop.data_ptr()
-        caches = (cache, tcache, stop)
+        cmask = torch.empty((n, (num_samples + 63) // 64), dtype=torch.int64, device=dev)
+        out.sample_cache_dev, out.trans_cache_dev, out.stop_cache_dev, out.chunk_mask_dev = cache.data_ptr(), tcache.data_ptr(), stop.data_ptr(), cmask.data_ptr()
+        caches = (cache, tcache, stop, cmask)
         if key_hist is not None:
             out.key_hist_dev, out.brick_size = key_hist.data_ptr(), int(brick_size)
     with _span(f"render_forward[{_variant(grid, flags)}{',save' if save else ''}]", dev):
@@ -267,9 +267,9 @@ def render_backward_raw(grid: VoxelGrid, origins: Tensor, directions: Tensor, t_
     rb, tv = _ray_batch(origins, directions, num_samples, near, far, t_rand)
     grads = _lib.RFRenderGrads()
     grads.grad_colour_dev, grads.grad_depth_dev, grads.grad_acc_dev = _ptr(g_colour), _ptr(g_depth), _ptr(g_acc)
-    cache, tcache, stop = caches
+    cache, tcache, stop, cmask = caches
     fwd = _lib.RFRenderOut()
-    fwd.sample_cache_dev, fwd.trans_cache_dev, fwd.stop_cache_dev = cache.data_ptr(), tcache.data_ptr(), stop.data_ptr()
+    fwd.sample_cache_dev, fwd.trans_cache_dev, fwd.stop_cache_dev, fwd.chunk_mask_dev = cache.data_ptr(), tcache.data_ptr(), stop.data_ptr(), cmask.data_ptr()
     with _span(f"render_backward[{_variant(grid, flags)}]", dev):
         rc = lib.rf_render_backward(
             C.byref(rf_grid), C.byref(rb), _jitter_flags(flags, t_rand), C.byref(fwd), C.byref(grads), grad_first.data_ptr(), _ptr(grad_second), _stream(dev)
@@ -286,23 +286,23 @@ def brick_counts(grid: VoxelGrid, brick_size: int) -> Tuple[int, int, int]:
 
 def render_backward_emit_raw(grid: VoxelGrid, origins: Tensor, directions: Tensor, t_rand: Optional[Tensor], num_samples: int,
                              near: float, far: float, flags: int, caches, g_colour: Optional[Tensor], g_depth: Optional[Tensor],
-                             g_acc: Optional[Tensor], brick_size: int, keys: Tensor, records: Tensor, ray_basis: Optional[Tensor],
+                             g_acc: Optional[Tensor], brick_size: int, keys: Tensor, records: Tensor,
                              hist: Optional[Tensor] = None) -> None:
-    """Enqueue rf_render_backward_emit: per-sample gradient records + brick keys instead of a scatter; ``hist`` (int32
-    [8 * num_bricks], optional) is incremented by the number of records per key (for ``bin_records_by_brick``)."""
+    """Enqueue rf_render_backward_emit: per-slot gradient records ([N*S, record_floats]) + brick keys instead of a scatter;
+    ``hist`` (int32 [8 * num_bricks], optional) is incremented by the number of records per key (for ``bin_records_by_brick``)."""
     lib = _lib.load()
     dev = origins.device
     rf_grid = grid.to_rf_grid(use_occupancy=bool(flags & _lib.FLAG_OCCUPANCY_SKIP))
     rb, tv = _ray_batch(origins, directions, num_samples, near, far, t_rand)
     grads = _lib.RFRenderGrads()
     grads.grad_colour_dev, grads.grad_depth_dev, grads.grad_acc_dev = _ptr(g_colour), _ptr(g_depth), _ptr(g_acc)
-    cache, tcache, stop = caches
+    cache, tcache, stop, cmask = caches
     fwd = _lib.RFRenderOut()
-    fwd.sample_cache_dev, fwd.trans_cache_dev, fwd.stop_cache_dev = cache.data_ptr(), tcache.data_ptr(), stop.data_ptr()
+    fwd.sample_cache_dev, fwd.trans_cache_dev, fwd.stop_cache_dev, fwd.chunk_mask_dev = cache.data_ptr(), tcache.data_ptr(), stop.data_ptr(), cmask.data_ptr()
     with _span(f"render_backward_emit[{_variant(grid, flags)}]", dev):
         rc = lib.rf_render_backward_emit(
             C.byref(rf_grid), C.byref(rb), _jitter_flags(flags, t_rand), C.byref(fwd), C.byref(grads), int(brick_size), keys.data_ptr(), records.data_ptr(),
-            _ptr(ray_basis), _ptr(hist), _stream(dev),
+            _ptr(hist), _stream(dev),
         )
     _lib.check(rc, "rf_render_backward_emit")
 
@@ -319,9 +319,9 @@ def render_backward_emit_direct_raw(grid: VoxelGrid, origins: Tensor, directions
     rb, tv = _ray_batch(origins, directions, num_samples, near, far, t_rand)
     grads = _lib.RFRenderGrads()
     grads.grad_colour_dev, grads.grad_depth_dev, grads.grad_acc_dev = _ptr(g_colour), _ptr(g_depth), _ptr(g_acc)
-    cache, tcache, stop = caches
+    cache, tcache, stop, cmask = caches
     fwd = _lib.RFRenderOut()
-    fwd.sample_cache_dev, fwd.trans_cache_dev, fwd.stop_cache_dev = cache.data_ptr(), tcache.data_ptr(), stop.data_ptr()
+    fwd.sample_cache_dev, fwd.trans_cache_dev, fwd.stop_cache_dev, fwd.chunk_mask_dev = cache.data_ptr(), tcache.data_ptr(), stop.data_ptr(), cmask.data_ptr()
     with _span(f"render_backward_emit_direct[{_variant(grid, flags)}]", dev):
         rc = lib.rf_render_backward_emit_direct(
             C.byref(rf_grid), C.byref(rb), _jitter_flags(flags, t_rand), C.byref(fwd), C.byref(grads), int(brick_size), cursor.data_ptr(),
@@ -341,11 +341,12 @@ def bin_offsets(hist: Tensor, offsets: Tensor, cursor: Tensor) -> Tensor:
 
 
 def expanded_record_floats(grid: VoxelGrid, render_diffuse: bool = False) -> int:
-    """floats per record in the sorted, expanded list consumed by rf_brick_accumulate (diffuse passes: base channels only)"""
+    """floats per record in the sorted lists consumed by rf_brick_accumulate: 12 (compact: index, d density, d raw rgb, unit view
+    direction -- the SH expansion happens inside the brick pass), or 8 for degree-0 grids and render_diffuse passes"""
     return int(_lib.load().rf_expanded_record_floats(3 if render_diffuse else int(grid.num_features)))
 
 
-def sort_records_by_brick(grid: VoxelGrid, keys: Tensor, records: Tensor, ray_basis: Optional[Tensor], render_diffuse: bool,
+def sort_records_by_brick(grid: VoxelGrid, keys: Tensor, records: Tensor, render_diffuse: bool,
                           records_sorted: Tensor, offsets: Tensor, boundaries: Tensor) -> Tensor:
     """Sort the dense key array (16-bit radix sort; key = brick * 8 + boundary flags, -1 = slot without gradient) and
     write the records of keyed samples, expanded to per-channel values, in that order.  ``offsets``
@@ -360,12 +361,12 @@ def sort_records_by_brick(grid: VoxelGrid, keys: Tensor, records: Tensor, ray_ba
     rf_grid = grid.to_rf_grid()
     with _span("expand_records", dev):
         rc = lib.rf_expand_records(C.byref(rf_grid), records.data_ptr(), perm.data_ptr(), offsets.data_ptr(), keys.numel(),
-                                   _ptr(ray_basis), int(bool(render_diffuse)), records_sorted.data_ptr(), _stream(dev))
+                                   int(bool(render_diffuse)), records_sorted.data_ptr(), _stream(dev))
     _lib.check(rc, "rf_expand_records")
     return offsets
 
 
-def bin_records_by_brick(grid: VoxelGrid, keys: Tensor, records: Tensor, ray_basis: Optional[Tensor], render_diffuse: bool,
+def bin_records_by_brick(grid: VoxelGrid, keys: Tensor, records: Tensor, render_diffuse: bool,
                          hist: Tensor, cursor: Tensor, records_sorted: Tensor, offsets: Tensor) -> Tensor:
     """Counting sort instead of torch.sort: ``hist`` (filled by render_backward_emit_raw) -> ``offsets``
     [8 * num_bricks + 1] (int64; positions start at 0) and ``cursor`` (int32 scratch); every keyed slot then takes the
@@ -378,7 +379,7 @@ def bin_records_by_brick(grid: VoxelGrid, keys: Tensor, records: Tensor, ray_bas
     rf_grid = grid.to_rf_grid()
     with _span(f"scatter_records[{'diffuse' if render_diffuse or grid.sh_degree == 0 else 'sh' + str(grid.sh_degree)}]", dev):
         rc = lib.rf_scatter_records(C.byref(rf_grid), keys.data_ptr(), records.data_ptr(), keys.numel(), cursor.data_ptr(),
-                                    _ptr(ray_basis), int(bool(render_diffuse)), records_sorted.data_ptr(), hist.data_ptr(), int(hist.numel()), _stream(dev))
+                                    int(bool(render_diffuse)), records_sorted.data_ptr(), hist.data_ptr(), int(hist.numel()), _stream(dev))
     _lib.check(rc, "rf_scatter_records")
     return offsets
 
@@ -399,16 +400,18 @@ def brick_accumulate_raw(grid: VoxelGrid, brick_size: int, lists, grad_first: Te
 
 
 def brick_accumulate_adam_raw(grid: VoxelGrid, brick_size: int, lists, exp_avg, exp_avg_sq, lr: float, beta1: float, beta2: float,
-                              eps: float, step: int) -> None:
+                              eps: float, step: int, brick_range=None) -> None:
     """Enqueue rf_brick_accumulate_adam: the brick pass over ``lists`` (as in ``brick_accumulate_raw``; all renders of the
-    iteration) with the Adam update of the grid's own tensors applied in the flush.  ``exp_avg`` / ``exp_avg_sq`` are pairs of
-    tensors shaped like ``grid.kernel_tensors()`` (second entry None when the grid has no second tensor)."""
+    iteration -- of all ranks, under data parallelism) with the Adam update of the grid's own tensors applied in the flush.
+    ``exp_avg`` / ``exp_avg_sq`` are pairs of tensors shaped like ``grid.kernel_tensors()`` (second entry None when the grid has no
+    second tensor).  ``brick_range`` = (first_brick, num_bricks) restricts the pass (and the update) to those bricks.  An entry of
+    ``lists`` may give its records as an int (a raw device address) instead of a tensor."""
     lib = _lib.load()
     first, second = grid.kernel_tensors()
     dev = first.device
     arr = (_lib.RFBrickList * len(lists))()
     for i, (rec, off, diffuse) in enumerate(lists):
-        arr[i].records_sorted_dev, arr[i].offsets_dev, arr[i].render_diffuse = rec.data_ptr(), off.data_ptr(), int(bool(diffuse))
+        arr[i].records_sorted_dev, arr[i].offsets_dev, arr[i].render_diffuse = (rec if isinstance(rec, int) else rec.data_ptr()), off.data_ptr(), int(bool(diffuse))
     st = _lib.RFAdamState()
     st.param_first_dev, st.param_second_dev = first.data_ptr(), _ptr(second)
     st.exp_avg_first_dev, st.exp_avg_second_dev = exp_avg[0].data_ptr(), _ptr(exp_avg[1])
@@ -416,7 +419,10 @@ def brick_accumulate_adam_raw(grid: VoxelGrid, brick_size: int, lists, exp_avg, 
     st.lr, st.beta1, st.beta2, st.eps, st.step = float(lr), float(beta1), float(beta2), float(eps), int(step)
     rf_grid = grid.to_rf_grid()
     with _span(f"brick_accumulate_adam[{'diffuse' if lists[0][2] or grid.sh_degree == 0 else 'sh' + str(grid.sh_degree)}]", dev):
-        rc = lib.rf_brick_accumulate_adam(C.byref(rf_grid), int(brick_size), arr, len(lists), C.byref(st), _stream(dev))
+        if brick_range is None:
+            rc = lib.rf_brick_accumulate_adam(C.byref(rf_grid), int(brick_size), arr, len(lists), C.byref(st), _stream(dev))
+        else:
+            rc = lib.rf_brick_accumulate_adam_range(C.byref(rf_grid), int(brick_size), arr, len(lists), C.byref(st), int(brick_range[0]), int(brick_range[1]), _stream(dev))
     _lib.check(rc, "rf_brick_accumulate_adam")
 
 
@@ -427,6 +433,7 @@ def brick_accumulate_adam_raw(grid: VoxelGrid, brick_size: int, lists, exp_avg, 
 # reference-storage iteration of bench.py's strict drop-in leg: 2.79 -> 1.99 ms with the diffuse adjoint binned as well), atomic
 # otherwise.
 AUTOGRAD_BACKWARD = "auto"
+AUTOGRAD_BINNED_MAX_BYTES = 1 << 30
 AUTOGRAD_BRICK_SIZE = 8
 
 
@@ -438,6 +445,10 @@ def _autograd_uses_bricks(grid, flags: int, n: int, num_samples: int) -> bool:
         return False
     if AUTOGRAD_BACKWARD == "binned":
         return True
+    # the binned adjoint allocates one worst-case record list per backward (48 B per sample slot): above AUTOGRAD_BINNED_MAX_BYTES
+    # the atomic kernel, which needs no scratch, is used instead (user code that fitted before keeps fitting)
+    if n * num_samples * 4 * expanded_record_floats(grid) > AUTOGRAD_BINNED_MAX_BYTES:
+        return False
     return grid.sh_degree == 2 and n * num_samples >= (1 << 20)
 
 
@@ -487,8 +498,8 @@ class _ReluFieldRender(torch.autograd.Function):
         saved = list(ctx.saved_tensors)
         first = saved.pop(0)
         second = saved.pop(0) if ctx.has_second else None
-        origins, directions, cache, tcache, stop = saved[:5]
-        t_rand = saved[5] if ctx.has_rand else ctx.keyed
+        origins, directions, cache, tcache, stop, cmask = saved[:6]
+        t_rand = saved[6] if ctx.has_rand else ctx.keyed
         grid: VoxelGrid = ctx.grid
         cur_first, cur_second = grid.kernel_tensors()
         if cur_first.data_ptr() != first.data_ptr() or (second is not None and cur_second.data_ptr() != second.data_ptr()):
@@ -523,14 +534,14 @@ class _ReluFieldRender(torch.autograd.Function):
             records = torch.empty((origins.shape[0] * ctx.num_samples, expanded_record_floats(grid, diffuse)), dtype=torch.float32, device=dev)
             bin_offsets(hist, offsets, cursor)
             render_backward_emit_direct_raw(
-                grid, origins, directions, t_rand, ctx.num_samples, ctx.near, ctx.far, ctx.flags, (cache, tcache, stop),
+                grid, origins, directions, t_rand, ctx.num_samples, ctx.near, ctx.far, ctx.flags, (cache, tcache, stop, cmask),
                 prep(g_colour), prep(g_depth), prep(g_acc), AUTOGRAD_BRICK_SIZE, cursor, records, hist_clear=None,
             )
             brick_accumulate_raw(grid, AUTOGRAD_BRICK_SIZE, [(records, offsets, diffuse)], gd, gf, accumulate=not overwrite)
             ctx.key_hist = None  # (a second backward through the same graph would find the counters consumed)
         else:
             render_backward_raw(
-                grid, origins, directions, t_rand, ctx.num_samples, ctx.near, ctx.far, ctx.flags, (cache, tcache, stop),
+                grid, origins, directions, t_rand, ctx.num_samples, ctx.near, ctx.far, ctx.flags, (cache, tcache, stop, cmask),
                 prep(g_colour), prep(g_depth), prep(g_acc), gd, gf,
             )
         return ret_d, ret_f, None, None, None, None, None, None, None, None, None

@@ -143,15 +143,19 @@ def render_sh_voxel_grid_frame(
     voxel_grid = as_kernel_grid(voxel_grid)
     _check_supported(render_config)
     jitter = None
+    # (the reference's own config class has neither ``jitter`` nor ``use_occupancy_mask`` nor ``consume_reference_rng``)
+    use_occupancy = bool(getattr(render_config, "use_occupancy_mask", False))
+    if getattr(render_config, "consume_reference_rng", False):
+        raise ValueError("render_sh_voxel_grid_frame draws no per-chunk torch.randn: with consume_reference_rng use the chunked path")
     if render_config.perturb_sampled_points:
-        if render_config.jitter != "keyed":
+        if getattr(render_config, "jitter", "keyed") != "keyed":
             raise ValueError("render_sh_voxel_grid_frame draws its jitter inside the kernel: SHVoxGridRenderConfig.jitter must be 'keyed'")
         jitter = KeyedJitter(draw_jitter_key(), 0)
-    if render_config.use_occupancy_mask and not voxel_grid.occupancy_current():
+    if use_occupancy and not voxel_grid.occupancy_current():
         voxel_grid.build_occupancy()
     height, width, focal = camera_intrinsics
     bounds = render_config.camera_bounds
-    flags = render_flags(render_config.white_bkgd, render_config.render_diffuse, render_config.optimized_sampling, render_config.use_occupancy_mask)
+    flags = render_flags(render_config.white_bkgd, render_config.render_diffuse, render_config.optimized_sampling, use_occupancy)
     colour, depth, acc, disparity = render_frame_raw(
         voxel_grid, int(height), int(width), float(focal), camera_pose.rotation, camera_pose.translation, int(render_config.num_samples_per_ray),
         float(np.float32(bounds.near)), float(np.float32(bounds.far)), flags, jitter, first_ray=first_ray, num_rays=num_rays,

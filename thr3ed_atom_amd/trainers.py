@@ -205,10 +205,16 @@ class TrainStepper:
             raise ValueError("merge_bricks needs the fused, binned, non-deterministic step with the diffuse render")
         # fuse_optimizer (merged steps on one GPU, split/bricked storage, SH degree 0 or 2 = whole float4s per node): the brick
         # flush applies the Adam update itself (rf_brick_accumulate_adam) -- no gradient bucket in HBM, no separate optimizer pass
-        can_fuse = self.merged_bricks and single and grid.storage != "reference" and (grid.num_features + 1) % 4 == 0
+        # (the flush keeps element offsets in 31 bits: rf_brick_accumulate_adam refuses larger grids, e.g. 512^3 at degree 2 --
+        # those keep the gradient bucket and the separate optimizer kernel)
+        padded_nodes = 1
+        for d in grid.grid_dims:
+            padded_nodes *= (d + 7) // 8 * 8
+        fits_flush = padded_nodes * max(4, grid.num_features - 3) < (1 << 31)
+        can_fuse = self.merged_bricks and single and grid.storage != "reference" and (grid.num_features + 1) % 4 == 0 and fits_flush
         self.fuse_optimizer = can_fuse if fuse_optimizer is None else bool(fuse_optimizer)
         if self.fuse_optimizer and not can_fuse:
-            raise ValueError("fuse_optimizer needs a merged brick pass on a single process, split or bricked storage and SH degree 0 or 2")
+            raise ValueError("fuse_optimizer needs a merged brick pass on a single process, split or bricked storage, SH degree 0 or 2 and fewer than 2^31 elements per grid tensor")
 
     def select(self, dataset: PosedImagesInMemory, image_ids: Tensor):
         """Synchronous random subset of rays and pixels of the given images
@@ -277,7 +283,7 @@ class TrainStepper:
         self._grad_clean = False
         return StepStats(spec_loss, diff_loss, spec_mse, diff_mse)
 
-    def _draw_jitter(self, cfg, n: int, S: int, device, given, i: int):
+    def _draw_jitter(self, cfg, n: int, S: int, device, given, i: int, first_ray: int = 0):
         if given is not None:
             t = given[i].detach().to(device, torch.float32).contiguous()
             if tuple(t.shape) != (n, S):
@@ -286,7 +292,9 @@ class TrainStepper:
         if not cfg.perturb_sampled_points:
             t = None
         elif cfg.jitter == "keyed":  # counter-based jitter inside the kernels, keyed from torch's CPU generator
-            t = ops.KeyedJitter(ops.draw_jitter_key(), 0)
+            # ``first_ray``: this rank's offset in a GLOBAL batch, so that N ranks draw the jitter of rays lo..hi of the same
+            # stream the single-GPU iteration draws for rays 0..n (global_batch data parallelism)
+            t = ops.KeyedJitter(ops.draw_jitter_key(), int(first_ray))
         elif cfg.jitter == "torch":
             t = torch.rand(n, S, dtype=torch.float32, device=device)
         else:
@@ -387,6 +395,7 @@ class TrainStepper:
             p = {
                 "colour": torch.empty((n, 3), **f32), "depth": torch.empty(n, **f32), "acc": torch.empty(n, **f32), "disparity": torch.empty(n, **f32),
                 "cache": torch.empty((n, S, 4), **f32), "tcache": torch.empty((n, S), **f32), "stop": torch.empty(n, dtype=torch.int32, device=device),
+                "cmask": torch.empty((n, (S + 63) // 64), dtype=torch.int64, device=device),
                 "g_colour": torch.empty((n, 3), **f32),
                 "hist": torch.zeros(nkeys, dtype=torch.int32, device=device), "cursor": torch.empty(nkeys, dtype=torch.int32, device=device),
                 "offsets": torch.empty(nkeys + 1, dtype=torch.int64, device=device),
@@ -396,7 +405,7 @@ class TrainStepper:
             ps = step.pass_[i]
             o = ps.out
             o.colour_dev, o.depth_dev, o.acc_dev, o.disparity_dev = p["colour"].data_ptr(), p["depth"].data_ptr(), p["acc"].data_ptr(), p["disparity"].data_ptr()
-            o.sample_cache_dev, o.trans_cache_dev, o.stop_cache_dev = p["cache"].data_ptr(), p["tcache"].data_ptr(), p["stop"].data_ptr()
+            o.sample_cache_dev, o.trans_cache_dev, o.stop_cache_dev, o.chunk_mask_dev = p["cache"].data_ptr(), p["tcache"].data_ptr(), p["stop"].data_ptr(), p["cmask"].data_ptr()
             o.key_hist_dev, o.brick_size = p["hist"].data_ptr(), int(self.brick_size)
             ps.grad_colour_dev, ps.cursor_dev, ps.offsets_dev, ps.records_sorted_dev = p["g_colour"].data_ptr(), p["cursor"].data_ptr(), p["offsets"].data_ptr(), p["sorted"].data_ptr()
         opt = self.optimizer
@@ -499,7 +508,6 @@ class TrainStepper:
                 # buffers (stream order).  Measured on the fresh field (bench.py --dp-style-step): emit 0.060 + offsets 0.011 +
                 # bricks 0.146 = 0.22 ms against 0.30 ms for the atomic scatter of the same gradient (a 4-channel brick pass is
                 # all per-brick fixed cost; on a trained, sparse field the two are about even).
-                basis = None if diffuse else bins["ray_basis"]
                 if fused_binning:
                     # counting sort whose counting ran inside the forward pass: offsets, then the backward pass writes
                     # the expanded records straight to their final positions (and clears the counters)
@@ -511,9 +519,9 @@ class TrainStepper:
                 else:  # stable 16-bit radix sort of per-slot keys: fixed summation order
                     render_backward_emit_raw(
                         grid, origins, directions, t_rand, S, near, far, flags, caches, g_colour, None, None, self.brick_size,
-                        bins["keys"], bins["records"], basis, None,
+                        bins["keys"], bins["records"], None,
                     )
-                    offsets = sort_records_by_brick(grid, bins["keys"], bins["records"], basis, diffuse, bins["sorted"], bins["offsets"], bins["boundaries"])
+                    offsets = sort_records_by_brick(grid, bins["keys"], bins["records"], diffuse, bins["sorted"], bins["offsets"], bins["boundaries"])
                 brick_accumulate_raw(grid, self.brick_size, [(bins["sorted"], offsets, diffuse)], gd, gf, accumulate=diffuse)
             else:
                 render_backward_raw(grid, origins, directions, t_rand, S, near, far, flags, caches, g_colour, None, None, gd, gf)
@@ -556,11 +564,10 @@ class TrainStepper:
             b = {
                 "shape": (n, S),
                 "num_bricks": num_bricks,
-                # per-slot keys / 32-byte records: only the deterministic (radix sort) path needs them
+                # per-slot keys / records: only the deterministic (radix sort) path needs them
                 "keys": torch.empty(n * S if self.deterministic else 0, dtype=torch.int16, device=device),
-                "records": torch.empty((n * S if self.deterministic else 0, 8), dtype=torch.float32, device=device),
+                "records": torch.empty((n * S if self.deterministic else 0, expanded_record_floats(grid)), dtype=torch.float32, device=device),
                 "sorted": torch.empty((n * S, expanded_record_floats(grid)), dtype=torch.float32, device=device),
-                "ray_basis": torch.zeros((n, 16), dtype=torch.float32, device=device),
                 "boundaries": torch.arange(num_bricks * 8, dtype=torch.int16, device=device) if self.deterministic else None,
                 "offsets": torch.full((num_bricks * 8 + 1,), n * S, dtype=torch.int64, device=device),
                 "hist": torch.zeros(num_bricks * 8, dtype=torch.int32, device=device),

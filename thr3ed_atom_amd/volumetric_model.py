@@ -122,6 +122,7 @@ class VolumetricModel:
             and gpu_render
             and not verbose
             and (not getattr(cfg, "perturb_sampled_points", False) or getattr(cfg, "jitter", "keyed") == "keyed")
+            and not getattr(cfg, "consume_reference_rng", False)  # (that flag asks for the reference's per-chunk torch.randn draws)
         ):
             # the HIP procedure renders a frame (or this rank's share of it) in ONE launch: rays and jitter are generated inside
             # the kernel, so there is nothing to chunk -- ``parallel_rays_chunk_size`` does not change a single bit of the result

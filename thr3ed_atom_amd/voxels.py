@@ -9,6 +9,8 @@ arithmetic itself (normalise -> trilinear gather -> ReLU) lives in the HIP kerne
 """
 from typing import Any, Callable, Dict, NamedTuple, Optional, Tuple
 
+import weakref
+
 import numpy as np
 import torch
 from torch import Tensor
@@ -121,6 +123,12 @@ def resolve_density_mode(pre: Callable, post: Callable) -> str:
     )
 
 
+# per-object caches of the operators (ctypes descriptors, foreign-grid views), weakly keyed by the grid object so that nothing
+# un-picklable ever lives in a module's __dict__ (copy.deepcopy(module) / torch.save(module) keep working after a HIP render)
+_RF_GRID_CACHE: "weakref.WeakKeyDictionary" = weakref.WeakKeyDictionary()
+_RF_VIEW_CACHE: "weakref.WeakKeyDictionary" = weakref.WeakKeyDictionary()
+
+
 class KernelGridInterface:
     """What the render operators need from a grid object -- described to the C ABI (RFGrid) from a handful of attributes:
     ``kernel_tensors()``, ``grid_dims``, ``_aabb``, ``_expected_density_scale``, ``density_mode``, ``storage``, ``_num_features``.
@@ -150,7 +158,8 @@ class KernelGridInterface:
         occ_ptr = self._occupancy.data_ptr() if (use_occupancy and self._occupancy is not None) else None
         mode = self.density_mode
         key = (d.data_ptr(), None if f is None else f.data_ptr(), occ_ptr, self._aabb, self._expected_density_scale, mode, tuple(d.shape))
-        cached = self.__dict__.get("_rf_grid_cache")
+        # (kept OUTSIDE the object: a ctypes struct with pointers in a module's __dict__ breaks copy.deepcopy / torch.save of it)
+        cached = _RF_GRID_CACHE.get(self)
         if cached is not None and cached[0] == key:
             return cached[1]
         g = _lib.RFGrid()
@@ -171,7 +180,7 @@ class KernelGridInterface:
         g.density_scale = float(self._expected_density_scale)
         g.density_mode = _lib.DENSITY_MODES[mode]
         g.occupancy_dev = occ_ptr
-        self.__dict__["_rf_grid_cache"] = (key, g)
+        _RF_GRID_CACHE[self] = (key, g)
         return g
 
     def build_occupancy(self, threshold: float = 0.0) -> Tensor:
@@ -453,8 +462,15 @@ class ForeignVoxelGridView(KernelGridInterface):
         missing = [a for a in ("densities", "features", "aabb", "_expected_density_scale", "_density_preactivation", "_density_postactivation") if not hasattr(module, a)]
         if missing:
             raise TypeError(f"render_sh_voxel_grid (HIP) needs a VoxelGrid-like module; {type(module).__name__} lacks {missing}")
-        self.module = module
+        self._module_ref = weakref.ref(module)  # (the view is cached weakly keyed by the module: no cycle that keeps it alive)
         self._occupancy = None
+
+    @property
+    def module(self):
+        m = self._module_ref()
+        if m is None:
+            raise ReferenceError("the grid module behind this view no longer exists")
+        return m
 
     def _check(self):
         m = self.module
@@ -509,13 +525,13 @@ def as_kernel_grid(module) -> KernelGridInterface:
     reference's) through a cached ForeignVoxelGridView."""
     if isinstance(module, KernelGridInterface):
         return module
-    view = module.__dict__.get("_rf_kernel_view") if hasattr(module, "__dict__") else None
+    try:
+        view = _RF_VIEW_CACHE.get(module)
+    except TypeError:  # not weakly referenceable / not hashable: just do not cache
+        return ForeignVoxelGridView(module)
     if view is None:
         view = ForeignVoxelGridView(module)
-        try:
-            module.__dict__["_rf_kernel_view"] = view
-        except Exception:  # objects without a writable __dict__: just do not cache
-            pass
+        _RF_VIEW_CACHE[module] = view
     return view
 
 

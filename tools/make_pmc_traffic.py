@@ -57,13 +57,18 @@ def main():
     ap.add_argument("--gt-frames", type=int, default=8)
     ap.add_argument("--frames-per-leg", type=int, default=3)
     ap.add_argument("--source", default="")
+    ap.add_argument("--bench-args", default="", help="the bench.py flags of the profiled command (recorded in the table)")
     ap.add_argument("--merge-into", default="", help="existing pmc_traffic.json: only ADD the kernels it does not have yet (profiles of another step variant)")
     args = ap.parse_args()
     by = {"FETCH_SIZE": defaultdict(list), "WRITE_SIZE": defaultdict(list)}
     for counter, root in (("FETCH_SIZE", args.fetch_dir), ("WRITE_SIZE", args.write_dir)):
         for _, name, val in per_dispatch(root, counter):
             by[counter][name].append(val)
-    out = {"_source": args.source or f"rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) of bench.py; hbm_bytes = FETCH_SIZE*1024*2 (gfx950) + WRITE_SIZE*1024, median per launch"}
+    import hashlib
+
+    hip = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "thr3ed_atom_amd", "csrc", "relu_field_kernels.hip")
+    out = {"_kernel_source_sha256": hashlib.sha256(open(hip, "rb").read()).hexdigest(), "_bench_args": args.bench_args,
+           "_source": args.source or f"rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) of bench.py; hbm_bytes = FETCH_SIZE*1024*2 (gfx950) + WRITE_SIZE*1024, median per launch"}
 
     def median(v):
         v = sorted(v)
