@@ -165,9 +165,10 @@ def cpu_baseline(grid, rays_cpu, pixels_cpu, num_samples, n_train, n_fwd, thread
         total.backward()
 
     def forward(n):
+        reps_ = (n + rays_cpu[0].shape[0] - 1) // rays_cpu[0].shape[0]  # (a chunk may hold more rays than one training batch: repeat it)
+        o, d = rays_cpu[0].repeat(reps_, 1)[:n], rays_cpu[1].repeat(reps_, 1)[:n]
         with torch.no_grad():
-            orc.render(dens, feat, rays_cpu[0][:n], rays_cpu[1][:n], aabb, NEAR, FAR, num_samples, rho, "relu", white_bkgd=True,
-                       t_rand=torch.rand(n, num_samples), interp="aten")
+            orc.render(dens, feat, o, d, aabb, NEAR, FAR, num_samples, rho, "relu", white_bkgd=True, t_rand=torch.rand(n, num_samples), interp="aten")
 
     def timed(fn, n):
         fn(min(256, n))  # warm-up (thread pool, page-in)
@@ -186,8 +187,8 @@ def cpu_baseline(grid, rays_cpu, pixels_cpu, num_samples, n_train, n_fwd, thread
     ncpu = os.cpu_count() or 1
     if threads <= 0 and ncpu > cores:
         torch.set_num_threads(ncpu)
-        n_all = max(64, n_train // 8)
-        train(min(64, n_all))
+        n_all = max(32, n_train // 32)
+        train(min(16, n_all))
         t0 = time.perf_counter()
         train(n_all)
         dt_all = time.perf_counter() - t0
@@ -296,13 +297,24 @@ def main():
     ap.add_argument("--deterministic", action="store_true", help="binned backward: stable radix sort instead of the counting sort")
     ap.add_argument("--no-fuse-optimizer", action="store_true", help="keep the gradient bucket and the separate Adam kernel on one GPU")
     ap.add_argument("--dp-style-step", action="store_true",
-                    help="run the step the way a data-parallel rank computes it (one brick pass per render, separate Adam) on one GPU")
+                    help="one GPU: run the step exactly the way a data-parallel rank runs it (a 1-rank RCCL group: same code path, collectives of world size 1)")
+    ap.add_argument("--exchange", choices=["auto", "owner", "dense"], default="auto",
+                    help="data-parallel exchange: owner = owner-computes (record slices all-to-all -> merged brick pass + Adam on the rank's own bricks -> "
+                    "parameter all-gather), dense = reduce-scatter of the gradient bucket -> sharded Adam -> all-gather")
     ap.add_argument("--timed-steps", type=int, default=5, help="how many of the --steps record per-kernel HIP events")
     ap.add_argument("--cpu-threads", type=int, default=0, help="torch CPU threads for cpu_baseline (0 = min(cores, 16))")
     args = ap.parse_args()
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ and "RANK" not in os.environ:
         respawn_under_torchrun(args.gpus)  # does not return
+    if args.dp_style_step and args.gpus == 1 and "WORLD_SIZE" not in os.environ:
+        import socket
+
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            port = sk.getsockname()[1]
+        torch.distributed.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1)
+        rfdist.FORCE_COLLECTIVES = True
     rank, local_rank, world = rfdist.init_from_env()
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus} (or without it: bench.py spawns the ranks itself)")
@@ -453,9 +465,10 @@ def main():
 
     # ---- training steps: the headline ---------------------------------------------------------------
     stepper = TrainStepper(model, R, learning_rate=0.03, apply_diffuse_render_regularization=True, ray_selection=args.ray_selection, backward=args.backward,
-                           deterministic=args.deterministic, fuse_optimizer=False if (args.no_fuse_optimizer or args.dp_style_step) else None,
-                           merge_bricks=False if args.dp_style_step else None)
-    executor = stepper.fused and stepper.merged_bricks and args.ray_selection == "keyed"
+                           deterministic=args.deterministic, fuse_optimizer=False if (args.no_fuse_optimizer or args.exchange == "dense") else None,
+                           merge_bricks=False if args.exchange == "dense" and (world > 1 or args.dp_style_step) else None, exchange=args.exchange)
+    owner = stepper.exchange == "owner"
+    executor = stepper.fused and stepper.merged_bricks and args.ray_selection == "keyed" and not owner
     torch.manual_seed(1234 + rank)  # every rank draws its own rays
     batches = dataset.image_batches(args.images)
     for _ in range(args.warmup):
@@ -464,7 +477,8 @@ def main():
     timer_stride = max(1, args.steps // max(1, args.timed_steps))
     timed_idx = [i for i in range(0, args.steps, timer_stride)] if args.timed_steps > 0 else []
     events = [ops.StepEvents() for _ in timed_idx] if executor else []
-    legacy_timer = ops.KernelTimer(preallocate=14 * len(timed_idx)) if (timed_idx and not executor) else None
+    legacy_timer = ops.KernelTimer(preallocate=14 * len(timed_idx)) if (timed_idx and not executor and not owner) else None
+    phase_events = []  # owner-computes step: torch events around its phases on the timed steps
     counts = torch.zeros((max(1, len(timed_idx)), 2), dtype=torch.int64, device=dev)  # records emitted per render on the event steps
     if world > 1:
         torch.distributed.barrier()
@@ -475,6 +489,8 @@ def main():
         on = k < len(timed_idx) and i == timed_idx[k]
         if executor:
             stepper.step_events = events[k] if on else None
+        elif owner:
+            stepper.phase_events = phase_events if on else None
         else:
             ops.KERNEL_TIMER = legacy_timer if on else None
         stats = stepper.step(dataset, next(batches))
@@ -491,16 +507,22 @@ def main():
     elapsed = time.perf_counter() - t0
     ops.KERNEL_TIMER = None
     stepper.step_events = None
+    stepper.phase_events = None
     exchange_bytes = 0
+    if owner and stepper.exchange_bytes:  # measured: record slices + offset tables + parameter chunks this rank sent, mean of the last steps
+        exchange_bytes = int(np.mean(stepper.exchange_bytes))
     if world > 1:
         te = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         torch.distributed.all_reduce(te, op=torch.distributed.ReduceOp.MAX)
         elapsed = float(te.item())
-        # reduce-scatter + all-gather (or all-reduce) of the flat bucket: 2 (N-1)/N x bucket bytes sent per rank per step
-        exchange_bytes = int(2 * (world - 1) / world * stepper.flat.flat_grad.numel() * 4)
+        if not owner:  # reduce-scatter + all-gather (or all-reduce) of the flat bucket: 2 (N-1)/N x bucket bytes sent per rank per step
+            exchange_bytes = int(2 * (world - 1) / world * stepper.flat.flat_grad.numel() * 4)
         # every rank leaves the group together, BEFORE rank 0 starts its single-process reporting legs
         torch.distributed.barrier()
         torch.distributed.destroy_process_group()
+    elif torch.distributed.is_initialized():  # --dp-style-step: the 1-rank group
+        torch.distributed.destroy_process_group()
+        rfdist.FORCE_COLLECTIVES = False
 
     if rank != 0:
         return
@@ -513,6 +535,11 @@ def main():
         per = [e.elapsed_ms() for e in events]
         for name in per[0]:
             kernels[name] = {"avg_ms": float(np.mean([p[name] for p in per])), "launches": len(per)}
+    elif owner and phase_events:
+        names_ = ["forward phase (select, 2 forward passes, losses + offsets)", "emit phase (2 launches; the offset-table all-gather + host read overlap it)",
+                  "record exchange (host wait + all-to-all of record slices)", "brick_accumulate_adam[owner bricks, all ranks' lists]", "parameter all-gather"]
+        for i, name in enumerate(names_):
+            kernels[name] = {"avg_ms": float(np.mean([e[i].elapsed_time(e[i + 1]) for e in phase_events])), "launches": len(phase_events)}
     elif legacy_timer is not None:
         for name, rec in legacy_timer.summary().items():
             kernels[name] = {"avg_ms": rec["avg_ms"], "launches": rec["launches"]}
@@ -529,16 +556,19 @@ def main():
         fused_opt = stepper.fuse_optimizer
         # algorithmic bytes (SURVEY 8d per-unit figures) on the units each launch really processes:
         #   forward:  8 corners x C x 4 B per sample whose features are gathered (= the records), 8 x 16 B (the base record) for
-        #             the other in-AABB samples (density only), 20 B of cache per slot written, 48 B per ray
-        #   emit:     20 B cache read + the expanded record written (128 B specular, 32 B diffuse) per record
-        #   bricks:   the scatter payload 8 x C x 4 B per specular record + 8 x 4 x 4 B per diffuse record, plus the optimizer
-        #             traffic when it is fused (3 reads + 3 writes of 4 B per parameter; else the bucket is written once)
+        #             the other in-AABB samples (density only), 20 B of cache per CACHED sample (= per record) + the chunk masks, 48 B per ray
+        #   emit:     20 B cache read + the record written (48 B specular, 32 B diffuse) per record
+        #   bricks:   COMPULSORY HBM bytes only: the records read once + the optimizer traffic when it is fused (3 reads + 3 writes
+        #             of 4 B per parameter; else the gradient bucket written once).  The scatter payload (8 corners x C channels per
+        #             record) is on-chip work and is not credited as bandwidth.
+        rec_b, rec_b_d = 4 * ops.expanded_record_floats(grid), 4 * ops.expanded_record_floats(grid, True)
+        mask_b = R * ((S + 63) // 64) * 8
         alg = {
-            "render_forward[spec,save]": rec_spec * 8 * C * 4 + max(n_in - rec_spec, 0) * 8 * 16 + R * S * 20 + R * 48,
-            "render_forward[diffuse,save]": n_in * 8 * 16 + R * S * 20 + R * 48,
-            "render_backward_emit_direct[spec]": rec_spec * (20 + 4 * ops.expanded_record_floats(grid)),
-            "render_backward_emit_direct[diffuse]": rec_diff * (20 + 4 * ops.expanded_record_floats(grid, True)),
-            "brick_accumulate": rec_spec * 8 * C * 4 + rec_diff * 8 * 4 * 4 + nparam * 4 * (6 if fused_opt else 1),
+            "render_forward[spec,save]": rec_spec * 8 * C * 4 + max(n_in - rec_spec, 0) * 8 * 16 + rec_spec * 20 + mask_b + R * 48,
+            "render_forward[diffuse,save]": n_in * 8 * 16 + rec_diff * 20 + mask_b + R * 48,
+            "render_backward_emit_direct[spec]": rec_spec * (20 + rec_b) + mask_b,
+            "render_backward_emit_direct[diffuse]": rec_diff * (20 + rec_b_d) + mask_b,
+            "brick_accumulate": rec_spec * rec_b + rec_diff * rec_b_d + nparam * 4 * (6 if fused_opt else 1),
         }
         names = {"brick_accumulate": f"brick_accumulate_adam[{spec}]" if fused_opt else f"brick_accumulate[{spec}]"}
         by_kernel = {}
@@ -578,6 +608,21 @@ def main():
             "by_kernel": by_kernel,
         }
 
+    if roofline is None and kernels and owner:
+        # owner-computes data-parallel step: the rank's brick pass (all ranks' record lists for its own 1/N of the bricks, Adam in the
+        # flush) priced on its compulsory HBM bytes: the records it consumed + 6 accesses x 4 B per OWN parameter
+        bname = [k for k in kernels if k.startswith("brick_accumulate_adam")][0]
+        recs = np.mean(np.array(stepper.owner_records, dtype=np.float64), axis=0) if stepper.owner_records else np.zeros(2)
+        bytes_ = recs[0] * 4 * ops.expanded_record_floats(grid) + recs[1] * 4 * ops.expanded_record_floats(grid, True) + nparam / world * 24
+        ms = kernels[bname]["avg_ms"]
+        roofline = {
+            "kernel": bname, "bound": "hbm", "peak": HBM_PEAK_GBS, "unit": "GB/s", "achieved": bytes_ / 1e9 / (ms / 1e3), "frac": frac(bytes_, ms, bname),
+            "traffic": None, "traffic_stale": bool(pmc_stale), "avg_launch_ms": ms,
+            "frac_basis": "compulsory HBM bytes of this rank's brick pass (records consumed + 24 B per own parameter) / its event time",
+            "units_processed": {"records_specular_consumed": float(recs[0]), "records_diffuse_consumed": float(recs[1]), "own_parameters": nparam / world},
+            "by_kernel": {k: {"avg_launch_ms": v["avg_ms"]} for k, v in kernels.items()},
+            "note": "owner-computes data-parallel step: phases timed with events on the compute stream (collectives included where they block it)",
+        }
     if roofline is None and kernels:
         # the data-parallel-style step (or any non-merged step): per-launch HIP events of ops.KernelTimer; byte figures where the
         # counter table has the kernel (same kernels as the single-GPU step, plus the per-render brick passes and the separate optimizer)
@@ -625,11 +670,13 @@ def main():
             "workload": f"configs[2]: train step on {G}^3 SH-degree-{args.sh_degree} ReLU field (U(-1,1) init), {args.images} synthetic {H}x{W} images, "
             f"{R} random distinct pixels/GPU/step out of all {args.images}x{H}x{W} ({args.ray_selection} selection), {S} jittered samples/ray, specular+diffuse fwd+bwd, L1+L1, "
             + ("Adam fused into the brick flush" if stepper.fuse_optimizer else "fused Adam kernel")
-            + (", gradient exchange over RCCL: reduce-scatter -> Adam on 1/N of the grid per rank -> all-gather" if world > 1 else ""),
+            + ((", owner-computes exchange over RCCL: all-gather of offset tables -> all-to-all of gradient-record slices -> merged brick pass + Adam on the rank's own x-slabs -> parameter all-gather"
+                if owner else ", gradient exchange over RCCL: reduce-scatter -> Adam on 1/N of the grid per rank -> all-gather") if (world > 1 or args.dp_style_step) else ""),
             "rays_per_gpu_per_step": R,
             "samples_per_ray": S,
             "renders_per_step": 2,
-            "parallelism": f"dp{world}" + ("+zero1" if world > 1 and stepper.shard_optimizer else ""),
+            "parallelism": f"dp{world}" + (("+owner-computes" if owner else ("+zero1" if stepper.shard_optimizer else "")) if (world > 1 or args.dp_style_step) else ""),
+            "exchange": stepper.exchange if (world > 1 or args.dp_style_step) else None,
             "grid_storage": args.storage,
             "ray_selection": args.ray_selection,
             "backward": stepper.backward,

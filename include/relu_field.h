@@ -391,9 +391,11 @@ typedef struct RFTrainStep {
   float* grad_second_dev;
   int64_t first_ray;            /* position of ray 0 in the keyed jitter streams (global-batch data parallelism: the rank's
                                    offset in the batch); 0 otherwise                                                          */
-  uint32_t phases;              /* 0 = the whole iteration; RF_STEP_FRONT: select .. emit only (the caller runs the brick pass
-                                   itself, e.g. rf_brick_accumulate_adam_range after a record exchange); RF_STEP_BRICKS: the
-                                   brick pass over pass[0..1]'s lists only                                                     */
+  uint32_t phases;              /* 0 = the whole iteration, else a set of RF_STEP_FORWARD (select, both forward passes, losses +
+                                   offsets), RF_STEP_EMIT (both adjoints as records), RF_STEP_BRICKS (the brick pass over
+                                   pass[0..1]'s lists): a data-parallel caller starts its exchange of the offset tables after
+                                   FORWARD, lets it overlap EMIT, and runs rf_brick_accumulate_adam_range itself after the
+                                   record exchange                                                                              */
   float loss_scale;             /* the L1 gradients are scaled by this (0 = 1): 1 / world size under data parallelism          */
   void* const* timing_events;   /* optional HOST array of RF_TRAIN_STEP_EVENTS hipEvent_t (created by the caller with timing
                                    enabled): event 0 is recorded on `stream` before the first launch, event k after launch k
@@ -402,7 +404,7 @@ typedef struct RFTrainStep {
                                    of the very call that is timed (only with phases == 0)                                      */
 } RFTrainStep;
 
-enum { RF_STEP_FRONT = 1, RF_STEP_BRICKS = 2 };
+enum { RF_STEP_FORWARD = 1, RF_STEP_EMIT = 2, RF_STEP_BRICKS = 4 };
 
 #define RF_TRAIN_STEP_EVENTS 11
 

@@ -84,6 +84,21 @@ def _worker(rank, world, port, result_dir):
     param[h.lo : h.hi] -= 0.1 * h.shard
     rfdist.all_gather_chunks_(param)
     assert torch.allclose(param, -0.1 * torch.arange(96.0) * (sum(range(1, world + 1)) / world))
+    # 5. owner-computes exchange primitives: equal-sized all-gather of tables, personalised exchange of (overlapping) slices
+    table = torch.arange(6, dtype=torch.int64).reshape(2, 3) + 100 * rank
+    tables = torch.empty((world, 2, 3), dtype=torch.int64)
+    assert rfdist.all_gather_rows_equal(tables, table, async_op=True) is None  # (gloo: completed on return)
+    assert all(torch.equal(tables[r2], torch.arange(6).reshape(2, 3) + 100 * r2) for r2 in range(world))
+    data = (torch.arange(40, dtype=torch.float32).reshape(10, 4) + 1000 * rank)
+    # rank r sends rows [2 d, 2 d + 3 + r) to rank d: the slices of neighbouring destinations overlap
+    send = [data[2 * d : 2 * d + 3 + rank] for d in range(world)]
+    recv = [torch.full((3 + s_, 4), -1.0) for s_ in range(world)]
+    rfdist.exchange_slices(send, recv)
+    for s_ in range(world):
+        if s_ == rank:
+            assert torch.equal(recv[s_], torch.full((3 + s_, 4), -1.0))  # the own entry is left alone
+        else:
+            assert torch.equal(recv[s_], torch.arange(40, dtype=torch.float32).reshape(10, 4)[2 * rank : 2 * rank + 3 + s_] + 1000 * s_)
     open(os.path.join(result_dir, f"ok{rank}"), "w").write("ok")
     dist.destroy_process_group()
 

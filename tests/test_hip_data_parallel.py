@@ -1,7 +1,8 @@
-"""Two REAL processes training data-parallel on one GPU: the full fused HIP step (binned backward, sharded Adam, strong
-and weak scaling modes) with the exchange going through torch.distributed -- gloo with device tensors here, because
-RCCL refuses two ranks on one device; the RCCL calls themselves are exercised by
-test_hip_training.py::test_data_parallel_step_through_rccl_single_rank and multi-GPU runs are the driver's."""
+"""Two REAL processes training data-parallel on one GPU: the full fused HIP step in both exchange schemes -- owner-computes
+(offset tables all-gathered, record slices exchanged, merged brick pass + Adam on the rank's own x-slabs, parameters all-gathered)
+and dense (reduce-scatter of the gradient bucket, sharded Adam, all-gather) --, strong and weak scaling modes, with the exchange
+going through torch.distributed -- gloo here, because RCCL refuses two ranks on one device; the RCCL calls themselves are exercised
+by test_hip_training.py::test_data_parallel_step_through_rccl_single_rank and multi-GPU runs are the driver's."""
 import os
 import socket
 
@@ -28,7 +29,7 @@ def _free_port():
         return s.getsockname()[1]
 
 
-def _setup(dev):
+def _setup(dev, jitter=False):
     cam = hotdog_like_camera()
     images = torch.from_numpy(hash_uniform((4, 3, 24, 24), 77, 0.0, 1.0)).to(dev)
     cams = [rf.pose_spherical(40.0 * k, -30.0, cam["radius"]) for k in range(4)]
@@ -39,7 +40,7 @@ def _setup(dev):
         rf.VoxelSize(3.0 / G, 3.0 / G, 3.0 / G), density_preactivation=torch.nn.Identity(), density_postactivation=torch.nn.ReLU(),
         expected_density_scale=100.0 / 3.0, tunable=True, storage="split",
     )
-    cfg = rf.SHVoxGridRenderConfig(S, data.camera_bounds, perturb_sampled_points=False, white_bkgd=True)
+    cfg = rf.SHVoxGridRenderConfig(S, data.camera_bounds, perturb_sampled_points=jitter, white_bkgd=True)
     return data, rf.VolumetricModel(grid, rf.render_sh_voxel_grid, cfg, device=dev)
 
 
@@ -51,26 +52,31 @@ def _train(stepper, data, steps=3):
     return stepper.flat.flat_param.clone()
 
 
-def _worker(rank, world, port, result_dir, shard_optimizer):
+def _worker(rank, world, port, result_dir, exchange, shard_optimizer, jitter):
     os.environ.update(RANK=str(rank), LOCAL_RANK="0", WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     dev = torch.device("cuda", 0)
     torch.cuda.set_device(dev)
     dist.init_process_group(backend="gloo", rank=rank, world_size=world)
     try:
         # strong scaling: the ranks split ONE global batch -> the run must equal the single-process run
-        data, model = _setup(dev)
-        dp = _train(TrainStepper(model, R, learning_rate=0.03, global_batch=True, shard_optimizer=shard_optimizer), data)
+        # (with the keyed jitter on, rank r must draw the jitter of rays lo..hi of the global batch: KeyedJitter.first_ray)
+        data, model = _setup(dev, jitter)
+        stepper = TrainStepper(model, R, learning_rate=0.03, global_batch=True, shard_optimizer=shard_optimizer, exchange=exchange)
+        assert stepper.exchange == exchange
+        dp = _train(stepper, data)
+        if exchange == "owner":
+            assert stepper.exchange_bytes and stepper.exchange_bytes[-1] > 0 and stepper.owner_records[-1][0] > 0
         gathered = [torch.empty_like(dp) for _ in range(world)]
         dist.all_gather(gathered, dp)
         assert all(torch.equal(gathered[0], t) for t in gathered), "replicas diverged"
-        data, model = _setup(dev)
+        data, model = _setup(dev, jitter)
         single = _train(TrainStepper(model, R, learning_rate=0.03, data_parallel=False), data)
         err = float((dp - single).abs().max())
         moved = float((single - torch.cat([t.reshape(-1) for t in model.thre3d_repr.kernel_tensors()]).detach()).abs().max())
         assert err <= 2e-4, f"data-parallel run differs from the single-process run by {err}"
         # weak scaling: every rank draws its own batch; replicas must still agree
-        data, model = _setup(dev)
-        stepper = TrainStepper(model, R // 2, learning_rate=0.03, shard_optimizer=shard_optimizer)
+        data, model = _setup(dev, jitter)
+        stepper = TrainStepper(model, R // 2, learning_rate=0.03, shard_optimizer=shard_optimizer, exchange=exchange)
         torch.manual_seed(11 + rank)
         for _ in range(2):
             stepper.step(data, torch.arange(4))
@@ -84,9 +90,9 @@ def _worker(rank, world, port, result_dir, shard_optimizer):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("shard_optimizer", [True, False])
-def test_two_processes_train_data_parallel_on_one_gpu(tmp_path, shard_optimizer):
+@pytest.mark.parametrize("exchange,shard_optimizer,jitter", [("owner", True, False), ("owner", True, True), ("dense", True, False), ("dense", False, True)])
+def test_two_processes_train_data_parallel_on_one_gpu(tmp_path, exchange, shard_optimizer, jitter):
     assert torch.cuda.is_available()
     world = 2
-    mp.spawn(_worker, args=(world, _free_port(), str(tmp_path), shard_optimizer), nprocs=world, join=True)
+    mp.spawn(_worker, args=(world, _free_port(), str(tmp_path), exchange, shard_optimizer, jitter), nprocs=world, join=True)
     assert sorted(os.listdir(tmp_path)) == [f"ok{r}" for r in range(world)]

@@ -634,11 +634,12 @@ def test_data_parallel_sharded_optimizer_wiring(hip_device, monkeypatch):
     assert calls == [("reduce_scatter", nr), ("reduce_scatter", nd), "wait", "wait", ("all_gather", nr), ("all_gather", nd)]
 
 
-@pytest.mark.parametrize("shard_optimizer", [True, False])
-def test_data_parallel_step_through_rccl_single_rank(hip_device, shard_optimizer):
+@pytest.mark.parametrize("exchange,shard_optimizer", [("owner", True), ("dense", True), ("dense", False)])
+def test_data_parallel_step_through_rccl_single_rank(hip_device, exchange, shard_optimizer):
     """The data-parallel train step with its collectives really going through RCCL (a process group of ONE rank on this
-    GPU: reduce_scatter_tensor / all_gather_into_tensor / asynchronous all_reduce with ReduceOp.AVG) must equal the
-    plain step.  (Multi-rank semantics are covered by the gloo tests; 2/4/8-GPU runs are the driver's.)"""
+    GPU: owner-computes = all_gather_into_tensor of the offset tables on RCCL's stream + the side-stream host read + all_to_all +
+    the brick pass over a brick range; dense = reduce_scatter_tensor / all_gather_into_tensor / asynchronous all_reduce with
+    ReduceOp.AVG) must equal the plain step.  (Multi-rank semantics are covered by the gloo tests; 2/4/8-GPU runs are the driver's.)"""
     import torch.distributed as dist
     from thr3ed_atom_amd import distributed as rfdist
 
@@ -657,7 +658,10 @@ def test_data_parallel_step_through_rccl_single_rank(hip_device, shard_optimizer
             grid = relu_grid(hip_device, T(hash_uniform((G, G, G, 1), 901)), T(hash_uniform((G, G, G, F), 900 + F)), G, storage="split")
             cfg = rf.SHVoxGridRenderConfig(S, rf.CameraBounds(float(g["near"]), float(g["far"])), perturb_sampled_points=False, white_bkgd=True)
             model = rf.VolumetricModel(grid, rf.render_sh_voxel_grid, cfg, device=hip_device)
-            stepper = TrainStepper(model, n_rays, learning_rate=float(g["lr"]), shard_optimizer=shard_optimizer)
+            # (the trajectory's grid is SH degree 0: the binned backward is asked for explicitly where the owner-computes step needs it)
+            stepper = TrainStepper(model, n_rays, learning_rate=float(g["lr"]), shard_optimizer=shard_optimizer, exchange=exchange if dp else "auto",
+                                   backward="binned" if exchange == "owner" else "auto")
+            assert stepper.exchange == (exchange if dp else "dense")
             for it in range(2):
                 rays = rf.Rays(T(g["origins"][it]).to(hip_device), T(g["directions"][it]).to(hip_device))
                 stepper.step_on(rays, T(g["pixels"][it]).to(hip_device))

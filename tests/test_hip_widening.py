@@ -145,7 +145,9 @@ def test_bench_line_contract(hip_device):
     np.testing.assert_allclose(line["value"], 2 * 16384 * 256 / (line["ms_per_step"] * 1e-3), rtol=1e-6)
     roof = line["roofline"]
     assert roof["bound"] == "hbm" and roof["unit"] == "GB/s" and roof["peak"] == 8000.0
-    assert 0.0 < roof["frac"] <= 1.0 and abs(roof["frac"] - roof["achieved"] / roof["peak"]) < 1e-9 and roof["traffic"] > 0
+    assert 0.0 < roof["frac"] <= 1.0 and abs(roof["frac"] - roof["achieved"] / roof["peak"]) < 1e-9
+    # the counter table is tied to the kernel source by hash: a stale table is never used (the fraction is then priced on the algorithmic bytes)
+    assert (roof["traffic"] is None and roof["traffic_stale"]) or (roof["traffic"] > 0 and not roof["traffic_stale"])
     for rec in roof["by_kernel"].values():
         assert rec.get("frac_hbm") is None or 0.0 < rec["frac_hbm"] <= 1.0
     assert line["roofline_model_errors"] == []

@@ -25,8 +25,9 @@ FLAG_RENDER_DIFFUSE = 2
 FLAG_AABB_SAMPLING = 4
 FLAG_OCCUPANCY_SKIP = 8
 FLAG_JITTER_KEYED = 16
-STEP_FRONT = 1
-STEP_BRICKS = 2
+STEP_FORWARD = 1
+STEP_EMIT = 2
+STEP_BRICKS = 4
 
 EXPORTED_SYMBOLS = [
     "rf_abi_version",

@@ -1338,13 +1338,15 @@ __global__ __launch_bounds__(kBlock) void render_emit_direct_kernel(GridArgs g, 
   // the unit viewing direction (process.py:53) travels in the record: the brick pass evaluates the SH basis from it
   const float vdir[3] = {st.d[0] / st.dnorm, st.d[1] / st.dnorm, st.d[2] / st.dnorm};
 
+  const int mask_words = (r.S + kWave - 1) / kWave;
   const int processed = fwd.stop[ray];
   const int nchunks = (processed + kWave - 1) / kWave;
-  const int mask_words = (r.S + kWave - 1) / kWave;
   float suffix = 0.0f;  // sum of w_j e_j over all samples beyond the current chunk
   constexpr int G = 4;  // chunks in flight
-  unsigned long long lane_masks = 0ull;
-  int masks_group = -1;
+  // the chunk masks, one per lane: requested before anything that depends on `processed` (the first group walked is almost always
+  // the last one of the ray: rays of at most 4096 samples have a single group)
+  int masks_group = (mask_words - 1) >> 6;
+  unsigned long long lane_masks = fwd.cmask[ray * (long long)mask_words + min(masks_group * kWave + lane, mask_words - 1)];
 
   for (int c0 = nchunks - 1; c0 >= 0; c0 -= G) {
     float4 cv[G];
@@ -2098,13 +2100,17 @@ __global__ __launch_bounds__(kBrickThreads, 4) void brick_gather_kernel(GridArgs
       }
       float* row = rows + rec_id * RW;
       if constexpr (EXPAND) {
-        float Y[16];
-        sh_basis<K>(q1.w, q2.x, q2.y, Y);
+        // the first thread of the record (which also did the weights and the tile set) writes the base quad -- density and the
+        // degree-0 channels, whose basis value is a constant --, the second evaluates the SH basis and writes the rest channels
         const float graw[3] = {q1.x, q1.y, q1.z};
-        constexpr int NQ = C4 / 4, QH = (NQ + 1) / 2;  // quads of a row; the first thread of the record writes [0, QH)
+        constexpr int NQ = C4 / 4;
+        if (half == 0) {
+          *reinterpret_cast<float4*>(row) = make_float4(q0.w, graw[0] * kC0, graw[1] * kC0, graw[2] * kC0);
+        } else {
+          float Y[16];
+          sh_basis<K>(q1.w, q2.x, q2.y, Y);
 #pragma unroll
-        for (int q = 0; q < NQ; ++q) {
-          if ((q < QH) == (half == 0)) {
+          for (int q = 1; q < NQ; ++q) {
             float v[4];
 #pragma unroll
             for (int x = 0; x < 4; ++x) v[x] = (4 * q + x < C) ? record_channel<K>(4 * q + x, q0.w, graw, Y) : 0.0f;
@@ -3540,7 +3546,8 @@ int rf_train_step(const RFGrid* grid, const RFTrainStep* step, void* stream) {
   if (step->pass[1].out.brick_size != step->pass[0].out.brick_size) return RF_ERR_BAD_SHAPE;
   const int nkeys = nb[0] * nb[1] * nb[2] * 8;
   if (nkeys > (1 << 21)) return RF_ERR_BAD_SHAPE;
-  const bool run_front = step->phases == 0 || (step->phases & RF_STEP_FRONT), run_bricks = step->phases == 0 || (step->phases & RF_STEP_BRICKS);
+  const bool run_forward = step->phases == 0 || (step->phases & RF_STEP_FORWARD), run_emit = step->phases == 0 || (step->phases & RF_STEP_EMIT),
+             run_bricks = step->phases == 0 || (step->phases & RF_STEP_BRICKS);
   if (run_bricks) {  // everything the last launch would refuse is refused before the first one
     if (step->adam) {
       rc = check_fused_adam(grid, step->adam, grid->num_features / 3, false);
@@ -3557,7 +3564,7 @@ int rf_train_step(const RFGrid* grid, const RFTrainStep* step, void* stream) {
   do {                                                                                                       \
     if (events && hipEventRecord((hipEvent_t)events[ev++], st) != hipSuccess) return RF_ERR_LAUNCH; \
   } while (0)
-  void* const* events = (run_front && run_bricks) ? step->timing_events : nullptr;  // (the per-launch events describe the whole iteration)
+  void* const* events = (run_forward && run_emit && run_bricks) ? step->timing_events : nullptr;  // (the per-launch events describe the whole iteration)
   RFRayBatch rays[2];
   uint32_t flags[2];
   for (int i = 0; i < 2; ++i) {
@@ -3575,7 +3582,7 @@ int rf_train_step(const RFGrid* grid, const RFTrainStep* step, void* stream) {
     rays[i].first_ray = step->first_ray;
     flags[i] = (step->flags & ~(uint32_t)RF_FLAG_RENDER_DIFFUSE) | (i == 1 ? (uint32_t)RF_FLAG_RENDER_DIFFUSE : 0u);
   }
-  if (run_front) {
+  if (run_forward) {
     RF_STEP_EVENT();
     if (step->select) {
       const RFRaySelection* s = step->select;
@@ -3587,7 +3594,6 @@ int rf_train_step(const RFGrid* grid, const RFTrainStep* step, void* stream) {
       return RF_ERR_LAUNCH;
     }
     RF_STEP_EVENT();
-    RFRenderGrads grads[2];
     for (int i = 0; i < 2; ++i) {
       const RFPassScratch& ps = step->pass[i];
       rc = rf_render_forward(grid, &rays[i], flags[i], &ps.out, stream);
@@ -3612,12 +3618,14 @@ int rf_train_step(const RFGrid* grid, const RFTrainStep* step, void* stream) {
         if (rc != RF_OK) return rc;
       }
       RF_STEP_EVENT();
-      grads[i] = RFRenderGrads{ps.grad_colour_dev, nullptr, nullptr};
     }
+  }
+  if (run_emit) {
     for (int i = 0; i < 2; ++i) {
       const RFPassScratch& ps = step->pass[i];
+      const RFRenderGrads grads = {ps.grad_colour_dev, nullptr, nullptr};
       RF_STEP_EVENT();  // (offsets[0] = the launch above, offsets[1] = nothing)
-      rc = rf_render_backward_emit_direct(grid, &rays[i], flags[i], &ps.out, &grads[i], ps.out.brick_size, ps.cursor_dev, ps.records_sorted_dev,
+      rc = rf_render_backward_emit_direct(grid, &rays[i], flags[i], &ps.out, &grads, ps.out.brick_size, ps.cursor_dev, ps.records_sorted_dev,
                                           ps.out.key_hist_dev, stream);
       if (rc != RF_OK) return rc;
       RF_STEP_EVENT();

@@ -160,6 +160,52 @@ def all_gather_chunks_(bucket: Tensor) -> Tensor:
     return bucket
 
 
+def all_gather_rows_equal(out: Tensor, mine: Tensor, async_op: bool = False):
+    """``out`` [N, ...] <- every rank's ``mine`` [...] (same shape on all ranks), row r from rank r.  Returns the work handle when
+    ``async_op`` (None when there is nothing to wait for)."""
+    n = world_size()
+    assert out.shape[0] == n and out[0].shape == mine.shape and out.is_contiguous() and mine.is_contiguous()
+    if not _collectives_on():
+        out[0].copy_(mine)
+        return None
+    if dist.get_backend() == "nccl":
+        work = dist.all_gather_into_tensor(out, mine, async_op=async_op)
+        return work if async_op else None
+    parts = [out[r] for r in range(n)]  # gloo: list form (rows of a contiguous tensor are contiguous views)
+    dist.all_gather(parts, mine)
+    return None
+
+
+def exchange_slices(send: list, recv: list) -> None:
+    """Personalised exchange: ``send[d]`` (a slice of this rank's data, any length, slices may overlap) goes to rank d and
+    ``recv[s]`` (pre-sized by the caller, who knows every count) receives what rank s sends here.  Entries for the own rank are
+    ignored (pass empty tensors).  RCCL: one grouped send/recv per pair (``all_to_all``) straight out of / into the given views
+    over xGMI; other backends (CPU tests of the wiring): staged through host memory."""
+    n, me = world_size(), rank()
+    assert len(send) == n and len(recv) == n
+    if not _collectives_on():
+        return
+    if dist.get_backend() == "nccl":
+        empty = send[me][:0]
+        ins = [empty if d == me else send[d] for d in range(n)]
+        outs = [recv[me][:0] if s_ == me else recv[s_] for s_ in range(n)]
+        dist.all_to_all(outs, ins)
+        return
+    # gloo: all_to_all_single on host copies (gloo has no list all_to_all and no device all_to_all)
+    width = tuple(send[0].shape[1:])
+    ins = [send[d][:0] if d == me else send[d] for d in range(n)]
+    packed = torch.cat([t.reshape((-1,) + width) for t in ins], dim=0).cpu()
+    in_split = [0 if d == me else int(send[d].shape[0]) for d in range(n)]
+    out_split = [0 if s_ == me else int(recv[s_].shape[0]) for s_ in range(n)]
+    got = torch.empty((sum(out_split),) + width, dtype=packed.dtype)
+    dist.all_to_all_single(got, packed, output_split_sizes=out_split, input_split_sizes=in_split)
+    pos = 0
+    for s_ in range(n):
+        if out_split[s_]:
+            recv[s_].copy_(got[pos : pos + out_split[s_]])
+            pos += out_split[s_]
+
+
 def broadcast_(tensor: Tensor, src: int = 0) -> Tensor:
     if world_size() > 1:
         dist.broadcast(tensor, src=src)

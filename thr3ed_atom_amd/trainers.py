@@ -145,6 +145,7 @@ class TrainStepper:
         global_batch: bool = False,
         merge_bricks: Optional[bool] = None,
         fuse_optimizer: Optional[bool] = None,
+        exchange: str = "auto",
     ):
         """``ray_selection``: "randperm" draws torch.randperm over all B*H*W pixels exactly like the reference
         (utils/misc.py:123) and keeps the first ``ray_batch_size``; "keyed" draws the same kind of sample
@@ -212,6 +213,28 @@ class TrainStepper:
             padded_nodes *= (d + 7) // 8 * 8
         fits_flush = padded_nodes * max(4, grid.num_features - 3) < (1 << 31)
         can_fuse = self.merged_bricks and single and grid.storage != "reference" and (grid.num_features + 1) % 4 == 0 and fits_flush
+        # exchange (data parallel; the reference has none: modules/trainers.py:338-341 is one device's backward + step):
+        #   "owner": OWNER-COMPUTES.  Every rank owns an equal range of x-slabs of bricks.  The ranks exchange their gradient RECORDS
+        #     (48 / 32 B each, already sorted by brick, so what an owner needs of a rank's list is ONE slice) instead of the dense
+        #     235 MB gradient; each owner runs the merged brick pass with Adam in its flush on its own bricks (1/N of the optimizer
+        #     traffic per rank), then the parameters are all-gathered.  ~280 MB per rank and step over xGMI at N = 8 instead of 411.
+        #   "dense": reduce-scatter of the gradient bucket -> sharded Adam -> all-gather (_fused_step_on).
+        #   "auto": owner where it applies (fused, merged, split/bricked storage, SH degree 0 or 2, X divisible by 8 N, N <= 8).
+        if exchange not in ("auto", "owner", "dense"):
+            raise ValueError("exchange must be 'auto', 'owner' or 'dense'")
+        world = rfdist.world_size()
+        can_owner = (not single and can_merge and merge_bricks is not False and fuse_optimizer is not False and grid.storage != "reference"
+                     and (grid.num_features + 1) % 4 == 0 and fits_flush and world <= 8 and self.brick_size == 8 and grid.grid_dims[0] % (8 * world) == 0)
+        if exchange == "owner" and not can_owner:
+            raise ValueError("exchange='owner' needs the fused, merged step on split or bricked storage, SH degree 0 or 2, at most 8 ranks and X divisible by 8 x ranks")
+        self.exchange = "owner" if (can_owner and exchange != "dense") else "dense"
+        self.owner_records = []
+        self.exchange_bytes = []  # bytes this rank SENT in each of the last steps (record slices + offset tables + parameter chunks)
+        self.phase_events = None  # a list: the owner step appends a tuple of torch events around its phases (bench.py)
+        self._owner = None
+        if self.exchange == "owner":
+            self.merged_bricks = True
+            can_fuse = True
         self.fuse_optimizer = can_fuse if fuse_optimizer is None else bool(fuse_optimizer)
         if self.fuse_optimizer and not can_fuse:
             raise ValueError("fuse_optimizer needs a merged brick pass on a single process, split or bricked storage, SH degree 0 or 2 and fewer than 2^31 elements per grid tensor")
@@ -257,7 +280,7 @@ class TrainStepper:
         if self.fused:
             if not self.merged_bricks:
                 stats = self._fused_step_on(rays, pixels, t_rand)
-            elif ops.KERNEL_TIMER is not None:
+            elif ops.KERNEL_TIMER is not None and self.exchange != "owner":
                 stats = self._merged_step_pieces(rays, pixels, t_rand)
             else:
                 stats = self._merged_step_on(rays, pixels, t_rand)
@@ -338,7 +361,9 @@ class TrainStepper:
             keep = (origins, directions, pixels)
         st.near, st.far = float(np.float32(cfg.camera_bounds.near)), float(np.float32(cfg.camera_bounds.far))
         flags = render_flags(cfg.white_bkgd, False, cfg.optimized_sampling, cfg.use_occupancy_mask)
-        jit = [self._draw_jitter(cfg, n, S, dev, t_rand, i) for i in range(2)]
+        jitter_first = int(selection[3]) if (selection is not None and self.global_batch) else 0
+        jit = [self._draw_jitter(cfg, n, S, dev, t_rand, i, jitter_first) for i in range(2)]
+        st.first_ray = jitter_first
         for i in range(2):
             if isinstance(jit[i], ops.KeyedJitter):
                 flags |= _lib.FLAG_JITTER_KEYED
@@ -348,6 +373,13 @@ class TrainStepper:
         st.flags = flags
         rf_grid = grid.to_rf_grid(use_occupancy=cfg.use_occupancy_mask)
         opt = self.optimizer
+        if self.exchange == "owner":
+            self._owner_step(ex, st, rf_grid, n, S, dev)
+            del keep, jit
+            self._grad_clean = True
+            means = ex["sums"] / float(3 * n)
+            return StepStats(means[0], means[2], means[1], means[3])
+        st.phases, st.loss_scale = 0, 1.0
         if self.fuse_optimizer:
             opt.step_count += 1
             ad = ex["adam"]
@@ -374,6 +406,116 @@ class TrainStepper:
         means = ex["sums"] / float(3 * n)
         return StepStats(means[0], means[2], means[1], means[3])
 
+    def _owner_state(self, ex, device):
+        """Persistent state of the owner-computes exchange: the ranks' offset tables, where every owner's key range starts and
+        ends in them, a pinned host copy of those bounds, the side stream that fetches it, the receive buffers."""
+        ow = self._owner
+        if ow is not None and ow["ex"] is ex:
+            return ow
+        grid = self.vol_mod.thre3d_repr
+        W, me = rfdist.world_size(), rfdist.rank()
+        nb = brick_counts(grid, self.brick_size)
+        nbyz, sp = nb[1] * nb[2], nb[0] // W
+        nkeys = nb[0] * nbyz * 8
+        # owner r: the x-slabs [r sp, (r + 1) sp) of bricks.  Everything that touches their nodes is the key range
+        # [key(slab r sp - 1, f_x = 1), key(slab (r + 1) sp, f_x = 0)) (brick_key: ((2 bx + f_x) nby nbz + ...) << 2)
+        idx = []
+        for r in range(W):
+            lo = 0 if r == 0 else (2 * r * sp - 1) * nbyz * 4
+            idx += [lo, 2 * (r + 1) * sp * nbyz * 4]
+        assert idx[-1] == nkeys
+        t = ex["tensors"]
+        ow = {
+            "ex": ex, "W": W, "me": me, "bricks": (me * sp * nbyz, sp * nbyz),
+            "all_offsets": torch.empty((W, 2, nkeys + 1), dtype=torch.int64, device=device),
+            "key_idx": torch.tensor(idx, dtype=torch.int64, device=device),
+            "bounds_host": torch.empty((W, 2, 2 * W), dtype=torch.int64).pin_memory(),
+            "side": torch.cuda.Stream(device), "forward_done": torch.cuda.Event(), "ready": torch.cuda.Event(),
+            "recv": [torch.empty((0, t[f"pass{k}"]["sorted"].shape[1]), dtype=torch.float32, device=device) for k in range(2)],
+        }
+        self._owner = ow
+        return ow
+
+    def _owner_step(self, ex, st, rf_grid, n: int, S: int, dev) -> None:
+        """The data-parallel iteration, owner-computes (see __init__): forward passes (+ losses, offsets) | all-gather of the offset
+        tables, overlapped with the emit launches; the host reads the N x N slice bounds (the one host round trip of the step: the
+        emit kernels keep the GPU busy meanwhile) | personalised exchange of record slices over RCCL | merged brick pass + Adam on
+        the own bricks over all ranks' lists | all-gather of the parameters."""
+        ow = self._owner_state(ex, dev)
+        W, me = ow["W"], ow["me"]
+        lib, grid, opt = _lib.load(), self.vol_mod.thre3d_repr, self.optimizer
+        main = torch.cuda.current_stream(dev)
+        t = ex["tensors"]
+        ev = [torch.cuda.Event(enable_timing=True) for _ in range(6)] if self.phase_events is not None else None
+        mark = (lambda i: ev[i].record(main)) if ev is not None else (lambda i: None)
+        st.adam, st.loss_scale = None, 1.0 / W
+        mark(0)
+        st.phases = _lib.STEP_FORWARD
+        _lib.check(lib.rf_train_step(C.byref(rf_grid), C.byref(st), main.cuda_stream), "rf_train_step[forward]")
+        mark(1)
+        work = rfdist.all_gather_rows_equal(ow["all_offsets"], t["offsets2"], async_op=True)
+        ow["forward_done"].record(main)
+        st.phases = _lib.STEP_EMIT
+        _lib.check(lib.rf_train_step(C.byref(rf_grid), C.byref(st), main.cuda_stream), "rf_train_step[emit]")
+        mark(2)
+        with torch.cuda.stream(ow["side"]):
+            ow["side"].wait_event(ow["forward_done"])
+            if work is not None:
+                work.wait()  # (makes the side stream wait for RCCL's stream)
+            ow["bounds_host"].copy_(ow["all_offsets"].index_select(2, ow["key_idx"]), non_blocking=True)
+            ow["ready"].record(ow["side"])
+        if work is not None:
+            work.wait()  # the brick pass on the main stream reads the tables too
+        ow["ready"].synchronize()
+        b = ow["bounds_host"].numpy()  # [source, list, (lo, hi) per owner]
+        sent = (W - 1) * t["offsets2"].numel() * 8  # the all-gather of the offset tables
+        lists = []
+        for k in range(2):
+            srt = t[f"pass{k}"]["sorted"]
+            rec_bytes = srt.shape[1] * 4
+            counts = [0 if s_ == me else int(b[s_, k, 2 * me + 1] - b[s_, k, 2 * me]) for s_ in range(W)]
+            total = sum(counts)
+            ow.setdefault("last_total", [0, 0])[k] = total
+            if ow["recv"][k].shape[0] < total:  # grow-only receive buffer (sizes change slowly from step to step)
+                ow["recv"][k] = torch.empty((int(total * 1.25) + 1024, srt.shape[1]), dtype=torch.float32, device=dev)
+            recv_buf = ow["recv"][k]
+            base, send, recv = [], [], []
+            pos = 0
+            for s_ in range(W):
+                base.append(pos)
+                recv.append(recv_buf[pos : pos + counts[s_]])
+                pos += counts[s_]
+                send.append(srt[int(b[me, k, 2 * s_]) : int(b[me, k, 2 * s_ + 1])] if s_ != me else srt[:0])
+                if s_ != me:
+                    sent += int(send[-1].shape[0]) * rec_bytes
+            if W > 1:
+                rfdist.exchange_slices(send, recv)
+            for s_ in range(W):
+                if s_ == me:
+                    lists.append((srt.data_ptr(), t["offsets2"][k], k == 1))
+                else:  # positioned such that ptr + offsets_s[key] * record size is the first record of `key` in the received slice
+                    lists.append((recv_buf.data_ptr() + (base[s_] - int(b[s_, k, 2 * me])) * rec_bytes, ow["all_offsets"][s_, k], k == 1))
+        mark(3)
+        opt.step_count += 1
+        nd = self.flat.flat_gradient_parts()[0].numel()
+        has_second = self.flat.flat_gradient_parts()[1] is not None
+        halves = lambda x: (x[:nd], x[nd:] if has_second else None)
+        brick_accumulate_adam_raw(grid, self.brick_size, lists, halves(opt.exp_avg), halves(opt.exp_avg_sq), opt.lr, opt.betas[0], opt.betas[1],
+                                  opt.eps, opt.step_count, brick_range=ow["bricks"])
+        mark(4)
+        if W > 1:
+            rfdist.all_gather_chunks_(self.flat.flat_param[:nd])
+            if has_second:
+                rfdist.all_gather_chunks_(self.flat.flat_param[nd:])
+            sent += (W - 1) * (self.flat.flat_param.numel() // W) * 4
+        mark(5)
+        self.exchange_bytes = (self.exchange_bytes + [sent])[-64:]
+        # records this rank's brick pass consumed (its own slice of its own lists + what it received), per list
+        own = [int(b[me, k, 2 * me + 1] - b[me, k, 2 * me]) for k in range(2)]
+        self.owner_records = (self.owner_records + [(own[0] + int(ow["last_total"][0]), own[1] + int(ow["last_total"][1]))])[-64:]
+        if ev is not None:
+            self.phase_events.append(ev)
+
     def _executor(self, n: int, S: int, device):
         """Persistent scratch + the ctypes description of one iteration (rebuilt when the batch shape changes)."""
         ex = self._exec
@@ -389,6 +531,7 @@ class TrainStepper:
             "origins": torch.empty((n, 3), **f32), "directions": torch.empty((n, 3), **f32), "pixels": torch.empty((n, 3), **f32),
             "sums": torch.zeros(4, **f32), "t_vals": ops.t_vals_for(S, device),
         }
+        t["offsets2"] = torch.empty((2, nkeys + 1), dtype=torch.int64, device=device)  # both lists' tables: ONE collective buffer
         step, sel, adam = _lib.RFTrainStep(), _lib.RFRaySelection(), _lib.RFAdamState()
         step.num_rays, step.num_samples, step.t_vals_dev, step.loss_sums_dev = n, S, t["t_vals"].data_ptr(), t["sums"].data_ptr()
         for i, diffuse in enumerate((False, True)):
@@ -398,7 +541,7 @@ class TrainStepper:
                 "cmask": torch.empty((n, (S + 63) // 64), dtype=torch.int64, device=device),
                 "g_colour": torch.empty((n, 3), **f32),
                 "hist": torch.zeros(nkeys, dtype=torch.int32, device=device), "cursor": torch.empty(nkeys, dtype=torch.int32, device=device),
-                "offsets": torch.empty(nkeys + 1, dtype=torch.int64, device=device),
+                "offsets": t["offsets2"][i],
                 "sorted": torch.empty((n * S, expanded_record_floats(grid, diffuse)), **f32),
             }
             t[f"pass{i}"] = p
@@ -584,7 +727,7 @@ class TrainStepper:
         return b
 
     def step(self, dataset: PosedImagesInMemory, image_ids: Tensor) -> StepStats:
-        if self.fused and self.merged_bricks and self.ray_selection == "keyed" and ops.KERNEL_TIMER is None:
+        if self.fused and self.merged_bricks and self.ray_selection == "keyed" and (ops.KERNEL_TIMER is None or self.exchange == "owner"):
             # the library call draws the batch as well (rf_select_rays_and_pixels is its first launch)
             grid, cfg = self.vol_mod.thre3d_repr, self.vol_mod.render_config
             if cfg.use_occupancy_mask and not grid.occupancy_current():
