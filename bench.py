@@ -321,8 +321,8 @@ def main():
     assert torch.cuda.is_available(), "bench.py needs a GPU (the render path has no CPU fallback)"
     dev = torch.device("cuda", local_rank)
     torch.cuda.set_device(dev)
-    backend = torch.distributed.get_backend() if world > 1 else None
-    rccl_world = torch.distributed.get_world_size() if world > 1 else 1
+    backend = torch.distributed.get_backend() if torch.distributed.is_initialized() else None
+    rccl_world = torch.distributed.get_world_size() if torch.distributed.is_initialized() else 1
 
     H = W = args.image_size
     focal = 1111.111 * (W / 800.0)

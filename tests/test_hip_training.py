@@ -645,6 +645,8 @@ def test_data_parallel_step_through_rccl_single_rank(hip_device, exchange, shard
 
     g = load_golden("g9_trainer_trajectory.npz")
     G, deg, hw, n_img, n_rays, steps, S = (int(v) for v in g["config"])
+    if exchange == "owner":
+        deg = 2  # (the trajectory's grid is SH degree 1; the optimizer in the brick flush needs whole float4s per node: degree 0 or 2)
     F = 3 * (deg + 1) ** 2
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
     os.environ.setdefault("MASTER_PORT", "29541")
@@ -658,7 +660,6 @@ def test_data_parallel_step_through_rccl_single_rank(hip_device, exchange, shard
             grid = relu_grid(hip_device, T(hash_uniform((G, G, G, 1), 901)), T(hash_uniform((G, G, G, F), 900 + F)), G, storage="split")
             cfg = rf.SHVoxGridRenderConfig(S, rf.CameraBounds(float(g["near"]), float(g["far"])), perturb_sampled_points=False, white_bkgd=True)
             model = rf.VolumetricModel(grid, rf.render_sh_voxel_grid, cfg, device=hip_device)
-            # (the trajectory's grid is SH degree 0: the binned backward is asked for explicitly where the owner-computes step needs it)
             stepper = TrainStepper(model, n_rays, learning_rate=float(g["lr"]), shard_optimizer=shard_optimizer, exchange=exchange if dp else "auto",
                                    backward="binned" if exchange == "owner" else "auto")
             assert stepper.exchange == (exchange if dp else "dense")

@@ -247,6 +247,7 @@ class TrainStepper:
         dev = dataset.pixels.device
         total = min(self.ray_batch_size, image_ids.numel() * hw)
         lo, hi = self._global_slice(total)
+        self._batch_first = lo  # position of this rank's rays in the (global) batch: offset into the keyed jitter streams
         if self.ray_selection == "keyed":
             key = int(torch.randint(-(2**63), 2**63 - 1, (1,), dtype=torch.int64).item())
             o, d, px = select_rays_and_pixels_hip(intr.height, intr.width, float(intr.focal), dataset.poses, image_ids, dataset.pixels, hi - lo, key, first_index=lo)
@@ -258,6 +259,10 @@ class TrainStepper:
         b = torch.div(perm, hw, rounding_mode="floor")
         pixels = dataset.pixels[image_ids[b] * hw + (perm - b * hw)]
         return Rays(origins, directions), pixels
+
+    def _jitter_first(self) -> int:
+        """Offset of this rank's rays in the keyed jitter streams: its position in the global batch (0 unless ``global_batch``)."""
+        return int(getattr(self, "_batch_first", 0)) if (self.global_batch and self.data_parallel) else 0
 
     def _global_slice(self, total: int):
         """[lo, hi) of the permutation prefix this rank renders (everything unless ``global_batch`` under data parallelism)."""
@@ -361,7 +366,7 @@ class TrainStepper:
             keep = (origins, directions, pixels)
         st.near, st.far = float(np.float32(cfg.camera_bounds.near)), float(np.float32(cfg.camera_bounds.far))
         flags = render_flags(cfg.white_bkgd, False, cfg.optimized_sampling, cfg.use_occupancy_mask)
-        jitter_first = int(selection[3]) if (selection is not None and self.global_batch) else 0
+        jitter_first = int(selection[3]) if selection is not None else self._jitter_first()
         jit = [self._draw_jitter(cfg, n, S, dev, t_rand, i, jitter_first) for i in range(2)]
         st.first_ray = jitter_first
         for i in range(2):
@@ -579,7 +584,7 @@ class TrainStepper:
         sums = torch.zeros(4, dtype=torch.float32, device=dev)
         passes = []
         for i, diffuse in enumerate((False, True)):
-            jit = self._draw_jitter(cfg, n, S, dev, t_rand, i)
+            jit = self._draw_jitter(cfg, n, S, dev, t_rand, i, self._jitter_first())
             flags = render_flags(cfg.white_bkgd, diffuse, cfg.optimized_sampling, cfg.use_occupancy_mask)
             b = bins["diffuse"] if diffuse else bins
             colour, _, _, _, caches = render_forward_raw(grid, origins, directions, jit, S, near, far, flags, save=True, key_hist=b["hist"], brick_size=self.brick_size)
@@ -635,7 +640,7 @@ class TrainStepper:
         reduce_async = rfdist.reduce_scatter_mean_async if sharded else rfdist.all_reduce_mean_async
         pending = []
         for i, diffuse in enumerate((False, True) if self.diffuse else (False,)):
-            t_rand = self._draw_jitter(cfg, n, S, origins.device, t_rand_given, i)
+            t_rand = self._draw_jitter(cfg, n, S, origins.device, t_rand_given, i, self._jitter_first())
             flags = render_flags(cfg.white_bkgd, diffuse, cfg.optimized_sampling, cfg.use_occupancy_mask)
             use_bricks = binned
             fused_binning = use_bricks and not self.deterministic  # the forward pass counts the records per key
