@@ -1939,6 +1939,9 @@ __device__ __forceinline__ void lds_wait(float& a, float& b, float& c, float& d,
   asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a), "+v"(b), "+v"(c), "+v"(d), "+v"(e), "+v"(f));
 }
 
+// tile tl (0..3) of wave `wave`: interleaved over the waves (a wave's four tiles are spread along x), so that a hot corner of the
+// brick does not land on one wave (0.414 -> 0.409 ms against four consecutive tiles per wave)
+#define RF_TILE_OF(wave, tl) ((tl) * 8 + (wave))
 constexpr int kGatherBatch = 256;  // records per batch (their indices travel as bytes)
 constexpr int kGatherWtab = 24;    // rows of the weight table: 3 axes x local node coordinate 0..7
 // Bank conflicts are what bounds the tile loop (6 LDS reads per instruction): table rows are kGatherBatch + 4 words apart, so that
@@ -2139,23 +2142,23 @@ __global__ __launch_bounds__(kBrickThreads, 4) void brick_gather_kernel(GridArgs
       if (!no_lists)
 #pragma unroll
       for (int wd = 0; wd < NW; ++wd) {
-        const uint32_t tmv = s_tmask[wd * 64 + lane] >> (4 * wave);
+        const uint32_t tmv = s_tmask[wd * 64 + lane] >> wave;
 #pragma unroll
         for (int tl = 0; tl < 4; ++tl) {
-          const bool hit = (tmv >> tl) & 1u;
+          const bool hit = (tmv >> (8 * tl)) & 1u;
           const unsigned long long m = __ballot(hit);
           const int pos = cnt[tl] + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0));
-          if (hit) s_list[4 * wave + tl][pos] = (unsigned char)(wd * 64 + lane);
+          if (hit) s_list[RF_TILE_OF(wave, tl)][pos] = (unsigned char)(wd * 64 + lane);
           cnt[tl] += __popcll(m);
         }
       }
 #pragma unroll
       for (int tl = 0; tl < 4; ++tl)
-        if (lane < 8) s_list[4 * wave + tl][cnt[tl] + lane] = 0;  // pad the last instructions with a record that exists
+        if (lane < 8) s_list[RF_TILE_OF(wave, tl)][cnt[tl] + lane] = 0;  // pad the last instructions with a record that exists
       // ... and multiplies them into the tiles' accumulators, four records per instruction, two instructions' operands in flight
 #pragma unroll
       for (int tl = 0; tl < 4; ++tl) {
-        const int t = wave * 4 + tl;
+        const int t = RF_TILE_OF(wave, tl);
         const int n = cnt[tl];
         if (t < ntiles && n > 0 && !no_tiles) {
           const int pz = t % npz, py = (t / npz) % npy, px = t / (npz * npy);
@@ -2276,7 +2279,7 @@ __global__ __launch_bounds__(kBrickThreads, 4) void brick_gather_kernel(GridArgs
     // 4 (lane >> 4) + e of the tile, channel 16 nt + (lane & 15)
 #pragma unroll
     for (int tl = 0; tl < 4; ++tl) {
-      const int t = wave * 4 + tl;
+      const int t = RF_TILE_OF(wave, tl);
       if (t < ntiles) {
         const int pz = t % npz, py = (t / npz) % npy, px = t / (npz * npy);
 #pragma unroll

@@ -493,8 +493,7 @@ class TrainStepper:
                 send.append(srt[int(b[me, k, 2 * s_]) : int(b[me, k, 2 * s_ + 1])] if s_ != me else srt[:0])
                 if s_ != me:
                     sent += int(send[-1].shape[0]) * rec_bytes
-            if W > 1:
-                rfdist.exchange_slices(send, recv)
+            rfdist.exchange_slices(send, recv)  # (a no-op without a process group; a 1-rank RCCL group goes through the same call)
             for s_ in range(W):
                 if s_ == me:
                     lists.append((srt.data_ptr(), t["offsets2"][k], k == 1))
@@ -508,11 +507,10 @@ class TrainStepper:
         brick_accumulate_adam_raw(grid, self.brick_size, lists, halves(opt.exp_avg), halves(opt.exp_avg_sq), opt.lr, opt.betas[0], opt.betas[1],
                                   opt.eps, opt.step_count, brick_range=ow["bricks"])
         mark(4)
-        if W > 1:
-            rfdist.all_gather_chunks_(self.flat.flat_param[:nd])
-            if has_second:
-                rfdist.all_gather_chunks_(self.flat.flat_param[nd:])
-            sent += (W - 1) * (self.flat.flat_param.numel() // W) * 4
+        rfdist.all_gather_chunks_(self.flat.flat_param[:nd])
+        if has_second:
+            rfdist.all_gather_chunks_(self.flat.flat_param[nd:])
+        sent += (W - 1) * (self.flat.flat_param.numel() // W) * 4
         mark(5)
         self.exchange_bytes = (self.exchange_bytes + [sent])[-64:]
         # records this rank's brick pass consumed (its own slice of its own lists + what it received), per list
