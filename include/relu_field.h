@@ -237,7 +237,7 @@ int rf_render_backward(const RFGrid* grid, const RFRayBatch* rays, uint32_t flag
  * element of the gradient tensors (no zero-fill needed; diffuse lists: only density + degree-0 gradients), accumulate = 1
  * adds.  Up to 16 lists per call, at most 8 of a kind, the full-width lists first: (specular list, render_diffuse list) = BOTH
  * renders of a training iteration (modules/trainers.py:306-341) in one pass (the base-channel records go into the first four
- * channel columns of the same accumulators); under data parallelism one pair per source rank.  SH degree <= 2. */
+ * channel columns of the same accumulators); under data parallelism one pair per source rank.  Any SH degree (degree 3: brick_size 8). */
 typedef struct RFBrickList {
   const float* records_sorted_dev; /* [capacity, rf_expanded_record_floats(F)] (diffuse lists: F = 3) */
   const int64_t* offsets_dev;      /* [8 * nbricks + 1] start of each (brick, flags) class            */

@@ -217,3 +217,148 @@ def test_one_call_step_equals_the_launch_by_launch_step(hip_device):
     err = (runs[0][1] - runs[1][1]).abs()
     assert float((err <= 2e-5).float().mean()) >= 0.999 and float(err.max()) <= 0.03 * 2 * 5 + 1e-6
     np.testing.assert_allclose(runs[0][2].cpu().numpy(), runs[1][2].cpu().numpy(), rtol=2e-3, atol=1e-7 * float(runs[1][2].abs().max()))
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# the headline path proper -- TrainStepper.step = ONE rf_train_step call that draws its own batch (keyed selection) and its own
+# jitter (keyed, in-kernel) -- against the oracle DIRECTLY at the BASELINE size, and PSNR after equal training steps
+# ---------------------------------------------------------------------------------------------------------------------
+def _posed_dataset(dev, num_images, hw, gt_seed=7):
+    """images of a procedural ground-truth field (the bench's sparse blob) rendered by the HIP renderer + their poses"""
+    from thr3ed_atom_amd.trainers import PosedImagesInMemory
+
+    cam = hotdog_like_camera()
+    bounds = rf.CameraBounds(cam["near"], cam["far"])
+    intr = rf.CameraIntrinsics(hw, hw, 1111.111 * hw / 800.0)
+    gt, _, _ = _uniform_grid(dev, 128, 27, gt_seed, "reference", sparse=True)
+    gt_model = rf.VolumetricModel(gt, rf.render_sh_voxel_grid, rf.SHVoxGridRenderConfig(256, bounds, perturb_sampled_points=False, white_bkgd=True), device=dev)
+    poses = [rf.pose_spherical(360.0 / num_images * k, -30.0, cam["radius"]) for k in range(num_images)]
+    with torch.no_grad():
+        images = torch.stack([gt_model.render(p, intr).colour.permute(2, 0, 1) for p in poses])
+    pose_mat = torch.stack([torch.cat([p.rotation, p.translation], dim=1) for p in poses]).to(dev)
+    return PosedImagesInMemory(images, pose_mat, intr, bounds), poses, cam
+
+
+def _predict_step_keys(seed, steps):
+    """the 64-bit keys TrainStepper.step draws from torch's CPU generator per iteration: ray selection, then the jitter of the
+    specular and of the diffuse render"""
+    from thr3ed_atom_amd import ops
+
+    torch.manual_seed(seed)
+    keys = []
+    for _ in range(steps):
+        sel = int(torch.randint(-(2**63), 2**63 - 1, (1,), dtype=torch.int64).item()) & 0xFFFFFFFFFFFFFFFF
+        keys.append((sel, ops.draw_jitter_key(), ops.draw_jitter_key()))
+    return keys
+
+
+def _oracle_batch(data, image_ids, sel_key, n):
+    """the batch rf_select_rays_and_pixels draws for ``sel_key``, restated: keyed permutation of the B*H*W pixels (oracle), the
+    oracle's cast_rays for the images, the pixel table"""
+    intr = data.camera_intrinsics
+    H, W = int(intr.height), int(intr.width)
+    hw = H * W
+    p = orc.keyed_permutation(np.arange(n), len(image_ids) * hw, sel_key)
+    b, rem = p // hw, p % hw
+    img = np.asarray(image_ids)[b]
+    origins, directions = torch.empty((n, 3)), torch.empty((n, 3))
+    for k in set(img.tolist()):
+        pose = data.poses[k].cpu()
+        o, d = orc.cast_rays(H, W, float(np.float32(intr.focal)), pose[:, :3], pose[:, 3:])
+        m = torch.from_numpy(img == k)
+        idx = torch.from_numpy(rem[img == k])
+        origins[m] = o.reshape(-1, 3)[idx]
+        directions[m] = d.reshape(-1, 3)[idx]
+    pixels = data.pixels.cpu()[torch.from_numpy(img * hw + rem)]
+    return origins, directions, pixels
+
+
+def test_one_call_keyed_step_against_oracle_at_baseline_size(hip_device):
+    """ONE rf_train_step call at 128^3 / SH-2 / 2048 rays x 256 samples, batch and jitter drawn inside the library (keyed
+    selection, keyed jitter: the bench's exact path), against the oracle on the batch and the jitter tables the oracle derives
+    from the same keys: losses and the parameters after Adam."""
+    G, S, n = 128, 256, 2048
+    data, _, cam = _posed_dataset(hip_device, 3, 160)
+    grid, dens, feat = _uniform_grid(hip_device, G, 27, 42, "split")
+    cfg = rf.SHVoxGridRenderConfig(S, rf.CameraBounds(cam["near"], cam["far"]), perturb_sampled_points=True, white_bkgd=True)
+    stepper = TrainStepper(rf.VolumetricModel(grid, rf.render_sh_voxel_grid, cfg, device=hip_device), n, learning_rate=0.03)
+    assert stepper.merged_bricks and stepper.fuse_optimizer and stepper.ray_selection == "keyed" and cfg.jitter == "keyed"
+    (sel, k0, k1), = _predict_step_keys(123, 1)
+    torch.manual_seed(123)
+    stats = stepper.step(data, torch.arange(3))
+    torch.cuda.synchronize()
+    # the batch the call drew (its scratch buffers) == the oracle's restatement of the selection
+    o, d, px = _oracle_batch(data, [0, 1, 2], sel, n)
+    ex = stepper._exec
+    assert torch.equal(ex["pixels"].cpu(), px)
+    np.testing.assert_allclose(ex["origins"].cpu().numpy(), o.numpy(), rtol=0, atol=0)
+    np.testing.assert_allclose(ex["directions"].cpu().numpy(), d.numpy(), rtol=0, atol=1e-6)
+    t_rands = [T(orc.keyed_jitter(k, 0, n, S)) for k in (k0, k1)]
+    cd, cf, losses = _oracle_step(dens, feat, rf.Rays(o, d), px, t_rands, cam, G, S)
+    np.testing.assert_allclose(stats.specular_loss.item(), losses[0].item(), rtol=2e-5)
+    np.testing.assert_allclose(stats.diffuse_loss.item(), losses[1].item(), rtol=2e-5)
+    torch.optim.Adam([{"params": [cd, cf], "lr": 0.03}], betas=(0.9, 0.999)).step()
+    for ours, ref in ((grid.densities, cd), (grid.features, cf)):
+        err = np.abs(ours.detach().cpu().numpy() - ref.detach().numpy())
+        assert np.mean(err <= 2e-5) >= 0.999 and err.max() <= 0.03 * 2 + 1e-6
+
+
+def test_psnr_after_equal_steps_matches_the_reference_path_at_baseline_size(hip_device):
+    """north_star: "PSNR within 0.05 dB of reference after equal training steps".  30 iterations of the default fused step
+    (one library call each: keyed selection, keyed jitter, merged brick pass, Adam in its flush) at 128^3 / SH-2 / 2048 rays x
+    256 samples, against the oracle (the reference's ATen ops + autograd) + torch.optim.Adam fed the SAME batches and the same
+    jitter tables (restated from the keys by the oracle).  Both parameter sets are then rendered from a held-out pose and
+    from a training pose; the PSNRs against the ground-truth images must agree to 0.05 dB (loop being matched:
+    modules/trainers.py:300-341)."""
+    import os
+
+    G, S, n, steps = 128, 256, 2048, 30
+    data_all, poses, cam = _posed_dataset(hip_device, 5, 160)
+    from thr3ed_atom_amd.trainers import PosedImagesInMemory
+
+    train_ids = [0, 1, 2, 3]  # image 4 is held out
+    data = PosedImagesInMemory(data_all.images[:4], data_all.poses[:4], data_all.camera_intrinsics, data_all.camera_bounds)
+    bounds = rf.CameraBounds(cam["near"], cam["far"])
+    cfg = rf.SHVoxGridRenderConfig(S, bounds, perturb_sampled_points=True, white_bkgd=True)
+    grid, dens, feat = _uniform_grid(hip_device, G, 27, 42, "split")
+    model = rf.VolumetricModel(grid, rf.render_sh_voxel_grid, cfg, device=hip_device)
+    stepper = TrainStepper(model, n, learning_rate=0.03)
+    keys = _predict_step_keys(2024, steps)
+    torch.manual_seed(2024)
+    hip_losses = []
+    for _ in range(steps):
+        st = stepper.step(data, torch.arange(4))
+        hip_losses.append(st.specular_loss)
+    hip_losses = [float(x) for x in hip_losses]
+
+    torch.set_num_threads(min(os.cpu_count() or 1, 16))
+    cd, cf = dens.clone().requires_grad_(True), feat.clone().requires_grad_(True)
+    opt = torch.optim.Adam([{"params": [cd, cf], "lr": 0.03}], betas=(0.9, 0.999))
+    aabb = orc.make_aabb((G,) * 3, (3.0 / G,) * 3)
+    ref_losses = []
+    for sel, k0, k1 in keys:
+        o, d, px = _oracle_batch(data, train_ids, sel, n)
+        opt.zero_grad()
+        total = 0.0
+        for diffuse, k in ((False, k0), (True, k1)):
+            out = orc.render(cd, cf, o, d, aabb, cam["near"], cam["far"], S, RHO, "relu", white_bkgd=True, render_diffuse=diffuse,
+                             t_rand=T(orc.keyed_jitter(k, 0, n, S)), interp="aten")
+            loss = torch.nn.functional.l1_loss(out["colour"], px)
+            if not diffuse:
+                ref_losses.append(float(loss))
+            total = total + loss
+        total.backward()
+        opt.step()
+    # the trajectories stay together (float32 summation order only) ...
+    np.testing.assert_allclose(hip_losses, ref_losses, rtol=2e-3)
+    # ... and so does the quality metric: full renders of both parameter sets (the HIP renderer is parity-tested elsewhere)
+    ref_grid = rf.VoxelGrid(cd.detach().to(hip_device), cf.detach().to(hip_device), rf.VoxelSize(3.0 / G, 3.0 / G, 3.0 / G), density_preactivation=torch.nn.Identity(),
+                            density_postactivation=torch.nn.ReLU(), expected_density_scale=RHO, tunable=False)
+    ref_model = rf.VolumetricModel(ref_grid, rf.render_sh_voxel_grid, cfg, device=hip_device)
+    psnr = lambda img, target: float(-10.0 * torch.log10(torch.nn.functional.mse_loss(img, target)))
+    for view in (4, 0):  # held-out, training
+        target = data_all.images[view].permute(1, 2, 0)
+        ours = model.render(poses[view], data_all.camera_intrinsics, perturb_sampled_points=False).colour
+        theirs = ref_model.render(poses[view], data_all.camera_intrinsics, perturb_sampled_points=False).colour
+        a, b = psnr(ours, target), psnr(theirs, target)
+        assert abs(a - b) <= 0.05, f"view {view}: PSNR {a:.4f} dB (HIP step) vs {b:.4f} dB (reference path) after {steps} equal steps"

@@ -484,12 +484,12 @@ def _binned_gradients(grid, rays, cfg, target, device, diffuse_too=True, accumul
 
 @pytest.mark.parametrize("accumulate,binning", [(False, "sort"), (True, "sort"), (False, "count"), (False, "fused"), (False, "merged"), (True, "merged")])
 @pytest.mark.parametrize("storage", ["reference", "split", "bricked"])
-@pytest.mark.parametrize("case", ["grid16_sh2", "aniso_sh2_abs", "aniso_sh1_softplus", "cube20_sh0"])
+@pytest.mark.parametrize("case", ["grid16_sh2", "aniso_sh2_abs", "aniso_sh1_softplus", "cube20_sh0", "aniso_sh3"])
 def test_binned_backward_equals_atomic_backward(hip_device, storage, case, accumulate, binning):
     """The LDS-aggregated backward (emit -> 16-bit sort by (brick, flags) -> one workgroup per 8^3-node brick that owns
     its nodes exclusively -> plain coalesced stores) gives the gradient of the atomic scatter (and therefore of the reference)
-    for specular + diffuse renders, including partial bricks, the grid border, SH degree 0-2 and the abs / softplus
-    density modes."""
+    for specular + diffuse renders, including partial bricks, the grid border, SH degree 0-3 (degree 3 = four 16-channel
+    accumulator blocks per tile) and the abs / softplus density modes."""
     from thr3ed_atom_amd.voxels import unpack_split
 
     cam = hotdog_like_camera()
@@ -501,6 +501,7 @@ def test_binned_backward_equals_atomic_backward(hip_device, storage, case, accum
         "aniso_sh2_abs": ((13, 9, 18), 27, "abs", (0.22, 0.3, 0.16), (0.1, -0.05, 0.1), 1.0),
         "aniso_sh1_softplus": ((9, 17, 8), 12, "softplus", (0.3, 0.17, 0.35), (0.0, 0.0, 0.0), 5.0),
         "cube20_sh0": ((20, 20, 20), 3, "relu", (0.15,) * 3, (0.0, 0.0, 0.0), 100.0 / 3.0),
+        "aniso_sh3": ((11, 17, 9), 48, "relu", (0.27, 0.17, 0.3), (0.0, 0.05, 0.0), 20.0),
     }[case]
     acts = {"relu": (torch.nn.Identity(), torch.nn.ReLU()), "softplus": (torch.nn.Identity(), torch.nn.Softplus()), "abs": (torch.abs, torch.nn.Identity())}[mode]
     dens, feat = procedural_grid(dims, F, 303)

@@ -1938,6 +1938,9 @@ __device__ __forceinline__ void lds_wait(uint32_t& a, uint32_t& b) { asm volatil
 __device__ __forceinline__ void lds_wait(float& a, float& b, float& c, float& d, float& e, uint32_t& f) {
   asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a), "+v"(b), "+v"(c), "+v"(d), "+v"(e), "+v"(f));
 }
+__device__ __forceinline__ void lds_wait(float& a, float& b, float& c, float& d, float& e, float& e2, float& e3, uint32_t& f) {
+  asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a), "+v"(b), "+v"(c), "+v"(d), "+v"(e), "+v"(e2), "+v"(e3), "+v"(f));
+}
 
 // tile tl (0..3) of wave `wave`: interleaved over the waves (a wave's four tiles are spread along x), so that a hot corner of the
 // brick does not land on one wave (0.414 -> 0.409 ms against four consecutive tiles per wave)
@@ -1960,14 +1963,16 @@ __host__ __device__ inline int gather_lds_words(int B, int C) {
   return batch > image ? batch : image;
 }
 
+// (SH degree 3: 49 channels = four 16-channel blocks, 64 accumulator registers and 123 KB of LDS -- one workgroup per CU, which
+// leaves a wave 256 registers)
 template <int K, bool ADAM>
-__global__ __launch_bounds__(kBrickThreads, 4) void brick_gather_kernel(GridArgs g, BrickArgs a, float* gdens, float* gfeat) {
+__global__ __launch_bounds__(kBrickThreads, (K > 9 ? 2 : 4)) void brick_gather_kernel(GridArgs g, BrickArgs a, float* gdens, float* gfeat) {
   constexpr int C = 3 * K + 1;
   constexpr int C4 = (C + 3) / 4 * 4;
   constexpr int QW = record_quads(K);      // quads of a full-width record in HBM
   constexpr int QN = record_quads(1);      // quads of a base-channel (render_diffuse) record
   constexpr int NT = (C4 + 15) / 16;       // 16-channel blocks per tile
-  static_assert(NT <= 2, "SH degree <= 2 (two 16-channel blocks)");
+  static_assert(NT == 1 || NT == 2 || NT == 4, "one, two or four 16-channel blocks (SH degree 0 / base lists, 1-2, 3)");
   constexpr int CS = C4;
   constexpr int NW = kGatherBatch / 64;    // mask words per tile
   static_assert(2 * kGatherBatch == kBrickThreads, "two threads per record of a batch");
@@ -2175,39 +2180,54 @@ __global__ __launch_bounds__(kBrickThreads, 4) void brick_gather_kernel(GridArgs
           // two register sets (A: even instructions, B: odd ones), no rotation copies.  WIDE: channels >= C4 of the second block
           // read into the row's padding / the next row; those accumulator columns are never stored
           uint32_t ra = 0, rb = 0;
-          float aw0 = 0.f, aw1 = 0.f, aw2 = 0.f, ag0 = 0.f, ag1 = 0.f, bw0 = 0.f, bw1 = 0.f, bw2 = 0.f, bg0 = 0.f, bg1 = 0.f;
-          auto request_ops = [&](float& w0, float& w1, float& w2, float& g0, float& g1, uint32_t r) {
+          float aw0 = 0.f, aw1 = 0.f, aw2 = 0.f, bw0 = 0.f, bw1 = 0.f, bw2 = 0.f;
+          float ag0 = 0.f, ag1 = 0.f, ag2 = 0.f, ag3 = 0.f, bg0 = 0.f, bg1 = 0.f, bg2 = 0.f, bg3 = 0.f;  // (blocks 2, 3: SH degree 3 only)
+          auto request_ops = [&](float& w0, float& w1, float& w2, float& g0, float& g1, float& g2, float& g3, uint32_t r) {
             lds_request_f32<0>(w0, a_x + 4 * r);
             lds_request_f32<0>(w1, a_y + 4 * r);
             lds_request_f32<0>(w2, a_z + 4 * r);
             lds_request_f32<0>(g0, a_g + r * (RW * 4));
             if constexpr (NTW > 1) lds_request_f32<64>(g1, a_g + r * (RW * 4));
+            if constexpr (NTW > 2) {
+              lds_request_f32<128>(g2, a_g + r * (RW * 4));
+              lds_request_f32<192>(g3, a_g + r * (RW * 4));
+            }
           };
-          auto multiply = [&](float w0, float w1, float w2, float g0, float g1, int q) {
+          auto wait_ops = [&](float& w0, float& w1, float& w2, float& g0, float& g1, float& g2, float& g3, uint32_t& r) {
+            if constexpr (NTW > 2)
+              lds_wait(w0, w1, w2, g0, g1, g2, g3, r);
+            else
+              lds_wait(w0, w1, w2, g0, g1, r);
+          };
+          auto multiply = [&](float w0, float w1, float w2, float g0, float g1, float g2, float g3, int q) {
             const float wv = (w0 * w1) * w2;
             const float wa = (4 * q + kk < n) ? wv : 0.0f;
             const float ga = (WIDE || jj < 4) ? g0 : 0.0f;
             accr[tl][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(wa, ga, accr[tl][0], 0, 0, 0);
-            if constexpr (NTW > 1) accr[tl][NTW - 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(wa, g1, accr[tl][NTW - 1], 0, 0, 0);
+            if constexpr (NTW > 1) accr[tl][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(wa, g1, accr[tl][1], 0, 0, 0);
+            if constexpr (NTW > 2) {
+              accr[tl][2] = __builtin_amdgcn_mfma_f32_16x16x4f32(wa, g2, accr[tl][2], 0, 0, 0);
+              accr[tl][3] = __builtin_amdgcn_mfma_f32_16x16x4f32(wa, g3, accr[tl][3], 0, 0, 0);
+            }
           };
           lds_request_u8(ra, a_list);      // record index of instruction 0
           lds_request_u8(rb, a_list + 4);  // ... 1
           lds_wait(ra, rb);
-          request_ops(aw0, aw1, aw2, ag0, ag1, ra);
+          request_ops(aw0, aw1, aw2, ag0, ag1, ag2, ag3, ra);
           for (int q = 0; q < nq; q += 2) {
-            lds_wait(aw0, aw1, aw2, ag0, ag1, rb);
+            wait_ops(aw0, aw1, aw2, ag0, ag1, ag2, ag3, rb);
             lds_request_u8(ra, a_list + 4 * q + 8);  // index of instruction q + 2 (the list has slack behind its capacity)
-            request_ops(bw0, bw1, bw2, bg0, bg1, rb);
-            multiply(aw0, aw1, aw2, ag0, ag1, q);
+            request_ops(bw0, bw1, bw2, bg0, bg1, bg2, bg3, rb);
+            multiply(aw0, aw1, aw2, ag0, ag1, ag2, ag3, q);
             if (q + 1 < nq) {
-              lds_wait(bw0, bw1, bw2, bg0, bg1, ra);
+              wait_ops(bw0, bw1, bw2, bg0, bg1, bg2, bg3, ra);
               lds_request_u8(rb, a_list + 4 * q + 12);
-              request_ops(aw0, aw1, aw2, ag0, ag1, ra);
-              multiply(bw0, bw1, bw2, bg0, bg1, q + 1);
+              request_ops(aw0, aw1, aw2, ag0, ag1, ag2, ag3, ra);
+              multiply(bw0, bw1, bw2, bg0, bg1, bg2, bg3, q + 1);
             }
           }
-          lds_wait(aw0, aw1, aw2, ag0, ag1, ra);  // nothing of this tile stays in flight
-          lds_wait(bw0, bw1, bw2, bg0, bg1, rb);
+          wait_ops(aw0, aw1, aw2, ag0, ag1, ag2, ag3, ra);  // nothing of this tile stays in flight
+          wait_ops(bw0, bw1, bw2, bg0, bg1, bg2, bg3, rb);
         }
       }
       RF_PROF_MARK(3);  // lists + tiles (MFMA), thread 0's own work
@@ -3005,7 +3025,7 @@ const char* rf_error_string(int code) {
     case RF_ERR_BAD_SHAPE:
       return "bad shape, size or stride";
     case RF_ERR_UNSUPPORTED:
-      return "unsupported configuration (SH degree must be 0..3 -- 0..2 for the binned backward --, density mode a RF_DENSITY_* value, brick size 4 or 8 with at most 4096 bricks for 16-bit keys)";
+      return "unsupported configuration (SH degree must be 0..3, density mode a RF_DENSITY_* value, brick size 4 or 8 -- 8 for SH degree 3 -- with at most 4096 bricks for 16-bit keys; the optimizer in the brick flush needs split storage and SH degree 0 or 2)";
     case RF_ERR_LAUNCH:
       return "HIP kernel launch failed";
     default:
@@ -3199,7 +3219,6 @@ int rf_render_backward_emit_direct(const RFGrid* grid, const RFRayBatch* rays, u
                                    float* records_sorted_dev, int32_t* hist_clear_dev, void* stream) {
   if (!grid) return RF_ERR_NULL_POINTER;
   if (!cursor_dev || !records_sorted_dev) return RF_ERR_NULL_POINTER;
-  if (grid->num_features > 27) return RF_ERR_UNSUPPORTED;
   int shift, nb[3];
   const int rc = brick_geometry(grid, brick_size, &shift, nb, false);
   if (rc != RF_OK) return rc;
@@ -3231,7 +3250,6 @@ int rf_expand_records(const RFGrid* grid, const float* records_dev, const int64_
   if (capacity == 0) return RF_OK;
   if (!records_dev || !perm_dev || !begin_dev || !records_sorted_dev) return RF_ERR_NULL_POINTER;
   if (capacity < 0) return RF_ERR_BAD_SHAPE;
-  if (grid->num_features > 27) return RF_ERR_UNSUPPORTED;
   const int diffuse = render_diffuse || grid->num_features == 3;
   hipStream_t st = (hipStream_t)stream;
   if (diffuse) return launch_expand<2>(records_dev, perm_dev, begin_dev, capacity, records_sorted_dev, st);  // base-channel records
@@ -3277,7 +3295,6 @@ int rf_scatter_records(const RFGrid* grid, const int16_t* keys_dev, const float*
   if (capacity == 0) return RF_OK;
   if (!keys_dev || !records_dev || !cursor_dev || !records_sorted_dev) return RF_ERR_NULL_POINTER;
   if (capacity < 0) return RF_ERR_BAD_SHAPE;
-  if (grid->num_features > 27) return RF_ERR_UNSUPPORTED;
   const int diffuse = render_diffuse || grid->num_features == 3;
   hipStream_t st = (hipStream_t)stream;
   if (diffuse) return launch_scatter<2>(keys_dev, records_dev, capacity, cursor_dev, records_sorted_dev, hist_dev, num_keys, st);
@@ -3340,7 +3357,6 @@ static int brick_accumulate_impl(const RFGrid* grid, int32_t brick_size, const R
     if (!grad_features_dev && !(grid->layout != RF_LAYOUT_REFERENCE && grid->num_features == 3)) return RF_ERR_NULL_POINTER;
   }
   if (num_lists < 1 || num_lists > 2 * kMaxListsPerKind) return RF_ERR_BAD_SHAPE;
-  if (grid->num_features > 27) return RF_ERR_UNSUPPORTED;  // the accumulators of a brick must fit the LDS (SH degree <= 2)
   int shift, nb[3];
   rc = brick_geometry(grid, brick_size, &shift, nb, false);
   if (rc != RF_OK) return rc;
@@ -3413,8 +3429,10 @@ static int brick_accumulate_impl(const RFGrid* grid, int32_t brick_size, const R
       return launch_gather<1, false>(g, a, nbricks, grad_densities_dev, grad_features_dev, st);
     case 4:
       return launch_gather<4, false>(g, a, nbricks, grad_densities_dev, grad_features_dev, st);
-    default:
+    case 9:
       return launch_gather<9, false>(g, a, nbricks, grad_densities_dev, grad_features_dev, st);
+    default:
+      return launch_gather<16, false>(g, a, nbricks, grad_densities_dev, grad_features_dev, st);
   }
 }
 
@@ -3558,8 +3576,7 @@ int rf_train_step(const RFGrid* grid, const RFTrainStep* step, void* stream) {
     } else if (!step->grad_first_dev || (!step->grad_second_dev && !(grid->layout != RF_LAYOUT_REFERENCE && grid->num_features == 3))) {
       return RF_ERR_NULL_POINTER;
     }
-    if (grid->num_features > 27) return RF_ERR_UNSUPPORTED;
-  }
+    }
   const float loss_scale = step->loss_scale != 0.0f ? step->loss_scale : 1.0f;
   hipStream_t st = (hipStream_t)stream;
   int ev = 0;

@@ -427,8 +427,8 @@ def brick_accumulate_adam_raw(grid: VoxelGrid, brick_size: int, lists, exp_avg, 
 
 
 # How the autograd op computes its adjoint: "atomic" = rf_render_backward (float32 atomic scatter, any configuration), "binned" =
-# counting in the forward pass -> rf_render_backward_emit_direct -> rf_brick_accumulate (no float atomics; SH degree <= 2),
-# "auto" = binned for renders (specular and render_diffuse) of SH-degree-2 grids with at least 2^20 samples (where the atomic
+# counting in the forward pass -> rf_render_backward_emit_direct -> rf_brick_accumulate (no float atomics),
+# "auto" = binned for renders (specular and render_diffuse) of SH-degree-2 / -3 grids with at least 2^20 samples (where the atomic
 # scatter is pinned on the memory-side atomic unit: 0.97 vs 0.40 ms for the specular adjoint of 16384 x 256 samples at 128^3; the
 # reference-storage iteration of bench.py's strict drop-in leg: 2.79 -> 1.99 ms with the diffuse adjoint binned as well), atomic
 # otherwise.
@@ -438,7 +438,7 @@ AUTOGRAD_BRICK_SIZE = 8
 
 
 def _autograd_uses_bricks(grid, flags: int, n: int, num_samples: int) -> bool:
-    if AUTOGRAD_BACKWARD == "atomic" or grid.sh_degree > 2:
+    if AUTOGRAD_BACKWARD == "atomic":
         return False
     nb = brick_counts(grid, AUTOGRAD_BRICK_SIZE)
     if nb[0] * nb[1] * nb[2] * 8 > (1 << 21):
@@ -449,7 +449,7 @@ def _autograd_uses_bricks(grid, flags: int, n: int, num_samples: int) -> bool:
     # the atomic kernel, which needs no scratch, is used instead (user code that fitted before keeps fitting)
     if n * num_samples * 4 * expanded_record_floats(grid) > AUTOGRAD_BINNED_MAX_BYTES:
         return False
-    return grid.sh_degree == 2 and n * num_samples >= (1 << 20)
+    return grid.sh_degree >= 2 and n * num_samples >= (1 << 20)
 
 
 class _ReluFieldRender(torch.autograd.Function):

@@ -159,12 +159,12 @@ class TrainStepper:
         # fused=False goes through torch.autograd like a user of render_rays would.  Same arithmetic either way.
         self.fused = bool(fused)
         self._grad_clean = True  # FlatGrid starts zero-filled
-        # backward="binned" (fused steps only, SH degree <= 2): both passes write per-sample gradient records, bin them by
+        # backward="binned" (fused steps only): both passes write per-sample gradient records, bin them by
         # (8^3-node brick, boundary flags) and sum each brick on chip without float atomics -- one
         # brick pass over both record lists on a single GPU (merge_bricks), one per render in the data-parallel order.
         # deterministic=True bins with a stable radix sort instead of the counting sort: no atomics anywhere, fixed
         # float32 summation order, run-to-run bit-identical gradients (slower).
-        # "auto" = binned where it was measured faster (fused step, SH degree 2), else atomic.
+        # "auto" = binned for SH degree 2 and 3 (fused step; measured faster at degree 2), else atomic.
         if backward not in ("auto", "atomic", "binned"):
             raise ValueError("backward must be 'auto', 'atomic' or 'binned'")
         self.deterministic = bool(deterministic)
@@ -192,7 +192,7 @@ class TrainStepper:
         self.optimizer = FusedAdam(self.flat, lr=learning_rate, betas=(0.9, 0.999))
         if backward == "auto":
             nb = brick_counts(grid, self.brick_size)
-            backward = "binned" if (self.fused and grid.sh_degree == 2 and nb[0] * nb[1] * nb[2] * 8 <= (1 << 21)) else "atomic"
+            backward = "binned" if (self.fused and grid.sh_degree >= 2 and nb[0] * nb[1] * nb[2] * 8 <= (1 << 21)) else "atomic"
         self.backward = backward
         # merge_bricks (binned, non-deterministic steps with the diffuse regulariser): BOTH renders emit their records first and
         # ONE brick pass sums them (the 4-channel diffuse records in the first channel columns of the same accumulators), so
@@ -705,8 +705,6 @@ class TrainStepper:
                 raise ValueError("deterministic binned backward needs at most 4096 bricks ((brick, flags) keys are 16-bit sort keys)")
             if num_bricks * 8 > (1 << 21):
                 raise ValueError("backward='binned' needs at most 2^18 bricks")
-            if grid.sh_degree > 2:
-                raise ValueError("backward='binned' supports SH degree <= 2 (the brick's accumulator image must fit the LDS)")
             b = {
                 "shape": (n, S),
                 "num_bricks": num_bricks,
