@@ -437,31 +437,38 @@ def main():
     # ---- strict drop-in: reference storage, torch.autograd.Function ops, torch.randperm selection, torch.rand jitter ----
     dropin = None
     if args.dropin_steps > 0 and rank == 0 and world == 1:
-        dgrid = make_grid(dev, G, args.sh_degree, seed=42, storage="reference")
-        dcfg = rf.SHVoxGridRenderConfig(S, bounds, perturb_sampled_points=True, white_bkgd=True, jitter="torch")
-        dmodel = rf.VolumetricModel(dgrid, rf.render_sh_voxel_grid, dcfg, device=dev)
-        dstep = TrainStepper(dmodel, R, learning_rate=0.03, fused=False, ray_selection="randperm", backward="atomic", data_parallel=False)
-        torch.manual_seed(99)
-        dbatches = dataset.image_batches(args.images)
-        for _ in range(5):
-            dstep.step(dataset, next(dbatches))
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        for _ in range(args.dropin_steps):
-            dstep.step(dataset, next(dbatches))
-        torch.cuda.synchronize()
-        dt = (time.perf_counter() - t0) / args.dropin_steps
+        def dropin_leg(selection):
+            dgrid = make_grid(dev, G, args.sh_degree, seed=42, storage="reference")
+            dcfg = rf.SHVoxGridRenderConfig(S, bounds, perturb_sampled_points=True, white_bkgd=True, jitter="torch")
+            dmodel = rf.VolumetricModel(dgrid, rf.render_sh_voxel_grid, dcfg, device=dev)
+            dstep = TrainStepper(dmodel, R, learning_rate=0.03, fused=False, ray_selection=selection, backward="atomic", data_parallel=False)
+            torch.manual_seed(99)
+            dbatches = dataset.image_batches(args.images)
+            for _ in range(5):
+                dstep.step(dataset, next(dbatches))
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(args.dropin_steps):
+                dstep.step(dataset, next(dbatches))
+            torch.cuda.synchronize()
+            dt = (time.perf_counter() - t0) / args.dropin_steps
+            dstep.flat.detach()
+            del dstep, dmodel, dgrid
+            torch.cuda.empty_cache()
+            return dt
+
+        dt = dropin_leg("keyed")
+        dt_randperm = dropin_leg("randperm")
         dropin = {
-            "workload": "the same iteration the way a reference user gets it: VoxelGrid in the reference's two tensors, render_sh_voxel_grid as a "
-            "torch.autograd.Function (rf_render_forward / rf_render_backward), torch.randperm over all pixels, torch.rand jitter, L1 via autograd, fused Adam",
+            "workload": "the same iteration the way a reference user gets it: VoxelGrid in the reference's two tensors (forward passes gather from its split-layout shadow, "
+            "gradients in the Parameters' layout), render_sh_voxel_grid as a torch.autograd.Function (rf_render_forward / binned adjoint), torch.rand jitter, L1 via autograd, "
+            "fused Adam; the batch = distinct uniformly random pixels by the keyed bijection (the law of torch.randperm(P)[:R] without sorting 5.12 M keys)",
             "ms_per_step": dt * 1e3,
             "ray_samples_per_s": 2 * R * S / dt,
+            "ms_per_step_with_torch_randperm_selection": dt_randperm * 1e3,
             "steps": args.dropin_steps,
             "warmup": 5,
         }
-        dstep.flat.detach()
-        del dstep, dmodel, dgrid
-        torch.cuda.empty_cache()
 
     # ---- training steps: the headline ---------------------------------------------------------------
     stepper = TrainStepper(model, R, learning_rate=0.03, apply_diffuse_render_regularization=True, ray_selection=args.ray_selection, backward=args.backward,

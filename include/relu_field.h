@@ -331,6 +331,11 @@ int rf_build_occupancy(const RFGrid* grid, float threshold, uint32_t* occupancy_
  * compatibly: no existing struct or signature changed.) */
 int rf_upsample_grid(const RFGrid* src, const RFGrid* dst, void* stream);
 
+/* Re-layout: every (node, channel) of `src` copied into the tensors `dst` describes (same dims and num_features, any layouts;
+ * dst's tensors are overwritten, its AABB / activation fields are not used).  A binding that must keep the reference's own two
+ * Parameters (thre3d_reprs/voxels.py:70-71) can keep an RF_LAYOUT_SPLIT shadow of them for the forward passes this way. */
+int rf_convert_grid(const RFGrid* src, const RFGrid* dst, void* stream);
+
 /* The loss of the training iteration (modules/trainers.py:311-317, 329-336) in one launch:
  * grad_colour_dev [N,3] = scale * d(mean |colour - target|)/d colour = scale * sign(colour - target) / (3N);
  * sums_dev[0] += sum |colour - target|, sums_dev[1] += sum (colour - target)^2  (L1 loss and MSE/PSNR for

@@ -52,6 +52,7 @@ EXPORTED_SYMBOLS = [
     "rf_grid_query_backward",
     "rf_build_occupancy",
     "rf_upsample_grid",
+    "rf_convert_grid",
     "rf_l1_loss_grad",
     "rf_adam_step",
     "rf_train_step",
@@ -272,6 +273,7 @@ def load() -> C.CDLL:
     lib.rf_grid_query.argtypes = [C.POINTER(RFGrid), vp, i64, vp, vp]
     lib.rf_grid_query_backward.argtypes = [C.POINTER(RFGrid), vp, i64, vp, vp, vp, vp]
     lib.rf_upsample_grid.argtypes = [C.POINTER(RFGrid), C.POINTER(RFGrid), vp]
+    lib.rf_convert_grid.argtypes = [C.POINTER(RFGrid), C.POINTER(RFGrid), vp]
     lib.rf_build_occupancy.argtypes = [C.POINTER(RFGrid), f32, vp, vp]
     lib.rf_l1_loss_grad.argtypes = [vp, vp, i64, f32, vp, vp, vp]
     lib.rf_adam_step.argtypes = [vp, vp, vp, vp, i64, f32, f32, f32, f32, i32, i32, vp]

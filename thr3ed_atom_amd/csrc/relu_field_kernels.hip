@@ -2411,6 +2411,59 @@ __global__ void upsample_grid_kernel(GridArgs src, GridArgs dst, float* dst_firs
   }
 }
 
+// Re-layout of a whole grid: every (node, channel) of `src` copied to where `dst`'s storage keeps it (same dims, same F).  One
+// thread per element, channel fastest.  Used to keep a split-layout SHADOW of a grid held in the reference's two tensors: the
+// forward passes gather from the shadow (aligned 16-byte base records, density and degree-0 colour in one gather), the
+// gradients are produced in the layout of the Parameters.
+__global__ void convert_grid_kernel(GridArgs src, GridArgs dst, float* dst_first, float* dst_second, unsigned int nodes) {
+  // threadIdx.x = channel (32 or 64 lanes per node, the ones beyond F + 1 idle), threadIdx.y = node within the block: no
+  // division for the channel, 32-bit index arithmetic throughout (node counts are < 2^32)
+  const int C = dst.F + 1, K = dst.F / 3;
+  const int ch = threadIdx.x;
+  const bool linear = !src.bricked && !dst.bricked;  // node index = linear index in both
+  for (unsigned int node = blockIdx.x * blockDim.y + threadIdx.y; node < nodes; node += gridDim.x * blockDim.y) {
+    if (ch >= C) continue;
+    unsigned int ls = node, ld = node;
+    if (!linear) {
+      const unsigned int z = node % (unsigned)dst.Z, t = node / (unsigned)dst.Z;
+      const unsigned int y = t % (unsigned)dst.Y, x = t / (unsigned)dst.Y;
+      ls = node_lin(src, (int)x, (int)y, (int)z);
+      ld = node_lin(dst, (int)x, (int)y, (int)z);
+    }
+    bool sf, df;
+    const long long so = channel_offset(src, ls, ch, K, sf);
+    const long long doff = channel_offset(dst, ld, ch, K, df);
+    (df ? dst_first : dst_second)[doff] = (sf ? src.dens : src.feat)[so];
+  }
+}
+
+// The common case of the re-layout -- reference tensors -> split tensors, both in linear node order, whole quads per node (SH degree
+// 0 or 2) -- one thread per destination float4: quad 0 of a node = (density, degree-0 r, g, b), quad q >= 1 = rest[4 (q - 1) ..].
+// The four source floats are 4-byte gathers inside the node's 108-byte feature record (cache hits); the store is a coalesced 16 B.
+template <int K>
+__global__ void reference_to_split_kernel(const float* __restrict__ dens, const float* __restrict__ feat, long long dstride, long long fstride,
+                                          float4* __restrict__ base, float4* __restrict__ rest, unsigned int nodes) {
+  constexpr int QN = (3 * K + 1) / 4;  // quads per node
+  constexpr int KR = K > 1 ? K - 1 : 1;
+  const unsigned int total = nodes * QN;
+  for (unsigned int it = blockIdx.x * blockDim.x + threadIdx.x; it < total; it += gridDim.x * blockDim.x) {
+    const unsigned int node = it / QN, q = it - node * QN;
+    const float* f = feat + (long long)node * fstride;
+    if (q == 0) {
+      base[node] = make_float4(dens[(long long)node * dstride], f[0], f[K], f[2 * K]);
+    } else {
+      float v[4];
+#pragma unroll
+      for (int x = 0; x < 4; ++x) {
+        const unsigned int r = 4 * (q - 1) + x;
+        const unsigned int colour = r / KR, k = r - colour * KR + 1;
+        v[x] = f[colour * K + k];
+      }
+      rest[(long long)node * (QN - 1) + (q - 1)] = make_float4(v[0], v[1], v[2], v[3]);
+    }
+  }
+}
+
 // =============================================================================================
 // standalone point query: VoxelGrid.forward (thre3d_reprs/voxels.py:276-331) and its adjoint.
 // One thread per (point, output channel); channel c < F is feature c in the reference order (colour*K + k),
@@ -3505,6 +3558,36 @@ int rf_upsample_grid(const RFGrid* src, const RFGrid* dst, void* stream) {
   const long long total = (long long)gd.X * gd.Y * gd.Z * (gd.F + 1);
   hipLaunchKernelGGL(upsample_grid_kernel, dim3(grid_1d(total, 256, 256LL * 64)), dim3(256), 0, (hipStream_t)stream, gs, gd,
                      const_cast<float*>(dst->densities_dev), const_cast<float*>(dst->features_dev), total);
+  return launch_status();
+}
+
+int rf_convert_grid(const RFGrid* src, const RFGrid* dst, void* stream) {
+  int rc = check_grid(src);
+  if (rc != RF_OK) return rc;
+  rc = check_grid(dst);
+  if (rc != RF_OK) return rc;
+  if (src->num_features != dst->num_features) return RF_ERR_BAD_SHAPE;
+  for (int a = 0; a < 3; ++a)
+    if (src->dims[a] != dst->dims[a]) return RF_ERR_BAD_SHAPE;
+  if (src->densities_dev == dst->densities_dev || (dst->features_dev && src->features_dev == dst->features_dev)) return RF_ERR_BAD_SHAPE;
+  const GridArgs gs = to_args(src), gd = to_args(dst);
+  const unsigned int nodes = (unsigned)gd.X * (unsigned)gd.Y * (unsigned)gd.Z;
+  const int K = gd.F / 3;
+  if (src->layout == RF_LAYOUT_REFERENCE && dst->layout == RF_LAYOUT_SPLIT && (K == 1 || K == 9) && dst->density_stride == 4 &&
+      (K == 1 || dst->feature_stride == gd.F - 3) && (((uintptr_t)dst->densities_dev | (uintptr_t)dst->features_dev) & 15u) == 0 &&
+      (unsigned long long)nodes * 7ull < (1ull << 32)) {
+    float4* base = reinterpret_cast<float4*>(const_cast<float*>(dst->densities_dev));
+    float4* rest = reinterpret_cast<float4*>(const_cast<float*>(dst->features_dev));
+    const unsigned blocks = grid_1d((long long)nodes * ((gd.F + 1) / 4), 256, 256LL * 64);
+    if (K == 1)
+      hipLaunchKernelGGL((reference_to_split_kernel<1>), dim3(blocks), dim3(256), 0, (hipStream_t)stream, gs.dens, gs.feat, gs.dstride, gs.fstride, base, rest, nodes);
+    else
+      hipLaunchKernelGGL((reference_to_split_kernel<9>), dim3(blocks), dim3(256), 0, (hipStream_t)stream, gs.dens, gs.feat, gs.dstride, gs.fstride, base, rest, nodes);
+    return launch_status();
+  }
+  const int cw = gd.F + 1 <= 32 ? 32 : 64, per_block = 256 / cw;
+  hipLaunchKernelGGL(convert_grid_kernel, dim3(grid_1d(nodes, per_block, 256LL * 256)), dim3(cw, per_block), 0, (hipStream_t)stream, gs, gd,
+                     const_cast<float*>(dst->densities_dev), const_cast<float*>(dst->features_dev), nodes);
   return launch_status();
 }
 

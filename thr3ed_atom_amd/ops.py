@@ -191,7 +191,7 @@ def render_forward_raw(grid: VoxelGrid, origins: Tensor, directions: Tensor, t_r
         _require_hip(t, name)
     n = origins.shape[0]
     dev = origins.device
-    rf_grid = grid.to_rf_grid(use_occupancy=bool(flags & _lib.FLAG_OCCUPANCY_SKIP))
+    rf_grid = grid.forward_rf_grid(use_occupancy=bool(flags & _lib.FLAG_OCCUPANCY_SKIP))  # (reference storage: its split shadow)
     rb, tv = _ray_batch(origins, directions, num_samples, near, far, t_rand)
     colour = torch.empty((n, 3), dtype=torch.float32, device=dev)
     depth = torch.empty((n, 1), dtype=torch.float32, device=dev)
@@ -243,7 +243,7 @@ def render_frame_raw(grid: VoxelGrid, height: int, width: int, focal: float, rot
     if jitter is not None:
         rb.jitter_key = int(jitter.key) & 0xFFFFFFFFFFFFFFFF
         flags = int(flags) | _lib.FLAG_JITTER_KEYED
-    rf_grid = grid.to_rf_grid(use_occupancy=bool(flags & _lib.FLAG_OCCUPANCY_SKIP))
+    rf_grid = grid.forward_rf_grid(use_occupancy=bool(flags & _lib.FLAG_OCCUPANCY_SKIP))
     colour = torch.empty((n, 3), dtype=torch.float32, device=dev)
     depth = torch.empty((n, 1), dtype=torch.float32, device=dev)
     acc = torch.empty((n, 1), dtype=torch.float32, device=dev)

@@ -9,6 +9,7 @@ arithmetic itself (normalise -> trilinear gather -> ReLU) lives in the HIP kerne
 """
 from typing import Any, Callable, Dict, NamedTuple, Optional, Tuple
 
+import ctypes as C
 import weakref
 
 import numpy as np
@@ -127,6 +128,9 @@ def resolve_density_mode(pre: Callable, post: Callable) -> str:
 # un-picklable ever lives in a module's __dict__ (copy.deepcopy(module) / torch.save(module) keep working after a HIP render)
 _RF_GRID_CACHE: "weakref.WeakKeyDictionary" = weakref.WeakKeyDictionary()
 _RF_VIEW_CACHE: "weakref.WeakKeyDictionary" = weakref.WeakKeyDictionary()
+_RF_SHADOW_CACHE: "weakref.WeakKeyDictionary" = weakref.WeakKeyDictionary()
+# forward passes of reference-storage grids gather from a split-layout shadow (KernelGridInterface.forward_rf_grid)
+SPLIT_SHADOW = True
 
 
 class KernelGridInterface:
@@ -183,6 +187,37 @@ class KernelGridInterface:
         _RF_GRID_CACHE[self] = (key, g)
         return g
 
+    def forward_rf_grid(self, use_occupancy: bool = False) -> "_lib.RFGrid":
+        """The descriptor the FORWARD passes should gather from.  A grid held in the reference's two tensors (one corner = 108
+        unaligned feature bytes + 4 bytes in another tensor) is rendered from a split-layout SHADOW instead -- base [X,Y,Z,4] +
+        rest [X,Y,Z,F-3], refreshed by one re-layout launch (rf_convert_grid) whenever the Parameters changed: their data pointers,
+        their in-place version counters, or invalidate_occupancy() (what the fused optimizer calls after writing through raw
+        pointers).  Measured on the 128^3 / SH-2 training step: diffuse forward 0.288 -> 0.084 ms for a 0.08 ms refresh per
+        optimizer step.  Adjoints are unaffected: they produce gradients in the layout of the Parameters."""
+        if self.storage != "reference" or not SPLIT_SHADOW:
+            return self.to_rf_grid(use_occupancy)
+        d, f = self.kernel_tensors()
+        real = self.to_rf_grid(use_occupancy)
+        sh = _RF_SHADOW_CACHE.get(self)
+        stamp = (d.data_ptr(), f.data_ptr(), d._version, f._version, self.__dict__.get("_shadow_epoch", 0), tuple(d.shape), tuple(f.shape))
+        if sh is None or sh["shape"] != (tuple(d.shape), tuple(f.shape)) or sh["device"] != d.device:
+            X, Y, Z = d.shape[:3]
+            F = f.shape[-1]
+            sh = {"shape": (tuple(d.shape), tuple(f.shape)), "device": d.device, "stamp": None,
+                  "base": torch.empty((X, Y, Z, 4), dtype=torch.float32, device=d.device),
+                  "rest": torch.empty((X, Y, Z, F - 3), dtype=torch.float32, device=d.device) if F > 3 else None}
+            _RF_SHADOW_CACHE[self] = sh
+        g = _lib.RFGrid()
+        C.memmove(C.byref(g), C.byref(real), C.sizeof(_lib.RFGrid))
+        g.densities_dev = sh["base"].data_ptr()
+        g.features_dev = None if sh["rest"] is None else sh["rest"].data_ptr()
+        g.density_stride, g.feature_stride = 4, 0 if sh["rest"] is None else int(sh["rest"].shape[-1])
+        g.layout = _lib.LAYOUTS["split"]
+        if sh["stamp"] != stamp:
+            _lib.check(_lib.load().rf_convert_grid(C.byref(real), C.byref(g), torch.cuda.current_stream(d.device).cuda_stream), "rf_convert_grid")
+            sh["stamp"] = stamp
+        return g
+
     def build_occupancy(self, threshold: float = 0.0) -> Tensor:
         """(Re)build the exact empty-cell bit mask used by RF_FLAG_OCCUPANCY_SKIP.  Must be called again
         whenever the densities change."""
@@ -206,6 +241,7 @@ class KernelGridInterface:
         """The densities were changed behind autograd's back (a fused optimizer kernel writes through raw pointers): the
         mask has to be rebuilt before its next use."""
         self._occupancy_stamp = None
+        self.__dict__["_shadow_epoch"] = self.__dict__.get("_shadow_epoch", 0) + 1  # (the split shadow of forward_rf_grid is stale too)
 
     def occupancy_current(self) -> bool:
         """True when a mask exists AND the density tensor is the one (same storage, same in-place version counter) it was
