@@ -31,6 +31,16 @@
 
 namespace {
 
+// render_emit_direct_kernel: chunks of a ray in flight together / waves per SIMD asked of the register allocator.  Measured on the
+// bench step (specular + diffuse launch): 4 chunks at 4 waves 0.056 + 0.055 ms, 3 at 5 0.059 + 0.053, 2 at 6 (76-80 registers, no
+// spills) 0.052 + 0.046, 2 at 7 (spills) 0.052 + 0.058, 1 at 8 0.056 + 0.045: occupancy hides the chunk's dependent chain
+// (cache load -> key -> cursor atomic -> stores) better than unrolling it does.
+#ifndef RF_EMIT_WAVES
+#define RF_EMIT_WAVES 6
+#endif
+#ifndef RF_EMIT_G
+#define RF_EMIT_G 2
+#endif
 constexpr int kWave = 64;
 constexpr int kWavesPerBlock = 4;
 constexpr int kBlock = kWave * kWavesPerBlock;
@@ -1300,7 +1310,7 @@ __global__ __launch_bounds__(kBlock) void render_backward_kernel(GridArgs g, Ray
 // Every sample the forward pass counted (flag in the sign bit of its cached transmittance) writes index quad + dL/d(interpolated
 // channel) for all channels (SH basis of the ray multiplied in) at the next free position of its (brick, flags) key class.
 // The per-chunk dependency chain -- cache load (HBM) -> key -> returning cursor atomic (L2) -> record stores -- is what bounds this
-// kernel, not arithmetic or bandwidth (0.3 of the HBM peak by counters), so a ray's chunks are processed FOUR at a time: all
+// kernel, not arithmetic or bandwidth (0.3 of the HBM peak by counters), so a ray's chunks are processed in groups (RF_EMIT_G): all
 // cache loads first, then all cursor atomics back to back (their results are not touched yet), then the gradients far-to-near
 // with the running suffix sum.  Measured on the bench step (specular / diffuse render): 0.098 / 0.073 ms; by ablation the geometry
 // and gradient arithmetic alone took 0.036 / 0.034 ms, the cache loads ~0.03, the cursor atomics ~0.025, the record stores
@@ -1313,7 +1323,7 @@ __global__ __launch_bounds__(kBlock) void render_backward_kernel(GridArgs g, Ray
 // 16-byte pieces of 64 different lines -- slower (0.113 / 0.078 ms): the L2 merges the partial lines at no cost that matters here.
 // =============================================================================================
 template <int K, bool DIFFUSE>
-__global__ __launch_bounds__(kBlock) void render_emit_direct_kernel(GridArgs g, RayArgs r, OutArgs fwd, GradArgs gr, uint32_t flags) {
+__global__ __launch_bounds__(kBlock, RF_EMIT_WAVES) void render_emit_direct_kernel(GridArgs g, RayArgs r, OutArgs fwd, GradArgs gr, uint32_t flags) {
   const int lane = threadIdx.x & (kWave - 1);
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const long long ray = (long long)blockIdx.x * kWavesPerBlock + wave;
@@ -1342,7 +1352,7 @@ __global__ __launch_bounds__(kBlock) void render_emit_direct_kernel(GridArgs g, 
   const int processed = fwd.stop[ray];
   const int nchunks = (processed + kWave - 1) / kWave;
   float suffix = 0.0f;  // sum of w_j e_j over all samples beyond the current chunk
-  constexpr int G = 4;  // chunks in flight
+  constexpr int G = RF_EMIT_G;  // chunks in flight
   // the chunk masks, one per lane: requested before anything that depends on `processed` (the first group walked is almost always
   // the last one of the ray: rays of at most 4096 samples have a single group)
   int masks_group = (mask_words - 1) >> 6;
