@@ -409,7 +409,7 @@ typedef struct RFTrainStep {
                                    of the very call that is timed (only with phases == 0)                                      */
 } RFTrainStep;
 
-enum { RF_STEP_FORWARD = 1, RF_STEP_EMIT = 2, RF_STEP_BRICKS = 4 };
+enum { RF_STEP_FORWARD = 1, RF_STEP_EMIT = 2, RF_STEP_BRICKS = 4, RF_STEP_EMIT_SPECULAR = 8, RF_STEP_EMIT_DIFFUSE = 16 /* one adjoint at a time */ };
 
 #define RF_TRAIN_STEP_EVENTS 11
 

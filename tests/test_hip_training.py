@@ -636,7 +636,7 @@ def test_data_parallel_sharded_optimizer_wiring(hip_device, monkeypatch):
 
 
 @pytest.mark.parametrize("exchange,shard_optimizer", [("owner", True), ("dense", True), ("dense", False)])
-def test_data_parallel_step_through_rccl_single_rank(hip_device, exchange, shard_optimizer):
+def test_data_parallel_step_through_rccl_single_rank(hip_device, monkeypatch, exchange, shard_optimizer):
     """The data-parallel train step with its collectives really going through RCCL (a process group of ONE rank on this
     GPU: owner-computes = all_gather_into_tensor of the offset tables on RCCL's stream + the side-stream host read + all_to_all +
     the brick pass over a brick range; dense = reduce_scatter_tensor / all_gather_into_tensor / asynchronous all_reduce with
@@ -651,6 +651,7 @@ def test_data_parallel_step_through_rccl_single_rank(hip_device, exchange, shard
     F = 3 * (deg + 1) ** 2
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
     os.environ.setdefault("MASTER_PORT", "29541")
+    monkeypatch.setenv("RF_OWNER_FORCE_COLLECTIVES", "1")  # (a 1-rank group: run the exchange and all-gather calls anyway)
     created = not dist.is_initialized()
     if created:
         dist.init_process_group(backend="nccl", rank=0, world_size=1)

@@ -28,6 +28,8 @@ FLAG_JITTER_KEYED = 16
 STEP_FORWARD = 1
 STEP_EMIT = 2
 STEP_BRICKS = 4
+STEP_EMIT_SPECULAR = 8
+STEP_EMIT_DIFFUSE = 16
 
 EXPORTED_SYMBOLS = [
     "rf_abi_version",

@@ -3662,6 +3662,7 @@ int rf_train_step(const RFGrid* grid, const RFTrainStep* step, void* stream) {
   if (nkeys > (1 << 21)) return RF_ERR_BAD_SHAPE;
   const bool run_forward = step->phases == 0 || (step->phases & RF_STEP_FORWARD), run_emit = step->phases == 0 || (step->phases & RF_STEP_EMIT),
              run_bricks = step->phases == 0 || (step->phases & RF_STEP_BRICKS);
+  const bool emit_one[2] = {run_emit || (step->phases & RF_STEP_EMIT_SPECULAR) != 0, run_emit || (step->phases & RF_STEP_EMIT_DIFFUSE) != 0};
   if (run_bricks) {  // everything the last launch would refuse is refused before the first one
     if (step->adam) {
       rc = check_fused_adam(grid, step->adam, grid->num_features / 3, false);
@@ -3733,8 +3734,9 @@ int rf_train_step(const RFGrid* grid, const RFTrainStep* step, void* stream) {
       RF_STEP_EVENT();
     }
   }
-  if (run_emit) {
+  if (emit_one[0] || emit_one[1]) {
     for (int i = 0; i < 2; ++i) {
+      if (!emit_one[i]) continue;
       const RFPassScratch& ps = step->pass[i];
       const RFRenderGrads grads = {ps.grad_colour_dev, nullptr, nullptr};
       RF_STEP_EVENT();  // (offsets[0] = the launch above, offsets[1] = nothing)

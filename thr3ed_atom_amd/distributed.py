@@ -176,21 +176,23 @@ def all_gather_rows_equal(out: Tensor, mine: Tensor, async_op: bool = False):
     return None
 
 
-def exchange_slices(send: list, recv: list) -> None:
+def exchange_slices(send: list, recv: list, async_op: bool = False):
     """Personalised exchange: ``send[d]`` (a slice of this rank's data, any length, slices may overlap) goes to rank d and
     ``recv[s]`` (pre-sized by the caller, who knows every count) receives what rank s sends here.  Entries for the own rank are
     ignored (pass empty tensors).  RCCL: one grouped send/recv per pair (``all_to_all``) straight out of / into the given views
-    over xGMI; other backends (CPU tests of the wiring): staged through host memory."""
+    over xGMI -- with ``async_op`` the work handle is returned (the exchange is ordered after the CURRENT stream's work and runs
+    beside whatever is enqueued next); other backends (CPU tests of the wiring): staged through host memory, complete on return
+    (None)."""
     n, me = world_size(), rank()
     assert len(send) == n and len(recv) == n
     if not _collectives_on():
-        return
+        return None
     if dist.get_backend() == "nccl":
         empty = send[me][:0]
         ins = [empty if d == me else send[d] for d in range(n)]
         outs = [recv[me][:0] if s_ == me else recv[s_] for s_ in range(n)]
-        dist.all_to_all(outs, ins)
-        return
+        work = dist.all_to_all(outs, ins, async_op=async_op)
+        return work if async_op else None
     # gloo: all_to_all_single on host copies (gloo has no list all_to_all and no device all_to_all)
     width = tuple(send[0].shape[1:])
     ins = [send[d][:0] if d == me else send[d] for d in range(n)]
@@ -204,6 +206,7 @@ def exchange_slices(send: list, recv: list) -> None:
         if out_split[s_]:
             recv[s_].copy_(got[pos : pos + out_split[s_]])
             pos += out_split[s_]
+    return None
 
 
 def broadcast_(tensor: Tensor, src: int = 0) -> Tensor:

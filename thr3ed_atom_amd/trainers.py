@@ -436,6 +436,7 @@ class TrainStepper:
             "key_idx": torch.tensor(idx, dtype=torch.int64, device=device),
             "bounds_host": torch.empty((W, 2, 2 * W), dtype=torch.int64).pin_memory(),
             "side": torch.cuda.Stream(device), "forward_done": torch.cuda.Event(), "ready": torch.cuda.Event(),
+            "comm": torch.cuda.Stream(device), "emitted": [torch.cuda.Event(), torch.cuda.Event()], "exchanged": [torch.cuda.Event(), torch.cuda.Event()],
             "recv": [torch.empty((0, t[f"pass{k}"]["sorted"].shape[1]), dtype=torch.float32, device=device) for k in range(2)],
         }
         self._owner = ow
@@ -448,6 +449,9 @@ class TrainStepper:
         the own bricks over all ranks' lists | all-gather of the parameters."""
         ow = self._owner_state(ex, dev)
         W, me = ow["W"], ow["me"]
+        # a 1-rank group (bench.py --dp-style-step, tests) has nothing to exchange: the record exchange and the parameter all-gather
+        # are skipped unless RF_OWNER_FORCE_COLLECTIVES asks for the calls themselves to be exercised (tests do)
+        collect = W > 1 or bool(os.environ.get("RF_OWNER_FORCE_COLLECTIVES"))
         lib, grid, opt = _lib.load(), self.vol_mod.thre3d_repr, self.optimizer
         main = torch.cuda.current_stream(dev)
         t = ex["tensors"]
@@ -460,8 +464,14 @@ class TrainStepper:
         mark(1)
         work = rfdist.all_gather_rows_equal(ow["all_offsets"], t["offsets2"], async_op=True)
         ow["forward_done"].record(main)
-        st.phases = _lib.STEP_EMIT
-        _lib.check(lib.rf_train_step(C.byref(rf_grid), C.byref(st), main.cuda_stream), "rf_train_step[emit]")
+        # the two adjoints as two launches with an event between them: the exchange of the specular slices is ordered after the
+        # first one only (on the communication stream) and runs beside the diffuse adjoint
+        st.phases = _lib.STEP_EMIT_SPECULAR
+        _lib.check(lib.rf_train_step(C.byref(rf_grid), C.byref(st), main.cuda_stream), "rf_train_step[emit specular]")
+        ow["emitted"][0].record(main)
+        st.phases = _lib.STEP_EMIT_DIFFUSE
+        _lib.check(lib.rf_train_step(C.byref(rf_grid), C.byref(st), main.cuda_stream), "rf_train_step[emit diffuse]")
+        ow["emitted"][1].record(main)
         mark(2)
         with torch.cuda.stream(ow["side"]):
             ow["side"].wait_event(ow["forward_done"])
@@ -474,7 +484,7 @@ class TrainStepper:
         ow["ready"].synchronize()
         b = ow["bounds_host"].numpy()  # [source, list, (lo, hi) per owner]
         sent = (W - 1) * t["offsets2"].numel() * 8  # the all-gather of the offset tables
-        lists = []
+        lists, pending = [], []
         for k in range(2):
             srt = t[f"pass{k}"]["sorted"]
             rec_bytes = srt.shape[1] * 4
@@ -493,12 +503,22 @@ class TrainStepper:
                 send.append(srt[int(b[me, k, 2 * s_]) : int(b[me, k, 2 * s_ + 1])] if s_ != me else srt[:0])
                 if s_ != me:
                     sent += int(send[-1].shape[0]) * rec_bytes
-            rfdist.exchange_slices(send, recv)  # (a no-op without a process group; a 1-rank RCCL group goes through the same call)
+            # (a no-op without a process group; a 1-rank RCCL group goes through the same calls)
+            if collect:
+                with torch.cuda.stream(ow["comm"]):
+                    ow["comm"].wait_event(ow["emitted"][k])
+                    pending.append(rfdist.exchange_slices(send, recv, async_op=True))
+                    ow["exchanged"][k].record(ow["comm"])
             for s_ in range(W):
                 if s_ == me:
                     lists.append((srt.data_ptr(), t["offsets2"][k], k == 1))
                 else:  # positioned such that ptr + offsets_s[key] * record size is the first record of `key` in the received slice
                     lists.append((recv_buf.data_ptr() + (base[s_] - int(b[s_, k, 2 * me])) * rec_bytes, ow["all_offsets"][s_, k], k == 1))
+        for k, wk in enumerate(pending):  # the brick pass waits for both exchanges
+            if wk is not None:
+                wk.wait()
+            main.wait_event(ow["exchanged"][k])
+        del pending
         mark(3)
         opt.step_count += 1
         nd = self.flat.flat_gradient_parts()[0].numel()
@@ -507,9 +527,10 @@ class TrainStepper:
         brick_accumulate_adam_raw(grid, self.brick_size, lists, halves(opt.exp_avg), halves(opt.exp_avg_sq), opt.lr, opt.betas[0], opt.betas[1],
                                   opt.eps, opt.step_count, brick_range=ow["bricks"])
         mark(4)
-        rfdist.all_gather_chunks_(self.flat.flat_param[:nd])
-        if has_second:
-            rfdist.all_gather_chunks_(self.flat.flat_param[nd:])
+        if collect:
+            rfdist.all_gather_chunks_(self.flat.flat_param[:nd])
+            if has_second:
+                rfdist.all_gather_chunks_(self.flat.flat_param[nd:])
         sent += (W - 1) * (self.flat.flat_param.numel() // W) * 4
         mark(5)
         self.exchange_bytes = (self.exchange_bytes + [sent])[-64:]
