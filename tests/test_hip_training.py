@@ -670,7 +670,10 @@ def test_data_parallel_step_through_rccl_single_rank(hip_device, monkeypatch, ex
                 stepper.step_on(rays, T(g["pixels"][it]).to(hip_device))
             out.append(stepper.flat.flat_param.clone())
         torch.cuda.synchronize()
-        assert torch.allclose(out[0], out[1], atol=1e-6)
+        # (the record order inside a key class depends on atomic timing, so the two runs sum in different orders: parameters whose
+        # gradient is ~1e-8 amplify that through Adam's first steps -- same criterion as the trajectory tests)
+        err = (out[0] - out[1]).abs()
+        assert float((err <= 2e-5).float().mean()) >= 0.999 and float(err.max()) <= float(g["lr"]) * 2 * 2 + 1e-6
     finally:
         rfdist.FORCE_COLLECTIVES = False
         if created:
@@ -972,3 +975,50 @@ def test_brick_pass_over_two_lists_of_the_same_kind(hip_device, storage, deg):
     one_d, one_f = grid.unpack(gd2, gf2)
     np.testing.assert_allclose(both_d.cpu().numpy(), one_d.cpu().numpy(), rtol=1e-5, atol=1e-7 * float(total_d.abs().max()))
     np.testing.assert_allclose(both_f.cpu().numpy(), one_f.cpu().numpy(), rtol=1e-5, atol=1e-7 * float(total_f.abs().max()))
+
+
+def test_autograd_trainer_with_deferred_gradients_equals_the_fused_step(hip_device):
+    """TrainStepper(fused=False) on a grid in the reference's own two tensors: forward passes through the torch.autograd.Function
+    (rendered from the split shadow), every backward leaves a sorted record list, FusedAdam.step sums all of them in ONE merged brick
+    pass with Adam in its flush on the shadow and re-lays the result out into the Parameters.  Must equal the fused step on split
+    storage iteration by iteration; ``FlatGrid.materialize()`` must equal plain autograd's gradients."""
+    g = load_golden("g9_trainer_trajectory.npz")
+    G, _, hw, n_img, n_rays, steps, S = (int(v) for v in g["config"])
+    F = 27
+    cfg = rf.SHVoxGridRenderConfig(S, rf.CameraBounds(float(g["near"]), float(g["far"])), perturb_sampled_points=False, white_bkgd=True)
+    runs = []
+    for storage, fused in (("reference", False), ("split", True)):
+        grid = relu_grid(hip_device, T(hash_uniform((G, G, G, 1), 901)), T(hash_uniform((G, G, G, F), 900 + F)), G, storage=storage)
+        model = rf.VolumetricModel(grid, rf.render_sh_voxel_grid, cfg, device=hip_device)
+        stepper = TrainStepper(model, n_rays, learning_rate=float(g["lr"]), fused=fused, data_parallel=False)
+        assert stepper.flat.deferred == (not fused)
+        losses = []
+        for it in range(4):
+            rays = rf.Rays(T(g["origins"][it]).to(hip_device), T(g["directions"][it]).to(hip_device))
+            st = stepper.step_on(rays, T(g["pixels"][it]).to(hip_device))
+            losses.append((st.specular_loss.item(), st.diffuse_loss.item()))
+        if not fused:  # the Parameters themselves were updated (they are what a reference user reads and checkpoints)
+            assert isinstance(grid.densities, torch.nn.Parameter) and grid.densities.data_ptr() == stepper.flat.flat_param.data_ptr()
+        runs.append((losses, grid.densities.detach().clone(), grid.features.detach().clone(), stepper.optimizer.step_count))
+    np.testing.assert_allclose(np.array(runs[0][0]), np.array(runs[1][0]), rtol=2e-5)
+    assert runs[0][3] == runs[1][3] == 4
+    for a, b in ((runs[0][1], runs[1][1]), (runs[0][2], runs[1][2])):
+        err = (a - b).abs()
+        assert float((err <= 2e-5).float().mean()) >= 0.999 and float(err.max()) <= 0.03 * 2 * 4 + 1e-6
+    # the pending lists, summed on demand, are the gradient plain autograd computes
+    grids = [relu_grid(hip_device, T(hash_uniform((G, G, G, 1), 901)), T(hash_uniform((G, G, G, F), 900 + F)), G) for _ in range(2)]
+    flat = FlatGrid(grids[1], deferred=True)
+    assert flat.deferred
+    rays = rf.Rays(T(g["origins"][0]).to(hip_device), T(g["directions"][0]).to(hip_device))
+    target = T(g["pixels"][0]).to(hip_device)
+    for grid in grids:
+        model = rf.VolumetricModel(grid, rf.render_sh_voxel_grid, cfg, device=hip_device)
+        loss = torch.nn.functional.l1_loss(model.render_rays(rays).colour, target)
+        loss = loss + torch.nn.functional.l1_loss(model.render_rays(rays, render_diffuse=True).colour, target)
+        loss.backward()
+    assert len(flat.pending) == 2
+    flat.materialize()
+    for a, b in ((grids[0].densities.grad, grids[1].densities.grad), (grids[0].features.grad, grids[1].features.grad)):
+        np.testing.assert_allclose(b.cpu().numpy(), a.cpu().numpy(), rtol=2e-4, atol=2e-6 * float(a.abs().max()))
+    flat.zero_grad()
+    assert flat.pending == []

@@ -2140,7 +2140,7 @@ __global__ __launch_bounds__(kBrickThreads, (K > 9 ? 2 : 4)) void brick_gather_k
       }
     };
     // -- bin the batch to the tiles it touches and multiply it into the tiles' accumulators (WIDE: rows of C4 channels, else 4)
-    auto process = [&](auto wide_tag) {
+    auto process = [&](auto wide_tag, int nrec) {
       constexpr bool WIDE = decltype(wide_tag)::value;
       constexpr int RW = gather_record_words(WIDE ? C4 : 4);  // words per row in LDS
       constexpr int NTW = WIDE ? NT : 1;
@@ -2157,6 +2157,7 @@ __global__ __launch_bounds__(kBrickThreads, (K > 9 ? 2 : 4)) void brick_gather_k
       if (!no_lists)
 #pragma unroll
       for (int wd = 0; wd < NW; ++wd) {
+        if (wd * 64 >= nrec) break;  // (wave-uniform: the short batches at the end of a list fill one or two words only)
         const uint32_t tmv = s_tmask[wd * 64 + lane] >> wave;
 #pragma unroll
         for (int tl = 0; tl < 4; ++tl) {
@@ -2295,7 +2296,7 @@ __global__ __launch_bounds__(kBrickThreads, (K > 9 ? 2 : 4)) void brick_gather_k
       RF_PROF_MARK(1);  // waiting for the batch's loads, record pass
       fetch_wide(min(s + 1, nba - 1));  // (the last batch again at the end: cheaper than a conditional)
       RF_PROF_MARK(6);  // issuing the next batch's loads
-      process(Yes{});
+      process(Yes{}, nrec);
     }
     for (int sd = 0; sd < nbd; ++sd) {
       const int nrec = min(kGatherBatch, total_d - sd * kGatherBatch);
@@ -2303,7 +2304,7 @@ __global__ __launch_bounds__(kBrickThreads, (K > 9 ? 2 : 4)) void brick_gather_k
       RF_PROF_MARK(1);
       fetch_narrow(min(sd + 1, nbd - 1));
       RF_PROF_MARK(6);
-      process(No{});
+      process(No{}, nrec);
     }
     // -- the accumulator image for the flush (the batch buffers are dead).  Accumulator register e of a lane: node row
     // 4 (lane >> 4) + e of the tile, channel 16 nt + (lane & 15)
@@ -2470,6 +2471,36 @@ __global__ void reference_to_split_kernel(const float* __restrict__ dens, const 
         v[x] = f[colour * K + k];
       }
       rest[(long long)node * (QN - 1) + (q - 1)] = make_float4(v[0], v[1], v[2], v[3]);
+    }
+  }
+}
+
+// ... and back: split tensors -> reference tensors, one thread per SOURCE float4 (coalesced 16-byte load, four 4-byte stores inside the
+// node's feature record).  Used when the split shadow is the copy the optimizer updated (deferred gradients, optim.FlatGrid).
+template <int K>
+__global__ void split_to_reference_kernel(const float4* __restrict__ base, const float4* __restrict__ rest, float* __restrict__ dens,
+                                          float* __restrict__ feat, long long dstride, long long fstride, unsigned int nodes) {
+  constexpr int QN = (3 * K + 1) / 4;
+  constexpr int KR = K > 1 ? K - 1 : 1;
+  const unsigned int total = nodes * QN;
+  for (unsigned int it = blockIdx.x * blockDim.x + threadIdx.x; it < total; it += gridDim.x * blockDim.x) {
+    const unsigned int node = it / QN, q = it - node * QN;
+    float* f = feat + (long long)node * fstride;
+    if (q == 0) {
+      const float4 v = base[node];
+      dens[(long long)node * dstride] = v.x;
+      f[0] = v.y;
+      f[K] = v.z;
+      f[2 * K] = v.w;
+    } else {
+      const float4 v4 = rest[(long long)node * (QN - 1) + (q - 1)];
+      const float v[4] = {v4.x, v4.y, v4.z, v4.w};
+#pragma unroll
+      for (int x = 0; x < 4; ++x) {
+        const unsigned int r = 4 * (q - 1) + x;
+        const unsigned int colour = r / KR, k = r - colour * KR + 1;
+        f[colour * K + k] = v[x];
+      }
     }
   }
 }
@@ -3593,6 +3624,20 @@ int rf_convert_grid(const RFGrid* src, const RFGrid* dst, void* stream) {
       hipLaunchKernelGGL((reference_to_split_kernel<1>), dim3(blocks), dim3(256), 0, (hipStream_t)stream, gs.dens, gs.feat, gs.dstride, gs.fstride, base, rest, nodes);
     else
       hipLaunchKernelGGL((reference_to_split_kernel<9>), dim3(blocks), dim3(256), 0, (hipStream_t)stream, gs.dens, gs.feat, gs.dstride, gs.fstride, base, rest, nodes);
+    return launch_status();
+  }
+  if (src->layout == RF_LAYOUT_SPLIT && dst->layout == RF_LAYOUT_REFERENCE && (K == 1 || K == 9) && src->density_stride == 4 &&
+      (K == 1 || src->feature_stride == gd.F - 3) && (((uintptr_t)src->densities_dev | (uintptr_t)src->features_dev) & 15u) == 0 &&
+      (unsigned long long)nodes * 7ull < (1ull << 32)) {
+    const float4* base = reinterpret_cast<const float4*>(src->densities_dev);
+    const float4* rest = reinterpret_cast<const float4*>(src->features_dev);
+    float* dd = const_cast<float*>(dst->densities_dev);
+    float* df = const_cast<float*>(dst->features_dev);
+    const unsigned blocks = grid_1d((long long)nodes * ((gd.F + 1) / 4), 256, 256LL * 64);
+    if (K == 1)
+      hipLaunchKernelGGL((split_to_reference_kernel<1>), dim3(blocks), dim3(256), 0, (hipStream_t)stream, base, rest, dd, df, gd.dstride, gd.fstride, nodes);
+    else
+      hipLaunchKernelGGL((split_to_reference_kernel<9>), dim3(blocks), dim3(256), 0, (hipStream_t)stream, base, rest, dd, df, gd.dstride, gd.fstride, nodes);
     return launch_status();
   }
   const int cw = gd.F + 1 <= 32 ? 32 : 64, per_block = 256 / cw;

@@ -400,14 +400,15 @@ def brick_accumulate_raw(grid: VoxelGrid, brick_size: int, lists, grad_first: Te
 
 
 def brick_accumulate_adam_raw(grid: VoxelGrid, brick_size: int, lists, exp_avg, exp_avg_sq, lr: float, beta1: float, beta2: float,
-                              eps: float, step: int, brick_range=None) -> None:
+                              eps: float, step: int, brick_range=None, rf_grid=None, params=None) -> None:
     """Enqueue rf_brick_accumulate_adam: the brick pass over ``lists`` (as in ``brick_accumulate_raw``; all renders of the
     iteration -- of all ranks, under data parallelism) with the Adam update of the grid's own tensors applied in the flush.
     ``exp_avg`` / ``exp_avg_sq`` are pairs of tensors shaped like ``grid.kernel_tensors()`` (second entry None when the grid has no
     second tensor).  ``brick_range`` = (first_brick, num_bricks) restricts the pass (and the update) to those bricks.  An entry of
-    ``lists`` may give its records as an int (a raw device address) instead of a tensor."""
+    ``lists`` may give its records as an int (a raw device address) instead of a tensor.  ``rf_grid`` / ``params``: update these
+    tensors (described by this RFGrid) instead of the grid's own -- the split-layout shadow of a reference-storage grid."""
     lib = _lib.load()
-    first, second = grid.kernel_tensors()
+    first, second = grid.kernel_tensors() if params is None else params
     dev = first.device
     arr = (_lib.RFBrickList * len(lists))()
     for i, (rec, off, diffuse) in enumerate(lists):
@@ -417,7 +418,8 @@ def brick_accumulate_adam_raw(grid: VoxelGrid, brick_size: int, lists, exp_avg, 
     st.exp_avg_first_dev, st.exp_avg_second_dev = exp_avg[0].data_ptr(), _ptr(exp_avg[1])
     st.exp_avg_sq_first_dev, st.exp_avg_sq_second_dev = exp_avg_sq[0].data_ptr(), _ptr(exp_avg_sq[1])
     st.lr, st.beta1, st.beta2, st.eps, st.step = float(lr), float(beta1), float(beta2), float(eps), int(step)
-    rf_grid = grid.to_rf_grid()
+    if rf_grid is None:
+        rf_grid = grid.to_rf_grid()
     with _span(f"brick_accumulate_adam[{'diffuse' if lists[0][2] or grid.sh_degree == 0 else 'sh' + str(grid.sh_degree)}]", dev):
         if brick_range is None:
             rc = lib.rf_brick_accumulate_adam(C.byref(rf_grid), int(brick_size), arr, len(lists), C.byref(st), _stream(dev))
@@ -438,10 +440,15 @@ AUTOGRAD_BRICK_SIZE = 8
 
 
 def _autograd_uses_bricks(grid, flags: int, n: int, num_samples: int) -> bool:
-    if AUTOGRAD_BACKWARD == "atomic":
-        return False
     nb = brick_counts(grid, AUTOGRAD_BRICK_SIZE)
+    deferred = getattr(getattr(grid, "_grad_bucket", None), "deferred", False)
     if nb[0] * nb[1] * nb[2] * 8 > (1 << 21):
+        if deferred:
+            raise ValueError("deferred gradients (optim.FlatGrid(deferred=True)) need at most 2^18 bricks")
+        return False
+    if deferred:  # the optimizer consumes record lists: every adjoint is binned
+        return True
+    if AUTOGRAD_BACKWARD == "atomic":
         return False
     if AUTOGRAD_BACKWARD == "binned":
         return True
@@ -537,7 +544,11 @@ class _ReluFieldRender(torch.autograd.Function):
                 grid, origins, directions, t_rand, ctx.num_samples, ctx.near, ctx.far, ctx.flags, (cache, tcache, stop, cmask),
                 prep(g_colour), prep(g_depth), prep(g_acc), AUTOGRAD_BRICK_SIZE, cursor, records, hist_clear=None,
             )
-            brick_accumulate_raw(grid, AUTOGRAD_BRICK_SIZE, [(records, offsets, diffuse)], gd, gf, accumulate=not overwrite)
+            if bucket is not None and getattr(bucket, "deferred", False) and bucket.matches(first, second):
+                # deferred gradients: the sorted list IS the gradient of this render; the optimizer sums all lists of the iteration
+                bucket.pending.append((records, offsets, diffuse))
+            else:
+                brick_accumulate_raw(grid, AUTOGRAD_BRICK_SIZE, [(records, offsets, diffuse)], gd, gf, accumulate=not overwrite)
             ctx.key_hist = None  # (a second backward through the same graph would find the counters consumed)
         else:
             render_backward_raw(

@@ -24,7 +24,13 @@ from .voxels import VoxelGrid
 
 
 class FlatGrid:
-    def __init__(self, grid: VoxelGrid):
+    def __init__(self, grid: VoxelGrid, deferred: bool = False):
+        """``deferred`` (opt-in; reference storage, SH degree 0 or 2, single process): the autograd op does not sum its gradient
+        into the bucket at all.  Every backward pass leaves its gradient as a sorted RECORD LIST (``pending``); ``FusedAdam.step``
+        sums all lists of the iteration in ONE merged brick pass that applies Adam in its flush on the grid's split-layout shadow
+        (voxels.KernelGridInterface.forward_rf_grid) and re-lays the result out into the Parameters -- the fused single-GPU
+        step, driven by torch.autograd.  ``.grad`` / ``flat_grad`` are then NOT populated (``materialize()`` fills them from the
+        pending lists for inspection)."""
         d, f = grid.kernel_tensors()  # (densities, features) or (base, rest); f is None for split storage at degree 0
         if not (isinstance(d, torch.nn.Parameter) and (f is None or isinstance(f, torch.nn.Parameter))):
             raise ValueError("FlatGrid needs a tunable VoxelGrid")
@@ -44,6 +50,12 @@ class FlatGrid:
             self._gf = self.flat_grad[nd:].view(f.shape)
             f.grad = self._gf
         grid._grad_bucket = self
+        from . import distributed as rfdist
+        from . import voxels
+
+        self.deferred = (bool(deferred) and grid.storage == "reference" and (grid.num_features + 1) % 4 == 0 and voxels.SPLIT_SHADOW
+                         and not rfdist._collectives_on())
+        self.pending = []  # [(records, offsets, render_diffuse)] of the backward passes since the last zero_grad / step
 
     # ---- protocol used by ops._ReluFieldRender.backward -------------------------------------
     def matches(self, first: Tensor, second: Optional[Tensor]) -> bool:
@@ -66,7 +78,22 @@ class FlatGrid:
         return None, None
 
     # ---------------------------------------------------------------------------------------
+    def materialize(self) -> Tensor:
+        """deferred mode: sum the pending record lists into ``flat_grad`` (reference layout; overwrites it) -- for inspection, the
+        optimizer does not need it."""
+        from .ops import AUTOGRAD_BRICK_SIZE, brick_accumulate_raw
+
+        if self.deferred and self.pending:
+            lists = sorted(self.pending, key=lambda l: bool(l[2]))  # full-width lists first
+            if all(l[2] for l in lists) and self.grid.num_features != 3:
+                self.flat_grad.zero_()  # (render_diffuse lists only cover the base channels)
+            brick_accumulate_raw(self.grid, AUTOGRAD_BRICK_SIZE, lists, self._gd, self._gf, accumulate=False)
+        return self.flat_grad
+
     def zero_grad(self) -> None:
+        self.pending = []
+        if self.deferred:  # (no gradient tensor is in use)
+            return
         self.flat_grad.zero_()
         if self._d.grad is not self._gd:
             self._d.grad = self._gd
@@ -86,8 +113,9 @@ class FusedAdam:
         self.lr = float(lr)
         self.betas = (float(betas[0]), float(betas[1]))
         self.eps = float(eps)
-        self.exp_avg = torch.zeros_like(flat.flat_param)
-        self.exp_avg_sq = torch.zeros_like(flat.flat_param)
+        self._split_moments = None  # deferred gradients: the moments live in the split layout of the shadow the flush updates
+        self.exp_avg = None if flat.deferred else torch.zeros_like(flat.flat_param)
+        self.exp_avg_sq = None if flat.deferred else torch.zeros_like(flat.flat_param)
         self.step_count = 0
 
     @property
@@ -103,6 +131,9 @@ class FusedAdam:
         the update to those slices of the flat buffer, with the (averaged) gradients of each slice given separately
         (sharded data-parallel optimizer: the moments of the other slices stay untouched on this rank, their
         parameters arrive by all-gather)."""
+        if self.flat.deferred:
+            self._deferred_step()
+            return
         self.step_count += 1
         if ranges is None:
             ranges = [(0, self.flat.flat_param.numel(), self.flat.flat_grad)]
@@ -114,6 +145,28 @@ class FusedAdam:
                     self.lr, self.betas[0], self.betas[1], self.eps, self.step_count, zero_grad,
                 )
         self.flat.grid.invalidate_occupancy()  # the kernel wrote the densities through raw pointers
+
+
+    def _deferred_step(self) -> None:
+        """All record lists of the iteration -> ONE merged brick pass with Adam in its flush on the split shadow -> Parameters."""
+        from .ops import AUTOGRAD_BRICK_SIZE, brick_accumulate_adam_raw
+
+        flat, grid = self.flat, self.flat.grid
+        if not flat.pending:
+            return  # nothing was rendered since the last step
+        lists = sorted(flat.pending, key=lambda l: bool(l[2]))  # full-width lists first
+        if sum(1 for l in lists if not l[2]) > 8 or sum(1 for l in lists if l[2]) > 8:
+            raise ValueError("deferred gradients: at most 8 specular and 8 render_diffuse backward passes per optimizer step")
+        self.step_count += 1
+        sh, rf_grid = grid._shadow(refresh=True)
+        if self._split_moments is None:
+            z = lambda t: None if t is None else torch.zeros_like(t)
+            self._split_moments = ((z(sh["base"]), z(sh["rest"])), (z(sh["base"]), z(sh["rest"])))
+        m, v = self._split_moments
+        brick_accumulate_adam_raw(grid, AUTOGRAD_BRICK_SIZE, lists, m, v, self.lr, self.betas[0], self.betas[1], self.eps, self.step_count,
+                                  rf_grid=rf_grid, params=(sh["base"], sh["rest"]))
+        grid.adopt_shadow()
+        flat.pending = []
 
 
 class ExponentialLR:

@@ -188,7 +188,9 @@ class TrainStepper:
         self.ray_batch_size = int(ray_batch_size)
         self.diffuse = bool(apply_diffuse_render_regularization)
         self.data_parallel = data_parallel
-        self.flat = FlatGrid(grid)
+        # autograd steps (fused=False) on a grid in the reference's own tensors: the backward passes leave record lists and the
+        # optimizer sums them in one merged brick pass with Adam in its flush (optim.FlatGrid(deferred=True))
+        self.flat = FlatGrid(grid, deferred=not self.fused and not (self.data_parallel and rfdist._collectives_on()))
         self.optimizer = FusedAdam(self.flat, lr=learning_rate, betas=(0.9, 0.999))
         if backward == "auto":
             nb = brick_counts(grid, self.brick_size)
@@ -307,7 +309,8 @@ class TrainStepper:
         if self.data_parallel:
             rfdist.all_reduce_mean_(self.flat.flat_grad)
         self.optimizer.step()
-        grid.invalidate_occupancy()
+        if not self.flat.deferred:  # (the deferred step re-laid the Parameters out and marked shadow and mask state itself)
+            grid.invalidate_occupancy()
         self._grad_clean = False
         return StepStats(spec_loss, diff_loss, spec_mse, diff_mse)
 

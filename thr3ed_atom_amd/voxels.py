@@ -192,14 +192,22 @@ class KernelGridInterface:
         unaligned feature bytes + 4 bytes in another tensor) is rendered from a split-layout SHADOW instead -- base [X,Y,Z,4] +
         rest [X,Y,Z,F-3], refreshed by one re-layout launch (rf_convert_grid) whenever the Parameters changed: their data pointers,
         their in-place version counters, or invalidate_occupancy() (what the fused optimizer calls after writing through raw
-        pointers).  Measured on the 128^3 / SH-2 training step: diffuse forward 0.288 -> 0.084 ms for a 0.08 ms refresh per
-        optimizer step.  Adjoints are unaffected: they produce gradients in the layout of the Parameters."""
+        pointers; edits through ``.data`` bypass the version counter: call invalidate_occupancy() after them).  Measured on the
+        128^3 / SH-2 training step: diffuse forward 0.288 -> 0.084 ms for a 0.13 ms refresh per optimizer step.  Adjoints are
+        unaffected: they produce gradients in the layout of the Parameters."""
         if self.storage != "reference" or not SPLIT_SHADOW:
             return self.to_rf_grid(use_occupancy)
+        return self._shadow(use_occupancy, refresh=True)[1]
+
+    def _shadow_stamp(self):
+        d, f = self.kernel_tensors()
+        return (d.data_ptr(), f.data_ptr(), d._version, f._version, self.__dict__.get("_shadow_epoch", 0), tuple(d.shape), tuple(f.shape))
+
+    def _shadow(self, use_occupancy: bool = False, refresh: bool = True):
+        """(shadow tensors dict, RFGrid describing them); ``refresh``: re-layout from the Parameters when they changed."""
         d, f = self.kernel_tensors()
         real = self.to_rf_grid(use_occupancy)
         sh = _RF_SHADOW_CACHE.get(self)
-        stamp = (d.data_ptr(), f.data_ptr(), d._version, f._version, self.__dict__.get("_shadow_epoch", 0), tuple(d.shape), tuple(f.shape))
         if sh is None or sh["shape"] != (tuple(d.shape), tuple(f.shape)) or sh["device"] != d.device:
             X, Y, Z = d.shape[:3]
             F = f.shape[-1]
@@ -213,10 +221,22 @@ class KernelGridInterface:
         g.features_dev = None if sh["rest"] is None else sh["rest"].data_ptr()
         g.density_stride, g.feature_stride = 4, 0 if sh["rest"] is None else int(sh["rest"].shape[-1])
         g.layout = _lib.LAYOUTS["split"]
-        if sh["stamp"] != stamp:
-            _lib.check(_lib.load().rf_convert_grid(C.byref(real), C.byref(g), torch.cuda.current_stream(d.device).cuda_stream), "rf_convert_grid")
-            sh["stamp"] = stamp
-        return g
+        if refresh:
+            stamp = self._shadow_stamp()
+            if sh["stamp"] != stamp:
+                _lib.check(_lib.load().rf_convert_grid(C.byref(real), C.byref(g), torch.cuda.current_stream(d.device).cuda_stream), "rf_convert_grid")
+                sh["stamp"] = stamp
+        return sh, g
+
+    def adopt_shadow(self) -> None:
+        """The split shadow is the newer copy (an optimizer updated it in place): re-layout it into the Parameters (raw-pointer
+        write: their version counters do not move) and mark the two as in sync."""
+        d, _ = self.kernel_tensors()
+        sh, g = self._shadow(refresh=False)
+        real = self.to_rf_grid()
+        _lib.check(_lib.load().rf_convert_grid(C.byref(g), C.byref(real), torch.cuda.current_stream(d.device).cuda_stream), "rf_convert_grid")
+        self.invalidate_occupancy()  # the densities changed
+        sh["stamp"] = self._shadow_stamp()
 
     def build_occupancy(self, threshold: float = 0.0) -> Tensor:
         """(Re)build the exact empty-cell bit mask used by RF_FLAG_OCCUPANCY_SKIP.  Must be called again
