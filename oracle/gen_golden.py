@@ -357,6 +357,37 @@ def g7_g8_end_to_end():
     save("g7_grid16_render.npz", near=np.float64(cam["near"]), far=np.float64(cam["far"]), rho=np.float64(rho), **out)
 
 
+def g11_density_noise():
+    """stochastic_density_noise_std != 0 (accumulate.py:58-62): with perturb_sampled_points off the render's only RNG draw is
+    torch.randn(N, S), so the noise table is reproducible from the seed and stored beside the outputs."""
+    cam = hotdog_like_camera()
+    bounds = CameraBounds(cam["near"], cam["far"])
+    rho = 100.0 / 3.0
+    dens, feat = procedural_grid((16, 16, 16), 27, 81)
+    o, d = random_rays(160, 92, spread=1.6)
+    rays = Rays(o, d)
+    target = torch.from_numpy(hash_uniform((160, 3), 93, 0.0, 1.0))
+    out = {"origins": o, "directions": d, "target": target}
+    for tag, mode, std, over in (("relu", "relu", 0.7, dict()), ("relu_diffuse_black", "relu", 0.25, dict(render_diffuse=True, white_bkgd=False)),
+                                 ("softplus", "softplus", 1.5, dict())):
+        grid = make_grid(dens, feat, (3.0 / 16,) * 3, mode=mode, rho=rho, tunable=True)
+        kw = dict(num_samples_per_ray=40, camera_bounds=bounds, perturb_sampled_points=False, white_bkgd=True, stochastic_density_noise_std=std)
+        kw.update(over)
+        cfg = SHVoxGridRenderConfig(**kw)
+        torch.manual_seed(777)
+        out[f"{tag}_noise"] = torch.randn(160, 40) * std
+        torch.manual_seed(777)
+        res, loss, gd, gf = run_render(grid, rays, cfg, target)
+        out[f"{tag}_std"] = np.float64(std)
+        out[f"{tag}_colour"] = res.colour
+        out[f"{tag}_depth"] = res.depth
+        out[f"{tag}_acc"] = res.extra["accumulated_weight"]
+        out[f"{tag}_loss"] = loss
+        out[f"{tag}_gd"] = gd
+        out[f"{tag}_gf"] = gf
+    save("g11_density_noise.npz", near=np.float64(cam["near"]), far=np.float64(cam["far"]), rho=np.float64(rho), **out)
+
+
 def g10_single_cube():
     """The reference's only render test scene (thre3d_reprs/tests/test_voxels.py:88-134): a 2x2x2
     grid with +-10 RGB logits on the corners, viewed from the 6 axis directions -- here at
@@ -401,6 +432,7 @@ if __name__ == "__main__":
         "g56": g5_g6_process_accumulate,
         "g78": g7_g8_end_to_end,
         "g10": g10_single_cube,
+        "g11": g11_density_noise,
     }
     for name, fn in jobs.items():
         if not wanted or name in wanted:

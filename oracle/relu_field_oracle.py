@@ -324,8 +324,10 @@ def process_points(
 # --------------------------------------------------------------------------------------------
 # compositing -- rendering/volumetric/accumulate.py:31-113
 # --------------------------------------------------------------------------------------------
-def accumulate(processed: Tensor, depths: Tensor, directions: Tensor, white_bkgd: bool) -> Dict[str, Tensor]:
+def accumulate(processed: Tensor, depths: Tensor, directions: Tensor, white_bkgd: bool, density_noise: Optional[Tensor] = None) -> Dict[str, Tensor]:
     """Front-to-back alpha compositing of processed[N, S, 4] at ray parameters depths[N, S].
+    ``density_noise`` [N, S] = the reference's ``torch.randn(raw_density.shape) * stochastic_density_noise_std``
+    (accumulate.py:58-62), added to the (activated, masked) density of EVERY sample before density2occupancy.
 
     delta_i = (z_{i+1} - z_i) |d|, delta_last = 1e10 |d|; alpha = 1 - exp(-sigma delta);
     T_i = prod_{j<i} (1 - alpha_j) (exclusive cumulative product, no epsilon); w = alpha T;
@@ -336,6 +338,8 @@ def accumulate(processed: Tensor, depths: Tensor, directions: Tensor, white_bkgd
     dnorm = directions.norm(dim=-1, keepdim=True)
     gaps = depths[:, 1:] - depths[:, :-1]
     gaps = torch.cat([gaps, torch.full_like(depths[:, :1], INFINITY)], dim=-1) * dnorm
+    if density_noise is not None:
+        sigma = sigma + density_noise.to(sigma.dtype)
     alpha = 1.0 - torch.exp(-(sigma * gaps))
     ones = torch.ones_like(alpha[:, :1])
     trans = torch.cumprod(torch.cat([ones, 1.0 - alpha], dim=-1), dim=-1)[:, :-1]
@@ -376,6 +380,7 @@ def render(
     optimized_sampling: bool = False,
     t_rand: Optional[Tensor] = None,
     interp: str = "recipe",
+    density_noise: Optional[Tensor] = None,
 ) -> Dict[str, Tensor]:
     """sample -> interpolate (+ReLU) -> SH -> mask -> composite for flat rays.  The dtype of
     ``origins`` selects the arithmetic (float32 / float64); grids are cast to it."""
@@ -391,7 +396,7 @@ def render(
     processed = process_points(
         pts, directions, densities, features, aabb, density_scale, density_mode, render_diffuse, interp
     )
-    out = accumulate(processed, z, directions, white_bkgd)
+    out = accumulate(processed, z, directions, white_bkgd, density_noise)
     out["processed"] = processed
     out["z"] = z
     return out
