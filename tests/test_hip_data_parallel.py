@@ -21,6 +21,7 @@ pytestmark = pytest.mark.gpu
 
 G, DEG, S, R = 16, 2, 32, 512
 F = 3 * (DEG + 1) ** 2
+GRID = {"G": G}  # (the 4-rank test trains a 32^3 grid: 4 x-slabs of bricks, one per owner, so that the middle owners' slices are exercised)
 
 
 def _free_port():
@@ -35,6 +36,7 @@ def _setup(dev, jitter=False):
     cams = [rf.pose_spherical(40.0 * k, -30.0, cam["radius"]) for k in range(4)]
     poses = torch.stack([torch.cat([c.rotation, c.translation.reshape(3, 1)], dim=1) for c in cams]).to(dev)
     data = PosedImagesInMemory(images, poses, rf.CameraIntrinsics(24, 24, 33.0), rf.CameraBounds(cam["near"], cam["far"]))
+    G = GRID["G"]
     grid = rf.VoxelGrid(
         torch.from_numpy(hash_uniform((G, G, G, 1), 901)).to(dev), torch.from_numpy(hash_uniform((G, G, G, F), 900 + F)).to(dev),
         rf.VoxelSize(3.0 / G, 3.0 / G, 3.0 / G), density_preactivation=torch.nn.Identity(), density_postactivation=torch.nn.ReLU(),
@@ -52,7 +54,8 @@ def _train(stepper, data, steps=3):
     return stepper.flat.flat_param.clone()
 
 
-def _worker(rank, world, port, result_dir, exchange, shard_optimizer, jitter):
+def _worker(rank, world, port, result_dir, exchange, shard_optimizer, jitter, grid_size=16):
+    GRID["G"] = grid_size
     os.environ.update(RANK=str(rank), LOCAL_RANK="0", WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     dev = torch.device("cuda", 0)
     torch.cuda.set_device(dev)
@@ -95,4 +98,13 @@ def test_two_processes_train_data_parallel_on_one_gpu(tmp_path, exchange, shard_
     assert torch.cuda.is_available()
     world = 2
     mp.spawn(_worker, args=(world, _free_port(), str(tmp_path), exchange, shard_optimizer, jitter), nprocs=world, join=True)
+    assert sorted(os.listdir(tmp_path)) == [f"ok{r}" for r in range(world)]
+
+
+def test_four_processes_owner_computes_on_one_gpu(tmp_path):
+    """Four ranks, one x-slab of bricks each (32^3 grid): the two middle owners receive slices that start with the x-flagged
+    records of the slab below them and end before the slab above -- the general case of the slice formula; keyed jitter on."""
+    assert torch.cuda.is_available()
+    world = 4
+    mp.spawn(_worker, args=(world, _free_port(), str(tmp_path), "owner", True, True, 32), nprocs=world, join=True)
     assert sorted(os.listdir(tmp_path)) == [f"ok{r}" for r in range(world)]
