@@ -409,7 +409,13 @@ typedef struct RFTrainStep {
                                    of the very call that is timed (only with phases == 0)                                      */
 } RFTrainStep;
 
-enum { RF_STEP_FORWARD = 1, RF_STEP_EMIT = 2, RF_STEP_BRICKS = 4, RF_STEP_EMIT_SPECULAR = 8, RF_STEP_EMIT_DIFFUSE = 16 /* one adjoint at a time */ };
+enum {
+  RF_STEP_FORWARD = 1, RF_STEP_EMIT = 2, RF_STEP_BRICKS = 4,
+  RF_STEP_EMIT_SPECULAR = 8, RF_STEP_EMIT_DIFFUSE = 16,  /* one adjoint at a time */
+  /* RF_STEP_FORWARD in two pieces, the render_diffuse pass first: it reads the base tensor only, so a data-parallel caller runs it
+     while the `rest` parameters of the previous iteration are still being all-gathered */
+  RF_STEP_SELECT_AND_DIFFUSE_FORWARD = 32, RF_STEP_SPECULAR_FORWARD_AND_LOSSES = 64
+};
 
 #define RF_TRAIN_STEP_EVENTS 11
 

@@ -30,6 +30,8 @@ STEP_EMIT = 2
 STEP_BRICKS = 4
 STEP_EMIT_SPECULAR = 8
 STEP_EMIT_DIFFUSE = 16
+STEP_SELECT_AND_DIFFUSE_FORWARD = 32
+STEP_SPECULAR_FORWARD_AND_LOSSES = 64
 
 EXPORTED_SYMBOLS = [
     "rf_abi_version",

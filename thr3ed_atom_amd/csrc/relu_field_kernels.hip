@@ -3745,6 +3745,9 @@ int rf_train_step(const RFGrid* grid, const RFTrainStep* step, void* stream) {
   const bool run_forward = step->phases == 0 || (step->phases & RF_STEP_FORWARD), run_emit = step->phases == 0 || (step->phases & RF_STEP_EMIT),
              run_bricks = step->phases == 0 || (step->phases & RF_STEP_BRICKS);
   const bool emit_one[2] = {run_emit || (step->phases & RF_STEP_EMIT_SPECULAR) != 0, run_emit || (step->phases & RF_STEP_EMIT_DIFFUSE) != 0};
+  // the forward part in two pieces, diffuse render first (it reads the base tensor only: a data-parallel caller lets it run while the
+  // all-gather of the `rest` parameters of the previous iteration is still arriving)
+  const bool fwd_a = (step->phases & RF_STEP_SELECT_AND_DIFFUSE_FORWARD) != 0, fwd_b = (step->phases & RF_STEP_SPECULAR_FORWARD_AND_LOSSES) != 0;
   if (run_bricks) {  // everything the last launch would refuse is refused before the first one
     if (step->adam) {
       rc = check_fused_adam(grid, step->adam, grid->num_features / 3, false);
@@ -3778,42 +3781,59 @@ int rf_train_step(const RFGrid* grid, const RFTrainStep* step, void* stream) {
     rays[i].first_ray = step->first_ray;
     flags[i] = (step->flags & ~(uint32_t)RF_FLAG_RENDER_DIFFUSE) | (i == 1 ? (uint32_t)RF_FLAG_RENDER_DIFFUSE : 0u);
   }
-  if (run_forward) {
-    RF_STEP_EVENT();
+  auto launch_select = [&]() -> int {
     if (step->select) {
       const RFRaySelection* s = step->select;
-      rc = select_impl(s->height, s->width, s->focal, s->poses_dev, s->image_ids_dev, s->num_batch_images, s->pixel_table_dev, s->key,
-                       s->first_index, step->num_rays, step->origins_dev, step->directions_dev, step->pixels_dev, nullptr,
-                       step->loss_sums_dev /* cleared by the same launch */, stream);
-      if (rc != RF_OK) return rc;
-    } else if (hipMemsetAsync(step->loss_sums_dev, 0, 4 * sizeof(float), st) != hipSuccess) {
-      return RF_ERR_LAUNCH;
+      return select_impl(s->height, s->width, s->focal, s->poses_dev, s->image_ids_dev, s->num_batch_images, s->pixel_table_dev, s->key,
+                         s->first_index, step->num_rays, step->origins_dev, step->directions_dev, step->pixels_dev, nullptr,
+                         step->loss_sums_dev /* cleared by the same launch */, stream);
     }
+    return hipMemsetAsync(step->loss_sums_dev, 0, 4 * sizeof(float), st) == hipSuccess ? RF_OK : RF_ERR_LAUNCH;
+  };
+  auto launch_losses_and_offsets = [&]() -> int {  // the losses of both renders and the offsets of both record lists in one launch
+    L1Sets sets = {};
+    BinLists bl = {};
+    for (int k = 0; k < 2; ++k) {
+      sets.colour[k] = step->pass[k].out.colour_dev;
+      sets.grad[k] = step->pass[k].grad_colour_dev;
+      sets.sums[k] = step->loss_sums_dev + 2 * k;
+      bl.hist[k] = step->pass[k].out.key_hist_dev;
+      bl.offsets[k] = reinterpret_cast<long long*>(step->pass[k].offsets_dev);
+      bl.cursor[k] = step->pass[k].cursor_dev;
+    }
+    const long long n3 = (long long)step->num_rays * 3;
+    const int loss_blocks = (int)grid_1d(n3, 1024 * 2, 64), offset_blocks = (nkeys + 1023) / 1024;
+    hipLaunchKernelGGL(loss_and_offsets_kernel, dim3(loss_blocks > offset_blocks ? loss_blocks : offset_blocks, 4), dim3(1024), 0, st, sets,
+                       step->pixels_dev, n3, loss_scale / (float)n3, loss_blocks, bl, nkeys, offset_blocks);
+    return launch_status();
+  };
+  if (run_forward) {
+    RF_STEP_EVENT();
+    rc = launch_select();
+    if (rc != RF_OK) return rc;
     RF_STEP_EVENT();
     for (int i = 0; i < 2; ++i) {
-      const RFPassScratch& ps = step->pass[i];
-      rc = rf_render_forward(grid, &rays[i], flags[i], &ps.out, stream);
+      rc = rf_render_forward(grid, &rays[i], flags[i], &step->pass[i].out, stream);
       if (rc != RF_OK) return rc;
       RF_STEP_EVENT();
-      if (i == 1) {  // the losses of both renders and the offsets of both record lists in one launch
-        L1Sets sets = {};
-        BinLists bl = {};
-        for (int k = 0; k < 2; ++k) {
-          sets.colour[k] = step->pass[k].out.colour_dev;
-          sets.grad[k] = step->pass[k].grad_colour_dev;
-          sets.sums[k] = step->loss_sums_dev + 2 * k;
-          bl.hist[k] = step->pass[k].out.key_hist_dev;
-          bl.offsets[k] = reinterpret_cast<long long*>(step->pass[k].offsets_dev);
-          bl.cursor[k] = step->pass[k].cursor_dev;
-        }
-        const long long n3 = (long long)step->num_rays * 3;
-        const int loss_blocks = (int)grid_1d(n3, 1024 * 2, 64), offset_blocks = (nkeys + 1023) / 1024;
-        hipLaunchKernelGGL(loss_and_offsets_kernel, dim3(loss_blocks > offset_blocks ? loss_blocks : offset_blocks, 4), dim3(1024), 0, st, sets,
-                           step->pixels_dev, n3, loss_scale / (float)n3, loss_blocks, bl, nkeys, offset_blocks);
-        rc = launch_status();
+      if (i == 1) {
+        rc = launch_losses_and_offsets();
         if (rc != RF_OK) return rc;
       }
       RF_STEP_EVENT();
+    }
+  } else {
+    if (fwd_a) {
+      rc = launch_select();
+      if (rc != RF_OK) return rc;
+      rc = rf_render_forward(grid, &rays[1], flags[1], &step->pass[1].out, stream);
+      if (rc != RF_OK) return rc;
+    }
+    if (fwd_b) {
+      rc = rf_render_forward(grid, &rays[0], flags[0], &step->pass[0].out, stream);
+      if (rc != RF_OK) return rc;
+      rc = launch_losses_and_offsets();
+      if (rc != RF_OK) return rc;
     }
   }
   if (emit_one[0] || emit_one[1]) {

@@ -142,22 +142,24 @@ def reduce_scatter_mean_async(bucket: Tensor, out: Optional[Tensor] = None) -> _
     return _ShardHandle(None, out.mul_(1.0 / n), lo, lo + chunk, None)
 
 
-def all_gather_chunks_(bucket: Tensor) -> Tensor:
-    """Every rank contributes chunk r of ``bucket`` and receives all the others (in ``bucket``)."""
+def all_gather_chunks_(bucket: Tensor, async_op: bool = False):
+    """Every rank contributes chunk r of ``bucket`` and receives all the others (in ``bucket``).  Returns ``bucket``, or with
+    ``async_op`` the work handle (RCCL; None on backends that complete on return)."""
     n = world_size()
+    work = None
     if _collectives_on():
         assert bucket.numel() % n == 0
         chunk = bucket.numel() // n
         lo = rank() * chunk
         mine = bucket[lo : lo + chunk].clone()  # separate send buffer: no aliasing with the receive buffer
         if dist.get_backend() == "nccl":
-            dist.all_gather_into_tensor(bucket, mine)
+            work = dist.all_gather_into_tensor(bucket, mine, async_op=async_op)
         else:
             parts = [torch.empty(chunk, dtype=bucket.dtype, device=bucket.device) for _ in range(n)]
             dist.all_gather(parts, mine)
             for r, part in enumerate(parts):
                 bucket[r * chunk : (r + 1) * chunk].copy_(part)
-    return bucket
+    return (work if async_op else bucket)
 
 
 def all_gather_rows_equal(out: Tensor, mine: Tensor, async_op: bool = False):

@@ -127,6 +127,24 @@ class StepStats:
         return out
 
 
+# owner-computes data parallelism: leave the all-gather of the `rest` parameters in flight across the iteration boundary (RF_OWNER_OVERLAP_PARAMETERS=0
+# makes every iteration wait for it at its end instead)
+OWNER_OVERLAP_PARAMETERS = os.environ.get("RF_OWNER_OVERLAP_PARAMETERS", "1") != "0"
+
+
+class _ParameterWait:
+    """Makes the CURRENT stream wait for an all-gather issued on the communication stream (RCCL work handle and / or event)."""
+
+    def __init__(self, work, event, device):
+        self.work, self.event, self.device = work, event, device
+
+    def __call__(self) -> None:
+        if self.work is not None:
+            self.work.wait()
+            self.work = None
+        torch.cuda.current_stream(self.device).wait_event(self.event)
+
+
 class TrainStepper:
     """One optimisation step of modules/trainers.py:278-341 on a grid held in a FlatGrid bucket."""
 
@@ -379,7 +397,7 @@ class TrainStepper:
             else:
                 st.pass_[i].t_rand_dev = None if jit[i] is None else jit[i].data_ptr()
         st.flags = flags
-        rf_grid = grid.to_rf_grid(use_occupancy=cfg.use_occupancy_mask)
+        rf_grid = grid.to_rf_grid(use_occupancy=cfg.use_occupancy_mask, wait_parameters=self.exchange != "owner")
         opt = self.optimizer
         if self.exchange == "owner":
             self._owner_step(ex, st, rf_grid, n, S, dev)
@@ -440,6 +458,7 @@ class TrainStepper:
             "bounds_host": torch.empty((W, 2, 2 * W), dtype=torch.int64).pin_memory(),
             "side": torch.cuda.Stream(device), "forward_done": torch.cuda.Event(), "ready": torch.cuda.Event(),
             "comm": torch.cuda.Stream(device), "emitted": [torch.cuda.Event(), torch.cuda.Event()], "exchanged": [torch.cuda.Event(), torch.cuda.Event()],
+            "bricks_done": torch.cuda.Event(), "rest_gathered": torch.cuda.Event(),
             "recv": [torch.empty((0, t[f"pass{k}"]["sorted"].shape[1]), dtype=torch.float32, device=device) for k in range(2)],
         }
         self._owner = ow
@@ -462,8 +481,18 @@ class TrainStepper:
         mark = (lambda i: ev[i].record(main)) if ev is not None else (lambda i: None)
         st.adam, st.loss_scale = None, 1.0 / W
         mark(0)
-        st.phases = _lib.STEP_FORWARD
-        _lib.check(lib.rf_train_step(C.byref(rf_grid), C.byref(st), main.cuda_stream), "rf_train_step[forward]")
+        pending_rest = grid.__dict__.pop("_params_pending", None)
+        if pending_rest is not None:
+            # the all-gather of the `rest` parameters of the previous iteration is still arriving: the batch selection and the
+            # diffuse render (which reads the base tensor only) run beside it, the specular render waits for it
+            st.phases = _lib.STEP_SELECT_AND_DIFFUSE_FORWARD
+            _lib.check(lib.rf_train_step(C.byref(rf_grid), C.byref(st), main.cuda_stream), "rf_train_step[select + diffuse forward]")
+            pending_rest()
+            st.phases = _lib.STEP_SPECULAR_FORWARD_AND_LOSSES
+            _lib.check(lib.rf_train_step(C.byref(rf_grid), C.byref(st), main.cuda_stream), "rf_train_step[specular forward + losses]")
+        else:
+            st.phases = _lib.STEP_FORWARD
+            _lib.check(lib.rf_train_step(C.byref(rf_grid), C.byref(st), main.cuda_stream), "rf_train_step[forward]")
         mark(1)
         work = rfdist.all_gather_rows_equal(ow["all_offsets"], t["offsets2"], async_op=True)
         ow["forward_done"].record(main)
@@ -533,7 +562,17 @@ class TrainStepper:
         if collect:
             rfdist.all_gather_chunks_(self.flat.flat_param[:nd])
             if has_second:
-                rfdist.all_gather_chunks_(self.flat.flat_param[nd:])
+                # `rest` (6/7 of the bytes) is left in flight: the next reader of the grid waits for it (VoxelGrid.wait_for_parameters) --
+                # the next iteration does so only in front of its specular render
+                ow["bricks_done"].record(main)
+                with torch.cuda.stream(ow["comm"]):
+                    ow["comm"].wait_event(ow["bricks_done"])
+                    work_rest = rfdist.all_gather_chunks_(self.flat.flat_param[nd:], async_op=True)
+                    ow["rest_gathered"].record(ow["comm"])
+                if OWNER_OVERLAP_PARAMETERS:
+                    grid.__dict__["_params_pending"] = _ParameterWait(work_rest, ow["rest_gathered"], dev)
+                else:
+                    _ParameterWait(work_rest, ow["rest_gathered"], dev)()
         sent += (W - 1) * (self.flat.flat_param.numel() // W) * 4
         mark(5)
         self.exchange_bytes = (self.exchange_bytes + [sent])[-64:]

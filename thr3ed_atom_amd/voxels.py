@@ -146,7 +146,16 @@ class KernelGridInterface:
     def sh_degree(self) -> int:
         return int(np.sqrt(self._num_features // 3)) - 1
 
-    def to_rf_grid(self, use_occupancy: bool = False) -> "_lib.RFGrid":
+    def wait_for_parameters(self) -> None:
+        """Data-parallel training leaves the all-gather of the second parameter tensor in flight across the iteration boundary
+        (trainers.TrainStepper._owner_step): whoever reads the grid next makes its stream wait for it here.  A no-op otherwise."""
+        pending = self.__dict__.pop("_params_pending", None)
+        if pending is not None:
+            pending()
+
+    def to_rf_grid(self, use_occupancy: bool = False, wait_parameters: bool = True) -> "_lib.RFGrid":
+        if wait_parameters:
+            self.wait_for_parameters()
         d, f = self.kernel_tensors()
         for t in (d, f):
             if t is None:
@@ -391,6 +400,7 @@ class VoxelGrid(Module, KernelGridInterface):
     def densities(self) -> Tensor:
         """[X,Y,Z,1].  The Parameter itself with reference storage; a strided VIEW of the base tensor with
         split storage (in-place edits reach the grid, but it is not a leaf: use reference_gradients())."""
+        self.wait_for_parameters()
         if self.storage == "reference":
             return self._densities
         if self.storage == "bricked":  # an assembled COPY (assign to the property to write)
@@ -414,6 +424,7 @@ class VoxelGrid(Module, KernelGridInterface):
     def features(self) -> Tensor:
         """[X,Y,Z,F], index = colour*K + k.  The Parameter itself with reference storage; an assembled COPY
         with split storage (assign to the property to write)."""
+        self.wait_for_parameters()
         if self.storage == "reference":
             return self._features
         return unpack_storage(self._base, self._rest, self.storage, self.grid_dims)[1]
