@@ -315,6 +315,8 @@ def main():
             port = sk.getsockname()[1]
         torch.distributed.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1)
         rfdist.FORCE_COLLECTIVES = True
+    if int(os.environ.get("WORLD_SIZE", "1")) != args.gpus:  # (checked before any rendezvous is attempted)
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={os.environ.get('WORLD_SIZE', '1')}: launch with torch.distributed.run --nproc-per-node {args.gpus} (or without it: bench.py spawns the ranks itself)")
     rank, local_rank, world = rfdist.init_from_env()
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus} (or without it: bench.py spawns the ranks itself)")
