@@ -367,7 +367,7 @@ typedef struct RFRaySelection { /* arguments of rf_select_rays_and_pixels */
 } RFRaySelection;
 
 typedef struct RFPassScratch { /* one per render of the iteration: [0] specular, [1] render_diffuse */
-  RFRenderOut out;           /* all seven per-ray / per-sample buffers, key_hist_dev [8 * nbricks] (zero on entry; left
+  RFRenderOut out;           /* all eight per-ray / per-sample buffers, key_hist_dev [8 * nbricks] (zero on entry; left
                                 zero) and brick_size                                                              */
   float* grad_colour_dev;    /* [N, 3]                                                                           */
   int32_t* cursor_dev;       /* [8 * nbricks]                                                                    */
