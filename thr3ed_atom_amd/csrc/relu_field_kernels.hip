@@ -1525,6 +1525,7 @@ struct AdamArgs {
   float step;      // lr / (1 - beta1^t)
   float b1, b2, eps;
   float inv_bc2_sqrt;  // 1 / sqrt(1 - beta2^t)
+  int byte_offsets_fit_32_bits;  // every element of the grid tensors lies below 2^30: the one-round flush addresses with 32-bit byte offsets
 };
 
 struct BrickArgs {
@@ -1741,7 +1742,7 @@ __device__ __forceinline__ void brick_range_entry(const BrickArgs& a, const long
 // The last phase of a brick workgroup: the sums of the B^3 owned nodes (LDS accumulators `acc`, node (x, y, z) channel c at
 // x * SX + y * SY + z * CS + c; all zero when `any` is false) go out with plain stores -- or, ADAM, are consumed by the
 // optimizer step on the spot.
-template <int K, bool ADAM>
+template <int K, bool ADAM, bool ONE_ROUND>
 __device__ __forceinline__ void brick_flush(const GridArgs& g, const BrickArgs& a, const float* acc, bool any, int X0, int Y0, int Z0,
                                             float* gdens, float* gfeat) {
   constexpr int C = 3 * K + 1;
@@ -1772,12 +1773,83 @@ __device__ __forceinline__ void brick_flush(const GridArgs& g, const BrickArgs& 
       // the only phase of the kernel that waits on HBM: a thread issues the 3 x U loads of U quads before it touches the
       // first one (one quad at a time kept ~24 KB per CU in flight and ran at a third of the HBM rate).
       // Element offsets are kept as 32-bit (host-checked) to stay inside the 128-register budget of 4 waves per SIMD.
-      // Two rounds (4 + 3 quads per thread).  vmcnt counts loads and stores together and does not order them against each other,
-      // so the second round's wait also sits out the first round's stores; issuing ALL 21 loads before the first store (tried,
-      // with uniform tensor bases + 32-bit byte offsets = saddr addressing) needs 84 data registers, spills 12 of them right
-      // behind their loads and is slower (0.394 -> 0.419 ms).
+      // vmcnt counts loads and stores together and does not order them against each other, so a second round's first wait also sits
+      // out the first round's stores: the flush was two dependent memory round trips (4 + 3 quads per thread; 0.414 ms for the
+      // pass).  ALL 21 loads of a thread in flight before its first store needs 84 data registers -- and fits the 128-register budget
+      // only when the addresses cost next to nothing: round 2 tried it with per-lane tensor selection (64-bit addresses per
+      // load: spills, 0.419 ms); the quad -> thread assignment below makes every instruction address ONE tensor: 0.366 ms.
       constexpr int U = (QN == 7) ? 4 : 1;
       const AdamArgs& ad = a.adam;
+      if constexpr (ONE_ROUND) {  // (host: bricks of 8^3 nodes, every element of the grid tensors below 2^30)
+        // ONE round: thread t takes the base quad of node t (512 nodes) and rest quads t, t + 512, ... of the brick's 3072 -- so that
+        // every load / store instruction of a wave addresses ONE tensor: uniform base (SGPR pair) + a 32-bit byte offset per lane,
+        // the same offset for parameter, exp_avg and exp_avg_sq.  7 offsets + 84 data registers: all 21 loads of a thread are in
+        // flight before its first store (vmcnt counts loads and stores together, so a second round's first wait would also sit out
+        // the first round's stores).  (Byte offsets in 32 bits: the host checks the tensors for < 2^30 elements.)
+        unsigned int bo[QN];  // byte offset inside the quad's tensor; 0xffffffff: nothing to do
+        int lds_at[QN];
+        float4 p4[QN];
+        vf4 m4[QN], v4[QN];
+#pragma unroll
+        for (int u = 0; u < QN; ++u) {
+          int fx, fy, fz, qd;
+          if (u == 0) {
+            fx = tid >> 6;
+            fy = (tid >> 3) & 7;
+            fz = tid & 7;
+            qd = 0;
+          } else {
+            const int j = (u - 1) * 512 + tid, col = j / 48, r = j - col * 48;
+            fz = r / 6;
+            qd = 1 + r - 6 * fz;
+            fx = col >> 3;
+            fy = col & 7;
+          }
+          const bool ok = X0 + fx < g.X && Y0 + fy < g.Y && Z0 + fz < g.Z;
+          const unsigned int lin = ok ? node_lin(g, X0 + fx, Y0 + fy, Z0 + fz) : 0u;
+          const unsigned int o = u == 0 ? lin * (unsigned)g.dstride : lin * (unsigned)g.fstride + 4u * (unsigned)(qd - 1);
+          bo[u] = ok ? o * 4u : 0xffffffffu;
+          lds_at[u] = fx * SX + fy * SY + fz * CS + 4 * qd;
+        }
+#pragma unroll
+        for (int u = 0; u < QN; ++u) {
+          if (bo[u] != 0xffffffffu) {
+            const char* pb = reinterpret_cast<const char*>(u == 0 ? ad.p1 : ad.p2);
+            const char* mb = reinterpret_cast<const char*>(u == 0 ? ad.m1 : ad.m2);
+            const char* vb = reinterpret_cast<const char*>(u == 0 ? ad.v1 : ad.v2);
+            p4[u] = *reinterpret_cast<const float4*>(pb + bo[u]);
+            m4[u] = __builtin_nontemporal_load(reinterpret_cast<const vf4*>(mb + bo[u]));
+            v4[u] = __builtin_nontemporal_load(reinterpret_cast<const vf4*>(vb + bo[u]));
+          }
+        }
+#pragma unroll
+        for (int u = 0; u < QN; ++u) {
+          if (bo[u] == 0xffffffffu) continue;
+          const float4 gq = any ? *reinterpret_cast<const float4*>(&acc[lds_at[u]]) : make_float4(0.f, 0.f, 0.f, 0.f);
+          float gg[4] = {gq.x, gq.y, gq.z, gq.w};
+          float pn[4] = {p4[u].x, p4[u].y, p4[u].z, p4[u].w};
+          if (u == 0 && g.mode == RF_DENSITY_ABS) {  // d|x|/dx of the raw density (the parameter before its update)
+            const float dv = pn[0] * g.rho;
+            gg[0] = (dv > 0.f) ? gg[0] : ((dv < 0.f) ? -gg[0] : 0.0f);
+          }
+          vf4 mn, vn;
+#pragma unroll
+          for (int c = 0; c < 4; ++c) {
+            float mm = m4[u][c], vv = v4[u][c];
+            adam_update(pn[c], mm, vv, gg[c], ad.step, ad.b1, ad.b2, ad.eps, ad.inv_bc2_sqrt);
+            mn[c] = mm;
+            vn[c] = vv;
+          }
+          char* pb = reinterpret_cast<char*>(u == 0 ? ad.p1 : ad.p2);
+          char* mb = reinterpret_cast<char*>(u == 0 ? ad.m1 : ad.m2);
+          char* vb = reinterpret_cast<char*>(u == 0 ? ad.v1 : ad.v2);
+          *reinterpret_cast<float4*>(pb + bo[u]) = make_float4(pn[0], pn[1], pn[2], pn[3]);
+          __builtin_nontemporal_store(mn, reinterpret_cast<vf4*>(mb + bo[u]));
+          __builtin_nontemporal_store(vn, reinterpret_cast<vf4*>(vb + bo[u]));
+        }
+        return;
+      } else {
+      // (bricks of 4^3 nodes, tensors of 2^30 elements and more: two rounds of 4 + 3 quads per thread with per-lane tensor selection)
       for (int i0 = tid; i0 < nq; i0 += kBrickThreads * U) {
         unsigned int off[U];  // bit 31: rest tensor; 0xffffffff: nothing to do
         float4 p4[U];
@@ -1838,6 +1910,7 @@ __device__ __forceinline__ void brick_flush(const GridArgs& g, const BrickArgs& 
           __builtin_nontemporal_store(mn, reinterpret_cast<vf4*>((rest ? ad.m2 : ad.m1) + o));
           __builtin_nontemporal_store(vn, reinterpret_cast<vf4*>((rest ? ad.v2 : ad.v1) + o));
         }
+      }
       }
       return;
     }
@@ -1975,7 +2048,7 @@ __host__ __device__ inline int gather_lds_words(int B, int C) {
 
 // (SH degree 3: 49 channels = four 16-channel blocks, 64 accumulator registers and 123 KB of LDS -- one workgroup per CU, which
 // leaves a wave 256 registers)
-template <int K, bool ADAM>
+template <int K, bool ADAM, bool ONE_ROUND = false>
 __global__ __launch_bounds__(kBrickThreads, (K > 9 ? 2 : 4)) void brick_gather_kernel(GridArgs g, BrickArgs a, float* gdens, float* gfeat) {
   constexpr int C = 3 * K + 1;
   constexpr int C4 = (C + 3) / 4 * 4;
@@ -2328,7 +2401,7 @@ __global__ __launch_bounds__(kBrickThreads, (K > 9 ? 2 : 4)) void brick_gather_k
     __syncthreads();
     RF_PROF_MARK(5);  // accumulator image
   }
-  brick_flush<K, ADAM>(g, a, acc, any, X0, Y0, Z0, gdens, gfeat);
+  brick_flush<K, ADAM, ONE_ROUND>(g, a, acc, any, X0, Y0, Z0, gdens, gfeat);
   RF_PROF_MARK(4);  // flush (stores issued, not necessarily retired)
   RF_PROF_END();
 }
@@ -3424,7 +3497,7 @@ int rf_scatter_records(const RFGrid* grid, const int16_t* keys_dev, const float*
 int32_t rf_expanded_record_floats(int32_t num_features) { return 4 * record_quads(num_features / 3); }
 
 extern "C++" {
-template <int K, bool ADAM>
+template <int K, bool ADAM, bool ONE_ROUND = false>
 static int launch_gather(const GridArgs& g, const BrickArgs& a, int nbricks, float* gd, float* gf, hipStream_t st) {
   const int B = 1 << a.shift;
   const size_t lds = (size_t)gather_lds_words(B, 3 * K + 1) * sizeof(float);
@@ -3433,12 +3506,12 @@ static int launch_gather(const GridArgs& g, const BrickArgs& a, int nbricks, flo
   int dev = 0;
   if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return RF_ERR_LAUNCH;
   if (lds > configured[dev].load(std::memory_order_relaxed)) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&brick_gather_kernel<K, ADAM>),
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&brick_gather_kernel<K, ADAM, ONE_ROUND>),
                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
       return RF_ERR_LAUNCH;
     configured[dev].store(lds, std::memory_order_relaxed);
   }
-  hipLaunchKernelGGL((brick_gather_kernel<K, ADAM>), dim3(nbricks), dim3(kBrickThreads), lds, st, g, a, gd, gf);
+  hipLaunchKernelGGL((brick_gather_kernel<K, ADAM, ONE_ROUND>), dim3(nbricks), dim3(kBrickThreads), lds, st, g, a, gd, gf);
   return launch_status();
 }
 }  // extern "C++"
@@ -3531,17 +3604,24 @@ static int brick_accumulate_impl(const RFGrid* grid, int32_t brick_size, const R
     a.adam.b2 = adam->beta2;
     a.adam.eps = adam->eps;
     a.adam.inv_bc2_sqrt = (float)(1.0 / sqrt(bc2));
+    {
+      unsigned long long nodes = 1;
+      for (int ax = 0; ax < 3; ++ax) nodes *= (unsigned long long)((grid->dims[ax] + 7) / 8 * 8);
+      const unsigned long long smax = (unsigned long long)(grid->density_stride > grid->feature_stride ? grid->density_stride : grid->feature_stride);
+      a.adam.byte_offsets_fit_32_bits = nodes * smax < (1ull << 30);
+    }
 #ifdef RF_BRICK_PROFILE
     {
       const char* e = getenv("RF_BRICK_STAGGER");
       a.stagger = e ? atoi(e) : 0;
     }
 #endif
+    const bool one_round = a.adam.byte_offsets_fit_32_bits && shift == 3;
     switch (K) {
       case 1:
-        return launch_gather<1, true>(g, a, nbricks, nullptr, nullptr, st);
+        return one_round ? launch_gather<1, true, true>(g, a, nbricks, nullptr, nullptr, st) : launch_gather<1, true, false>(g, a, nbricks, nullptr, nullptr, st);
       default:
-        return launch_gather<9, true>(g, a, nbricks, nullptr, nullptr, st);
+        return one_round ? launch_gather<9, true, true>(g, a, nbricks, nullptr, nullptr, st) : launch_gather<9, true, false>(g, a, nbricks, nullptr, nullptr, st);
     }
   }
   switch (K) {

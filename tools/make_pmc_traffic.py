@@ -32,8 +32,12 @@ BENCH_NAMES = {
     "render_backward_kernel<9, false, 0>": "render_backward[sh2]",
     "render_backward_kernel<1, true, 0>": "render_backward[diffuse]",
     "brick_gather_kernel<9, true>": "brick_accumulate_adam[sh2]",
+    "brick_gather_kernel<9, true, true>": "brick_accumulate_adam[sh2]",
+    "brick_gather_kernel<9, true, false>": "brick_accumulate_adam[sh2]",
     "brick_gather_kernel<9, false>": "brick_accumulate[sh2]",
+    "brick_gather_kernel<9, false, false>": "brick_accumulate[sh2]",
     "brick_gather_kernel<1, false>": "brick_accumulate[base]",
+    "brick_gather_kernel<1, false, false>": "brick_accumulate[base]",
     "adam_kernel": "adam_step",
     "bin_offsets_kernel": "bin_offsets",
     "loss_and_offsets_kernel": "l1_loss_grad+bin_offsets[both]",
