@@ -80,6 +80,12 @@ struct GridArgs {
   int nby, nbz;
   unsigned int step[3];  // index step to the next node along x, y, z (inside a brick for the bricked order)
   unsigned int jump[3];  // bricked: step from the last node of a brick to the first node of the next brick on that axis
+  // "near" addressing (host-checked: <= 2^24 nodes, byte strides < 2^24, both tensors inside one 4 GB window that starts at `base`):
+  // a corner's address = uniform 64-bit base (scalar registers) + 32-bit byte offset built with full-rate 24-bit multiplies, instead
+  // of a 64-bit multiply-add per corner -- the gathers of the render kernels are bound by vector-ALU issue, not by memory
+  const char* base;
+  unsigned int dens_off, feat_off;  // byte offsets of dens / feat from base
+  int near32;
 };
 
 // index of node (x, y, z) in the grid tensors (to be multiplied by the tensor's channel stride)
@@ -156,6 +162,7 @@ struct __attribute__((packed, aligned(4))) f4u {
 struct __attribute__((packed, aligned(4))) f3u {
   float v[3];
 };
+typedef float vf2 __attribute__((ext_vector_type(2)));  // packed pair: v_pk_mul_f32 / v_pk_add_f32
 typedef float vf4 __attribute__((ext_vector_type(4)));  // naturally aligned 16-byte vector (non-temporal builtins)
 
 // ---------------------------------------------------------------------------------------------
@@ -302,6 +309,7 @@ __device__ __forceinline__ uint32_t pack_cell(const Cell& c) {
 
 struct Corners {
   unsigned int lin[8];  // linear voxel index of the (clamped) corner k = dx + 2 dy + 4 dz
+  unsigned int s[3];    // index steps from corner 000 to its x / y / z upper neighbour (0 where clamping collapses them)
   float w[8];           // trilinear weight, forced to 0 for corners outside the grid
 };
 
@@ -321,6 +329,9 @@ __device__ __forceinline__ Corners corners_of(uint32_t packed, const float wts[6
   const unsigned int sz = (okz[0] && okz[1]) ? ((g.bricked && (cz0 & 7) == 7) ? g.jump[2] : g.step[2]) : 0u;
   const float wxy[4] = {wts[0] * wts[2], wts[1] * wts[2], wts[0] * wts[3], wts[1] * wts[3]};  // [dx + 2 dy]
   Corners c;
+  c.s[0] = sx;
+  c.s[1] = sy;
+  c.s[2] = sz;
 #pragma unroll
   for (int k = 0; k < 8; ++k) {
     const int dx = k & 1, dy = (k >> 1) & 1, dz = k >> 2;
@@ -335,10 +346,23 @@ __device__ __forceinline__ float density_post(float pre, int mode);
 
 // density: post( interp( pre(D * rho) ) )  (voxels.py:292-309)
 __device__ __forceinline__ float interp_density(const Corners& c, const GridArgs& g, float& pre_out) {
+  float raw[8];
+  if (g.near32) {  // (wave-uniform)
+    const unsigned int sb = (unsigned int)g.dstride * 4u;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      const unsigned int o = __umul24(c.lin[k], sb);
+      raw[k] = *reinterpret_cast<const float*>(reinterpret_cast<const char*>(g.dens) + (size_t)o);
+    }
+  } else {
+#pragma unroll
+    for (int k = 0; k < 8; ++k) raw[k] = g.dens[c.lin[k] * g.dstride];
+    asm volatile("" ::: "memory");  // (keeps the two branches' loads apart: merged, they lose the scalar-base addressing)
+  }
   float acc = 0.0f;
 #pragma unroll
   for (int k = 0; k < 8; ++k) {
-    float v = g.dens[c.lin[k] * g.dstride] * g.rho;
+    float v = raw[k] * g.rho;
     if (g.mode == RF_DENSITY_ABS) v = fabsf(v);
     acc = acc + v * c.w[k];
   }
@@ -555,6 +579,9 @@ struct LaneSlice {
   bool active;
   float yb[4];
   int chan[4];
+  int colour;               // split layout: the one colour all owned elements of this lane feed (-1: base lane, inactive lane)
+  bool closes_colour;       // split layout: last lane of its colour's run of lanes
+  unsigned int strideB, offB;  // near addressing: byte stride of the lane's tensor, byte offset of the lane's slice from g.base
 };
 
 template <int K, int LPS>
@@ -573,31 +600,43 @@ __device__ __forceinline__ LaneSlice lane_slice(const GridArgs& g, const float d
   LaneSlice ls;
   if (g.layout == RF_LAYOUT_SPLIT) {
     if (sub == 0) {
+      // (idle: P0 reads the whole 16-byte base record of a corner for the density and interpolates the degree-0 colour there)
       ls.src = g.dens;
       ls.stride = g.dstride;
       ls.off = 0;
-      ls.active = true;
+      ls.active = false;
+      ls.colour = -1;
+      ls.closes_colour = false;
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
-        ls.chan[j] = j - 1;  // element 0 is sigma: chan = -1
-        ls.yb[j] = (j >= 1) ? ldsY[0] : 0.0f;
+        ls.chan[j] = -1;
+        ls.yb[j] = 0.0f;
       }
     } else {
+      // colour-aligned: lanes 1 + c * LC + q, q < LC = ceil((K-1) / 4), hold the rest coefficients 4q.. of colour c, so that a
+      // lane's four products feed ONE colour and the reduction is a sum over LC neighbouring lanes (rest_colour_sums)
+      constexpr int KR = K - 1, LC = (KR + 3) / 4;
       const int t = sub - 1;
+      const int c = t / LC, q = t - c * LC;
+      const int first = c * KR + 4 * q;  // first owned rest element
+      const int last = min(first + 4, (c + 1) * KR);
       ls.src = g.feat;
       ls.stride = g.fstride;
-      ls.off = min(4 * t, R - 4);
-      ls.active = 4 * t < R;
-      const int j0 = 4 * t - ls.off;
+      ls.off = min(first, R - 4);  // (the read never leaves the node's record)
+      ls.active = c < 3;
+      ls.colour = ls.active ? c : -1;
+      ls.closes_colour = ls.active && q == LC - 1;
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
         const int rr = ls.off + j;
-        const bool own = ls.active && (j >= j0);
-        ls.chan[j] = own ? rr / (K - 1) : -1;
-        ls.yb[j] = own ? ldsY[rr % (K - 1) + 1] : 0.0f;
+        const bool own = ls.active && rr >= first && rr < last;
+        ls.chan[j] = own ? c : -1;
+        ls.yb[j] = own ? ldsY[rr - c * KR + 1] : 0.0f;
       }
     }
   } else {
+    ls.colour = -1;
+    ls.closes_colour = false;
     ls.src = g.feat;
     ls.stride = g.fstride;
     ls.off = min(4 * sub, F - 4);
@@ -611,8 +650,22 @@ __device__ __forceinline__ LaneSlice lane_slice(const GridArgs& g, const float d
       ls.yb[j] = own ? ldsY[f % K] : 0.0f;
     }
   }
+  ls.strideB = (unsigned int)ls.stride * 4u;
+  ls.offB = (ls.src == g.dens ? g.dens_off : g.feat_off) + (unsigned int)ls.off * 4u;
   wave_lds_fence();
   return ls;
+}
+
+// Split layout, colour-aligned lanes (lane_slice): p[j] = basis * interpolated coefficient of the lane's four elements.  Returns, in
+// the lane that closes colour c (LaneSlice::closes_colour), the sum of the colour's rest terms (the LC lanes in front of and
+// including this one).  Call with all lanes of the wave enabled.
+template <int K>
+__device__ __forceinline__ float rest_colour_sums(const float p[4]) {
+  constexpr int LC = (K - 1 + 3) / 4;
+  float dot = (p[0] + p[1]) + (p[2] + p[3]);
+  if (LC >= 2) dot += dpp_move<kDppRowShr1, 0xf>(0.0f, dot);
+  if (LC >= 4) dot += dpp_move<kDppRowShr2, 0xf>(0.0f, dot);
+  return dot;
 }
 
 // Lanes hold the keys of 64 consecutive sample slots (-1 = none).  Consecutive samples of a ray mostly share their
@@ -817,24 +870,37 @@ __global__ __launch_bounds__(kBlock) void render_forward_kernel(GridArgs g, RayA
     Corners cn;
     float wts[6] = {sm.cell.w0[0], sm.cell.w1[0], sm.cell.w0[1], sm.cell.w1[1], sm.cell.w0[2], sm.cell.w1[2]};
     const uint32_t packed = pack_cell(sm.cell);
-    // Degree-0 / render_diffuse passes on split storage: the 16-byte base record of a corner holds the density AND the three
-    // degree-0 coefficients, so P0's one gather per corner already has everything -- colour is interpolated right here
-    // (ATen's corner order) and the work list + second gather of P1 are skipped.
-    const bool fast_base = L::kCorner && g.layout == RF_LAYOUT_SPLIT;  // wave-uniform
+    // Split storage: the 16-byte base record of a corner holds the density AND the three degree-0 coefficients, so P0's one gather
+    // per corner already brings the degree-0 colour -- interpolated right here (ATen's corner order).  Degree-0 / render_diffuse
+    // passes then skip the work list and P1 altogether; the others gather only the rest coefficients in P1.
+    const bool base_in_p0 = g.layout == RF_LAYOUT_SPLIT;  // wave-uniform
+    const bool fast_base = L::kCorner && base_in_p0;
     float fast_rgb[3] = {0.f, 0.f, 0.f};
     if (live) {
       cn = corners_of(packed, wts, g);
-      if (fast_base) {
+      if (base_in_p0) {
+        f4u t[8];
+        if (g.near32) {
+          const unsigned int sb = (unsigned int)g.dstride * 4u;
+#pragma unroll
+          for (int k = 0; k < 8; ++k) {
+            const unsigned int o = __umul24(cn.lin[k], sb);
+            t[k] = *reinterpret_cast<const f4u*>(reinterpret_cast<const char*>(g.dens) + (size_t)o);
+          }
+        } else {
+#pragma unroll
+          for (int k = 0; k < 8; ++k) t[k] = *reinterpret_cast<const f4u*>(g.dens + cn.lin[k] * g.dstride);
+          asm volatile("" ::: "memory");  // (keeps the two branches' loads apart: merged, they lose the scalar-base addressing)
+        }
         float acc = 0.0f, cr = 0.0f, cg = 0.0f, cb = 0.0f;
 #pragma unroll
         for (int k = 0; k < 8; ++k) {
-          const f4u t = *reinterpret_cast<const f4u*>(g.dens + cn.lin[k] * g.dstride);
-          float v = t.v[0] * g.rho;
+          float v = t[k].v[0] * g.rho;
           if (g.mode == RF_DENSITY_ABS) v = fabsf(v);
           acc = acc + v * cn.w[k];
-          cr = cr + t.v[1] * cn.w[k];
-          cg = cg + t.v[2] * cn.w[k];
-          cb = cb + t.v[3] * cn.w[k];
+          cr = cr + t[k].v[1] * cn.w[k];
+          cg = cg + t[k].v[2] * cn.w[k];
+          cb = cb + t[k].v[3] * cn.w[k];
         }
         sigma = density_post(acc, g.mode);
         fast_rgb[0] = kC0 * cr;
@@ -861,52 +927,38 @@ __global__ __launch_bounds__(kBlock) void render_forward_kernel(GridArgs g, RayA
     const int slot = __popcll(mask & ((1ull << lane) - 1ull));
     if (need && !fast_base) {
       uint32_t* e = my_entry + slot * kEntryFwd;
-      // corner k = dx + 2 dy + 4 dz (corners_of): lin[1] / lin[2] / lin[4] are the x / y / z upper neighbours
-      // bits 0..2: the step exists; bits 3..5: it is a jump into the next brick (bricked node order)
-      const uint32_t steps = (cn.lin[1] != cn.lin[0] ? 1u : 0u) | (cn.lin[2] != cn.lin[0] ? 2u : 0u) |
-                             (cn.lin[4] != cn.lin[0] ? 4u : 0u) | (cn.lin[1] - cn.lin[0] == g.jump[0] ? 8u : 0u) |
-                             (cn.lin[2] - cn.lin[0] == g.jump[1] ? 16u : 0u) | (cn.lin[4] - cn.lin[0] == g.jump[2] ? 32u : 0u);
       e[0] = cn.lin[0];
-      e[2] = (uint32_t)lane | (steps << 8);
+      e[1] = cn.s[0];
+      e[2] = cn.s[1];
+      e[3] = cn.s[2];
 #pragma unroll
       for (int k = 0; k < 8; ++k) e[4 + k] = __float_as_uint(cn.w[k]);
     }
-    my_rgb[lane * 4 + 0] = 0.f;
-    my_rgb[lane * 4 + 1] = 0.f;
-    my_rgb[lane * 4 + 2] = 0.f;
     wave_lds_fence();
 
     // ---------------- P1: LPS lanes per sample ----------------
+    // (the raw colour of the sample in work-list slot j lands in my_rgb[4 j ..]; P2's lane reads the slot it filled)
     for (int base = 0; base < count; base += GROUPS) {
       const int slot = base + group;
       const bool has = slot < count;
       float rgb[3] = {0.f, 0.f, 0.f};
-      int dst_lane = 0;
+      float prod[4] = {0.f, 0.f, 0.f, 0.f};
       if (has) {
         const uint32_t* e = my_entry + slot * kEntryFwd;
         const unsigned int lin0 = e[0];
-        const uint32_t meta = e[2];
-        dst_lane = (int)(meta & 0xffu);
-        // corner k = dx + 2 dy + 4 dz; the steps to the upper nodes are whole voxels or 0 (clamped at the border)
-        const unsigned int sx = (meta & (1u << 8)) ? ((meta & (8u << 8)) ? g.jump[0] : g.step[0]) : 0u;
-        const unsigned int sy = (meta & (2u << 8)) ? ((meta & (16u << 8)) ? g.jump[1] : g.step[1]) : 0u;
-        const unsigned int sz = (meta & (4u << 8)) ? ((meta & (32u << 8)) ? g.jump[2] : g.step[2]) : 0u;
-        Corners c;
+        // corner k = dx + 2 dy + 4 dz; the steps to the upper nodes are whole voxels (a jump into the next brick in the bricked
+        // node order) or 0 (clamped at the border)
+        const unsigned int sx = e[1], sy = e[2], sz = e[3];
+        float w[8];
 #pragma unroll
-        for (int k = 0; k < 8; ++k) {
-          c.lin[k] = lin0 + ((k & 1) ? sx : 0u) + ((k & 2) ? sy : 0u) + ((k & 4) ? sz : 0u);
-          c.w[k] = __uint_as_float(e[4 + k]);
-        }
+        for (int k = 0; k < 8; ++k) w[k] = __uint_as_float(e[4 + k]);
         if constexpr (L::kCorner) {
           // lane = corner `sub`; channels 0, K_full, 2*K_full of that corner
           const int kfull = g.F / 3;
-          unsigned int lin = c.lin[0];
-          float wk = c.w[0];
+          const unsigned int lin = lin0 + ((sub & 1) ? sx : 0u) + ((sub & 2) ? sy : 0u) + ((sub & 4) ? sz : 0u);
+          float wk = w[0];
 #pragma unroll
-          for (int k = 1; k < 8; ++k) {
-            lin = (sub == k) ? c.lin[k] : lin;
-            wk = (sub == k) ? c.w[k] : wk;
-          }
+          for (int k = 1; k < 8; ++k) wk = (sub == k) ? w[k] : wk;
           float v0, v1, v2;
           if (g.layout == RF_LAYOUT_SPLIT) {
             // base record = (sigma, sh0 r, sh0 g, sh0 b): one 16-byte load per corner
@@ -930,43 +982,71 @@ __global__ __launch_bounds__(kBlock) void render_forward_kernel(GridArgs g, RayA
           rgb[1] = v1 * wk;
           rgb[2] = v2 * wk;
         } else {
-          float a4[4] = {0.f, 0.f, 0.f, 0.f};
+          vf2 a01 = {0.f, 0.f}, a23 = {0.f, 0.f};
           if (ls.active) {
             f4u v[8];
+            if (g.near32) {  // (wave-uniform)
+              const unsigned int o0 = __umul24(lin0, ls.strideB) + ls.offB;
+              const unsigned int bx = __umul24(sx, ls.strideB), by = __umul24(sy, ls.strideB), bz = __umul24(sz, ls.strideB);
 #pragma unroll
-            for (int k = 0; k < 8; ++k) v[k] = *reinterpret_cast<const f4u*>(ls.src + c.lin[k] * ls.stride + ls.off);
+              for (int k = 0; k < 8; ++k) {
+                const unsigned int o = o0 + ((k & 1) ? bx : 0u) + ((k & 2) ? by : 0u) + ((k & 4) ? bz : 0u);
+                v[k] = *reinterpret_cast<const f4u*>(g.base + (size_t)o);
+              }
+            } else {
 #pragma unroll
-            for (int k = 0; k < 8; ++k) {
+              for (int k = 0; k < 8; ++k) {
+                const unsigned int lin = lin0 + ((k & 1) ? sx : 0u) + ((k & 2) ? sy : 0u) + ((k & 4) ? sz : 0u);
+                v[k] = *reinterpret_cast<const f4u*>(ls.src + lin * ls.stride + ls.off);
+              }
+              asm volatile("" ::: "memory");  // (keeps the two branches' loads apart: merged, they lose the scalar-base addressing)
+            }
 #pragma unroll
-              for (int j = 0; j < 4; ++j) a4[j] = a4[j] + v[k].v[j] * c.w[k];
+            for (int k = 0; k < 8; ++k) {  // (two elements per packed multiply / add; same roundings as one by one)
+              const vf2 lo = {v[k].v[0], v[k].v[1]}, hi = {v[k].v[2], v[k].v[3]};
+              a01 = a01 + lo * w[k];
+              a23 = a23 + hi * w[k];
             }
           }
+          prod[0] = ls.yb[0] * a01.x;
+          prod[1] = ls.yb[1] * a01.y;
+          prod[2] = ls.yb[2] * a23.x;
+          prod[3] = ls.yb[3] * a23.y;
+          if (g.layout != RF_LAYOUT_SPLIT) {
 #pragma unroll
-          for (int j = 0; j < 4; ++j) {
-            const float term = ls.yb[j] * a4[j];
+            for (int j = 0; j < 4; ++j) {
 #pragma unroll
-            for (int ch = 0; ch < 3; ++ch) rgb[ch] += (ls.chan[j] == ch) ? term : 0.0f;
+              for (int ch = 0; ch < 3; ++ch) rgb[ch] += (ls.chan[j] == ch) ? prod[j] : 0.0f;
+            }
           }
         }
       }
-#pragma unroll
-      for (int ch = 0; ch < 3; ++ch) rgb[ch] = group_sum_to_last<LPS>(rgb[ch]);
-      if (has && sub == LPS - 1) {
-        if constexpr (L::kCorner) {
-#pragma unroll
-          for (int ch = 0; ch < 3; ++ch) rgb[ch] = kC0 * rgb[ch];
+      if (!L::kCorner && g.layout == RF_LAYOUT_SPLIT) {  // (wave-uniform)
+        if constexpr (!L::kCorner) {
+          const float rest = rest_colour_sums<K>(prod);
+          if (has && ls.closes_colour) my_rgb[slot * 4 + ls.colour] = rest;
         }
-        my_rgb[dst_lane * 4 + 0] = rgb[0];
-        my_rgb[dst_lane * 4 + 1] = rgb[1];
-        my_rgb[dst_lane * 4 + 2] = rgb[2];
+      } else {
+#pragma unroll
+        for (int ch = 0; ch < 3; ++ch) rgb[ch] = group_sum_to_last<LPS>(rgb[ch]);
+        if (has && sub == LPS - 1) {
+          if constexpr (L::kCorner) {
+#pragma unroll
+            for (int ch = 0; ch < 3; ++ch) rgb[ch] = kC0 * rgb[ch];
+          }
+          my_rgb[slot * 4 + 0] = rgb[0];
+          my_rgb[slot * 4 + 1] = rgb[1];
+          my_rgb[slot * 4 + 2] = rgb[2];
+        }
       }
     }
     wave_lds_fence();
 
     // ---------------- P2: lanes = samples ----------------
-    const float raw_r = fast_base ? (need ? fast_rgb[0] : 0.0f) : my_rgb[lane * 4 + 0];
-    const float raw_g = fast_base ? (need ? fast_rgb[1] : 0.0f) : my_rgb[lane * 4 + 1];
-    const float raw_b = fast_base ? (need ? fast_rgb[2] : 0.0f) : my_rgb[lane * 4 + 2];
+    // (lanes without `need` read some other sample's slot or stale words: never used)
+    const float raw_r = fast_base ? fast_rgb[0] : (base_in_p0 ? fast_rgb[0] + my_rgb[slot * 4 + 0] : my_rgb[slot * 4 + 0]);
+    const float raw_g = fast_base ? fast_rgb[1] : (base_in_p0 ? fast_rgb[1] + my_rgb[slot * 4 + 1] : my_rgb[slot * 4 + 1]);
+    const float raw_b = fast_base ? fast_rgb[2] : (base_in_p0 ? fast_rgb[2] + my_rgb[slot * 4 + 2] : my_rgb[slot * 4 + 2]);
     if (need) {
       part_c[0] += w * sigmoidf_(raw_r);
       part_c[1] += w * sigmoidf_(raw_g);
@@ -3086,6 +3166,19 @@ GridArgs to_args(const RFGrid* g) {
     a.step[0] = a.jump[0] = (unsigned)a.Y * (unsigned)a.Z;
     a.step[1] = a.jump[1] = (unsigned)a.Z;
     a.step[2] = a.jump[2] = 1u;
+  }
+  {
+    unsigned long long nodes = 1;
+    for (int i = 0; i < 3; ++i) nodes *= (unsigned long long)(a.bricked ? (g->dims[i] + 7) / 8 * 8 : g->dims[i]);
+    const unsigned long long db = (unsigned long long)a.dstride * 4ull, fb = (unsigned long long)a.fstride * 4ull;
+    const uintptr_t d0 = reinterpret_cast<uintptr_t>(a.dens), f0 = a.feat ? reinterpret_cast<uintptr_t>(a.feat) : d0;
+    const uintptr_t lo = d0 < f0 ? d0 : f0;
+    const unsigned long long dend = (d0 - lo) + nodes * db, fend = a.feat ? (f0 - lo) + nodes * fb : 0ull;
+    const unsigned long long span = (dend > fend ? dend : fend) + 16ull;
+    a.base = reinterpret_cast<const char*>(lo);
+    a.dens_off = (unsigned int)(d0 - lo);
+    a.feat_off = (unsigned int)(f0 - lo);
+    a.near32 = nodes <= (1ull << 24) && db < (1ull << 24) && fb < (1ull << 24) && span < (1ull << 32);
   }
   return a;
 }
