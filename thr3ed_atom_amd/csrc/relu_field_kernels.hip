@@ -35,6 +35,9 @@ namespace {
 // bench step (specular + diffuse launch): 4 chunks at 4 waves 0.056 + 0.055 ms, 3 at 5 0.059 + 0.053, 2 at 6 (76-80 registers, no
 // spills) 0.052 + 0.046, 2 at 7 (spills) 0.052 + 0.058, 1 at 8 0.056 + 0.045: occupancy hides the chunk's dependent chain
 // (cache load -> key -> cursor atomic -> stores) better than unrolling it does.
+#ifndef RF_FWD_WAVES
+#define RF_FWD_WAVES 4  // waves per SIMD the forward kernels are register-budgeted for (128 registers)
+#endif
 #ifndef RF_EMIT_WAVES
 #define RF_EMIT_WAVES 6
 #endif
@@ -327,7 +330,11 @@ __device__ __forceinline__ Corners corners_of(uint32_t packed, const float wts[6
   const unsigned int sx = (okx[0] && okx[1]) ? ((g.bricked && (cx0 & 7) == 7) ? g.jump[0] : g.step[0]) : 0u;
   const unsigned int sy = (oky[0] && oky[1]) ? ((g.bricked && (cy0 & 7) == 7) ? g.jump[1] : g.step[1]) : 0u;
   const unsigned int sz = (okz[0] && okz[1]) ? ((g.bricked && (cz0 & 7) == 7) ? g.jump[2] : g.step[2]) : 0u;
-  const float wxy[4] = {wts[0] * wts[2], wts[1] * wts[2], wts[0] * wts[3], wts[1] * wts[3]};  // [dx + 2 dy]
+  // (a node outside the grid gets weight 0: masked per axis -- 0 times the finite weights of the other axes is the same +0)
+  const float ax[2] = {okx[0] ? wts[0] : 0.0f, okx[1] ? wts[1] : 0.0f};
+  const float ay[2] = {oky[0] ? wts[2] : 0.0f, oky[1] ? wts[3] : 0.0f};
+  const float az[2] = {okz[0] ? wts[4] : 0.0f, okz[1] ? wts[5] : 0.0f};
+  const float wxy[4] = {ax[0] * ay[0], ax[1] * ay[0], ax[0] * ay[1], ax[1] * ay[1]};  // [dx + 2 dy]
   Corners c;
   c.s[0] = sx;
   c.s[1] = sy;
@@ -336,8 +343,7 @@ __device__ __forceinline__ Corners corners_of(uint32_t packed, const float wts[6
   for (int k = 0; k < 8; ++k) {
     const int dx = k & 1, dy = (k >> 1) & 1, dz = k >> 2;
     c.lin[k] = lin0 + (dx ? sx : 0u) + (dy ? sy : 0u) + (dz ? sz : 0u);
-    const float w = wxy[dx + 2 * dy] * wts[4 + dz];
-    c.w[k] = (okx[dx] && oky[dy] && okz[dz]) ? w : 0.0f;
+    c.w[k] = wxy[dx + 2 * dy] * az[dz];
   }
   return c;
 }
@@ -780,7 +786,7 @@ __device__ __forceinline__ bool chunk_outside_box(const BoxSpan& b, const RaySta
 // forward
 // =============================================================================================
 template <int K, bool DIFFUSE, bool SAVE>
-__global__ __launch_bounds__(kBlock) void render_forward_kernel(GridArgs g, RayArgs r, OutArgs out, uint32_t flags) {
+__global__ __launch_bounds__(kBlock, RF_FWD_WAVES) void render_forward_kernel(GridArgs g, RayArgs r, OutArgs out, uint32_t flags) {
   using L = Layout<K, DIFFUSE>;
   constexpr int LPS = L::kLPS;
   constexpr int GROUPS = L::kGroups;
@@ -892,19 +898,22 @@ __global__ __launch_bounds__(kBlock) void render_forward_kernel(GridArgs g, RayA
           for (int k = 0; k < 8; ++k) t[k] = *reinterpret_cast<const f4u*>(g.dens + cn.lin[k] * g.dstride);
           asm volatile("" ::: "memory");  // (keeps the two branches' loads apart: merged, they lose the scalar-base addressing)
         }
-        float acc = 0.0f, cr = 0.0f, cg = 0.0f, cb = 0.0f;
+        // density in the reference's operation order (separately rounded products, ATen's corner order: it decides which samples
+        // the ReLU keeps); the colour coefficients with fused multiply-adds, two per instruction
+        float acc = 0.0f, cb = 0.0f;
+        vf2 crg = {0.f, 0.f};
 #pragma unroll
         for (int k = 0; k < 8; ++k) {
           float v = t[k].v[0] * g.rho;
           if (g.mode == RF_DENSITY_ABS) v = fabsf(v);
           acc = acc + v * cn.w[k];
-          cr = cr + t[k].v[1] * cn.w[k];
-          cg = cg + t[k].v[2] * cn.w[k];
-          cb = cb + t[k].v[3] * cn.w[k];
+          const vf2 rg = {t[k].v[1], t[k].v[2]}, wk = {cn.w[k], cn.w[k]};
+          crg = __builtin_elementwise_fma(rg, wk, crg);
+          cb = __builtin_fmaf(t[k].v[3], cn.w[k], cb);
         }
         sigma = density_post(acc, g.mode);
-        fast_rgb[0] = kC0 * cr;
-        fast_rgb[1] = kC0 * cg;
+        fast_rgb[0] = kC0 * crg.x;
+        fast_rgb[1] = kC0 * crg.y;
         fast_rgb[2] = kC0 * cb;
       } else {
         float pre;
@@ -1002,10 +1011,10 @@ __global__ __launch_bounds__(kBlock) void render_forward_kernel(GridArgs g, RayA
               asm volatile("" ::: "memory");  // (keeps the two branches' loads apart: merged, they lose the scalar-base addressing)
             }
 #pragma unroll
-            for (int k = 0; k < 8; ++k) {  // (two elements per packed multiply / add; same roundings as one by one)
-              const vf2 lo = {v[k].v[0], v[k].v[1]}, hi = {v[k].v[2], v[k].v[3]};
-              a01 = a01 + lo * w[k];
-              a23 = a23 + hi * w[k];
+            for (int k = 0; k < 8; ++k) {  // two elements per packed fused multiply-add (v_pk_fma_f32)
+              const vf2 lo = {v[k].v[0], v[k].v[1]}, hi = {v[k].v[2], v[k].v[3]}, wk = {w[k], w[k]};
+              a01 = __builtin_elementwise_fma(lo, wk, a01);
+              a23 = __builtin_elementwise_fma(hi, wk, a23);
             }
           }
           prod[0] = ls.yb[0] * a01.x;
