@@ -1836,7 +1836,7 @@ __device__ __forceinline__ void brick_flush(const GridArgs& g, const BrickArgs& 
                                             float* gdens, float* gfeat) {
   constexpr int C = 3 * K + 1;
   constexpr int CS = (C + 3) / 4 * 4;
-  const int B = 1 << a.shift;
+  const int B = ONE_ROUND ? 8 : (1 << a.shift);  // (ONE_ROUND: the host launches it for 8^3 bricks only -- strides fold to constants)
   const int SY = brick_row_stride(B, C), SX = brick_slab_stride(B, C);
   const int tid = threadIdx.x;
   // ---- write the brick out: plain stores (exclusive owner), contiguous runs along z
@@ -1896,7 +1896,8 @@ __device__ __forceinline__ void brick_flush(const GridArgs& g, const BrickArgs& 
           }
           const bool ok = X0 + fx < g.X && Y0 + fy < g.Y && Z0 + fz < g.Z;
           const unsigned int lin = ok ? node_lin(g, X0 + fx, Y0 + fy, Z0 + fz) : 0u;
-          const unsigned int o = u == 0 ? lin * (unsigned)g.dstride : lin * (unsigned)g.fstride + 4u * (unsigned)(qd - 1);
+          // (24-bit multiplies: the host launches this path for <= 2^24 nodes and strides < 2^24 only)
+          const unsigned int o = u == 0 ? __umul24(lin, (unsigned)g.dstride) : __umul24(lin, (unsigned)g.fstride) + 4u * (unsigned)(qd - 1);
           bo[u] = ok ? o * 4u : 0xffffffffu;
           lds_at[u] = fx * SX + fy * SY + fz * CS + 4 * qd;
         }
@@ -2156,7 +2157,8 @@ __global__ __launch_bounds__(kBrickThreads, (K > 9 ? 2 : 4)) void brick_gather_k
   __shared__ int s_wstart[kMaxRangesKind], s_wcum[kMaxRangesKind + 1];  // ranges of the full-width lists: first record, running count
   __shared__ int s_nstart[kMaxRangesKind], s_ncum[kMaxRangesKind + 1];  // ... of the base-channel lists of a mixed call
   __shared__ int s_part[4];
-  const int B = 1 << a.shift;
+  const int B = ONE_ROUND ? 8 : (1 << a.shift);  // (ONE_ROUND: 8^3 bricks only -- tile counts and image strides fold to constants)
+  const int bshift = ONE_ROUND ? 3 : a.shift;
   const int SY = brick_row_stride(B, C), SX = brick_slab_stride(B, C);
 
   RF_PROF_START();
@@ -2165,7 +2167,7 @@ __global__ __launch_bounds__(kBrickThreads, (K > 9 ? 2 : 4)) void brick_gather_k
   const int wave = tid >> 6;
   const int brick = a.brick_first + (int)blockIdx.x;
   const int bz = brick % a.nbz, by = (brick / a.nbz) % a.nby, bx = brick / (a.nbz * a.nby);
-  const int X0 = bx << a.shift, Y0 = by << a.shift, Z0 = bz << a.shift;
+  const int X0 = bx << bshift, Y0 = by << bshift, Z0 = bz << bshift;
   // ---- range set-up: waves 0, 1 = the 15 ranges of each full-width list, waves 2, 3 = of each base-channel list; running
   // counts by wave scan (empty ranges stay in the tables with zero length: the record -> range walk skips them)
   {
@@ -2359,11 +2361,12 @@ __global__ __launch_bounds__(kBrickThreads, (K > 9 ? 2 : 4)) void brick_gather_k
             lds_request_f32<0>(w0, a_x + 4 * r);
             lds_request_f32<0>(w1, a_y + 4 * r);
             lds_request_f32<0>(w2, a_z + 4 * r);
-            lds_request_f32<0>(g0, a_g + r * (RW * 4));
-            if constexpr (NTW > 1) lds_request_f32<64>(g1, a_g + r * (RW * 4));
+            const uint32_t a_row = a_g + (uint32_t)__umul24(r, RW * 4);  // (r is a byte: a full-rate 24-bit multiply-add, not a 64-bit one)
+            lds_request_f32<0>(g0, a_row);
+            if constexpr (NTW > 1) lds_request_f32<64>(g1, a_row);
             if constexpr (NTW > 2) {
-              lds_request_f32<128>(g2, a_g + r * (RW * 4));
-              lds_request_f32<192>(g3, a_g + r * (RW * 4));
+              lds_request_f32<128>(g2, a_row);
+              lds_request_f32<192>(g3, a_row);
             }
           };
           auto wait_ops = [&](float& w0, float& w1, float& w2, float& g0, float& g1, float& g2, float& g3, uint32_t& r) {
@@ -3710,7 +3713,7 @@ static int brick_accumulate_impl(const RFGrid* grid, int32_t brick_size, const R
       unsigned long long nodes = 1;
       for (int ax = 0; ax < 3; ++ax) nodes *= (unsigned long long)((grid->dims[ax] + 7) / 8 * 8);
       const unsigned long long smax = (unsigned long long)(grid->density_stride > grid->feature_stride ? grid->density_stride : grid->feature_stride);
-      a.adam.byte_offsets_fit_32_bits = nodes * smax < (1ull << 30);
+      a.adam.byte_offsets_fit_32_bits = nodes * smax < (1ull << 30) && nodes <= (1ull << 24) && smax < (1ull << 24);
     }
 #ifdef RF_BRICK_PROFILE
     {
