@@ -406,7 +406,11 @@ typedef struct RFTrainStep {
                                    enabled): event 0 is recorded on `stream` before the first launch, event k after launch k
                                    in the order select, forward[0], (nothing), forward[1], losses of both renders + offsets of
                                    both lists (one launch), (nothing), emit[0], (nothing), emit[1], bricks -- per-kernel durations
-                                   of the very call that is timed (only with phases == 0)                                      */
+                                   of the very call that is timed (only with phases == 0).  A full iteration runs both forward
+                                   renders in ONE launch and both adjoints in ONE launch (the render_diffuse pass walks the same
+                                   rays as the specular one: it finds the base records of its corners on chip); slot [0] of a
+                                   pair then holds the launch and slot [1] is empty.  $RF_FWD_PAIR=0 / $RF_EMIT_PAIR=0 in the
+                                   environment restore one launch per render (A/B measurements)                                */
 } RFTrainStep;
 
 enum {

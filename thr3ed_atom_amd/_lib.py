@@ -200,6 +200,13 @@ class RFTrainStep(C.Structure):
 
 
 TRAIN_STEP_EVENTS = 11
+def train_step_pairing():
+    """(forward renders paired, emit launches paired): rf_train_step runs both renders of an iteration -- and both adjoints -- in ONE
+    launch each unless $RF_FWD_PAIR / $RF_EMIT_PAIR say 0 (the library reads the same variables); the first slot of a pair then holds
+    the launch and the second one is empty."""
+    return os.environ.get("RF_FWD_PAIR", "1") != "0", os.environ.get("RF_EMIT_PAIR", "1") != "0"
+
+
 TRAIN_STEP_EVENT_NAMES = ["select_rays_and_pixels", "render_forward[spec,save]", "(no launch: loss slot of the first render)", "render_forward[diffuse,save]",
                           "l1_loss_grad+bin_offsets[both]", "(no launch: offsets slot)", "render_backward_emit_direct[spec]",
                           "(no launch: offsets slot of the second list)", "render_backward_emit_direct[diffuse]", "brick_accumulate"]

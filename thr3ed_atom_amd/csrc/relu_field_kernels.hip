@@ -785,18 +785,13 @@ __device__ __forceinline__ bool chunk_outside_box(const BoxSpan& b, const RaySta
 // =============================================================================================
 // forward
 // =============================================================================================
+// one wave = one ray; my_entry / my_rgb: the wave's own kWave * kEntryFwd words and kWave * 4 floats of LDS
 template <int K, bool DIFFUSE, bool SAVE>
-__global__ __launch_bounds__(kBlock, RF_FWD_WAVES) void render_forward_kernel(GridArgs g, RayArgs r, OutArgs out, uint32_t flags) {
+__device__ __forceinline__ void render_forward_ray(const GridArgs& g, const RayArgs& r, const OutArgs& out, uint32_t flags, long long ray, int lane,
+                                                   uint32_t* my_entry, float* my_rgb) {
   using L = Layout<K, DIFFUSE>;
   constexpr int LPS = L::kLPS;
   constexpr int GROUPS = L::kGroups;
-
-  __shared__ __attribute__((aligned(16))) uint32_t s_entry[kWavesPerBlock][kWave * kEntryFwd];
-  __shared__ __attribute__((aligned(16))) float s_rgb[kWavesPerBlock][kWave * 4];
-
-  const int lane = threadIdx.x & (kWave - 1);
-  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const long long ray = (long long)blockIdx.x * kWavesPerBlock + wave;
   if (ray >= r.n) return;
 
   const RayState st = load_ray(r, g, ray, flags);
@@ -809,10 +804,7 @@ __global__ __launch_bounds__(kBlock, RF_FWD_WAVES) void render_forward_kernel(Gr
   LaneSlice ls;
   ls.src = nullptr;
   ls.active = false;
-  if constexpr (!L::kCorner) ls = lane_slice<K, LPS>(g, st.d, st.dnorm, lane, s_rgb[wave]);
-
-  uint32_t* my_entry = s_entry[wave];
-  float* my_rgb = s_rgb[wave];
+  if constexpr (!L::kCorner) ls = lane_slice<K, LPS>(g, st.d, st.dnorm, lane, my_rgb);
 
   float T_carry = 1.0f;
   float part_c[3] = {0.f, 0.f, 0.f};
@@ -1102,6 +1094,41 @@ __global__ __launch_bounds__(kBlock, RF_FWD_WAVES) void render_forward_kernel(Gr
   if constexpr (SAVE) {
     flush_cmasks(cmask_group);
     for (int gq = cmask_group + 1; gq * kWave < nchunks; ++gq) flush_cmasks(gq);  // (chunks never reached: zero masks)
+  }
+}
+
+template <int K, bool DIFFUSE, bool SAVE>
+__global__ __launch_bounds__(kBlock, RF_FWD_WAVES) void render_forward_kernel(GridArgs g, RayArgs r, OutArgs out, uint32_t flags) {
+  __shared__ __attribute__((aligned(16))) uint32_t s_entry[kWavesPerBlock][kWave * kEntryFwd];
+  __shared__ __attribute__((aligned(16))) float s_rgb[kWavesPerBlock][kWave * 4];
+  const int lane = threadIdx.x & (kWave - 1);
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  render_forward_ray<K, DIFFUSE, SAVE>(g, r, out, flags, (long long)blockIdx.x * kWavesPerBlock + wave, lane, s_entry[wave], s_rgb[wave]);
+}
+
+// The two renders of a training iteration -- specular, and render_diffuse with its own jitter stream -- of the SAME rays in one launch:
+// a block takes two rays, waves 0, 1 walk them for the specular render, waves 2, 3 for the diffuse one.  Sample s of both renders lies
+// in the same stratum of the ray, i.e. in the same or a neighbouring cell: the second render finds the 16-byte base records of its
+// corners in the CU's L1 / the XCD's L2 instead of fetching them from HBM a second time.
+struct ForwardPair {
+  RayArgs r[2];
+  OutArgs out[2];
+  uint32_t flags[2];
+};
+template <int K>
+__global__ __launch_bounds__(kBlock, RF_FWD_WAVES) void render_forward_pair_kernel(GridArgs g, ForwardPair p) {
+  __shared__ __attribute__((aligned(16))) uint32_t s_entry[kWavesPerBlock][kWave * kEntryFwd];
+  __shared__ __attribute__((aligned(16))) float s_rgb[kWavesPerBlock][kWave * 4];
+  const int lane = threadIdx.x & (kWave - 1);
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const long long ray = (long long)blockIdx.x * (kWavesPerBlock / 2) + (wave & 1);
+  if (wave < 2) {
+    if constexpr (K == 1)
+      render_forward_ray<1, true, true>(g, p.r[0], p.out[0], p.flags[0], ray, lane, s_entry[wave], s_rgb[wave]);
+    else
+      render_forward_ray<K, false, true>(g, p.r[0], p.out[0], p.flags[0], ray, lane, s_entry[wave], s_rgb[wave]);
+  } else {
+    render_forward_ray<1, true, true>(g, p.r[1], p.out[1], p.flags[1], ray, lane, s_entry[wave], s_rgb[wave]);
   }
 }
 
@@ -1412,10 +1439,8 @@ __global__ __launch_bounds__(kBlock) void render_backward_kernel(GridArgs g, Ray
 // 16-byte pieces of 64 different lines -- slower (0.113 / 0.078 ms): the L2 merges the partial lines at no cost that matters here.
 // =============================================================================================
 template <int K, bool DIFFUSE>
-__global__ __launch_bounds__(kBlock, RF_EMIT_WAVES) void render_emit_direct_kernel(GridArgs g, RayArgs r, OutArgs fwd, GradArgs gr, uint32_t flags) {
-  const int lane = threadIdx.x & (kWave - 1);
-  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const long long ray = (long long)blockIdx.x * kWavesPerBlock + wave;
+__device__ __forceinline__ void render_emit_direct_ray(const GridArgs& g, const RayArgs& r, const OutArgs& fwd, const GradArgs& gr, uint32_t flags, long long ray,
+                                                       int lane) {
   // the forward pass's counters have been turned into offsets: clear them for the next iteration (every thread of the grid
   // takes part, including the waves without a ray)
   if (gr.hist_clear)
@@ -1559,6 +1584,42 @@ __global__ __launch_bounds__(kBlock, RF_EMIT_WAVES) void render_emit_direct_kern
         }
       }
     }
+  }
+}
+
+template <int K, bool DIFFUSE>
+__global__ __launch_bounds__(kBlock, RF_EMIT_WAVES) void render_emit_direct_kernel(GridArgs g, RayArgs r, OutArgs fwd, GradArgs gr, uint32_t flags) {
+  const int lane = threadIdx.x & (kWave - 1);
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  render_emit_direct_ray<K, DIFFUSE>(g, r, fwd, gr, flags, (long long)blockIdx.x * kWavesPerBlock + wave, lane);
+}
+
+// the adjoints of both renders of a training iteration in one launch (waves 0, 1 of a block: specular, waves 2, 3: render_diffuse, of
+// the same two rays): the kernel is bound by its per-ray dependency chains, and one launch of twice the waves has one tail instead of two
+struct EmitPair {
+  RayArgs r[2];
+  OutArgs fwd[2];
+  GradArgs gr[2];
+  uint32_t flags[2];
+};
+template <int K>
+__global__ __launch_bounds__(kBlock, RF_EMIT_WAVES) void render_emit_direct_pair_kernel(GridArgs g, EmitPair p) {
+  const int lane = threadIdx.x & (kWave - 1);
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const long long ray = (long long)blockIdx.x * (kWavesPerBlock / 2) + (wave & 1);
+  // (the counters of BOTH forward passes are cleared by all threads of the grid here; the per-ray bodies get no clearing job)
+  for (int i = 0; i < 2; ++i)
+    if (p.gr[i].hist_clear)
+      for (long long k = (long long)blockIdx.x * blockDim.x + threadIdx.x; k < p.gr[i].nkeys; k += (long long)gridDim.x * blockDim.x) p.gr[i].hist_clear[k] = 0;
+  GradArgs gr = p.gr[wave < 2 ? 0 : 1];
+  gr.hist_clear = nullptr;
+  if (wave < 2) {
+    if constexpr (K == 1)
+      render_emit_direct_ray<1, true>(g, p.r[0], p.fwd[0], gr, p.flags[0], ray, lane);
+    else
+      render_emit_direct_ray<K, false>(g, p.r[0], p.fwd[0], gr, p.flags[0], ray, lane);
+  } else {
+    render_emit_direct_ray<1, true>(g, p.r[1], p.fwd[1], gr, p.flags[1], ray, lane);
   }
 }
 
@@ -3453,6 +3514,46 @@ int rf_render_forward(const RFGrid* grid, const RFRayBatch* rays, uint32_t flags
   return launch_status();
 }
 
+// both saving forward renders of a training iteration (0 = specular, 1 = render_diffuse) over the same rays in ONE launch
+// (render_forward_pair_kernel); RF_ERR_UNSUPPORTED when the two calls do not pair up -- the caller then launches them one by one
+static int forward_pair_impl(const RFGrid* grid, const RFRayBatch* const rays[2], const uint32_t flags[2], const RFRenderOut* const outs[2], void* stream) {
+  int rc = check_grid(grid);
+  if (rc != RF_OK) return rc;
+  ForwardPair p;
+  for (int i = 0; i < 2; ++i) {
+    rc = check_rays(rays[i]);
+    if (rc != RF_OK) return rc;
+    const RFRenderOut* out = outs[i];
+    if (!out || !out->colour_dev || !out->depth_dev || !out->acc_dev || !out->disparity_dev) return RF_ERR_NULL_POINTER;
+    if (!out->sample_cache_dev || !out->trans_cache_dev || !out->stop_cache_dev || !out->chunk_mask_dev) return RF_ERR_UNSUPPORTED;
+    if ((flags[i] & RF_FLAG_OCCUPANCY_SKIP) && !grid->occupancy_dev) return RF_ERR_NULL_POINTER;
+    p.r[i] = to_args(rays[i], flags[i]);
+    p.out[i] = to_args(out);
+    p.flags[i] = flags[i];
+    if (out->key_hist_dev) {
+      int shift, nb[3];
+      rc = brick_geometry(grid, out->brick_size, &shift, nb, false);
+      if (rc != RF_OK) return rc;
+      p.out[i].hist = out->key_hist_dev;
+      p.out[i].brick_shift = shift;
+      p.out[i].nby = nb[1];
+      p.out[i].nbz = nb[2];
+    }
+  }
+  if (rays[0]->num_rays != rays[1]->num_rays || (flags[0] & RF_FLAG_RENDER_DIFFUSE) || !(flags[1] & RF_FLAG_RENDER_DIFFUSE)) return RF_ERR_UNSUPPORTED;
+  if (rays[0]->num_rays == 0) return RF_OK;
+  const GridArgs g = to_args(grid);
+  const unsigned blocks = (unsigned)((rays[0]->num_rays + 1) / 2);
+  hipStream_t st = (hipStream_t)stream;
+  switch (grid->num_features / 3) {
+    case 1: hipLaunchKernelGGL((render_forward_pair_kernel<1>), dim3(blocks), dim3(kBlock), 0, st, g, p); break;
+    case 4: hipLaunchKernelGGL((render_forward_pair_kernel<4>), dim3(blocks), dim3(kBlock), 0, st, g, p); break;
+    case 9: hipLaunchKernelGGL((render_forward_pair_kernel<9>), dim3(blocks), dim3(kBlock), 0, st, g, p); break;
+    default: hipLaunchKernelGGL((render_forward_pair_kernel<16>), dim3(blocks), dim3(kBlock), 0, st, g, p); break;
+  }
+  return launch_status();
+}
+
 static int backward_impl(const RFGrid* grid, const RFRayBatch* rays, uint32_t flags, const RFRenderOut* fwd,
                          const RFRenderGrads* grads, GradArgs gr, void* stream) {
   int rc = check_grid(grid);
@@ -3510,6 +3611,49 @@ int rf_render_backward_emit(const RFGrid* grid, const RFRayBatch* rays, uint32_t
   gr.nbz = nb[2];
   gr.hist = hist_dev;
   return backward_impl(grid, rays, flags, fwd, grads, gr, stream);
+}
+
+// the direct-emit adjoints of both renders of a training iteration (0 = specular, 1 = render_diffuse) in ONE launch
+static int emit_pair_impl(const RFGrid* grid, const RFRayBatch* const rays[2], const uint32_t flags[2], const RFPassScratch* const pass[2], void* stream) {
+  int rc = check_grid(grid);
+  if (rc != RF_OK) return rc;
+  EmitPair p;
+  for (int i = 0; i < 2; ++i) {
+    rc = check_rays(rays[i]);
+    if (rc != RF_OK) return rc;
+    const RFPassScratch& ps = *pass[i];
+    const RFRenderOut* fwd = &ps.out;
+    if (!ps.cursor_dev || !ps.records_sorted_dev || !ps.grad_colour_dev) return RF_ERR_NULL_POINTER;
+    if (!fwd->sample_cache_dev || !fwd->trans_cache_dev || !fwd->stop_cache_dev || !fwd->chunk_mask_dev) return RF_ERR_NULL_POINTER;
+    int shift, nb[3];
+    rc = brick_geometry(grid, fwd->brick_size, &shift, nb, false);
+    if (rc != RF_OK) return rc;
+    p.r[i] = to_args(rays[i], flags[i]);
+    p.fwd[i] = to_args(fwd);
+    p.flags[i] = flags[i];
+    GradArgs gr = {};
+    gr.cursor = ps.cursor_dev;
+    gr.sorted = reinterpret_cast<float4*>(ps.records_sorted_dev);
+    gr.hist_clear = fwd->key_hist_dev;
+    gr.nkeys = nb[0] * nb[1] * nb[2] * 8;
+    gr.brick_shift = shift;
+    gr.nby = nb[1];
+    gr.nbz = nb[2];
+    gr.gcolour = ps.grad_colour_dev;
+    p.gr[i] = gr;
+  }
+  if (rays[0]->num_rays != rays[1]->num_rays || (flags[0] & RF_FLAG_RENDER_DIFFUSE) || !(flags[1] & RF_FLAG_RENDER_DIFFUSE)) return RF_ERR_UNSUPPORTED;
+  if (rays[0]->num_rays == 0) return RF_OK;
+  const GridArgs g = to_args(grid);
+  const unsigned blocks = (unsigned)((rays[0]->num_rays + 1) / 2);
+  hipStream_t st = (hipStream_t)stream;
+  switch (grid->num_features / 3) {
+    case 1: hipLaunchKernelGGL((render_emit_direct_pair_kernel<1>), dim3(blocks), dim3(kBlock), 0, st, g, p); break;
+    case 4: hipLaunchKernelGGL((render_emit_direct_pair_kernel<4>), dim3(blocks), dim3(kBlock), 0, st, g, p); break;
+    case 9: hipLaunchKernelGGL((render_emit_direct_pair_kernel<9>), dim3(blocks), dim3(kBlock), 0, st, g, p); break;
+    default: hipLaunchKernelGGL((render_emit_direct_pair_kernel<16>), dim3(blocks), dim3(kBlock), 0, st, g, p); break;
+  }
+  return launch_status();
 }
 
 int rf_render_backward_emit_direct(const RFGrid* grid, const RFRayBatch* rays, uint32_t flags, const RFRenderOut* fwd,
@@ -3997,10 +4141,24 @@ int rf_train_step(const RFGrid* grid, const RFTrainStep* step, void* stream) {
     rc = launch_select();
     if (rc != RF_OK) return rc;
     RF_STEP_EVENT();
+    static const bool pair_forwards = [] {
+      const char* e = getenv("RF_FWD_PAIR");
+      return e ? atoi(e) != 0 : true;
+    }();
+    bool paired = false;
+    if (pair_forwards) {  // both renders in one launch: the second finds the base records of its corners on chip
+      const RFRayBatch* const rr[2] = {&rays[0], &rays[1]};
+      const RFRenderOut* const oo[2] = {&step->pass[0].out, &step->pass[1].out};
+      rc = forward_pair_impl(grid, rr, flags, oo, stream);
+      if (rc != RF_OK && rc != RF_ERR_UNSUPPORTED) return rc;
+      paired = rc == RF_OK;
+    }
     for (int i = 0; i < 2; ++i) {
-      rc = rf_render_forward(grid, &rays[i], flags[i], &step->pass[i].out, stream);
-      if (rc != RF_OK) return rc;
-      RF_STEP_EVENT();
+      if (!paired) {
+        rc = rf_render_forward(grid, &rays[i], flags[i], &step->pass[i].out, stream);
+        if (rc != RF_OK) return rc;
+      }
+      RF_STEP_EVENT();  // (paired: the first forward slot holds the launch, the second is empty)
       if (i == 1) {
         rc = launch_losses_and_offsets();
         if (rc != RF_OK) return rc;
@@ -4022,7 +4180,27 @@ int rf_train_step(const RFGrid* grid, const RFTrainStep* step, void* stream) {
     }
   }
   if (emit_one[0] || emit_one[1]) {
-    for (int i = 0; i < 2; ++i) {
+    static const bool pair_emits = [] {
+      const char* e = getenv("RF_EMIT_PAIR");
+      return e ? atoi(e) != 0 : true;
+    }();
+    bool paired = false;
+    if (pair_emits && emit_one[0] && emit_one[1]) {
+      RF_STEP_EVENT();
+      const RFRayBatch* const rr[2] = {&rays[0], &rays[1]};
+      const RFPassScratch* const pp[2] = {&step->pass[0], &step->pass[1]};
+      rc = emit_pair_impl(grid, rr, flags, pp, stream);
+      if (rc != RF_OK && rc != RF_ERR_UNSUPPORTED) return rc;
+      paired = rc == RF_OK;
+      if (paired) {  // (the first emit slot holds the launch, the second is empty)
+        RF_STEP_EVENT();
+        RF_STEP_EVENT();
+        RF_STEP_EVENT();
+      } else if (events) {
+        --ev;
+      }
+    }
+    for (int i = 0; i < 2 && !paired; ++i) {
       if (!emit_one[i]) continue;
       const RFPassScratch& ps = step->pass[i];
       const RFRenderGrads grads = {ps.grad_colour_dev, nullptr, nullptr};

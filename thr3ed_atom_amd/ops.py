@@ -101,6 +101,15 @@ class StepEvents:
             if hip.hipEventElapsedTime(C.byref(ms), C.c_void_p(self.array[i]), C.c_void_p(self.array[i + 1])) != 0:
                 raise RuntimeError("hipEventElapsedTime failed (events not recorded or not complete)")
             out[name] = float(ms.value)
+        # paired launches (both renders / both adjoints of the iteration in one launch): one entry per launch
+        fwd_pair, emit_pair = _lib.train_step_pairing()
+        for paired, first, gap, second, merged in (
+                (fwd_pair, "render_forward[spec,save]", "(no launch: loss slot of the first render)", "render_forward[diffuse,save]", "render_forward[spec+diffuse,save]"),
+                (emit_pair, "render_backward_emit_direct[spec]", "(no launch: offsets slot of the second list)", "render_backward_emit_direct[diffuse]",
+                 "render_backward_emit_direct[spec+diffuse]")):
+            if paired:
+                # (the launch sits in the pair's first slot; the two empty slots behind it hold nothing but the cost of recording an event)
+                out = {(merged if k == first else k): v for k, v in out.items() if k not in (gap, second)}
         return out
 
     def __del__(self):

@@ -1,7 +1,7 @@
 # A/B of environment settings on the training step (GPU box, repo root): tools/ab_env.sh "VAR=a" "VAR=b" ...
 for setting in "$@"; do
   for rep in 1 2; do
-    env $setting python bench.py --steps 40 --warmup 10 --render-frames 0 --highres-frames 0 --dropin-steps 0 --cpu-rays 0 2>/dev/null | python -c "
+    env $setting python bench.py ${AB_STEPS:---steps 40 --warmup 10} --render-frames 0 --highres-frames 0 --dropin-steps 0 --cpu-rays 0 2>/dev/null | python -c "
 import json,sys
 l=json.loads([x for x in sys.stdin if x.startswith('{')][0])
 k=l['kernels']
