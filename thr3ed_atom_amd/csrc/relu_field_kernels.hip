@@ -2215,8 +2215,8 @@ __global__ __launch_bounds__(kBrickThreads, (K > 9 ? 2 : 4)) void brick_gather_k
   float* wtab = acc + kGatherBatch * gather_record_words(C4);   // [3][8][kGatherRow]: axis, local node coordinate, record
   __shared__ uint32_t s_tmask[kGatherBatch];                   // record -> bit t: it touches tile t
   __shared__ unsigned char s_list[32][kGatherBatch + 24];      // tile -> its records (+ padding of the last instructions, + read-ahead slack)
-  __shared__ int s_wstart[kMaxRangesKind], s_wcum[kMaxRangesKind + 1];  // ranges of the full-width lists: first record, running count
-  __shared__ int s_nstart[kMaxRangesKind], s_ncum[kMaxRangesKind + 1];  // ... of the base-channel lists of a mixed call
+  __shared__ __attribute__((aligned(16))) int s_wstart[kMaxRangesKind], s_wcum[kMaxRangesKind + 8];  // ranges of the full-width lists: first record, running count
+  __shared__ __attribute__((aligned(16))) int s_nstart[kMaxRangesKind], s_ncum[kMaxRangesKind + 8];  // ... of the base-channel lists of a mixed call
   __shared__ int s_part[4];
   const int B = ONE_ROUND ? 8 : (1 << a.shift);  // (ONE_ROUND: 8^3 bricks only -- tile counts and image strides fold to constants)
   const int bshift = ONE_ROUND ? 3 : a.shift;
@@ -2237,8 +2237,9 @@ __global__ __launch_bounds__(kBrickThreads, (K > 9 ? 2 : 4)) void brick_gather_k
     if (tid < 256) {
       const int nl = kind ? a.nnarrow : a.nwide;
       if (i < kRangeEntries * nl) {
-        const int l = i / kRangeEntries;
-        brick_range_entry(a, kind ? a.narrow[l].offsets : a.wide[l].offsets, bx, by, bz, i - l * kRangeEntries, start, cnt);
+        const int l = nl == 1 ? 0 : i / kRangeEntries;
+        const long long* offs = nl == 1 ? (kind ? a.narrow[0].offsets : a.wide[0].offsets) : (kind ? a.narrow[l].offsets : a.wide[l].offsets);
+        brick_range_entry(a, offs, bx, by, bz, i - l * kRangeEntries, start, cnt);
       }
     }
     int cum = cnt;
@@ -2283,9 +2284,6 @@ __global__ __launch_bounds__(kBrickThreads, (K > 9 ? 2 : 4)) void brick_gather_k
 
   if (any) {
     const int nba = (total + kGatherBatch - 1) / kGatherBatch, nbd = (total_d + kGatherBatch - 1) / kGatherBatch;
-    // the weight table starts zero-filled; a record's thread clears the entries of the previous batch before it writes new ones
-    for (int i = tid; i < kGatherRow * kGatherWtab / 4; i += kBrickThreads) reinterpret_cast<float4*>(wtab)[i] = make_float4(0.f, 0.f, 0.f, 0.f);
-    __syncthreads();
     uint32_t wprev = 0x00ffffffu;  // the lower nodes (c + 1, one byte per axis) this thread's record of the previous batch had; 0xff = none
     const int rec_id = tid & (kGatherBatch - 1);  // this thread's record of every batch; the two threads of a record split its channels
     const int half = tid >> 8;
@@ -2482,15 +2480,28 @@ __global__ __launch_bounds__(kBrickThreads, (K > 9 ? 2 : 4)) void brick_gather_k
     const float4* rptr = a.wide[0].rec;    // list base + (start of the range - its position in the concatenation)
     const float4* dptr = a.narrow[0].rec;
     float4 w0 = make_float4(0.f, 0.f, 0.f, 0.f), w1 = w0, w2 = w0, d0 = w0, d1 = w0;
+    // the range that holds record v of the concatenation: the largest i with cum[i] <= v.  One list (15 ranges, the single-GPU case):
+    // the whole table in four independent 16-byte reads and 15 compares -- the walk below is a chain of dependent LDS reads
+    auto range_of = [&](const int* cum, int v, int nlists, int from) -> int {
+      if (nlists == 1) {  // (wave-uniform)
+        const int4* c4 = reinterpret_cast<const int4*>(cum);
+        const int4 c0 = c4[0], c1 = c4[1], c2 = c4[2], c3 = c4[3];
+        return (c0.y <= v) + (c0.z <= v) + (c0.w <= v) + (c1.x <= v) + (c1.y <= v) + (c1.z <= v) + (c1.w <= v) + (c2.x <= v) + (c2.y <= v) + (c2.z <= v) +
+               (c2.w <= v) + (c3.x <= v) + (c3.y <= v) + (c3.z <= v);  // (cum[15] = the total > v)
+      }
+      int i = from;
+      while (cum[i] > v) --i;  // (only when the last batch is fetched a second time)
+      while (cum[i + 1] <= v) ++i;
+      return i;
+    };
     auto fetch_wide = [&](int s) {
       const int nrec = min(kGatherBatch, total - s * kGatherBatch);
       const int v = s * kGatherBatch + min(rec_id, nrec - 1);  // record of the concatenated ranges
       if (v < rlo || v >= rhi) {  // the range of the previous batch's record no longer holds this one
-        while (s_wcum[sri] > v) --sri;  // (only when the last batch is fetched a second time)
-        while (s_wcum[sri + 1] <= v) ++sri;
+        sri = range_of(s_wcum, v, a.nwide, sri);
         rlo = s_wcum[sri];
         rhi = s_wcum[sri + 1];
-        rptr = a.wide[sri / kRangeEntries].rec + (long long)(s_wstart[sri] - rlo) * QW;
+        rptr = (a.nwide == 1 ? a.wide[0].rec : a.wide[sri / kRangeEntries].rec) + (long long)(s_wstart[sri] - rlo) * QW;
       }
       const float4* p = rptr + (long long)v * QW;
       w0 = p[0];
@@ -2501,11 +2512,10 @@ __global__ __launch_bounds__(kBrickThreads, (K > 9 ? 2 : 4)) void brick_gather_k
       const int nrec = min(kGatherBatch, total_d - sd * kGatherBatch);
       const int v = sd * kGatherBatch + min(rec_id, nrec - 1);
       if (v < dlo || v >= dhi) {
-        while (s_ncum[dri] > v) --dri;
-        while (s_ncum[dri + 1] <= v) ++dri;
+        dri = range_of(s_ncum, v, a.nnarrow, dri);
         dlo = s_ncum[dri];
         dhi = s_ncum[dri + 1];
-        dptr = a.narrow[dri / kRangeEntries].rec + (long long)(s_nstart[dri] - dlo) * QN;
+        dptr = (a.nnarrow == 1 ? a.narrow[0].rec : a.narrow[dri / kRangeEntries].rec) + (long long)(s_nstart[dri] - dlo) * QN;
       }
       const float4* p = dptr + (long long)v * QN;
       d0 = p[0];
@@ -2513,6 +2523,10 @@ __global__ __launch_bounds__(kBrickThreads, (K > 9 ? 2 : 4)) void brick_gather_k
     };
     if (nbd > 0) fetch_narrow(0);
     if (nba > 0) fetch_wide(0);
+    // (behind the first batches' loads:) the weight table starts zero-filled; a record's thread clears the entries of the previous
+    // batch before it writes new ones
+    for (int i = tid; i < kGatherRow * kGatherWtab / 4; i += kBrickThreads) reinterpret_cast<float4*>(wtab)[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+    __syncthreads();
     for (int s = 0; s < nba; ++s) {
       const int nrec = min(kGatherBatch, total - s * kGatherBatch);
       if constexpr (K > 1)
