@@ -197,6 +197,7 @@ class TrainStepper:
         self._bins = None
         self._exec = None
         self.step_events = None  # an ops.StepEvents: the next rf_train_step call records its per-launch HIP events there
+        self.host_timing = None  # a list: the owner-computes step appends the host-side durations of its sections (seconds)
         grid = vol_mod.thre3d_repr
         if not isinstance(grid, VoxelGrid):
             raise AssertionError(f"cannot train a {type(grid)}; only a VoxelGrid can be used")
@@ -471,6 +472,8 @@ class TrainStepper:
         the own bricks over all ranks' lists | all-gather of the parameters."""
         ow = self._owner_state(ex, dev)
         W, me = ow["W"], ow["me"]
+        ht = [time.perf_counter()] if self.host_timing is not None else None  # host-side time line of the step (development aid)
+        tick = (lambda: ht.append(time.perf_counter())) if ht is not None else (lambda: None)
         # a 1-rank group (bench.py --dp-style-step, tests) has nothing to exchange: the record exchange and the parameter all-gather
         # are skipped unless RF_OWNER_FORCE_COLLECTIVES asks for the calls themselves to be exercised (tests do)
         collect = W > 1 or bool(os.environ.get("RF_OWNER_FORCE_COLLECTIVES"))
@@ -513,7 +516,9 @@ class TrainStepper:
             ow["ready"].record(ow["side"])
         if work is not None:
             work.wait()  # the brick pass on the main stream reads the tables too
+        tick()  # [1] forward + emit phases issued
         ow["ready"].synchronize()
+        tick()  # [2] slice bounds on the host
         b = ow["bounds_host"].numpy()  # [source, list, (lo, hi) per owner]
         sent = (W - 1) * t["offsets2"].numel() * 8  # the all-gather of the offset tables
         lists, pending = [], []
@@ -552,6 +557,7 @@ class TrainStepper:
             main.wait_event(ow["exchanged"][k])
         del pending
         mark(3)
+        tick()  # [3] exchanges issued
         opt.step_count += 1
         nd = self.flat.flat_gradient_parts()[0].numel()
         has_second = self.flat.flat_gradient_parts()[1] is not None
@@ -559,6 +565,7 @@ class TrainStepper:
         brick_accumulate_adam_raw(grid, self.brick_size, lists, halves(opt.exp_avg), halves(opt.exp_avg_sq), opt.lr, opt.betas[0], opt.betas[1],
                                   opt.eps, opt.step_count, brick_range=ow["bricks"])
         mark(4)
+        tick()  # [4] brick pass issued
         if collect:
             rfdist.all_gather_chunks_(self.flat.flat_param[:nd])
             if has_second:
@@ -581,6 +588,9 @@ class TrainStepper:
         self.owner_records = (self.owner_records + [(own[0] + int(ow["last_total"][0]), own[1] + int(ow["last_total"][1]))])[-64:]
         if ev is not None:
             self.phase_events.append(ev)
+        if ht is not None:
+            tick()  # [5] parameter all-gathers issued
+            self.host_timing.append([b_ - a_ for a_, b_ in zip(ht[:-1], ht[1:])])
 
     def _executor(self, n: int, S: int, device):
         """Persistent scratch + the ctypes description of one iteration (rebuilt when the batch shape changes)."""
