@@ -746,7 +746,8 @@ __device__ __forceinline__ int brick_key(const int i0[3], const GridArgs& g, int
     b3[a] = lo >> shift;
     f3[a] = (up < dims3[a] && (up >> shift) != b3[a]) ? 1 : 0;
   }
-  return (((((b3[0] << 1) | f3[0]) * nby + b3[1]) * nbz + b3[2]) << 2) | f3[1] | (f3[2] << 1);
+  // (brick counts are far below 2^24: full-rate 24-bit multiplies)
+  return (int)((__umul24(__umul24((unsigned)((b3[0] << 1) | f3[0]), (unsigned)nby) + (unsigned)b3[1], (unsigned)nbz) + (unsigned)b3[2]) << 2) | f3[1] | (f3[2] << 1);
 }
 
 // Parameter interval of a ray inside the box (same slab test as the AABB sampler, reciprocal-based: only used with a generous
@@ -1472,6 +1473,9 @@ __device__ __forceinline__ void render_emit_direct_ray(const GridArgs& g, const 
   int masks_group = (mask_words - 1) >> 6;
   unsigned long long lane_masks = fwd.cmask[ray * (long long)mask_words + min(masks_group * kWave + lane, mask_words - 1)];
 
+  // z of the sample behind the last chunk walked (lane 63 of a chunk takes its "next sample" from lane 0 of the chunk behind it, which
+  // the previous group of the far-to-near walk evaluated: one z per sample instead of two)
+  float z_edge = z_of(st, r, ray, nchunks * kWave);
   for (int c0 = nchunks - 1; c0 >= 0; c0 -= G) {
     float4 cv[G];
     float Tc[G], zz[G], zn[G];
@@ -1493,7 +1497,7 @@ __device__ __forceinline__ void render_emit_direct_ray(const GridArgs& g, const 
     // -- A1: every load of the group -- sample caches, t_vals (and the jitter table, if one is used) -- before the first use.
     // All unconditional, with clamped indices: a load under a condition is followed by a register merge that waits for it, which
     // had serialised the four chunks' cache loads and the t_vals reads of every sample into as many exposed memory latencies.
-    ZRequests zq[G][2];
+    ZRequests zq[G];
 #pragma unroll
     for (int u = 0; u < G; ++u) {
       const int chunk = max(c0 - u, 0);
@@ -1501,14 +1505,15 @@ __device__ __forceinline__ void render_emit_direct_ray(const GridArgs& g, const 
       const long long idx = cached_slot(ray, r.S, chunk, cm[u], lane);
       cv[u] = reinterpret_cast<const float4*>(fwd.cache)[idx];
       Tc[u] = fwd.tcache[idx];
-      zq[u][0] = z_requests(r, s);
-      zq[u][1] = z_requests(r, s + 1);
+      zq[u] = z_requests(r, s);
     }
 #pragma unroll
+    for (int u = 0; u < G; ++u) zz[u] = z_from(st, r, zq[u], ray, max(c0 - u, 0) * kWave + lane);
+#pragma unroll
     for (int u = 0; u < G; ++u) {
-      const int s = max(c0 - u, 0) * kWave + lane;
-      zz[u] = z_from(st, r, zq[u][0], ray, s);
-      zn[u] = z_from(st, r, zq[u][1], ray, s + 1);
+      const float up = dpp_move<kDppWaveShl1, 0xf>(0.0f, zz[u]);  // lane i <- lane i + 1
+      zn[u] = (lane == kWave - 1) ? z_edge : up;
+      z_edge = read_lane(zz[u], 0);  // the chunk in front of this one ends at it
     }
     // -- A2: geometry, keys and the cursor atomics of the group, back to back
     float dl[G], ix[G][3];
