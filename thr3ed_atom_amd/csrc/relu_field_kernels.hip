@@ -3271,6 +3271,8 @@ GridArgs to_args(const RFGrid* g) {
     a.dens_off = (unsigned int)(d0 - lo);
     a.feat_off = (unsigned int)(f0 - lo);
     a.near32 = nodes <= (1ull << 24) && db < (1ull << 24) && fb < (1ull << 24) && span < (1ull << 32);
+    // ($RF_FAR_ADDRESSING=1: the general 64-bit path on grids that would not need it -- tests compare the two)
+    if (const char* e = getenv("RF_FAR_ADDRESSING")) a.near32 = a.near32 && atoi(e) == 0;
   }
   return a;
 }
