@@ -2204,6 +2204,8 @@ __host__ __device__ inline int gather_lds_words(int B, int C) {
 
 // (SH degree 3: 49 channels = four 16-channel blocks, 64 accumulator registers and 123 KB of LDS -- one workgroup per CU, which
 // leaves a wave 256 registers)
+// ONE_ROUND: the launch is for 8^3-node bricks (the brick edge folds to a constant); with ADAM it also selects the one-round flush
+// (which additionally needs 32-bit byte offsets: the host checks)
 template <int K, bool ADAM, bool ONE_ROUND = false>
 __global__ __launch_bounds__(kBrickThreads, (K > 9 ? 2 : 4)) void brick_gather_kernel(GridArgs g, BrickArgs a, float* gdens, float* gfeat) {
   constexpr int C = 3 * K + 1;
@@ -3896,13 +3898,17 @@ static int brick_accumulate_impl(const RFGrid* grid, int32_t brick_size, const R
   }
   switch (K) {
     case 1:
-      return launch_gather<1, false>(g, a, nbricks, grad_densities_dev, grad_features_dev, st);
+      return shift == 3 ? launch_gather<1, false, true>(g, a, nbricks, grad_densities_dev, grad_features_dev, st)
+                        : launch_gather<1, false, false>(g, a, nbricks, grad_densities_dev, grad_features_dev, st);
     case 4:
-      return launch_gather<4, false>(g, a, nbricks, grad_densities_dev, grad_features_dev, st);
+      return shift == 3 ? launch_gather<4, false, true>(g, a, nbricks, grad_densities_dev, grad_features_dev, st)
+                        : launch_gather<4, false, false>(g, a, nbricks, grad_densities_dev, grad_features_dev, st);
     case 9:
-      return launch_gather<9, false>(g, a, nbricks, grad_densities_dev, grad_features_dev, st);
+      return shift == 3 ? launch_gather<9, false, true>(g, a, nbricks, grad_densities_dev, grad_features_dev, st)
+                        : launch_gather<9, false, false>(g, a, nbricks, grad_densities_dev, grad_features_dev, st);
     default:
-      return launch_gather<16, false>(g, a, nbricks, grad_densities_dev, grad_features_dev, st);
+      return shift == 3 ? launch_gather<16, false, true>(g, a, nbricks, grad_densities_dev, grad_features_dev, st)
+                        : launch_gather<16, false, false>(g, a, nbricks, grad_densities_dev, grad_features_dev, st);
   }
 }
 
