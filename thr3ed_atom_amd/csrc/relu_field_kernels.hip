@@ -24,8 +24,6 @@
 #include <stdint.h>
 
 #include <atomic>
-#include <mutex>
-#include <cstddef>
 #include <cstdlib>
 #include <type_traits>
 
@@ -1695,11 +1693,6 @@ struct BrickArgs {
   int accumulate;          // 0: grad = brick sum (no zero-fill needed), 1: grad += brick sum
   int fmul;                // reference layout: feature index of degree-0 colour c is c * fmul (base-only lists on an SH grid)
   int stagger;             // development builds (RF_BRICK_PROFILE): experiment / ablation switches from $RF_BRICK_STAGGER
-  // persistent workgroups: the grid is as many workgroups as fit the GPU at once; each takes bricks brick_first + ticket from a device
-  // counter until the tickets run out.  (One workgroup per brick left a fifth of the kernel's time between the end of a
-  // workgroup's code and the start of the next one's: its stores drain, the slot is released, a new workgroup is dispatched.)
-  int nbricks;
-  unsigned int* queue;     // [0] next ticket, [1] workgroups that have left; the last one to leave resets both for the next launch
   AdamArgs adam;           // only read by the ADAM instantiation
 };
 
@@ -1911,10 +1904,7 @@ __device__ __forceinline__ void brick_flush(const GridArgs& g, const BrickArgs& 
   constexpr int CS = (C + 3) / 4 * 4;
   const int B = ONE_ROUND ? 8 : (1 << a.shift);  // (ONE_ROUND: the host launches it for 8^3 bricks only -- strides fold to constants)
   const int SY = brick_row_stride(B, C), SX = brick_slab_stride(B, C);
-  // (opaque per call: inside the persistent loop of the caller everything derived from the thread index would be hoisted out of the
-  // loop -- 40 registers of addresses kept alive across the batches -- and spill)
-  int tid = threadIdx.x;
-  asm volatile("" : "+v"(tid));
+  const int tid = threadIdx.x;
   // ---- write the brick out: plain stores (exclusive owner), contiguous runs along z
   const bool split = g.layout == RF_LAYOUT_SPLIT;
   if (split && (C & 3) == 0 && (g.dstride & 3) == 0 && (C == 4 || (g.fstride & 3) == 0)) {
@@ -1951,18 +1941,20 @@ __device__ __forceinline__ void brick_flush(const GridArgs& g, const BrickArgs& 
         // the same offset for parameter, exp_avg and exp_avg_sq.  7 offsets + 84 data registers: all 21 loads of a thread are in
         // flight before its first store (vmcnt counts loads and stores together, so a second round's first wait would also sit out
         // the first round's stores).  (Byte offsets in 32 bits: the host checks the tensors for < 2^30 elements.)
-        // The quad's byte offset inside its tensor (0xffffffff: the node lies outside the grid) and the LDS position of its gradient are
-        // functions of (thread, u): evaluated once for the loads and AGAIN for the stores from a thread index the compiler cannot
-        // see through -- kept across the wait they would be 14 more registers next to the 84 of data.
-        auto quad_geometry = [&](int u, int t, unsigned int& bo, int& lds_at) {
+        unsigned int bo[QN];  // byte offset inside the quad's tensor; 0xffffffff: nothing to do
+        int lds_at[QN];
+        float4 p4[QN];
+        vf4 m4[QN], v4[QN];
+#pragma unroll
+        for (int u = 0; u < QN; ++u) {
           int fx, fy, fz, qd;
           if (u == 0) {
-            fx = t >> 6;
-            fy = (t >> 3) & 7;
-            fz = t & 7;
+            fx = tid >> 6;
+            fy = (tid >> 3) & 7;
+            fz = tid & 7;
             qd = 0;
           } else {
-            const int j = (u - 1) * 512 + t, col = j / 48, r = j - col * 48;
+            const int j = (u - 1) * 512 + tid, col = j / 48, r = j - col * 48;
             fz = r / 6;
             qd = 1 + r - 6 * fz;
             fx = col >> 3;
@@ -1972,34 +1964,24 @@ __device__ __forceinline__ void brick_flush(const GridArgs& g, const BrickArgs& 
           const unsigned int lin = ok ? node_lin(g, X0 + fx, Y0 + fy, Z0 + fz) : 0u;
           // (24-bit multiplies: the host launches this path for <= 2^24 nodes and strides < 2^24 only)
           const unsigned int o = u == 0 ? __umul24(lin, (unsigned)g.dstride) : __umul24(lin, (unsigned)g.fstride) + 4u * (unsigned)(qd - 1);
-          bo = ok ? o * 4u : 0xffffffffu;
-          lds_at = fx * SX + fy * SY + fz * CS + 4 * qd;
-        };
-        float4 p4[QN];
-        vf4 m4[QN], v4[QN];
+          bo[u] = ok ? o * 4u : 0xffffffffu;
+          lds_at[u] = fx * SX + fy * SY + fz * CS + 4 * qd;
+        }
 #pragma unroll
         for (int u = 0; u < QN; ++u) {
-          unsigned int bo;
-          int lds_at;
-          quad_geometry(u, tid, bo, lds_at);
-          if (bo != 0xffffffffu) {
+          if (bo[u] != 0xffffffffu) {
             const char* pb = reinterpret_cast<const char*>(u == 0 ? ad.p1 : ad.p2);
             const char* mb = reinterpret_cast<const char*>(u == 0 ? ad.m1 : ad.m2);
             const char* vb = reinterpret_cast<const char*>(u == 0 ? ad.v1 : ad.v2);
-            p4[u] = *reinterpret_cast<const float4*>(pb + bo);
-            m4[u] = __builtin_nontemporal_load(reinterpret_cast<const vf4*>(mb + bo));
-            v4[u] = __builtin_nontemporal_load(reinterpret_cast<const vf4*>(vb + bo));
+            p4[u] = *reinterpret_cast<const float4*>(pb + bo[u]);
+            m4[u] = __builtin_nontemporal_load(reinterpret_cast<const vf4*>(mb + bo[u]));
+            v4[u] = __builtin_nontemporal_load(reinterpret_cast<const vf4*>(vb + bo[u]));
           }
         }
-        int tid_again = tid;
-        asm volatile("" : "+v"(tid_again));
 #pragma unroll
         for (int u = 0; u < QN; ++u) {
-          unsigned int bo;
-          int lds_at;
-          quad_geometry(u, tid_again, bo, lds_at);
-          if (bo == 0xffffffffu) continue;
-          const float4 gq = any ? *reinterpret_cast<const float4*>(&acc[lds_at]) : make_float4(0.f, 0.f, 0.f, 0.f);
+          if (bo[u] == 0xffffffffu) continue;
+          const float4 gq = any ? *reinterpret_cast<const float4*>(&acc[lds_at[u]]) : make_float4(0.f, 0.f, 0.f, 0.f);
           float gg[4] = {gq.x, gq.y, gq.z, gq.w};
           float pn[4] = {p4[u].x, p4[u].y, p4[u].z, p4[u].w};
           if (u == 0 && g.mode == RF_DENSITY_ABS) {  // d|x|/dx of the raw density (the parameter before its update)
@@ -2017,9 +1999,9 @@ __device__ __forceinline__ void brick_flush(const GridArgs& g, const BrickArgs& 
           char* pb = reinterpret_cast<char*>(u == 0 ? ad.p1 : ad.p2);
           char* mb = reinterpret_cast<char*>(u == 0 ? ad.m1 : ad.m2);
           char* vb = reinterpret_cast<char*>(u == 0 ? ad.v1 : ad.v2);
-          *reinterpret_cast<float4*>(pb + bo) = make_float4(pn[0], pn[1], pn[2], pn[3]);
-          __builtin_nontemporal_store(mn, reinterpret_cast<vf4*>(mb + bo));
-          __builtin_nontemporal_store(vn, reinterpret_cast<vf4*>(vb + bo));
+          *reinterpret_cast<float4*>(pb + bo[u]) = make_float4(pn[0], pn[1], pn[2], pn[3]);
+          __builtin_nontemporal_store(mn, reinterpret_cast<vf4*>(mb + bo[u]));
+          __builtin_nontemporal_store(vn, reinterpret_cast<vf4*>(vb + bo[u]));
         }
         return;
       } else {
@@ -2222,26 +2204,10 @@ __host__ __device__ inline int gather_lds_words(int B, int C) {
 
 // (SH degree 3: 49 channels = four 16-channel blocks, 64 accumulator registers and 123 KB of LDS -- one workgroup per CU, which
 // leaves a wave 256 registers)
-// a kernel argument (or a part of one) read word by word through a pointer into the kernarg segment: scalar loads, placed where the
-// value is used (brick_gather_kernel hides the pointer from the optimizer once per brick of its persistent loop)
-typedef const __attribute__((address_space(4))) char* KernargBytes;
-template <class T>
-__device__ __forceinline__ T kernarg_words(KernargBytes p) {
-  static_assert(sizeof(T) % 4 == 0, "whole words");
-  union {
-    T value;
-    uint32_t words[sizeof(T) / 4];
-  } u;
-  const __attribute__((address_space(4))) uint32_t* src = (const __attribute__((address_space(4))) uint32_t*)p;
-#pragma unroll
-  for (size_t i = 0; i < sizeof(T) / 4; ++i) u.words[i] = src[i];
-  return u.value;
-}
-
 // ONE_ROUND: the launch is for 8^3-node bricks (the brick edge folds to a constant); with ADAM it also selects the one-round flush
 // (which additionally needs 32-bit byte offsets: the host checks)
 template <int K, bool ADAM, bool ONE_ROUND = false>
-__global__ __launch_bounds__(kBrickThreads, (K > 9 ? 2 : 4)) void brick_gather_kernel(GridArgs g_arg, BrickArgs a_arg, float* gdens_arg, float* gfeat_arg) {
+__global__ __launch_bounds__(kBrickThreads, (K > 9 ? 2 : 4)) void brick_gather_kernel(GridArgs g, BrickArgs a, float* gdens, float* gfeat) {
   constexpr int C = 3 * K + 1;
   constexpr int C4 = (C + 3) / 4 * 4;
   constexpr int QW = record_quads(K);      // quads of a full-width record in HBM
@@ -2259,52 +2225,15 @@ __global__ __launch_bounds__(kBrickThreads, (K > 9 ? 2 : 4)) void brick_gather_k
   __shared__ __attribute__((aligned(16))) int s_wstart[kMaxRangesKind], s_wcum[kMaxRangesKind + 8];  // ranges of the full-width lists: first record, running count
   __shared__ __attribute__((aligned(16))) int s_nstart[kMaxRangesKind], s_ncum[kMaxRangesKind + 8];  // ... of the base-channel lists of a mixed call
   __shared__ int s_part[4];
-  const int B = ONE_ROUND ? 8 : (1 << a_arg.shift);  // (ONE_ROUND: 8^3 bricks only -- tile counts and image strides fold to constants)
-  const int bshift = ONE_ROUND ? 3 : a_arg.shift;
+  const int B = ONE_ROUND ? 8 : (1 << a.shift);  // (ONE_ROUND: 8^3 bricks only -- tile counts and image strides fold to constants)
+  const int bshift = ONE_ROUND ? 3 : a.shift;
   const int SY = brick_row_stride(B, C), SX = brick_slab_stride(B, C);
 
-  __shared__ unsigned int s_ticket;
-  // the first brick's ticket; inside the loop thread 0 requests the NEXT ticket at the top of a brick (a returning atomic whose
-  // latency the whole brick hides) and publishes it at the bottom
-  if (threadIdx.x == 0) s_ticket = atomicAdd(&a_arg.queue[0], 1u);
-  __syncthreads();
-  for (;;) {
-  // (so are the kernel arguments: read through a pointer to the kernarg segment that the compiler cannot see through, they are
-  // fetched with scalar loads where a brick uses them -- hoisted out of the loop, the ~120 argument words spill into vector registers)
-  KernargBytes kp = (KernargBytes)__builtin_amdgcn_kernarg_segment_ptr();
-  asm volatile("" : "+s"(kp));
-  constexpr size_t kOffA = (sizeof(GridArgs) + 7) & ~size_t(7), kOffP = (kOffA + sizeof(BrickArgs) + 7) & ~size_t(7);
-  const GridArgs g = kernarg_words<GridArgs>(kp);
-  typedef const __attribute__((address_space(4))) BrickArgs* BrickArgsInPlace;
-  const BrickArgsInPlace ap = (BrickArgsInPlace)(kp + kOffA);  // (the lists are indexed dynamically: read in place)
-  BrickArgs a;  // the scalar part, copied
-  a.nwide = ap->nwide;
-  a.nnarrow = ap->nnarrow;
-  a.shift = ap->shift;
-  a.nbx = ap->nbx;
-  a.nby = ap->nby;
-  a.nbz = ap->nbz;
-  a.brick_first = ap->brick_first;
-  a.accumulate = ap->accumulate;
-  a.fmul = ap->fmul;
-  a.stagger = ap->stagger;
-  a.nbricks = ap->nbricks;
-  a.queue = ap->queue;
-  a.adam = kernarg_words<AdamArgs>(kp + kOffA + offsetof(BrickArgs, adam));
-  float* const gdens = kernarg_words<float*>(kp + kOffP);
-  float* const gfeat = kernarg_words<float*>(kp + kOffP + 8);
-  // (the thread index is made opaque per brick: everything derived from it -- lane roles, LDS addresses -- is then recomputed per
-  // brick instead of being hoisted out of the loop and kept in registers across the flush, which has none to spare)
-  int tid = threadIdx.x;
-  asm volatile("" : "+v"(tid));
+  RF_PROF_START();
+  const int tid = threadIdx.x;
   const int lane = tid & (kWave - 1);
   const int wave = tid >> 6;
-  const unsigned int ticket = s_ticket;
-  if (ticket >= (unsigned int)a.nbricks) break;  // (uniform)
-  unsigned int next_ticket = 0;
-  if (tid == 0) next_ticket = atomicAdd(&a.queue[0], 1u);
-  RF_PROF_START();
-  const int brick = a.brick_first + (int)ticket;
+  const int brick = a.brick_first + (int)blockIdx.x;
   const int bz = brick % a.nbz, by = (brick / a.nbz) % a.nby, bx = brick / (a.nbz * a.nby);
   const int X0 = bx << bshift, Y0 = by << bshift, Z0 = bz << bshift;
   // ---- range set-up: waves 0, 1 = the 15 ranges of each full-width list, waves 2, 3 = of each base-channel list; running
@@ -2316,7 +2245,7 @@ __global__ __launch_bounds__(kBrickThreads, (K > 9 ? 2 : 4)) void brick_gather_k
       const int nl = kind ? a.nnarrow : a.nwide;
       if (i < kRangeEntries * nl) {
         const int l = nl == 1 ? 0 : i / kRangeEntries;
-        const long long* offs = nl == 1 ? (kind ? ap->narrow[0].offsets : ap->wide[0].offsets) : (kind ? ap->narrow[l].offsets : ap->wide[l].offsets);
+        const long long* offs = nl == 1 ? (kind ? a.narrow[0].offsets : a.wide[0].offsets) : (kind ? a.narrow[l].offsets : a.wide[l].offsets);
         brick_range_entry(a, offs, bx, by, bz, i - l * kRangeEntries, start, cnt);
       }
     }
@@ -2343,8 +2272,8 @@ __global__ __launch_bounds__(kBrickThreads, (K > 9 ? 2 : 4)) void brick_gather_k
   const int total = s_wcum[kMaxRangesKind];
   const int total_d = s_ncum[kMaxRangesKind];
   const bool any = total > 0 || total_d > 0;
+  if (!any && a.accumulate) return;  // nothing reaches this brick
   RF_PROF_MARK(0);  // range set-up
-  if (any || !a.accumulate) {  // (else: nothing reaches this brick)
 
   // tiles: 2 x 2 x 4 nodes; tile t = (px * npy + py) * npz + pz
   const int npz = B >> 2, npy = B >> 1;
@@ -2555,8 +2484,8 @@ __global__ __launch_bounds__(kBrickThreads, (K > 9 ? 2 : 4)) void brick_gather_k
     // own registers per list kind (a conditionally assigned register is merged with a copy, and the copy waits for the load)
     int sri = 0, dri = 0;  // running range index of this thread (its records only move forward), the range's bounds cached
     int rlo = 0, rhi = 0, dlo = 0, dhi = 0;
-    const float4* rptr = ap->wide[0].rec;    // list base + (start of the range - its position in the concatenation)
-    const float4* dptr = ap->narrow[0].rec;
+    const float4* rptr = a.wide[0].rec;    // list base + (start of the range - its position in the concatenation)
+    const float4* dptr = a.narrow[0].rec;
     float4 w0 = make_float4(0.f, 0.f, 0.f, 0.f), w1 = w0, w2 = w0, d0 = w0, d1 = w0;
     // the range that holds record v of the concatenation: the largest i with cum[i] <= v.  One list (15 ranges, the single-GPU case):
     // the whole table in four independent 16-byte reads and 15 compares -- the walk below is a chain of dependent LDS reads
@@ -2579,7 +2508,7 @@ __global__ __launch_bounds__(kBrickThreads, (K > 9 ? 2 : 4)) void brick_gather_k
         sri = range_of(s_wcum, v, a.nwide, sri);
         rlo = s_wcum[sri];
         rhi = s_wcum[sri + 1];
-        rptr = (a.nwide == 1 ? ap->wide[0].rec : ap->wide[sri / kRangeEntries].rec) + (long long)(s_wstart[sri] - rlo) * QW;
+        rptr = (a.nwide == 1 ? a.wide[0].rec : a.wide[sri / kRangeEntries].rec) + (long long)(s_wstart[sri] - rlo) * QW;
       }
       const float4* p = rptr + (long long)v * QW;
       w0 = p[0];
@@ -2593,7 +2522,7 @@ __global__ __launch_bounds__(kBrickThreads, (K > 9 ? 2 : 4)) void brick_gather_k
         dri = range_of(s_ncum, v, a.nnarrow, dri);
         dlo = s_ncum[dri];
         dhi = s_ncum[dri + 1];
-        dptr = (a.nnarrow == 1 ? ap->narrow[0].rec : ap->narrow[dri / kRangeEntries].rec) + (long long)(s_nstart[dri] - dlo) * QN;
+        dptr = (a.nnarrow == 1 ? a.narrow[0].rec : a.narrow[dri / kRangeEntries].rec) + (long long)(s_nstart[dri] - dlo) * QN;
       }
       const float4* p = dptr + (long long)v * QN;
       d0 = p[0];
@@ -2648,23 +2577,7 @@ __global__ __launch_bounds__(kBrickThreads, (K > 9 ? 2 : 4)) void brick_gather_k
   }
   brick_flush<K, ADAM, ONE_ROUND>(g, a, acc, any, X0, Y0, Z0, gdens, gfeat);
   RF_PROF_MARK(4);  // flush (stores issued, not necessarily retired)
-  }
   RF_PROF_END();
-  // the next brick: its set-up overwrites the range tables and, later, the batch buffers the flush has just read the image from
-  __syncthreads();
-  if (tid == 0) s_ticket = next_ticket;
-  __syncthreads();
-  }
-  if (threadIdx.x == 0) {
-    const unsigned int left = atomicAdd(&a_arg.queue[1], 1u);
-    if (left == gridDim.x - 1) {  // every workgroup has drawn its last ticket: ready for the next launch (same stream)
-      a_arg.queue[0] = 0u;
-      a_arg.queue[1] = 0u;
-    }
-  }
-  (void)g_arg;
-  (void)gdens_arg;
-  (void)gfeat_arg;
 }
 
 // =============================================================================================
@@ -3855,22 +3768,6 @@ int rf_scatter_records(const RFGrid* grid, const int16_t* keys_dev, const float*
 
 int32_t rf_expanded_record_floats(int32_t num_features) { return 4 * record_quads(num_features / 3); }
 
-// the ticket counter of the persistent brick pass: two zeroed words per device, allocated once (the kernel leaves them zeroed; launches
-// of the pass on ONE device are expected on one stream at a time, as every caller in this library issues them)
-static unsigned int* brick_queue(int dev) {
-  static std::atomic<unsigned int*> queues[64];
-  unsigned int* q = queues[dev].load(std::memory_order_acquire);
-  if (q) return q;
-  static std::mutex mu;
-  std::lock_guard<std::mutex> lock(mu);
-  q = queues[dev].load(std::memory_order_acquire);
-  if (q) return q;
-  if (hipMalloc(reinterpret_cast<void**>(&q), 2 * sizeof(unsigned int)) != hipSuccess) return nullptr;
-  if (hipMemset(q, 0, 2 * sizeof(unsigned int)) != hipSuccess) return nullptr;
-  queues[dev].store(q, std::memory_order_release);
-  return q;
-}
-
 extern "C++" {
 template <int K, bool ADAM, bool ONE_ROUND = false>
 static int launch_gather(const GridArgs& g, const BrickArgs& a, int nbricks, float* gd, float* gf, hipStream_t st) {
@@ -3886,28 +3783,7 @@ static int launch_gather(const GridArgs& g, const BrickArgs& a, int nbricks, flo
       return RF_ERR_LAUNCH;
     configured[dev].store(lds, std::memory_order_relaxed);
   }
-  // persistent grid: as many workgroups as are resident at once (LDS admits two per CU for full-width lists), fed by a ticket counter
-  static std::atomic<int> resident[64];
-  int per_cu = resident[dev].load(std::memory_order_relaxed);
-  if (per_cu == 0) {
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void*>(&brick_gather_kernel<K, ADAM, ONE_ROUND>), kBrickThreads, lds) !=
-            hipSuccess ||
-        per_cu < 1)
-      per_cu = 1;
-    resident[dev].store(per_cu, std::memory_order_relaxed);
-  }
-  static std::atomic<int> cus[64];
-  int ncu = cus[dev].load(std::memory_order_relaxed);
-  if (ncu == 0) {
-    if (hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || ncu < 1) ncu = 1;
-    cus[dev].store(ncu, std::memory_order_relaxed);
-  }
-  BrickArgs b = a;
-  b.nbricks = nbricks;
-  b.queue = brick_queue(dev);
-  if (!b.queue) return RF_ERR_LAUNCH;
-  const int grid = nbricks < per_cu * ncu ? nbricks : per_cu * ncu;
-  hipLaunchKernelGGL((brick_gather_kernel<K, ADAM, ONE_ROUND>), dim3(grid), dim3(kBrickThreads), lds, st, g, b, gd, gf);
+  hipLaunchKernelGGL((brick_gather_kernel<K, ADAM, ONE_ROUND>), dim3(nbricks), dim3(kBrickThreads), lds, st, g, a, gd, gf);
   return launch_status();
 }
 }  // extern "C++"
