@@ -1692,7 +1692,8 @@ struct BrickArgs {
   int brick_first;         // workgroup i handles brick brick_first + i (data parallel: the rank's own x-slabs)
   int accumulate;          // 0: grad = brick sum (no zero-fill needed), 1: grad += brick sum
   int fmul;                // reference layout: feature index of degree-0 colour c is c * fmul (base-only lists on an SH grid)
-  int stagger;             // development builds (RF_BRICK_PROFILE): experiment / ablation switches from $RF_BRICK_STAGGER
+  int stagger;             // development builds (RF_BRICK_PROFILE / RF_BRICK_ABLATE): ablation switches from $RF_BRICK_STAGGER (0x100000 no tile
+                           // loop, 0x200000 no lists, 0x400000 no flush)
   AdamArgs adam;           // only read by the ADAM instantiation
 };
 
@@ -2379,7 +2380,7 @@ __global__ __launch_bounds__(kBrickThreads, (K > 9 ? 2 : 4)) void brick_gather_k
       RF_PROF_MARK(2);  // ... and its barrier
       // every wave lists the records of ITS tiles (ballot + prefix count: list order = record order) ...
       int cnt[4] = {0, 0, 0, 0};
-#ifdef RF_BRICK_PROFILE
+#if defined(RF_BRICK_PROFILE) || defined(RF_BRICK_ABLATE)
       const bool no_lists = a.stagger & 0x200000, no_tiles = a.stagger & 0x100000;
 #else
       constexpr bool no_lists = false, no_tiles = false;
@@ -2575,6 +2576,9 @@ __global__ __launch_bounds__(kBrickThreads, (K > 9 ? 2 : 4)) void brick_gather_k
     __syncthreads();
     RF_PROF_MARK(5);  // accumulator image
   }
+#if defined(RF_BRICK_PROFILE) || defined(RF_BRICK_ABLATE)
+  if (!(a.stagger & 0x400000))  // (ablation: the batch phases alone)
+#endif
   brick_flush<K, ADAM, ONE_ROUND>(g, a, acc, any, X0, Y0, Z0, gdens, gfeat);
   RF_PROF_MARK(4);  // flush (stores issued, not necessarily retired)
   RF_PROF_END();
@@ -3882,7 +3886,7 @@ static int brick_accumulate_impl(const RFGrid* grid, int32_t brick_size, const R
       const unsigned long long smax = (unsigned long long)(grid->density_stride > grid->feature_stride ? grid->density_stride : grid->feature_stride);
       a.adam.byte_offsets_fit_32_bits = nodes * smax < (1ull << 30) && nodes <= (1ull << 24) && smax < (1ull << 24);
     }
-#ifdef RF_BRICK_PROFILE
+#if defined(RF_BRICK_PROFILE) || defined(RF_BRICK_ABLATE)
     {
       const char* e = getenv("RF_BRICK_STAGGER");
       a.stagger = e ? atoi(e) : 0;

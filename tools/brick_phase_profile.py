@@ -48,9 +48,17 @@ for _ in range(5):
     stepper.step(data, next(batches))
 out = (C.c_ulonglong * 8)()
 lib.rf_debug_brick_profile(out, 1)
-for _ in range(steps):
+from thr3ed_atom_amd import ops  # noqa: E402
+
+events = [ops.StepEvents() for _ in range(steps)]
+for k in range(steps):
+    stepper.step_events = events[k]
     stepper.step(data, next(batches))
+stepper.step_events = None
+torch.cuda.synchronize()
 lib.rf_debug_brick_profile(out, 0)
+brick_ms = sum(e.elapsed_ms()["brick_accumulate"] for e in events) / steps
+print(f"brick pass of this instrumented build: {brick_ms:.4f} ms per launch ($RF_BRICK_STAGGER = {os.environ.get('RF_BRICK_STAGGER', '0')})")
 names = ["range set-up", "batch: wait for loads + LDS stores + barrier", "batch: barriers after record pass / tiles", "batch: lists + tiles (MFMA), wave 0", "flush / optimizer", "accumulator image", "batch: issue of the next loads", "batch: record pass, wave 0"]
 nb = 4096 * steps
 tot = sum(out[i] for i in range(len(names)))
