@@ -1022,3 +1022,54 @@ def test_autograd_trainer_with_deferred_gradients_equals_the_fused_step(hip_devi
         np.testing.assert_allclose(b.cpu().numpy(), a.cpu().numpy(), rtol=2e-4, atol=2e-6 * float(a.abs().max()))
     flat.zero_grad()
     assert flat.pending == []
+
+
+_PAIR_SCRIPT = r"""
+import json, sys
+import numpy as np, torch
+sys.path.insert(0, {root!r})
+import thr3ed_atom_amd as rf
+from thr3ed_atom_amd.trainers import TrainStepper
+from tests.helpers import hash_uniform, hotdog_like_camera, procedural_grid
+dev = torch.device("cuda:0")
+cam = hotdog_like_camera()
+dens, feat = procedural_grid((24, 24, 24), 27, 5)
+grid = rf.VoxelGrid(torch.from_numpy(np.asarray(dens)).to(dev), torch.from_numpy(np.asarray(feat)).to(dev), rf.VoxelSize(3.0 / 24, 3.0 / 24, 3.0 / 24),
+                    rf.VoxelGridLocation(), density_preactivation=torch.nn.Identity(), density_postactivation=torch.nn.ReLU(),
+                    expected_density_scale=30.0, tunable=True, storage="split")
+cfg = rf.SHVoxGridRenderConfig(96, rf.CameraBounds(cam["near"], cam["far"]), perturb_sampled_points=True, white_bkgd=True)
+model = rf.VolumetricModel(grid, rf.render_sh_voxel_grid, cfg, device=dev)
+rays = rf.flatten_rays(rf.cast_rays(rf.CameraIntrinsics(31, 33, 40.0), rf.pose_spherical(25.0, -35.0, cam["radius"]), dev))
+n = rays.origins.shape[0]
+pixels = torch.from_numpy(np.asarray(hash_uniform((n, 3), 19, 0.0, 1.0))).to(dev)
+st = TrainStepper(model, n, learning_rate=0.03, fused=True, backward="binned")
+losses = []
+for it in range(4):
+    t_rands = [torch.from_numpy(np.asarray(hash_uniform((n, 96), 100 + 2 * it + i, 0.0, 1.0))).clamp_(0.0, 1.0 - 2.0**-24).to(dev) for i in range(2)]
+    s = st.step_on(rays, pixels, t_rand=t_rands)
+    losses.append([float(s.specular_loss), float(s.diffuse_loss)])
+torch.cuda.synchronize()
+d, f = grid.densities.detach().double(), grid.features.detach().double()
+print("RESULT " + json.dumps(dict(losses=losses, sums=[float(d.sum()), float(d.abs().sum()), float(f.sum()), float(f.abs().sum())])))
+"""
+
+
+@pytest.mark.gpu
+def test_paired_launches_equal_one_launch_per_render(hip_device):
+    """rf_train_step runs both renders of an iteration in one launch and both adjoints in one launch; $RF_FWD_PAIR=0 / $RF_EMIT_PAIR=0
+    (read once per process) restore one launch per render: same losses, parameters equal to the rounding of the (unordered) cursor
+    atomics -- the per-ray code is the same function in both."""
+    import json
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    outs = []
+    for pair in ("1", "0"):
+        env = dict(os.environ, RF_FWD_PAIR=pair, RF_EMIT_PAIR=pair)
+        r = subprocess.run([sys.executable, "-c", _PAIR_SCRIPT.format(root=root)], env=env, capture_output=True, text=True, timeout=600, cwd=root)
+        line = [x for x in r.stdout.splitlines() if x.startswith("RESULT ")]
+        assert line, r.stdout[-2000:] + r.stderr[-2000:]
+        outs.append(json.loads(line[0][len("RESULT "):]))
+    np.testing.assert_allclose(np.array(outs[0]["losses"]), np.array(outs[1]["losses"]), rtol=2e-6)
+    np.testing.assert_allclose(outs[0]["sums"], outs[1]["sums"], rtol=1e-6)
