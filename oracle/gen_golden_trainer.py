@@ -8,7 +8,12 @@ the Adam step.  Only arrays are written (tests/golden/g9_trainer_trajectory.npz)
 The reference imports packages this image lacks for things OFF the render path (logging/IO only).  They
 are replaced, in THIS process only, by inert stand-ins: easydict (type annotation), imageio (PNG writer),
 lpips (test metric, unused in fast_debug_mode), torch.utils.tensorboard (scalar logger), torchvision
-(ToTensor / identity Resize for PIL images).  The reference's sources are not modified.
+(ToTensor / Resize for the image pyramid of the stage schedule).  The reference's sources are not modified.
+
+``python oracle/gen_golden_trainer.py``            -> G9  (one stage, 5 iterations; tests/golden/g9_trainer_trajectory.npz)
+``python oracle/gen_golden_trainer.py --stages``   -> G9b (the full stage schedule of trainers.py:125-152,227-250,462-470: two stages,
+    12^3 -> 24^3 at SH degree 2, per-stage Adam + ExponentialLR, stratified jitter ON, images of a procedural scene rendered by the
+    reference renderer, a held-out view rendered by the reference at the end; tests/golden/g9b_trainer_stages.npz)
 """
 import json
 import os
@@ -56,6 +61,19 @@ class _Identity:
         return x
 
 
+class _Resize:
+    """torchvision.transforms.Resize on a [C,H,W] tensor: identity at the native size (G9), antialiased bilinear otherwise (G9b's
+    coarse stage; the pixels the trainer then selects are recorded in the fixture, so the filter itself is not part of any parity claim)"""
+
+    def __init__(self, size, *a, **k):
+        self.size = tuple(int(v) for v in size)
+
+    def __call__(self, x):
+        if tuple(x.shape[-2:]) == self.size:
+            return x
+        return torch.nn.functional.interpolate(x[None], size=self.size, mode="bilinear", align_corners=False, antialias=True)[0].clamp(0.0, 1.0)
+
+
 class _Compose:
     def __init__(self, ts):
         self.ts = ts
@@ -72,7 +90,7 @@ _module("lpips", LPIPS=lambda *a, **k: None)
 _module("torch.utils.tensorboard", SummaryWriter=_Writer)
 _tv = _module("torchvision")
 _tv.transforms = _module(
-    "torchvision.transforms", Compose=_Compose, RandomHorizontalFlip=_Identity, Resize=_Identity, ToTensor=_ToTensor
+    "torchvision.transforms", Compose=_Compose, RandomHorizontalFlip=_Identity, Resize=_Resize, ToTensor=_ToTensor
 )
 
 from PIL import Image  # noqa: E402
@@ -214,5 +232,220 @@ def main():
     print(f"wrote {path}: {os.path.getsize(path) / 1024:.1f} KiB; losses {out['specular_loss']} {out['diffuse_loss']}")
 
 
+# ------------------------------------------------------------------------------------------------------------------------------
+# G9b: the stage schedule (modules/trainers.py:125-152 sizes + re-init, :227-250 per-stage Adam + ExponentialLR, :462-470 x2 up-scaling)
+# ------------------------------------------------------------------------------------------------------------------------------
+B_G, B_DEG, B_HW, B_RAYS, B_SAMPLES, B_ITERS, B_STAGES = 24, 2, 32, 512, 48, 300, 2
+B_F = 3 * (B_DEG + 1) ** 2
+B_LR, B_GAMMA, B_DECAY_STEPS, B_STAGE_GAMMA = 0.03, 0.5, 100, 0.9
+B_FOCAL, B_RADIUS = 44.4, 4.0311
+B_TRAIN_POSES = [(18.0 * i + 5.0, (-20.0, -40.0, -62.0)[i % 3]) for i in range(20)]   # (yaw, pitch) of pose_spherical
+B_HELDOUT_POSE = (63.0, -33.0)
+B_EVAL_SAMPLES = 96
+JITTER_SEED0 = 50_000  # t_rand of the k-th torch.rand call of the run = hash_uniform((N, S), JITTER_SEED0 + k, 0, 1)
+
+
+def ground_truth_scene(G=32):
+    """a smooth procedural scene: one soft ball with a position- and view-dependent colour (reference layout tensors)"""
+    ax = ((np.arange(G, dtype=np.float32) + 0.5) / G * 3.0 - 1.5)
+    x, y, z = np.meshgrid(ax, ax, ax, indexing="ij")
+    r = np.sqrt((x / 0.9) ** 2 + (y / 0.75) ** 2 + (z / 0.8) ** 2)
+    dens = (0.9 - r).astype(np.float32)[..., None] * 0.6  # raw density, positive inside the ellipsoid
+    K = (B_DEG + 1) ** 2
+    feat = np.zeros((G, G, G, 3, K), dtype=np.float32)
+    feat[..., 0, 0] = 2.0 * np.sin(2.1 * x) + 0.8
+    feat[..., 1, 0] = 2.0 * np.cos(1.7 * y) - 0.4
+    feat[..., 2, 0] = 2.0 * np.sin(1.3 * z + 0.5)
+    feat[..., :, 1:4] = 0.6 * hash_uniform((G, G, G, 3, 3), 4242)  # mild view dependence
+    return torch.from_numpy(dens), torch.from_numpy(feat.reshape(G, G, G, 3 * K))
+
+
+def main_stages():
+    from thre3d_atom.rendering.volumetric.utils.misc import cast_rays, flatten_rays
+    from thre3d_atom.utils.imaging_utils import CameraIntrinsics
+    from thre3d_atom.utils.metric_utils import mse2psnr
+
+    torch.manual_seed(4242)
+    np.random.seed(4242)
+    tmp = Path(tempfile.mkdtemp(prefix="g9b_"))
+    img_dir = tmp / "images"
+    img_dir.mkdir()
+
+    def relu_grid(dens, feat, G, tunable):
+        return VoxelGrid(densities=dens, features=feat, voxel_size=VoxelSize(3.0 / G, 3.0 / G, 3.0 / G), density_preactivation=torch.nn.Identity(),
+                         density_postactivation=torch.nn.ReLU(), expected_density_scale=100.0 / 3.0, tunable=tunable)
+
+    # ---- the scene, photographed by the REFERENCE renderer (8-bit PNGs: what a dataset on disk holds) ----
+    bounds_json = [2.0, 6.0]
+    gt_dens, gt_feat = ground_truth_scene()
+    near, far = np.float32(2.0) * 0.9, np.float32(6.0) * 1.1
+    from thre3d_atom.utils.imaging_utils import CameraBounds
+    gt_cfg = SHVoxGridRenderConfig(num_samples_per_ray=128, camera_bounds=CameraBounds(near, far), perturb_sampled_points=False, white_bkgd=True)
+    gt_model = VolumetricModel(relu_grid(gt_dens, gt_feat, 32, False), render_sh_voxel_grid, gt_cfg, device=torch.device("cpu"))
+    intr = CameraIntrinsics(B_HW, B_HW, B_FOCAL)
+    params = {}
+    for i, (yaw, pitch) in enumerate(B_TRAIN_POSES):
+        pose = pose_spherical(yaw, pitch, B_RADIUS)
+        img = gt_model.render(pose, intr).colour.clamp(0, 1).numpy()
+        name = f"img_{i:02d}.png"
+        Image.fromarray((img * 255.0 + 0.5).astype(np.uint8)).save(img_dir / name)
+        params[name] = {
+            "extrinsic": {"rotation": pose.rotation.numpy().tolist(), "translation": pose.translation.numpy().tolist()},
+            "intrinsic": {"height": B_HW, "width": B_HW, "focal": B_FOCAL, "bounds": bounds_json},
+        }
+    with open(tmp / "camera_params.json", "w") as fh:
+        json.dump(params, fh)
+    held_pose = pose_spherical(*B_HELDOUT_POSE, B_RADIUS)
+    held_truth = gt_model.render(held_pose, intr).colour.clamp(0, 1)
+
+    dataset = PosedImagesDataset(img_dir, tmp / "camera_params.json")
+    grid = relu_grid(torch.zeros(B_G, B_G, B_G, 1), torch.zeros(B_G, B_G, B_G, B_F), B_G, True)
+    cfg = SHVoxGridRenderConfig(num_samples_per_ray=B_SAMPLES, camera_bounds=dataset.camera_bounds, perturb_sampled_points=True, white_bkgd=True)
+    model = VolumetricModel(grid, render_sh_voxel_grid, cfg, device=torch.device("cpu"))
+
+    rec = {"image_ids": [], "sel": [], "losses": [], "snap": {}, "rand_calls": 0, "last_perm": None, "steps": 0, "datasets": {}}
+
+    # -- the trainer's random sources, recorded (randperm) or replaced by a procedural table (the stratified jitter: sample.py:63) --
+    real_getitem = PosedImagesDataset.__getitem__
+
+    def recording_getitem(self, index):
+        rec["datasets"].setdefault(self.camera_intrinsics.height, self)
+        rec["image_ids"].append(int(self._image_file_paths[index].name[4:6]))
+        return real_getitem(self, index)
+
+    real_randperm = torch.randperm
+
+    def recording_randperm(n, *a, **k):
+        out = real_randperm(n, *a, **k)
+        rec["last_perm"] = out
+        return out
+
+    real_rand = torch.rand
+
+    def procedural_rand(*size, **k):
+        shape = tuple(size[0]) if len(size) == 1 and not isinstance(size[0], int) else tuple(size)
+        t = torch.from_numpy(hash_uniform(shape, JITTER_SEED0 + rec["rand_calls"], 0.0, 1.0))
+        rec["rand_calls"] += 1
+        return t.to(k.get("device", "cpu"))
+
+    real_select = ref_trainers.sample_random_rays_and_pixels_synchronously
+
+    def recording_select(rays, pixels, sample_size):
+        n_before = len(rec["sel"])
+        r, p = real_select(rays, pixels, sample_size)
+        perm = rec["last_perm"]
+        assert perm is not None and perm.numel() == len(rays)
+        sel = perm[:sample_size]
+        assert torch.equal(r.origins, rays.origins[sel]) and torch.equal(p, pixels[sel])
+        rec["sel"].append(sel.to(torch.int16).clone())
+        rec["first_rand_call_of_step"] = rec.get("first_rand_call_of_step", []) + [rec["rand_calls"]]
+        assert len(rec["sel"]) == n_before + 1
+        return r, p
+
+    real_l1 = ref_trainers.l1_loss
+
+    def recording_l1(a, b):
+        out = real_l1(a, b)
+        rec["losses"].append(float(out.detach()))
+        return out
+
+    real_step = torch.optim.Adam.step
+
+    def recording_step(self, *a, **k):
+        out = real_step(self, *a, **k)
+        rec["steps"] += 1
+        ps = [p for g in self.param_groups for p in g["params"]]
+        if rec["steps"] in (1, B_ITERS, B_ITERS + 1, B_STAGES * B_ITERS):
+            rec["snap"][rec["steps"]] = (ps[0].detach().clone(), ps[1].detach().clone(), float(self.param_groups[0]["lr"]))
+        return out
+
+    real_scale = ref_trainers.scale_voxel_grid_with_required_output_size
+    scaled = []
+
+    def recording_scale(g, output_size, mode="trilinear"):
+        out = real_scale(g, output_size=output_size, mode=mode)
+        scaled.append((out.densities.detach().clone(), out.features.detach().clone()))
+        return out
+
+    PosedImagesDataset.__getitem__ = recording_getitem
+    torch.randperm = recording_randperm
+    torch.rand = procedural_rand
+    ref_trainers.sample_random_rays_and_pixels_synchronously = recording_select
+    ref_trainers.l1_loss = recording_l1
+    ref_trainers.visualize_sh_vox_grid_vol_mod_rendered_feedback = lambda **k: None
+    ref_trainers.scale_voxel_grid_with_required_output_size = recording_scale
+    torch.optim.Adam.step = recording_step
+    try:
+        ref_trainers.train_sh_vox_grid_vol_mod_with_posed_images(
+            vol_mod=model, train_dataset=dataset, output_dir=tmp / "out", random_initializer=procedural_init, image_batch_cache_size=8,
+            ray_batch_size=B_RAYS, num_stages=B_STAGES, num_iterations_per_stage=B_ITERS, scale_factor=2.0, learning_rate=B_LR,
+            lr_decay_gamma_per_stage=B_GAMMA, lr_decay_steps_per_stage=B_DECAY_STEPS, stagewise_lr_decay_gamma=B_STAGE_GAMMA,
+            save_freq=10**6, test_freq=10**6, feedback_freq=10**6, summary_freq=50, fast_debug_mode=True, verbose_rendering=False,
+        )
+        # the trained field, photographed by the reference from a view it never saw (jitter off)
+        held = model.render(held_pose, intr, perturb_sampled_points=False, num_samples_per_ray=B_EVAL_SAMPLES)
+        train0 = model.render(pose_spherical(*B_TRAIN_POSES[0], B_RADIUS), intr, perturb_sampled_points=False, num_samples_per_ray=B_EVAL_SAMPLES)
+    finally:
+        torch.optim.Adam.step = real_step
+        torch.randperm = real_randperm
+        torch.rand = real_rand
+        PosedImagesDataset.__getitem__ = real_getitem
+        ref_trainers.sample_random_rays_and_pixels_synchronously = real_select
+        ref_trainers.l1_loss = real_l1
+        ref_trainers.scale_voxel_grid_with_required_output_size = real_scale
+
+    total = B_STAGES * B_ITERS
+    # (the DataLoader of a stage is built -- and its first batch drawn -- once per stage; dataset[i] calls come 8 per iteration)
+    ids = np.array(rec["image_ids"][3:], dtype=np.int16)  # (the first three dataset[0] look-ups are the trainer's feedback-pose set-up, trainers.py:157-162)
+    assert len(rec["sel"]) == total and len(rec["losses"]) == 2 * total and ids.size == 8 * total, (len(rec["sel"]), ids.size)
+    assert rec["rand_calls"] == 2 * total and rec["first_rand_call_of_step"] == list(range(0, 2 * total, 2))
+    assert len(scaled) == 2  # the initial down-scaling (re-initialised afterwards) and the stage transition
+    psnr = lambda a, b: float(mse2psnr(torch.nn.functional.mse_loss(a, b)))
+    train0_truth = dataset[int(np.where(np.array([int(p.name[4:6]) for p in dataset._image_file_paths]) == 0)[0][0])][0].permute(1, 2, 0)
+    # per-stage tables: the images the stage trained on and every ray of every image (cast by the reference)
+    out = {}
+    for stage, h in ((1, B_HW // 2), (2, B_HW)):
+        ds = rec["datasets"][h]
+        order = np.argsort([int(p.name[4:6]) for p in ds._image_file_paths])
+        imgs, dirs, orgs = [], [], []
+        for j in order:
+            image, pose = real_getitem(ds, int(j))
+            rays = flatten_rays(cast_rays(ds.camera_intrinsics, ref_trainers.CameraPose(rotation=pose[:, :3], translation=pose[:, 3:]), device=torch.device("cpu")))
+            imgs.append(image.permute(1, 2, 0).reshape(-1, 3))
+            dirs.append(rays.directions)
+            orgs.append(rays.origins[0])
+        out[f"pixels_stage{stage}"] = torch.stack(imgs).numpy()        # [20, h*w, 3]
+        out[f"directions_stage{stage}"] = torch.stack(dirs).numpy()    # [20, h*w, 3]
+        out["camera_origins"] = torch.stack(orgs).numpy()              # [20, 3]
+        out[f"intrinsics_stage{stage}"] = np.array([ds.camera_intrinsics.height, ds.camera_intrinsics.width, ds.camera_intrinsics.focal], dtype=np.float64)
+    sub = (np.add.outer(np.add.outer(np.arange(B_G), np.arange(B_G)), np.arange(B_G)) % 4) == 0  # nodes of the up-scaled grid kept in the fixture
+    out.update({
+        "image_ids": ids.reshape(total, 8),
+        "selection": torch.stack(rec["sel"]).numpy(),                  # [total, 512] int16 into the step's 8 * h * w concatenated rays
+        "specular_loss": np.array(rec["losses"][0::2]), "diffuse_loss": np.array(rec["losses"][1::2]),
+        "dens_after_step1": rec["snap"][1][0].numpy(), "feat_after_step1": rec["snap"][1][1].numpy(),
+        "dens_stage1_end": rec["snap"][B_ITERS][0].numpy(), "feat_stage1_end": rec["snap"][B_ITERS][1].numpy(),
+        "upscaled_nodes_kept": sub, "dens_upscaled_kept": scaled[1][0].numpy()[sub], "feat_upscaled_kept": scaled[1][1].numpy()[sub],
+        "dens_final": rec["snap"][total][0].numpy(), "feat_final": rec["snap"][total][1].numpy(),
+        "lr_at": np.array([rec["snap"][k][2] for k in (1, B_ITERS, B_ITERS + 1, total)]),
+        "heldout_rotation": held_pose.rotation.numpy(), "heldout_translation": held_pose.translation.numpy(),
+        "heldout_truth": held_truth.numpy(), "heldout_render": held.colour.numpy(), "heldout_depth": held.depth.numpy(),
+        "train0_render": train0.colour.numpy(), "train0_truth": train0_truth.numpy(),
+        "heldout_psnr": np.float64(psnr(held.colour, held_truth)), "train0_psnr": np.float64(psnr(train0.colour, train0_truth)),
+        "near": np.float64(dataset.camera_bounds.near), "far": np.float64(dataset.camera_bounds.far),
+        "config": np.array([B_G, B_DEG, B_HW, len(B_TRAIN_POSES), B_RAYS, B_ITERS, B_SAMPLES, B_STAGES, B_EVAL_SAMPLES, JITTER_SEED0]),
+        "schedule": np.array([B_LR, B_GAMMA, B_DECAY_STEPS, B_STAGE_GAMMA]),
+        "meta": np.array([f"torch={torch.__version__}", "reference trainer: modules/trainers.py:49, num_stages=2, perturb on (procedural torch.rand)"]),
+    })
+    os.makedirs(GOLDEN_DIR, exist_ok=True)
+    path = os.path.join(GOLDEN_DIR, "g9b_trainer_stages.npz")
+    np.savez_compressed(path, **out)
+    print(f"wrote {path}: {os.path.getsize(path) / 1024:.1f} KiB; held-out PSNR {out['heldout_psnr']:.3f} dB, training view {out['train0_psnr']:.3f} dB; "
+          f"losses first/last {out['specular_loss'][0]:.4f} / {out['specular_loss'][-1]:.4f}; lr {out['lr_at']}")
+
+
 if __name__ == "__main__":
-    main()
+    if "--stages" in sys.argv[1:]:
+        main_stages()
+    else:
+        main()

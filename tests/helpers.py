@@ -60,3 +60,29 @@ def load_golden(name: str):
     path = os.path.join(GOLDEN_DIR, name)
     with np.load(path, allow_pickle=False) as z:
         return {k: z[k] for k in z.files}
+
+
+def g9b_batch(g, step: int):
+    """The batch the REAL reference trainer drew at global iteration ``step`` (0-based) of golden G9b
+    (oracle/gen_golden_trainer.py --stages): (origins, directions, pixels, t_rand of the specular render, t_rand of the diffuse render).
+    The fixture stores, per stage, every ray and pixel of every training image (cast / loaded by the reference) and, per step, the
+    image batch + the trainer's torch.randperm prefix; the stratified jitter of the run was procedural (hash_uniform)."""
+    G, deg, hw, n_img, n_rays, iters, S, stages, eval_S, seed0 = (int(v) for v in g["config"])
+    stage = 1 + step // iters
+    pix, dirs = g[f"pixels_stage{stage}"], g[f"directions_stage{stage}"]
+    per_image = pix.shape[1]
+    sel = g["selection"][step].astype(np.int64)
+    img = g["image_ids"][step].astype(np.int64)[sel // per_image]
+    within = sel % per_image
+    t_spec = hash_uniform((n_rays, S), seed0 + 2 * step, 0.0, 1.0)
+    t_diff = hash_uniform((n_rays, S), seed0 + 2 * step + 1, 0.0, 1.0)
+    return g["camera_origins"][img], dirs[img, within], pix[img, within], t_spec, t_diff
+
+
+def g9b_learning_rate(g, step: int) -> float:
+    """lr of global iteration ``step`` (0-based): stage lr = lr0 * stage_gamma^(stage-1), ExponentialLR(gamma) stepped every
+    ``decay_steps`` iterations of the stage (modules/trainers.py:227-250, 389-390)."""
+    iters = int(g["config"][5])
+    lr0, gamma, decay_steps, stage_gamma = (float(v) for v in g["schedule"])
+    stage, it = step // iters, step % iters
+    return lr0 * stage_gamma**stage * gamma ** (it // int(decay_steps))
