@@ -473,14 +473,40 @@ def main():
         }
 
     # ---- training steps: the headline ---------------------------------------------------------------
-    stepper = TrainStepper(model, R, learning_rate=0.03, apply_diffuse_render_regularization=True, ray_selection=args.ray_selection, backward=args.backward,
-                           deterministic=args.deterministic, fuse_optimizer=False if (args.no_fuse_optimizer or args.exchange == "dense") else None,
-                           merge_bricks=False if args.exchange == "dense" and (world > 1 or args.dp_style_step) else None, exchange=args.exchange)
-    owner = stepper.exchange == "owner"
-    executor = stepper.fused and stepper.merged_bricks and args.ray_selection == "keyed" and not owner
+    def make_stepper(exchange):
+        return TrainStepper(model, R, learning_rate=0.03, apply_diffuse_render_regularization=True, ray_selection=args.ray_selection, backward=args.backward,
+                            deterministic=args.deterministic, fuse_optimizer=False if (args.no_fuse_optimizer or exchange == "dense") else None,
+                            merge_bricks=False if exchange == "dense" and (world > 1 or args.dp_style_step) else None, exchange=exchange)
+
+    stepper = make_stepper(args.exchange)
+    exchange_fallback = None
     torch.manual_seed(1234 + rank)  # every rank draws its own rays
     batches = dataset.image_batches(args.images)
-    for _ in range(args.warmup):
+    if world > 1 and stepper.exchange == "owner":
+        # the owner-computes exchange validates itself on its first step (replica checksum); should it raise on ANY rank -- a
+        # collective RCCL refuses, diverged replicas -- ALL ranks fall back to the dense exchange (reduce-scatter -> sharded Adam ->
+        # all-gather) on a freshly initialised grid, and the line says so: a multi-GPU run always yields a valid, labelled number
+        failed, reason = 0, None
+        try:
+            stepper.step(dataset, next(batches))
+            torch.cuda.synchronize()
+        except Exception as exc:  # noqa: BLE001
+            failed, reason = 1, f"{type(exc).__name__}: {exc}"
+        flag = torch.tensor([failed], device=dev, dtype=torch.int32)
+        torch.distributed.all_reduce(flag, op=torch.distributed.ReduceOp.MAX)
+        if int(flag.item()):
+            exchange_fallback = reason or "the owner-computes step failed on another rank"
+            print(f"[rank {rank}] owner-computes exchange failed ({exchange_fallback}); falling back to --exchange dense", file=sys.stderr)
+            stepper.flat.detach()
+            del stepper
+            grid = make_grid(dev, G, args.sh_degree, seed=42, storage=args.storage)
+            model = rf.VolumetricModel(grid, rf.render_sh_voxel_grid, cfg, device=dev)
+            stepper = make_stepper("dense")
+            torch.manual_seed(1234 + rank)
+            batches = dataset.image_batches(args.images)
+    owner = stepper.exchange == "owner"
+    executor = stepper.fused and stepper.merged_bricks and args.ray_selection == "keyed" and not owner
+    for _ in range(args.warmup - (1 if (world > 1 and owner) else 0)):  # (the owner-computes step's self-check above was the first warm-up step)
         stepper.step(dataset, next(batches))
     # per-kernel HIP events on `--timed-steps` of the timed steps, recorded by the library between its own launches
     timer_stride = max(1, args.steps // max(1, args.timed_steps))
@@ -520,7 +546,10 @@ def main():
     exchange_bytes = 0
     if owner and stepper.exchange_bytes:  # measured: record slices + offset tables + parameter chunks this rank sent, mean of the last steps
         exchange_bytes = int(np.mean(stepper.exchange_bytes))
+    replicas_ok = None
     if world > 1:
+        model.thre3d_repr.wait_for_parameters()
+        replicas_ok = bool(rfdist.replicas_identical(stepper.flat.flat_param))  # every rank must hold the same parameters after the timed steps
         te = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         torch.distributed.all_reduce(te, op=torch.distributed.ReduceOp.MAX)
         elapsed = float(te.item())
@@ -545,10 +574,11 @@ def main():
         for name in per[0]:
             kernels[name] = {"avg_ms": float(np.mean([p[name] for p in per])), "launches": len(per)}
     elif owner and phase_events:
-        names_ = ["forward phase (select, 2 forward passes, losses + offsets)", "emit phase (2 launches; the offset-table all-gather + host read overlap it)",
-                  "record exchange (host wait + all-to-all of record slices)", "brick_accumulate_adam[owner bricks, all ranks' lists]", "parameter all-gather"]
-        for i, name in enumerate(names_):
-            kernels[name] = {"avg_ms": float(np.mean([e[i].elapsed_time(e[i + 1]) for e in phase_events])), "launches": len(phase_events)}
+        # the owner step's marks on the compute stream: the span in front of mark i is named after it ("wait: ..." spans = the compute
+        # stream blocked on communication = EXPOSED communication; the other spans = compute, incl. whatever a wait left over)
+        for i in range(1, len(phase_events[0])):
+            name = phase_events[0][i][0]
+            kernels[name] = {"avg_ms": float(np.mean([e[i - 1][1].elapsed_time(e[i][1]) for e in phase_events])), "launches": len(phase_events)}
     elif legacy_timer is not None:
         for name, rec in legacy_timer.summary().items():
             kernels[name] = {"avg_ms": rec["avg_ms"], "launches": rec["launches"]}
@@ -627,10 +657,10 @@ def main():
     if roofline is None and kernels and owner:
         # owner-computes data-parallel step: the rank's brick pass (all ranks' record lists for its own 1/N of the bricks, Adam in the
         # flush) priced on its compulsory HBM bytes: the records it consumed + 6 accesses x 4 B per OWN parameter
-        bname = [k for k in kernels if k.startswith("brick_accumulate_adam")][0]
+        bname = "brick pass + Adam (all halves)"
         recs = np.mean(np.array(stepper.owner_records, dtype=np.float64), axis=0) if stepper.owner_records else np.zeros(2)
         bytes_ = recs[0] * 4 * ops.expanded_record_floats(grid) + recs[1] * 4 * ops.expanded_record_floats(grid, True) + nparam / world * 24
-        ms = kernels[bname]["avg_ms"]
+        ms = sum(v["avg_ms"] for k, v in kernels.items() if k.startswith("brick pass"))
         roofline = {
             "kernel": bname, "bound": "hbm", "peak": HBM_PEAK_GBS, "unit": "GB/s", "achieved": bytes_ / 1e9 / (ms / 1e3), "frac": frac(bytes_, ms, bname),
             "traffic": None, "traffic_stale": bool(pmc_stale), "avg_launch_ms": ms,
@@ -700,8 +730,13 @@ def main():
             "fused_optimizer": bool(stepper.fuse_optimizer),
             "one_call_per_step": bool(executor),
         },
-        "distributed": {"backend": backend, "world_size_seen_by_collectives": rccl_world, "exchange_bytes_sent_per_rank_per_step": exchange_bytes},
-        "rays_per_s": world * 2 * R * args.steps / elapsed,
+        "distributed": {"backend": backend, "world_size_seen_by_collectives": rccl_world, "exchange_bytes_sent_per_rank_per_step": exchange_bytes,
+                        "exchange": stepper.exchange if (world > 1 or args.dp_style_step) else None,
+                        "exchange_fallback_reason": exchange_fallback,  # not None: the owner-computes step failed and the run fell back to the dense exchange
+                        "replicas_bit_identical": replicas_ok,  # parameter checksums of all ranks after the timed steps (None on one GPU)
+                        "exposed_communication_ms_per_step": ({k: v["avg_ms"] for k, v in kernels.items() if k.startswith("wait:")} if owner else None),
+                        "owner_halves": (stepper._owner or {}).get("H") if owner else None},
+        "rays_per_s": world * R * args.steps / elapsed,  # rays of the batch per second (each is rendered twice per step: renders_per_s = 2 x this)
         "final_specular_psnr": stats.psnr()["specular_psnr"],
         "inside_fraction": n_in / (R * S),
         "kernels": kernels,

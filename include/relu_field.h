@@ -418,7 +418,12 @@ enum {
   RF_STEP_EMIT_SPECULAR = 8, RF_STEP_EMIT_DIFFUSE = 16,  /* one adjoint at a time */
   /* RF_STEP_FORWARD in two pieces, the render_diffuse pass first: it reads the base tensor only, so a data-parallel caller runs it
      while the `rest` parameters of the previous iteration are still being all-gathered */
-  RF_STEP_SELECT_AND_DIFFUSE_FORWARD = 32, RF_STEP_SPECULAR_FORWARD_AND_LOSSES = 64
+  RF_STEP_SELECT_AND_DIFFUSE_FORWARD = 32, RF_STEP_SPECULAR_FORWARD_AND_LOSSES = 64,
+  /* the two renders' chains apart (pipelined owner-computes step): RF_STEP_DIFFUSE_CHAIN = selection, render_diffuse forward, loss +
+     offsets of list [1], its adjoint as records -- everything that reads the base tensor only and needs no other rank, so it runs
+     beside the arriving `rest` parameters of the previous iteration; RF_STEP_SPECULAR_FORWARD = specular forward, loss + offsets of
+     list [0] (then RF_STEP_EMIT_SPECULAR).  (Added compatibly: no struct or signature changed.) */
+  RF_STEP_DIFFUSE_CHAIN = 128, RF_STEP_SPECULAR_FORWARD = 256
 };
 
 #define RF_TRAIN_STEP_EVENTS 11

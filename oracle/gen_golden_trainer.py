@@ -260,50 +260,32 @@ def ground_truth_scene(G=32):
     return torch.from_numpy(dens), torch.from_numpy(feat.reshape(G, G, G, 3 * K))
 
 
-def main_stages():
-    from thre3d_atom.rendering.volumetric.utils.misc import cast_rays, flatten_rays
-    from thre3d_atom.utils.imaging_utils import CameraIntrinsics
-    from thre3d_atom.utils.metric_utils import mse2psnr
+def _perturbed_init(seed: int):
+    """procedural_init with a pseudo-random half of the entries moved by ONE float32 ulp: a second, equally valid "run of the
+    reference" (G9b's noise band: Adam turns rounding-level differences of near-zero gradients into full-size steps, so two
+    float32 evaluations of the same schedule -- CPU vs GPU, one summation order vs another -- drift apart chaotically)."""
 
-    torch.manual_seed(4242)
-    np.random.seed(4242)
-    tmp = Path(tempfile.mkdtemp(prefix="g9b_"))
-    img_dir = tmp / "images"
-    img_dir.mkdir()
+    def init(t: torch.Tensor) -> torch.Tensor:
+        procedural_init(t)
+        with torch.no_grad():
+            flip = torch.from_numpy(hash_uniform(tuple(t.shape), 7000 + 31 * seed + t.shape[-1], 0.0, 1.0) < 0.5)
+            moved = torch.nextafter(t, torch.full_like(t, 2.0))
+            t.copy_(torch.where(flip, moved, t))
+        return t
 
-    def relu_grid(dens, feat, G, tunable):
-        return VoxelGrid(densities=dens, features=feat, voxel_size=VoxelSize(3.0 / G, 3.0 / G, 3.0 / G), density_preactivation=torch.nn.Identity(),
-                         density_postactivation=torch.nn.ReLU(), expected_density_scale=100.0 / 3.0, tunable=tunable)
+    return init
 
-    # ---- the scene, photographed by the REFERENCE renderer (8-bit PNGs: what a dataset on disk holds) ----
-    bounds_json = [2.0, 6.0]
-    gt_dens, gt_feat = ground_truth_scene()
-    near, far = np.float32(2.0) * 0.9, np.float32(6.0) * 1.1
-    from thre3d_atom.utils.imaging_utils import CameraBounds
-    gt_cfg = SHVoxGridRenderConfig(num_samples_per_ray=128, camera_bounds=CameraBounds(near, far), perturb_sampled_points=False, white_bkgd=True)
-    gt_model = VolumetricModel(relu_grid(gt_dens, gt_feat, 32, False), render_sh_voxel_grid, gt_cfg, device=torch.device("cpu"))
-    intr = CameraIntrinsics(B_HW, B_HW, B_FOCAL)
-    params = {}
-    for i, (yaw, pitch) in enumerate(B_TRAIN_POSES):
-        pose = pose_spherical(yaw, pitch, B_RADIUS)
-        img = gt_model.render(pose, intr).colour.clamp(0, 1).numpy()
-        name = f"img_{i:02d}.png"
-        Image.fromarray((img * 255.0 + 0.5).astype(np.uint8)).save(img_dir / name)
-        params[name] = {
-            "extrinsic": {"rotation": pose.rotation.numpy().tolist(), "translation": pose.translation.numpy().tolist()},
-            "intrinsic": {"height": B_HW, "width": B_HW, "focal": B_FOCAL, "bounds": bounds_json},
-        }
-    with open(tmp / "camera_params.json", "w") as fh:
-        json.dump(params, fh)
-    held_pose = pose_spherical(*B_HELDOUT_POSE, B_RADIUS)
-    held_truth = gt_model.render(held_pose, intr).colour.clamp(0, 1)
 
-    dataset = PosedImagesDataset(img_dir, tmp / "camera_params.json")
-    grid = relu_grid(torch.zeros(B_G, B_G, B_G, 1), torch.zeros(B_G, B_G, B_G, B_F), B_G, True)
+def run_reference_trainer_stages(tmp: Path, dataset, init_fn, held_pose, intr, full: bool):
+    """One run of the REAL reference trainer over the two-stage schedule; returns what was recorded."""
+    grid = VoxelGrid(densities=torch.zeros(B_G, B_G, B_G, 1), features=torch.zeros(B_G, B_G, B_G, B_F), voxel_size=VoxelSize(3.0 / B_G, 3.0 / B_G, 3.0 / B_G),
+                     density_preactivation=torch.nn.Identity(), density_postactivation=torch.nn.ReLU(), expected_density_scale=100.0 / 3.0, tunable=True)
     cfg = SHVoxGridRenderConfig(num_samples_per_ray=B_SAMPLES, camera_bounds=dataset.camera_bounds, perturb_sampled_points=True, white_bkgd=True)
     model = VolumetricModel(grid, render_sh_voxel_grid, cfg, device=torch.device("cpu"))
+    torch.manual_seed(4242)  # every run draws the same image batches and the same randperm prefixes
+    np.random.seed(4242)
 
-    rec = {"image_ids": [], "sel": [], "losses": [], "snap": {}, "rand_calls": 0, "last_perm": None, "steps": 0, "datasets": {}}
+    rec = {"image_ids": [], "sel": [], "losses": [], "snap": {}, "rand_calls": 0, "last_perm": None, "steps": 0, "datasets": {}, "first_rand_call_of_step": [], "checkpoint_renders": []}
 
     # -- the trainer's random sources, recorded (randperm) or replaced by a procedural table (the stratified jitter: sample.py:63) --
     real_getitem = PosedImagesDataset.__getitem__
@@ -331,15 +313,13 @@ def main_stages():
     real_select = ref_trainers.sample_random_rays_and_pixels_synchronously
 
     def recording_select(rays, pixels, sample_size):
-        n_before = len(rec["sel"])
         r, p = real_select(rays, pixels, sample_size)
         perm = rec["last_perm"]
         assert perm is not None and perm.numel() == len(rays)
         sel = perm[:sample_size]
         assert torch.equal(r.origins, rays.origins[sel]) and torch.equal(p, pixels[sel])
         rec["sel"].append(sel.to(torch.int16).clone())
-        rec["first_rand_call_of_step"] = rec.get("first_rand_call_of_step", []) + [rec["rand_calls"]]
-        assert len(rec["sel"]) == n_before + 1
+        rec["first_rand_call_of_step"].append(rec["rand_calls"])
         return r, p
 
     real_l1 = ref_trainers.l1_loss
@@ -355,16 +335,18 @@ def main_stages():
         out = real_step(self, *a, **k)
         rec["steps"] += 1
         ps = [p for g in self.param_groups for p in g["params"]]
-        if rec["steps"] in (1, B_ITERS, B_ITERS + 1, B_STAGES * B_ITERS):
+        if full and rec["steps"] in (1, B_ITERS, B_ITERS + 1, B_STAGES * B_ITERS):
             rec["snap"][rec["steps"]] = (ps[0].detach().clone(), ps[1].detach().clone(), float(self.param_groups[0]["lr"]))
+        if rec["steps"] in B_CHECKPOINTS:  # (jitter off: no random number is drawn)
+            rec["checkpoint_renders"].append(model.render(held_pose, intr, perturb_sampled_points=False, num_samples_per_ray=B_EVAL_SAMPLES).colour.clone())
         return out
 
     real_scale = ref_trainers.scale_voxel_grid_with_required_output_size
-    scaled = []
+    rec["scaled"] = []
 
     def recording_scale(g, output_size, mode="trilinear"):
         out = real_scale(g, output_size=output_size, mode=mode)
-        scaled.append((out.densities.detach().clone(), out.features.detach().clone()))
+        rec["scaled"].append((out.densities.detach().clone(), out.features.detach().clone()))
         return out
 
     PosedImagesDataset.__getitem__ = recording_getitem
@@ -377,14 +359,14 @@ def main_stages():
     torch.optim.Adam.step = recording_step
     try:
         ref_trainers.train_sh_vox_grid_vol_mod_with_posed_images(
-            vol_mod=model, train_dataset=dataset, output_dir=tmp / "out", random_initializer=procedural_init, image_batch_cache_size=8,
+            vol_mod=model, train_dataset=dataset, output_dir=tmp / "out", random_initializer=init_fn, image_batch_cache_size=8,
             ray_batch_size=B_RAYS, num_stages=B_STAGES, num_iterations_per_stage=B_ITERS, scale_factor=2.0, learning_rate=B_LR,
             lr_decay_gamma_per_stage=B_GAMMA, lr_decay_steps_per_stage=B_DECAY_STEPS, stagewise_lr_decay_gamma=B_STAGE_GAMMA,
-            save_freq=10**6, test_freq=10**6, feedback_freq=10**6, summary_freq=50, fast_debug_mode=True, verbose_rendering=False,
+            save_freq=10**6, test_freq=10**6, feedback_freq=10**6, summary_freq=100, fast_debug_mode=True, verbose_rendering=False,
         )
         # the trained field, photographed by the reference from a view it never saw (jitter off)
-        held = model.render(held_pose, intr, perturb_sampled_points=False, num_samples_per_ray=B_EVAL_SAMPLES)
-        train0 = model.render(pose_spherical(*B_TRAIN_POSES[0], B_RADIUS), intr, perturb_sampled_points=False, num_samples_per_ray=B_EVAL_SAMPLES)
+        rec["held"] = model.render(held_pose, intr, perturb_sampled_points=False, num_samples_per_ray=B_EVAL_SAMPLES)
+        rec["train0"] = model.render(pose_spherical(*B_TRAIN_POSES[0], B_RADIUS), intr, perturb_sampled_points=False, num_samples_per_ray=B_EVAL_SAMPLES)
     finally:
         torch.optim.Adam.step = real_step
         torch.randperm = real_randperm
@@ -393,15 +375,68 @@ def main_stages():
         ref_trainers.sample_random_rays_and_pixels_synchronously = real_select
         ref_trainers.l1_loss = real_l1
         ref_trainers.scale_voxel_grid_with_required_output_size = real_scale
+    rec["real_getitem"] = real_getitem
+    return rec
+
+
+N_RERUNS = 12
+B_CHECKPOINTS = (25, 50, 100, 200, 300)  # global iterations after which the held-out view is photographed as well (all in stage 1 or at its end)
+
+
+def main_stages():
+    from thre3d_atom.rendering.volumetric.utils.misc import cast_rays, flatten_rays
+    from thre3d_atom.utils.imaging_utils import CameraBounds, CameraIntrinsics
+    from thre3d_atom.utils.metric_utils import mse2psnr
+
+    tmp = Path(tempfile.mkdtemp(prefix="g9b_"))
+    img_dir = tmp / "images"
+    img_dir.mkdir()
+
+    # ---- the scene, photographed by the REFERENCE renderer (8-bit PNGs: what a dataset on disk holds) ----
+    gt_dens, gt_feat = ground_truth_scene()
+    near, far = np.float32(2.0) * 0.9, np.float32(6.0) * 1.1
+    gt_cfg = SHVoxGridRenderConfig(num_samples_per_ray=128, camera_bounds=CameraBounds(near, far), perturb_sampled_points=False, white_bkgd=True)
+    gt_grid = VoxelGrid(densities=gt_dens, features=gt_feat, voxel_size=VoxelSize(3.0 / 32, 3.0 / 32, 3.0 / 32), density_preactivation=torch.nn.Identity(),
+                        density_postactivation=torch.nn.ReLU(), expected_density_scale=100.0 / 3.0, tunable=False)
+    gt_model = VolumetricModel(gt_grid, render_sh_voxel_grid, gt_cfg, device=torch.device("cpu"))
+    intr = CameraIntrinsics(B_HW, B_HW, B_FOCAL)
+    params = {}
+    for i, (yaw, pitch) in enumerate(B_TRAIN_POSES):
+        pose = pose_spherical(yaw, pitch, B_RADIUS)
+        img = gt_model.render(pose, intr).colour.clamp(0, 1).numpy()
+        name = f"img_{i:02d}.png"
+        Image.fromarray((img * 255.0 + 0.5).astype(np.uint8)).save(img_dir / name)
+        params[name] = {
+            "extrinsic": {"rotation": pose.rotation.numpy().tolist(), "translation": pose.translation.numpy().tolist()},
+            "intrinsic": {"height": B_HW, "width": B_HW, "focal": B_FOCAL, "bounds": [2.0, 6.0]},
+        }
+    with open(tmp / "camera_params.json", "w") as fh:
+        json.dump(params, fh)
+    held_pose = pose_spherical(*B_HELDOUT_POSE, B_RADIUS)
+    held_truth = gt_model.render(held_pose, intr).colour.clamp(0, 1)
+    dataset = PosedImagesDataset(img_dir, tmp / "camera_params.json")
+
+    rec = run_reference_trainer_stages(tmp, dataset, procedural_init, held_pose, intr, full=True)
+    real_getitem, scaled, held, train0 = rec["real_getitem"], rec["scaled"], rec["held"], rec["train0"]
 
     total = B_STAGES * B_ITERS
-    # (the DataLoader of a stage is built -- and its first batch drawn -- once per stage; dataset[i] calls come 8 per iteration)
-    ids = np.array(rec["image_ids"][3:], dtype=np.int16)  # (the first three dataset[0] look-ups are the trainer's feedback-pose set-up, trainers.py:157-162)
+    # (the first three dataset[0] look-ups are the trainer's feedback-pose set-up, trainers.py:157-162; then 8 per iteration)
+    ids = np.array(rec["image_ids"][3:], dtype=np.int16)
     assert len(rec["sel"]) == total and len(rec["losses"]) == 2 * total and ids.size == 8 * total, (len(rec["sel"]), ids.size)
-    assert rec["rand_calls"] == 2 * total and rec["first_rand_call_of_step"] == list(range(0, 2 * total, 2))
+    assert rec["rand_calls"] == 2 * total + 2 - 2 and rec["first_rand_call_of_step"] == list(range(0, 2 * total, 2))
     assert len(scaled) == 2  # the initial down-scaling (re-initialised afterwards) and the stage transition
     psnr = lambda a, b: float(mse2psnr(torch.nn.functional.mse_loss(a, b)))
     train0_truth = dataset[int(np.where(np.array([int(p.name[4:6]) for p in dataset._image_file_paths]) == 0)[0][0])][0].permute(1, 2, 0)
+
+    # ---- the reference against ITSELF: the same schedule, same batches, same jitter, initial parameters moved by one ulp ----
+    reruns = []
+    for k in range(N_RERUNS):
+        r = run_reference_trainer_stages(tmp, dataset, _perturbed_init(k + 1), held_pose, intr, full=False)
+        assert all(torch.equal(a, b) for a, b in zip(r["sel"], rec["sel"])) and r["image_ids"] == rec["image_ids"]
+        reruns.append({"ckpt": [psnr(c, held_truth) for c in r["checkpoint_renders"]], "held": psnr(r["held"].colour, held_truth), "train0": psnr(r["train0"].colour, train0_truth), "spec": np.array(r["losses"][0::2]),
+                       "diff": np.array(r["losses"][1::2]), "held_img": r["held"].colour.numpy()})
+        print(f"re-run {k + 1} (init moved by one ulp): held-out {reruns[-1]['held']:.3f} dB, training view {reruns[-1]['train0']:.3f} dB")
+
     # per-stage tables: the images the stage trained on and every ray of every image (cast by the reference)
     out = {}
     for stage, h in ((1, B_HW // 2), (2, B_HW)):
@@ -432,6 +467,13 @@ def main_stages():
         "heldout_truth": held_truth.numpy(), "heldout_render": held.colour.numpy(), "heldout_depth": held.depth.numpy(),
         "train0_render": train0.colour.numpy(), "train0_truth": train0_truth.numpy(),
         "heldout_psnr": np.float64(psnr(held.colour, held_truth)), "train0_psnr": np.float64(psnr(train0.colour, train0_truth)),
+        "checkpoints": np.array(B_CHECKPOINTS), "checkpoint_heldout_render": torch.stack(rec["checkpoint_renders"]).numpy(),
+        "checkpoint_heldout_psnr": np.array([psnr(c, held_truth) for c in rec["checkpoint_renders"]]),
+        "rerun_checkpoint_heldout_psnr": np.array([r["ckpt"] for r in reruns]),
+        # the reference's own spread (N_RERUNS runs whose initial parameters differ from the base run by one ulp)
+        "rerun_heldout_psnr": np.array([r["held"] for r in reruns]), "rerun_train0_psnr": np.array([r["train0"] for r in reruns]),
+        "rerun_specular_loss": np.stack([r["spec"] for r in reruns]), "rerun_diffuse_loss": np.stack([r["diff"] for r in reruns]),
+        "rerun_heldout_max_abs_image_difference": np.array([np.abs(r["held_img"] - held.colour.numpy()).max() for r in reruns]),
         "near": np.float64(dataset.camera_bounds.near), "far": np.float64(dataset.camera_bounds.far),
         "config": np.array([B_G, B_DEG, B_HW, len(B_TRAIN_POSES), B_RAYS, B_ITERS, B_SAMPLES, B_STAGES, B_EVAL_SAMPLES, JITTER_SEED0]),
         "schedule": np.array([B_LR, B_GAMMA, B_DECAY_STEPS, B_STAGE_GAMMA]),
@@ -442,6 +484,11 @@ def main_stages():
     np.savez_compressed(path, **out)
     print(f"wrote {path}: {os.path.getsize(path) / 1024:.1f} KiB; held-out PSNR {out['heldout_psnr']:.3f} dB, training view {out['train0_psnr']:.3f} dB; "
           f"losses first/last {out['specular_loss'][0]:.4f} / {out['specular_loss'][-1]:.4f}; lr {out['lr_at']}")
+    print("held-out PSNR at the checkpoints", B_CHECKPOINTS, ":", out["checkpoint_heldout_psnr"], "re-runs minus base:", out["rerun_checkpoint_heldout_psnr"] - out["checkpoint_heldout_psnr"][None])
+    rel = np.abs(out["rerun_specular_loss"] / out["specular_loss"][None] - 1.0)
+    print("specular loss relative difference of the re-runs, median per window of 50 iterations:", [float(np.median(rel[:, i:i + 50])) for i in range(0, rel.shape[1], 50)])
+    print(f"reference vs its one-ulp re-runs: held-out {out['rerun_heldout_psnr']}, training view {out['rerun_train0_psnr']}; specular loss relative "
+          f"difference median {np.median(rel):.4f}, 90 % {np.percentile(rel, 90):.4f}, max {rel.max():.4f}; image max-abs {out['rerun_heldout_max_abs_image_difference']}")
 
 
 if __name__ == "__main__":

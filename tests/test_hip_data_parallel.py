@@ -54,7 +54,7 @@ def _train(stepper, data, steps=3):
     return stepper.flat.flat_param.clone()
 
 
-def _worker(rank, world, port, result_dir, exchange, shard_optimizer, jitter, grid_size=16):
+def _worker(rank, world, port, result_dir, exchange, shard_optimizer, jitter, grid_size=16, halves=1):
     GRID["G"] = grid_size
     os.environ.update(RANK=str(rank), LOCAL_RANK="0", WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     dev = torch.device("cuda", 0)
@@ -69,6 +69,7 @@ def _worker(rank, world, port, result_dir, exchange, shard_optimizer, jitter, gr
         dp = _train(stepper, data)
         if exchange == "owner":
             assert stepper.exchange_bytes and stepper.exchange_bytes[-1] > 0 and stepper.owner_records[-1][0] > 0
+            assert stepper._owner["H"] == halves, (stepper._owner["H"], halves)  # interleaved ownership: the pipelined step
         gathered = [torch.empty_like(dp) for _ in range(world)]
         dist.all_gather(gathered, dp)
         assert all(torch.equal(gathered[0], t) for t in gathered), "replicas diverged"
@@ -93,18 +94,25 @@ def _worker(rank, world, port, result_dir, exchange, shard_optimizer, jitter, gr
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("exchange,shard_optimizer,jitter", [("owner", True, False), ("owner", True, True), ("dense", True, False), ("dense", False, True)])
-def test_two_processes_train_data_parallel_on_one_gpu(tmp_path, exchange, shard_optimizer, jitter):
+@pytest.mark.parametrize("exchange,shard_optimizer,jitter,grid_size,halves", [
+    ("owner", True, False, 16, 1), ("owner", True, True, 16, 1),
+    ("owner", True, True, 32, 2),  # 4 x-slabs of bricks: rank r owns slabs r and r + 2 -- the interleaved ownership of the pipelined step
+    ("owner", True, False, 64, 2),  # 8 x-slabs: two neighbouring slabs per rank and half
+    ("dense", True, False, 16, 1), ("dense", False, True, 16, 1)])
+def test_two_processes_train_data_parallel_on_one_gpu(tmp_path, exchange, shard_optimizer, jitter, grid_size, halves):
     assert torch.cuda.is_available()
     world = 2
-    mp.spawn(_worker, args=(world, _free_port(), str(tmp_path), exchange, shard_optimizer, jitter), nprocs=world, join=True)
+    mp.spawn(_worker, args=(world, _free_port(), str(tmp_path), exchange, shard_optimizer, jitter, grid_size, halves), nprocs=world, join=True)
     assert sorted(os.listdir(tmp_path)) == [f"ok{r}" for r in range(world)]
 
 
-def test_four_processes_owner_computes_on_one_gpu(tmp_path):
-    """Four ranks, one x-slab of bricks each (32^3 grid): the two middle owners receive slices that start with the x-flagged
-    records of the slab below them and end before the slab above -- the general case of the slice formula; keyed jitter on."""
+@pytest.mark.parametrize("grid_size,halves", [(32, 1), (64, 2)])
+def test_four_processes_owner_computes_on_one_gpu(tmp_path, grid_size, halves):
+    """Four ranks.  32^3 grid: one x-slab of bricks each -- the two middle owners receive slices that start with the x-flagged
+    records of the slab below them and end before the slab above (the general case of the slice formula).  64^3 grid: eight
+    slabs owned in two interleaved halves (rank r: slabs r and r + 4): per half, record exchange -> brick pass + Adam -> all-gather of
+    that half of the parameters, the pipelined step.  Keyed jitter on; both must equal the single-process run."""
     assert torch.cuda.is_available()
     world = 4
-    mp.spawn(_worker, args=(world, _free_port(), str(tmp_path), "owner", True, True, 32), nprocs=world, join=True)
+    mp.spawn(_worker, args=(world, _free_port(), str(tmp_path), "owner", True, True, grid_size, halves), nprocs=world, join=True)
     assert sorted(os.listdir(tmp_path)) == [f"ok{r}" for r in range(world)]

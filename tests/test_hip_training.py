@@ -662,8 +662,9 @@ def test_data_parallel_step_through_rccl_single_rank(hip_device, monkeypatch, ex
             grid = relu_grid(hip_device, T(hash_uniform((G, G, G, 1), 901)), T(hash_uniform((G, G, G, F), 900 + F)), G, storage="split")
             cfg = rf.SHVoxGridRenderConfig(S, rf.CameraBounds(float(g["near"]), float(g["far"])), perturb_sampled_points=False, white_bkgd=True)
             model = rf.VolumetricModel(grid, rf.render_sh_voxel_grid, cfg, device=hip_device)
+            # (dense: the deterministic binned adjoint on both sides -- a fixed summation order -- so that the comparison is tight)
             stepper = TrainStepper(model, n_rays, learning_rate=float(g["lr"]), shard_optimizer=shard_optimizer, exchange=exchange if dp else "auto",
-                                   backward="binned" if exchange == "owner" else "auto")
+                                   backward="binned", deterministic=exchange == "dense")
             assert stepper.exchange == (exchange if dp else "dense")
             for it in range(2):
                 rays = rf.Rays(T(g["origins"][it]).to(hip_device), T(g["directions"][it]).to(hip_device))
@@ -673,7 +674,10 @@ def test_data_parallel_step_through_rccl_single_rank(hip_device, monkeypatch, ex
         # (the record order inside a key class depends on atomic timing, so the two runs sum in different orders: parameters whose
         # gradient is ~1e-8 amplify that through Adam's first steps -- same criterion as the trajectory tests)
         err = (out[0] - out[1]).abs()
-        assert float((err <= 2e-5).float().mean()) >= 0.999 and float(err.max()) <= float(g["lr"]) * 2 * 2 + 1e-6
+        if exchange == "dense":  # same kernels, same record order, same Adam arithmetic: the collectives must not change a bit that matters
+            assert float(err.max()) <= 1e-6, float(err.max())
+        else:
+            assert float((err <= 2e-5).float().mean()) >= 0.999 and float(err.max()) <= float(g["lr"]) * 2 * 2 + 1e-6
     finally:
         rfdist.FORCE_COLLECTIVES = False
         if created:

@@ -32,6 +32,8 @@ STEP_EMIT_SPECULAR = 8
 STEP_EMIT_DIFFUSE = 16
 STEP_SELECT_AND_DIFFUSE_FORWARD = 32
 STEP_SPECULAR_FORWARD_AND_LOSSES = 64
+STEP_DIFFUSE_CHAIN = 128  # selection + render_diffuse forward + its loss/offsets + its adjoint (reads the base tensor only)
+STEP_SPECULAR_FORWARD = 256  # specular forward + its loss/offsets
 
 EXPORTED_SYMBOLS = [
     "rf_abi_version",

@@ -3194,7 +3194,8 @@ __global__ void l1_loss_grad_kernel(L1Sets sets, const float* __restrict__ targe
 // rf_train_step: the losses of both renders AND the offsets of both record lists -- everything between the forward passes and the
 // adjoints -- in one launch (1024-thread workgroups; blockIdx.y 0, 1: loss of render 0, 1; 2, 3: offsets of list 0, 1)
 __global__ __launch_bounds__(1024) void loss_and_offsets_kernel(L1Sets sets, const float* __restrict__ target, long long n3, float gscale,
-                                                                int loss_blocks, BinLists lists, int nkeys, int offset_blocks) {
+                                                                int loss_blocks, BinLists lists, int nkeys, int offset_blocks, int passes) {
+  if (!((passes >> (blockIdx.y & 1)) & 1)) return;  // (bit i: render i takes part -- a data-parallel caller runs the two renders' chains apart)
   if (blockIdx.y < 2) {
     if ((int)blockIdx.x < loss_blocks) l1_loss_grad_body(sets, target, n3, gscale, blockIdx.y, blockIdx.x, loss_blocks);
   } else if ((int)blockIdx.x < offset_blocks) {
@@ -4150,7 +4151,7 @@ int rf_train_step(const RFGrid* grid, const RFTrainStep* step, void* stream) {
     }
     return hipMemsetAsync(step->loss_sums_dev, 0, 4 * sizeof(float), st) == hipSuccess ? RF_OK : RF_ERR_LAUNCH;
   };
-  auto launch_losses_and_offsets = [&]() -> int {  // the losses of both renders and the offsets of both record lists in one launch
+  auto launch_losses_and_offsets = [&](int passes) -> int {  // the losses of both renders and the offsets of both record lists in one launch
     L1Sets sets = {};
     BinLists bl = {};
     for (int k = 0; k < 2; ++k) {
@@ -4164,7 +4165,7 @@ int rf_train_step(const RFGrid* grid, const RFTrainStep* step, void* stream) {
     const long long n3 = (long long)step->num_rays * 3;
     const int loss_blocks = (int)grid_1d(n3, 1024 * 2, 64), offset_blocks = (nkeys + 1023) / 1024;
     hipLaunchKernelGGL(loss_and_offsets_kernel, dim3(loss_blocks > offset_blocks ? loss_blocks : offset_blocks, 4), dim3(1024), 0, st, sets,
-                       step->pixels_dev, n3, loss_scale / (float)n3, loss_blocks, bl, nkeys, offset_blocks);
+                       step->pixels_dev, n3, loss_scale / (float)n3, loss_blocks, bl, nkeys, offset_blocks, passes);
     return launch_status();
   };
   if (run_forward) {
@@ -4191,7 +4192,7 @@ int rf_train_step(const RFGrid* grid, const RFTrainStep* step, void* stream) {
       }
       RF_STEP_EVENT();  // (paired: the first forward slot holds the launch, the second is empty)
       if (i == 1) {
-        rc = launch_losses_and_offsets();
+        rc = launch_losses_and_offsets(3);
         if (rc != RF_OK) return rc;
       }
       RF_STEP_EVENT();
@@ -4206,7 +4207,27 @@ int rf_train_step(const RFGrid* grid, const RFTrainStep* step, void* stream) {
     if (fwd_b) {
       rc = rf_render_forward(grid, &rays[0], flags[0], &step->pass[0].out, stream);
       if (rc != RF_OK) return rc;
-      rc = launch_losses_and_offsets();
+      rc = launch_losses_and_offsets(3);
+      if (rc != RF_OK) return rc;
+    }
+    // the two renders' chains apart (pipelined owner-computes step): everything of the render_diffuse pass that reads the base tensor
+    // only and needs no other rank -- selection, forward, loss + offsets of ITS list, adjoint -- then the specular forward + its loss/offsets
+    if (step->phases & RF_STEP_DIFFUSE_CHAIN) {
+      rc = launch_select();
+      if (rc != RF_OK) return rc;
+      rc = rf_render_forward(grid, &rays[1], flags[1], &step->pass[1].out, stream);
+      if (rc != RF_OK) return rc;
+      rc = launch_losses_and_offsets(2);
+      if (rc != RF_OK) return rc;
+      const RFPassScratch& ps = step->pass[1];
+      const RFRenderGrads grads = {ps.grad_colour_dev, nullptr, nullptr};
+      rc = rf_render_backward_emit_direct(grid, &rays[1], flags[1], &ps.out, &grads, ps.out.brick_size, ps.cursor_dev, ps.records_sorted_dev, ps.out.key_hist_dev, stream);
+      if (rc != RF_OK) return rc;
+    }
+    if (step->phases & RF_STEP_SPECULAR_FORWARD) {
+      rc = rf_render_forward(grid, &rays[0], flags[0], &step->pass[0].out, stream);
+      if (rc != RF_OK) return rc;
+      rc = launch_losses_and_offsets(1);
       if (rc != RF_OK) return rc;
     }
   }

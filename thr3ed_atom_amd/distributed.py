@@ -15,6 +15,7 @@ from typing import Optional
 
 import torch
 import torch.distributed as dist
+import torch.distributed.distributed_c10d as _c10d
 from torch import Tensor
 
 
@@ -134,6 +135,7 @@ def reduce_scatter_mean_async(bucket: Tensor, out: Optional[Tensor] = None) -> _
         out = torch.empty(chunk, dtype=bucket.dtype, device=bucket.device)
     assert out.numel() == chunk
     if dist.get_backend() == "nccl":
+        assert bucket.is_cuda and out.is_cuda and bucket.is_contiguous() and out.is_contiguous() and out.dtype == bucket.dtype == torch.float32
         work = dist.reduce_scatter_tensor(out, bucket, op=dist.ReduceOp.AVG, async_op=True)
         return _ShardHandle(work, out, lo, lo + chunk, None)
     # gloo has no reduce-scatter: reduce everything, keep the own chunk (CPU tests of the wiring)
@@ -148,11 +150,12 @@ def all_gather_chunks_(bucket: Tensor, async_op: bool = False):
     n = world_size()
     work = None
     if _collectives_on():
-        assert bucket.numel() % n == 0
+        assert bucket.dim() == 1 and bucket.is_contiguous() and bucket.numel() % n == 0, (tuple(bucket.shape), bucket.is_contiguous(), n)
         chunk = bucket.numel() // n
         lo = rank() * chunk
         mine = bucket[lo : lo + chunk].clone()  # separate send buffer: no aliasing with the receive buffer
         if dist.get_backend() == "nccl":
+            assert bucket.is_cuda and mine.numel() * n == bucket.numel() and mine.dtype == bucket.dtype
             work = dist.all_gather_into_tensor(bucket, mine, async_op=async_op)
         else:
             parts = [torch.empty(chunk, dtype=bucket.dtype, device=bucket.device) for _ in range(n)]
@@ -171,6 +174,7 @@ def all_gather_rows_equal(out: Tensor, mine: Tensor, async_op: bool = False):
         out[0].copy_(mine)
         return None
     if dist.get_backend() == "nccl":
+        assert out.is_cuda and mine.is_cuda and out.dtype == mine.dtype and out.numel() == n * mine.numel()
         work = dist.all_gather_into_tensor(out, mine, async_op=async_op)
         return work if async_op else None
     parts = [out[r] for r in range(n)]  # gloo: list form (rows of a contiguous tensor are contiguous views)
@@ -193,6 +197,11 @@ def exchange_slices(send: list, recv: list, async_op: bool = False):
         empty = send[me][:0]
         ins = [empty if d == me else send[d] for d in range(n)]
         outs = [recv[me][:0] if s_ == me else recv[s_] for s_ in range(n)]
+        # (every view contiguous, on the device, float32 rows of ONE width: RCCL moves bytes, a dtype or width mismatch between the
+        # two ends of a pair would go unnoticed)
+        width = tuple(send[me].shape[1:])
+        for t_ in ins + outs:
+            assert t_.is_cuda and t_.is_contiguous() and t_.dtype == torch.float32 and tuple(t_.shape[1:]) == width, (tuple(t_.shape), t_.dtype, width)
         work = dist.all_to_all(outs, ins, async_op=async_op)
         return work if async_op else None
     # gloo: all_to_all_single on host copies (gloo has no list all_to_all and no device all_to_all)
@@ -209,6 +218,63 @@ def exchange_slices(send: list, recv: list, async_op: bool = False):
             recv[s_].copy_(got[pos : pos + out_split[s_]])
             pos += out_split[s_]
     return None
+
+
+# ---- the per-step collectives of the owner-computes step, without torch.distributed's Python wrappers -------------------------------
+# dist.all_gather_into_tensor / dist.all_to_all spend ~25-30 us per call in argument checks and group look-ups; the data-parallel step
+# makes nine of them and is paced by its host side.  These go to the ProcessGroup object directly (the calls the wrappers end in),
+# always asynchronously: the collective is ordered after the work already enqueued on the CURRENT stream and runs on the backend's own
+# stream; ``work.wait()`` makes the then-current stream wait for it.  RCCL only; arguments are checked on the first calls.
+_FAST = {"group": None, "ag": None, "a2a": None, "checks": 64}
+
+
+def _fast_group():
+    if _FAST["group"] is None or _FAST["group"] is not dist.group.WORLD:
+        _FAST["group"] = dist.group.WORLD
+        _FAST["ag"], _FAST["a2a"] = _c10d.AllgatherOptions(), _c10d.AllToAllOptions()
+        _FAST["ag"].asyncOp = True
+        _FAST["a2a"].asyncOp = True
+        _FAST["checks"] = 64
+    return _FAST["group"]
+
+
+def fast_path() -> bool:
+    """True when the collectives above can be used: an initialised RCCL group."""
+    return dist.is_available() and dist.is_initialized() and dist.get_backend() == "nccl"
+
+
+def fast_all_gather_in_place(bucket: Tensor):
+    """``all_gather_chunks_`` without the staging copy: rank r's chunk of ``bucket`` is sent from where it lies (RCCL's in-place
+    all-gather: the send buffer IS chunk r of the receive buffer).  Returns the work handle."""
+    group = _fast_group()
+    n, r = group.size(), group.rank()
+    chunk = bucket.numel() // n
+    if _FAST["checks"] > 0:
+        _FAST["checks"] -= 1
+        assert bucket.is_cuda and bucket.dim() == 1 and bucket.is_contiguous() and chunk * n == bucket.numel(), (tuple(bucket.shape), n)
+    return group._allgather_base(bucket, bucket[r * chunk : (r + 1) * chunk], _FAST["ag"])
+
+
+def fast_all_gather_rows(out: Tensor, mine: Tensor):
+    group = _fast_group()
+    if _FAST["checks"] > 0:
+        _FAST["checks"] -= 1
+        assert out.is_cuda and mine.is_cuda and out.is_contiguous() and mine.is_contiguous() and out.dtype == mine.dtype and out.numel() == group.size() * mine.numel()
+    return group._allgather_base(out, mine, _FAST["ag"])
+
+
+def fast_exchange(outs: list, ins: list):
+    """``exchange_slices`` (list form of all_to_all: one grouped send/recv per pair straight out of / into the given views); the
+    entries for the own rank must be empty views."""
+    group = _fast_group()
+    if _FAST["checks"] > 0:
+        _FAST["checks"] -= 1
+        n, me = group.size(), group.rank()
+        assert len(outs) == n and len(ins) == n and outs[me].numel() == 0 and ins[me].numel() == 0
+        width = tuple(ins[me].shape[1:])
+        for t_ in ins + outs:
+            assert t_.is_cuda and t_.is_contiguous() and t_.dtype == torch.float32 and tuple(t_.shape[1:]) == width, (tuple(t_.shape), t_.dtype, width)
+    return group.alltoall(outs, ins, _FAST["a2a"])
 
 
 def broadcast_(tensor: Tensor, src: int = 0) -> Tensor:
@@ -241,3 +307,26 @@ def all_gather_rows(local: Tensor) -> Tensor:
     parts = [torch.empty_like(padded) for _ in range(w)]
     dist.all_gather(parts, padded)
     return torch.cat([p[:s] for p, s in zip(parts, sizes)], dim=0)
+
+
+def replica_checksum(flat: Tensor) -> Tensor:
+    """[3] float64 fingerprint of a parameter buffer: sum, sum of squares, and a position-weighted sum (a permutation of equal
+    values moves it)."""
+    x = flat.detach().reshape(-1).to(torch.float64)
+    w = torch.arange(x.numel(), dtype=torch.float64, device=x.device).remainder_(8191.0).add_(1.0)
+    return torch.stack([x.sum(), (x * x).sum(), (x * w).sum()])
+
+
+def replicas_identical(flat: Tensor) -> bool:
+    """True when every rank holds the same ``flat`` (compared through ``replica_checksum``; always True for a world of 1)."""
+    if not _collectives_on():
+        return True
+    mine = replica_checksum(flat)
+    every = [torch.empty_like(mine) for _ in range(world_size())]
+    dist.all_gather(every, mine)
+    return all(torch.equal(every[0], e) for e in every)
+
+
+def assert_replicas_identical(flat: Tensor, what: str) -> None:
+    if not replicas_identical(flat):
+        raise RuntimeError(f"data-parallel replicas diverged ({what}): the ranks hold different parameters")

@@ -417,7 +417,8 @@ def brick_accumulate_adam_raw(grid: VoxelGrid, brick_size: int, lists, exp_avg, 
     ``lists`` may give its records as an int (a raw device address) instead of a tensor.  ``rf_grid`` / ``params``: update these
     tensors (described by this RFGrid) instead of the grid's own -- the split-layout shadow of a reference-storage grid."""
     lib = _lib.load()
-    first, second = grid.kernel_tensors() if params is None else params
+    # (``_tensors``: no wait for parameters a data-parallel step left in flight -- that step orders its launches against them itself)
+    first, second = (grid._tensors() if rf_grid is not None else grid.kernel_tensors()) if params is None else params
     dev = first.device
     arr = (_lib.RFBrickList * len(lists))()
     for i, (rec, off, diffuse) in enumerate(lists):

@@ -130,19 +130,22 @@ class StepStats:
 # owner-computes data parallelism: leave the all-gather of the `rest` parameters in flight across the iteration boundary (RF_OWNER_OVERLAP_PARAMETERS=0
 # makes every iteration wait for it at its end instead)
 OWNER_OVERLAP_PARAMETERS = os.environ.get("RF_OWNER_OVERLAP_PARAMETERS", "1") != "0"
+# owner-computes data parallelism: the x-slabs of bricks are owned in this many interleaved "halves" (1 = one contiguous range per rank):
+# the brick pass of half h + 1 runs while the parameters of half h are all-gathered (TrainStepper._owner_state)
+OWNER_HALVES = int(os.environ.get("RF_OWNER_HALVES", "2"))
 
 
 class _ParameterWait:
-    """Makes the CURRENT stream wait for an all-gather issued on the communication stream (RCCL work handle and / or event)."""
+    """Makes the CURRENT stream wait for an all-gather that is still in flight on RCCL's stream (its work handle; None: the backend
+    completed the call on return).  ``tag``: which parameter tensor it fills ("base" / "rest")."""
 
-    def __init__(self, work, event, device):
-        self.work, self.event, self.device = work, event, device
+    def __init__(self, work, tag="rest"):
+        self.work, self.tag = work, tag
 
     def __call__(self) -> None:
         if self.work is not None:
             self.work.wait()
             self.work = None
-        torch.cuda.current_stream(self.device).wait_event(self.event)
 
 
 class TrainStepper:
@@ -245,9 +248,10 @@ class TrainStepper:
             raise ValueError("exchange must be 'auto', 'owner' or 'dense'")
         world = rfdist.world_size()
         can_owner = (not single and can_merge and merge_bricks is not False and fuse_optimizer is not False and grid.storage != "reference"
-                     and (grid.num_features + 1) % 4 == 0 and fits_flush and world <= 8 and self.brick_size == 8 and grid.grid_dims[0] % (8 * world) == 0)
+                     and (grid.num_features + 1) % 4 == 0 and fits_flush and world <= (8 if grid.num_features > 3 else 4) and self.brick_size == 8
+                     and grid.grid_dims[0] % (8 * world) == 0)  # (a degree-0 grid's 2 W lists are all of ONE kind: at most 8 per brick pass)
         if exchange == "owner" and not can_owner:
-            raise ValueError("exchange='owner' needs the fused, merged step on split or bricked storage, SH degree 0 or 2, at most 8 ranks and X divisible by 8 x ranks")
+            raise ValueError("exchange='owner' needs the fused, merged step on split or bricked storage, SH degree 0 or 2, at most 8 ranks (4 at degree 0) and X divisible by 8 x ranks")
         self.exchange = "owner" if (can_owner and exchange != "dense") else "dense"
         self.owner_records = []
         self.exchange_bytes = []  # bytes this rank SENT in each of the last steps (record slices + offset tables + parameter chunks)
@@ -434,163 +438,210 @@ class TrainStepper:
         return StepStats(means[0], means[2], means[1], means[3])
 
     def _owner_state(self, ex, device):
-        """Persistent state of the owner-computes exchange: the ranks' offset tables, where every owner's key range starts and
-        ends in them, a pinned host copy of those bounds, the side stream that fetches it, the receive buffers."""
+        """Persistent state of the owner-computes exchange: who owns which x-slabs of bricks, the ranks' offset tables, where every
+        piece's key range starts and ends in them, a pinned host copy of those bounds, the side / communication streams, the receive
+        buffers."""
         ow = self._owner
         if ow is not None and ow["ex"] is ex:
             return ow
         grid = self.vol_mod.thre3d_repr
         W, me = rfdist.world_size(), rfdist.rank()
         nb = brick_counts(grid, self.brick_size)
-        nbyz, sp = nb[1] * nb[2], nb[0] // W
+        nbyz = nb[1] * nb[2]
         nkeys = nb[0] * nbyz * 8
-        # owner r: the x-slabs [r sp, (r + 1) sp) of bricks.  Everything that touches their nodes is the key range
-        # [key(slab r sp - 1, f_x = 1), key(slab (r + 1) sp, f_x = 0)) (brick_key: ((2 bx + f_x) nby nbz + ...) << 2)
+        # OWNERSHIP, interleaved in H "halves" so that the step pipelines: the x-slabs of bricks are cut into H * W equal PIECES in slab
+        # order; piece p = h W + r (half h, rank r) = the slabs [p q, (p + 1) q).  Half h of every parameter tensor is one contiguous
+        # chunk made of the W ranks' pieces in rank order -- what an in-place all-gather wants -- so the parameters of half 0 travel
+        # while the brick pass of half 1 still runs.  H = 1 is the plain contiguous split.
+        H = OWNER_HALVES if (OWNER_HALVES > 1 and nb[0] % (OWNER_HALVES * W) == 0) else 1
+        q = nb[0] // (H * W)
+        assert q >= 1 and q * H * W == nb[0]
+        # everything that touches the nodes of piece p is the key range [key(slab p q - 1, f_x = 1), key(slab (p + 1) q, f_x = 0))
+        # (brick_key: ((2 bx + f_x) nby nbz + ...) << 2): ONE slice of a sorted list
         idx = []
-        for r in range(W):
-            lo = 0 if r == 0 else (2 * r * sp - 1) * nbyz * 4
-            idx += [lo, 2 * (r + 1) * sp * nbyz * 4]
+        for p in range(H * W):
+            lo = 0 if p == 0 else (2 * p * q - 1) * nbyz * 4
+            idx += [lo, 2 * (p + 1) * q * nbyz * 4]
         assert idx[-1] == nkeys
         t = ex["tensors"]
+        widths = [t[f"pass{k}"]["sorted"].shape[1] for k in range(2)]
+        ev = torch.cuda.Event
         ow = {
-            "ex": ex, "W": W, "me": me, "bricks": (me * sp * nbyz, sp * nbyz),
+            "ex": ex, "W": W, "me": me, "H": H, "q": q,
+            "bricks": [((h * W + me) * q * nbyz, q * nbyz) for h in range(H)],
             "all_offsets": torch.empty((W, 2, nkeys + 1), dtype=torch.int64, device=device),
             "key_idx": torch.tensor(idx, dtype=torch.int64, device=device),
-            "bounds_host": torch.empty((W, 2, 2 * W), dtype=torch.int64).pin_memory(),
-            "side": torch.cuda.Stream(device), "forward_done": torch.cuda.Event(), "ready": torch.cuda.Event(),
-            "comm": torch.cuda.Stream(device), "emitted": [torch.cuda.Event(), torch.cuda.Event()], "exchanged": [torch.cuda.Event(), torch.cuda.Event()],
-            "bricks_done": torch.cuda.Event(), "rest_gathered": torch.cuda.Event(),
-            "recv": [torch.empty((0, t[f"pass{k}"]["sorted"].shape[1]), dtype=torch.float32, device=device) for k in range(2)],
+            "bounds_host": torch.empty((W, 2, 2 * H * W), dtype=torch.int64).pin_memory(),
+            "side": torch.cuda.Stream(device), "forward_done": ev(), "ready": ev(),
+            "recv": [[torch.empty((0, widths[k]), dtype=torch.float32, device=device) for _ in range(H)] for k in range(2)],
+            "checked": False,
         }
         self._owner = ow
         return ow
 
     def _owner_step(self, ex, st, rf_grid, n: int, S: int, dev) -> None:
-        """The data-parallel iteration, owner-computes (see __init__): forward passes (+ losses, offsets) | all-gather of the offset
-        tables, overlapped with the emit launches; the host reads the N x N slice bounds (the one host round trip of the step: the
-        emit kernels keep the GPU busy meanwhile) | personalised exchange of record slices over RCCL | merged brick pass + Adam on
-        the own bricks over all ranks' lists | all-gather of the parameters."""
+        """The data-parallel iteration, owner-computes and pipelined (see __init__ and _owner_state):
+
+          [base of the previous step arrived]  selection, render_diffuse forward, its loss + offsets, its adjoint   (reads `base` only)
+          [rest of the previous step arrived]  specular forward, its loss + offsets
+          all-gather of the two offset tables  ||  specular adjoint; the host reads the N x N x H slice bounds (the ONE host round
+                                                   trip of the step, behind the specular adjoint)
+          per half h:  exchange of the record slices of half h (diffuse list first: its records exist since the first phase)
+                       -> merged brick pass + Adam on the rank's own bricks of half h over all ranks' lists
+                       -> all-gather of half h of `base`, then of `rest`, in flight while half h + 1 is summed -- and, for the last
+                          half, across the iteration boundary.
+
+        Streams: every kernel on the caller's stream; every collective is issued asynchronously from it -- RCCL orders it after the
+        work enqueued so far and runs it on its own stream, ``work.wait()`` makes the compute stream wait where (and only where) it
+        needs the result.  (gloo, the CPU-side test backend, completes every call on return.)"""
         ow = self._owner_state(ex, dev)
-        W, me = ow["W"], ow["me"]
+        W, me, H = ow["W"], ow["me"], ow["H"]
         ht = [time.perf_counter()] if self.host_timing is not None else None  # host-side time line of the step (development aid)
         tick = (lambda: ht.append(time.perf_counter())) if ht is not None else (lambda: None)
         # a 1-rank group (bench.py --dp-style-step, tests) has nothing to exchange: the record exchange and the parameter all-gather
         # are skipped unless RF_OWNER_FORCE_COLLECTIVES asks for the calls themselves to be exercised (tests do)
         collect = W > 1 or bool(os.environ.get("RF_OWNER_FORCE_COLLECTIVES"))
+        fast = collect and rfdist.fast_path()
         lib, grid, opt = _lib.load(), self.vol_mod.thre3d_repr, self.optimizer
         main = torch.cuda.current_stream(dev)
+        main_ptr = main.cuda_stream
         t = ex["tensors"]
-        ev = [torch.cuda.Event(enable_timing=True) for _ in range(6)] if self.phase_events is not None else None
-        mark = (lambda i: ev[i].record(main)) if ev is not None else (lambda i: None)
+        marks = [] if self.phase_events is not None else None
+
+        def mark(name):  # (bench.py: timing events on the compute stream around the phases and around the waits for communication)
+            if marks is not None:
+                e = torch.cuda.Event(enable_timing=True)
+                e.record(main)
+                marks.append((name, e))
+
+        def run(phases, what):
+            st.phases = phases
+            rc = lib.rf_train_step(rf_grid, st, main_ptr)
+            if rc:
+                _lib.check(rc, f"rf_train_step[{what}]")
+
         st.adam, st.loss_scale = None, 1.0 / W
-        mark(0)
-        pending_rest = grid.__dict__.pop("_params_pending", None)
-        if pending_rest is not None:
-            # the all-gather of the `rest` parameters of the previous iteration is still arriving: the batch selection and the
-            # diffuse render (which reads the base tensor only) run beside it, the specular render waits for it
-            st.phases = _lib.STEP_SELECT_AND_DIFFUSE_FORWARD
-            _lib.check(lib.rf_train_step(C.byref(rf_grid), C.byref(st), main.cuda_stream), "rf_train_step[select + diffuse forward]")
-            pending_rest()
-            st.phases = _lib.STEP_SPECULAR_FORWARD_AND_LOSSES
-            _lib.check(lib.rf_train_step(C.byref(rf_grid), C.byref(st), main.cuda_stream), "rf_train_step[specular forward + losses]")
+        mark("start")
+        waits = grid.take_parameter_waits()  # all-gathers of the previous iteration that are still arriving
+        for w_ in waits:
+            if w_.tag == "base":
+                w_()
+        mark("wait: base parameters of the previous iteration")
+        run(_lib.STEP_DIFFUSE_CHAIN, "diffuse chain")
+        mark("selection + diffuse forward + its loss/offsets + its adjoint")
+        for w_ in waits:
+            if w_.tag != "base":
+                w_()
+        mark("wait: rest parameters of the previous iteration")
+        run(_lib.STEP_SPECULAR_FORWARD, "specular forward")
+        mark("specular forward + its loss/offsets")
+        if fast:
+            work = rfdist.fast_all_gather_rows(ow["all_offsets"], t["offsets2"])
         else:
-            st.phases = _lib.STEP_FORWARD
-            _lib.check(lib.rf_train_step(C.byref(rf_grid), C.byref(st), main.cuda_stream), "rf_train_step[forward]")
-        mark(1)
-        work = rfdist.all_gather_rows_equal(ow["all_offsets"], t["offsets2"], async_op=True)
+            work = rfdist.all_gather_rows_equal(ow["all_offsets"], t["offsets2"], async_op=True)
         ow["forward_done"].record(main)
-        # the two adjoints as two launches with an event between them: the exchange of the specular slices is ordered after the
-        # first one only (on the communication stream) and runs beside the diffuse adjoint
-        st.phases = _lib.STEP_EMIT_SPECULAR
-        _lib.check(lib.rf_train_step(C.byref(rf_grid), C.byref(st), main.cuda_stream), "rf_train_step[emit specular]")
-        ow["emitted"][0].record(main)
-        st.phases = _lib.STEP_EMIT_DIFFUSE
-        _lib.check(lib.rf_train_step(C.byref(rf_grid), C.byref(st), main.cuda_stream), "rf_train_step[emit diffuse]")
-        ow["emitted"][1].record(main)
-        mark(2)
-        with torch.cuda.stream(ow["side"]):
-            ow["side"].wait_event(ow["forward_done"])
+        run(_lib.STEP_EMIT_SPECULAR, "emit specular")
+        mark("specular adjoint")
+        side = ow["side"]
+        with torch.cuda.stream(side):
+            side.wait_event(ow["forward_done"])
             if work is not None:
                 work.wait()  # (makes the side stream wait for RCCL's stream)
             ow["bounds_host"].copy_(ow["all_offsets"].index_select(2, ow["key_idx"]), non_blocking=True)
-            ow["ready"].record(ow["side"])
+            ow["ready"].record(side)
         if work is not None:
-            work.wait()  # the brick pass on the main stream reads the tables too
+            work.wait()  # the brick passes on the compute stream read the tables too
         tick()  # [1] forward + emit phases issued
         ow["ready"].synchronize()
         tick()  # [2] slice bounds on the host
-        b = ow["bounds_host"].numpy()  # [source, list, (lo, hi) per owner]
+        b = ow["bounds_host"].numpy()  # [source, list, (lo, hi) per piece]
+        lo_, hi_ = b[:, :, 0::2], b[:, :, 1::2]  # [source, list, piece]
+        cnt = hi_ - lo_
         sent = (W - 1) * t["offsets2"].numel() * 8  # the all-gather of the offset tables
-        lists, pending = [], []
-        for k in range(2):
-            srt = t[f"pass{k}"]["sorted"]
-            rec_bytes = srt.shape[1] * 4
-            counts = [0 if s_ == me else int(b[s_, k, 2 * me + 1] - b[s_, k, 2 * me]) for s_ in range(W)]
-            total = sum(counts)
-            ow.setdefault("last_total", [0, 0])[k] = total
-            if ow["recv"][k].shape[0] < total:  # grow-only receive buffer (sizes change slowly from step to step)
-                ow["recv"][k] = torch.empty((int(total * 1.25) + 1024, srt.shape[1]), dtype=torch.float32, device=dev)
-            recv_buf = ow["recv"][k]
-            base, send, recv = [], [], []
-            pos = 0
-            for s_ in range(W):
-                base.append(pos)
-                recv.append(recv_buf[pos : pos + counts[s_]])
-                pos += counts[s_]
-                send.append(srt[int(b[me, k, 2 * s_]) : int(b[me, k, 2 * s_ + 1])] if s_ != me else srt[:0])
-                if s_ != me:
-                    sent += int(send[-1].shape[0]) * rec_bytes
-            # (a no-op without a process group; a 1-rank RCCL group goes through the same calls)
-            if collect:
-                with torch.cuda.stream(ow["comm"]):
-                    ow["comm"].wait_event(ow["emitted"][k])
-                    pending.append(rfdist.exchange_slices(send, recv, async_op=True))
-                    ow["exchanged"][k].record(ow["comm"])
-            for s_ in range(W):
-                if s_ == me:
-                    lists.append((srt.data_ptr(), t["offsets2"][k], k == 1))
-                else:  # positioned such that ptr + offsets_s[key] * record size is the first record of `key` in the received slice
-                    lists.append((recv_buf.data_ptr() + (base[s_] - int(b[s_, k, 2 * me])) * rec_bytes, ow["all_offsets"][s_, k], k == 1))
-        for k, wk in enumerate(pending):  # the brick pass waits for both exchanges
-            if wk is not None:
-                wk.wait()
-            main.wait_event(ow["exchanged"][k])
-        del pending
-        mark(3)
-        tick()  # [3] exchanges issued
-        opt.step_count += 1
         nd = self.flat.flat_gradient_parts()[0].numel()
         has_second = self.flat.flat_gradient_parts()[1] is not None
-        halves = lambda x: (x[:nd], x[nd:] if has_second else None)
-        brick_accumulate_adam_raw(grid, self.brick_size, lists, halves(opt.exp_avg), halves(opt.exp_avg_sq), opt.lr, opt.betas[0], opt.betas[1],
-                                  opt.eps, opt.step_count, brick_range=ow["bricks"])
-        mark(4)
-        tick()  # [4] brick pass issued
-        if collect:
-            rfdist.all_gather_chunks_(self.flat.flat_param[:nd])
-            if has_second:
-                # `rest` (6/7 of the bytes) is left in flight: the next reader of the grid waits for it (VoxelGrid.wait_for_parameters) --
-                # the next iteration does so only in front of its specular render
-                ow["bricks_done"].record(main)
-                with torch.cuda.stream(ow["comm"]):
-                    ow["comm"].wait_event(ow["bricks_done"])
-                    work_rest = rfdist.all_gather_chunks_(self.flat.flat_param[nd:], async_op=True)
-                    ow["rest_gathered"].record(ow["comm"])
-                if OWNER_OVERLAP_PARAMETERS:
-                    grid.__dict__["_params_pending"] = _ParameterWait(work_rest, ow["rest_gathered"], dev)
-                else:
-                    _ParameterWait(work_rest, ow["rest_gathered"], dev)()
+        opt.step_count += 1
+        consumed = [0, 0]
+        new_waits, issue = [], []
+        for h in range(H):
+            piece = h * W + me
+            pending, entries = [], [None, None]
+            for k in (1, 0):  # the diffuse slices first: their records exist since the first phase of the step
+                srt = t[f"pass{k}"]["sorted"]
+                rec_bytes = srt.shape[1] * 4
+                counts = cnt[:, k, piece].tolist()
+                own = counts[me]
+                counts[me] = 0
+                total = sum(counts)
+                consumed[k] += total + own
+                if ow["recv"][k][h].shape[0] < total:  # grow-only receive buffer (sizes change slowly from step to step)
+                    ow["recv"][k][h] = torch.empty((int(total * 1.25) + 1024, srt.shape[1]), dtype=torch.float32, device=dev)
+                recv_buf = ow["recv"][k][h]
+                if collect:
+                    recv = list(recv_buf[:total].split(counts))
+                    s_lo, s_hi = lo_[me, k, h * W : (h + 1) * W].tolist(), hi_[me, k, h * W : (h + 1) * W].tolist()
+                    send = [srt[s_lo[d] : s_hi[d]] if d != me else srt[:0] for d in range(W)]
+                    sent += (int(cnt[me, k, h * W : (h + 1) * W].sum()) - own) * rec_bytes
+                    # (a 1-rank RCCL group goes through the same calls)
+                    pending.append(rfdist.fast_exchange(recv, send) if fast else rfdist.exchange_slices(send, recv, async_op=True))
+                # the lists of the brick pass: every source's slice positioned such that ptr + offsets_s[key] * record size is the first
+                # record of `key` (own list: where it lies; received ones: inside the receive buffer)
+                base_ptr, pos, entry = recv_buf.data_ptr(), 0, []
+                s_first = lo_[:, k, piece].tolist()
+                for s_ in range(W):
+                    if s_ == me:
+                        entry.append((srt.data_ptr(), t["offsets2"][k], k == 1))
+                    else:
+                        entry.append((base_ptr + (pos - s_first[s_]) * rec_bytes, ow["all_offsets"][s_, k], k == 1))
+                        pos += counts[s_]
+                entries[k] = entry
+            issue.append((h, entries[0] + entries[1], pending))  # (the brick pass takes the full-width lists first)
+        tick()  # [3] exchanges issued
+        exp_avg = (opt.exp_avg[:nd], opt.exp_avg[nd:] if has_second else None)
+        exp_avg_sq = (opt.exp_avg_sq[:nd], opt.exp_avg_sq[nd:] if has_second else None)
+        parts = (("base", self.flat.flat_param[:nd]), ("rest", self.flat.flat_param[nd:] if has_second else None))
+        for h, lists, pending in issue:
+            for wk in pending:  # the brick pass of this half waits for its two exchanges
+                if wk is not None:
+                    wk.wait()
+            mark(f"wait: record slices of half {h}")
+            brick_accumulate_adam_raw(grid, self.brick_size, lists, exp_avg, exp_avg_sq, opt.lr, opt.betas[0], opt.betas[1], opt.eps, opt.step_count,
+                                      brick_range=ow["bricks"][h], rf_grid=rf_grid)
+            mark(f"brick pass + Adam, half {h}")
+            if collect:
+                for tag, part in parts:
+                    if part is None:
+                        continue
+                    chunk = part.numel() // H
+                    half = part[h * chunk : (h + 1) * chunk]
+                    wk = rfdist.fast_all_gather_in_place(half) if fast else rfdist.all_gather_chunks_(half, async_op=True)
+                    new_waits.append(_ParameterWait(wk, tag))
+        tick()  # [4] brick passes + parameter all-gathers issued
         sent += (W - 1) * (self.flat.flat_param.numel() // W) * 4
-        mark(5)
+        if collect:
+            if OWNER_OVERLAP_PARAMETERS:
+                # left in flight: the next reader of the grid waits for them (VoxelGrid.wait_for_parameters) -- the next iteration
+                # piece by piece: `base` in front of its diffuse chain, `rest` only in front of its specular forward pass
+                for w_ in new_waits:
+                    grid.defer_parameter_wait(w_)
+            else:
+                for w_ in new_waits:
+                    w_()
+        mark("end")
         self.exchange_bytes = (self.exchange_bytes + [sent])[-64:]
-        # records this rank's brick pass consumed (its own slice of its own lists + what it received), per list
-        own = [int(b[me, k, 2 * me + 1] - b[me, k, 2 * me]) for k in range(2)]
-        self.owner_records = (self.owner_records + [(own[0] + int(ow["last_total"][0]), own[1] + int(ow["last_total"][1]))])[-64:]
-        if ev is not None:
-            self.phase_events.append(ev)
+        # records this rank's brick passes consumed (its own slices of its own lists + what it received), per list
+        self.owner_records = (self.owner_records + [(consumed[0], consumed[1])])[-64:]
+        if marks is not None:
+            self.phase_events.append(marks)
         if ht is not None:
-            tick()  # [5] parameter all-gathers issued
+            tick()  # [5] end of the host side
             self.host_timing.append([b_ - a_ for a_, b_ in zip(ht[:-1], ht[1:])])
+        if collect and not ow["checked"]:
+            # FIRST step of a run: the replicas must hold the same parameters (a wrong slice, a lost record or a torn all-gather shows
+            # here, not as a silently diverging run).  One device synchronisation, once.
+            ow["checked"] = True
+            grid.wait_for_parameters()
+            rfdist.assert_replicas_identical(self.flat.flat_param, "owner-computes exchange, first step")
 
     def _executor(self, n: int, S: int, device):
         """Persistent scratch + the ctypes description of one iteration (rebuilt when the batch shape changes)."""

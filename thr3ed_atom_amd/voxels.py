@@ -129,6 +129,10 @@ def resolve_density_mode(pre: Callable, post: Callable) -> str:
 _RF_GRID_CACHE: "weakref.WeakKeyDictionary" = weakref.WeakKeyDictionary()
 _RF_VIEW_CACHE: "weakref.WeakKeyDictionary" = weakref.WeakKeyDictionary()
 _RF_SHADOW_CACHE: "weakref.WeakKeyDictionary" = weakref.WeakKeyDictionary()
+# data-parallel training: parameter all-gathers still in flight on the communication stream (trainers.TrainStepper._owner_step), a list
+# of callables per grid that make the CURRENT stream wait for them.  Kept outside the module like the caches above (an RCCL work
+# handle / a HIP event in a module's __dict__ would break copy.deepcopy and torch.save of it).
+_RF_PENDING_PARAMETERS: "weakref.WeakKeyDictionary" = weakref.WeakKeyDictionary()
 # forward passes of reference-storage grids gather from a split-layout shadow (KernelGridInterface.forward_rf_grid)
 SPLIT_SHADOW = True
 
@@ -147,16 +151,28 @@ class KernelGridInterface:
         return int(np.sqrt(self._num_features // 3)) - 1
 
     def wait_for_parameters(self) -> None:
-        """Data-parallel training leaves the all-gather of the second parameter tensor in flight across the iteration boundary
-        (trainers.TrainStepper._owner_step): whoever reads the grid next makes its stream wait for it here.  A no-op otherwise."""
-        pending = self.__dict__.pop("_params_pending", None)
-        if pending is not None:
-            pending()
+        """Data-parallel training leaves all-gathers of the updated parameters in flight across the iteration boundary
+        (trainers.TrainStepper._owner_step): whoever reads the grid next -- an operator's descriptor, ``kernel_tensors()``,
+        ``.densities`` / ``.features``, ``state_dict()``, ``parameters()``, ``Module.to()`` -- makes its stream wait for them here.
+        A no-op otherwise."""
+        if _RF_PENDING_PARAMETERS:
+            pending = _RF_PENDING_PARAMETERS.pop(self, None)
+            if pending:
+                for wait in pending:
+                    wait()
+
+    def defer_parameter_wait(self, wait) -> None:
+        """(trainer) ``wait()`` makes the calling stream wait for parameters that are still arriving"""
+        _RF_PENDING_PARAMETERS.setdefault(self, []).append(wait)
+
+    def take_parameter_waits(self) -> list:
+        """(trainer) the pending waits, removed: the caller orders its own launches against them piece by piece"""
+        return _RF_PENDING_PARAMETERS.pop(self, None) or []
 
     def to_rf_grid(self, use_occupancy: bool = False, wait_parameters: bool = True) -> "_lib.RFGrid":
         if wait_parameters:
             self.wait_for_parameters()
-        d, f = self.kernel_tensors()
+        d, f = self._tensors()
         for t in (d, f):
             if t is None:
                 continue
@@ -371,10 +387,28 @@ class VoxelGrid(Module, KernelGridInterface):
                 state[prefix + "_rest"] = rest
 
     def kernel_tensors(self):
-        """The two tensors the kernels read, in storage order: (densities, features) or (base, rest)."""
+        """The two tensors the kernels read, in storage order: (densities, features) or (base, rest).  (Waits for parameters a
+        data-parallel step left in flight: the caller is about to read or describe them.)"""
+        self.wait_for_parameters()
+        return self._tensors()
+
+    def _tensors(self):
         if self.storage == "reference":
             return self._densities, self._features
         return self._base, self._rest
+
+    # readers that reach the Parameters without going through an accessor of this class
+    def named_parameters(self, *args, **kwargs):
+        self.wait_for_parameters()
+        return super().named_parameters(*args, **kwargs)
+
+    def _apply(self, fn, *args, **kwargs):
+        self.wait_for_parameters()
+        return super()._apply(fn, *args, **kwargs)
+
+    def state_dict(self, *args, **kwargs):
+        self.wait_for_parameters()
+        return super().state_dict(*args, **kwargs)
 
     def reference_gradients(self):
         """(dL/d densities, dL/d features) in the reference layout, whatever the storage."""
@@ -553,6 +587,8 @@ class ForeignVoxelGridView(KernelGridInterface):
     def kernel_tensors(self):
         self._check()
         return self.module.densities, self.module.features
+
+    _tensors = kernel_tensors
 
     @property
     def grid_dims(self):
