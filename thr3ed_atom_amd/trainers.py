@@ -100,31 +100,58 @@ class PosedImagesInMemory:
         ).clamp(0.0, 1.0)
         return PosedImagesInMemory(imgs, self.poses, intr, self.camera_bounds, self.downsample_factor * factor)
 
-    def image_batches(self, batch_size: int, generator: Optional[torch.Generator] = None) -> Iterator[Tensor]:
+    def image_batches(self, batch_size: int, generator: Optional[torch.Generator] = None, prefetch_epochs: int = 256) -> Iterator[Tensor]:
         """Endless stream of image-index batches: shuffled epochs, drop_last (the reference's
-        DataLoader(shuffle=True, drop_last=True) wrapped in infinite_dataloader, trainers.py:164-166)."""
+        DataLoader(shuffle=True, drop_last=True) wrapped in infinite_dataloader, trainers.py:164-166).
+        The shuffles come from a generator of their own (seeded from torch's global CPU generator when none is given:
+        ``torch.manual_seed`` keeps runs reproducible) and ``prefetch_epochs`` of them are drawn and copied to the device at a time;
+        the per-iteration batches are device-side slices.  A host->device copy per iteration is what this avoids: it comes out of
+        pageable memory, so the host waits for the stream to drain and the GPU then idles for a launch latency (~55 us of a
+        0.65 ms iteration, rocprofv3 kernel trace) -- and with 8 images and 8 images per batch every iteration is an epoch."""
         m = len(self)
         batch_size = min(batch_size, m)
+        if generator is None:
+            generator = torch.Generator()
+            generator.manual_seed(int(torch.randint(0, 2**62, (1,), dtype=torch.int64).item()))
         while True:
-            # one host->device copy per EPOCH; the per-iteration batches are device-side slices (a per-step copy
-            # of 8 indices from pageable memory stalls the stream for ~1 ms)
-            order = torch.randperm(m, generator=generator).to(self.images.device)
-            for s in range(0, m - batch_size + 1, batch_size):
-                yield order[s : s + batch_size]
+            orders = torch.stack([torch.randperm(m, generator=generator) for _ in range(int(prefetch_epochs))]).to(self.images.device)
+            for order in orders:
+                for s in range(0, m - batch_size + 1, batch_size):
+                    yield order[s : s + batch_size]
 
 
-@dataclasses.dataclass
 class StepStats:
-    specular_loss: Tensor
-    diffuse_loss: Optional[Tensor]
-    specular_mse: Tensor
-    diffuse_mse: Optional[Tensor]
+    """Losses of one iteration as 0-d device tensors: ``specular_loss`` / ``diffuse_loss`` (mean L1) and ``specular_mse`` /
+    ``diffuse_mse`` (for the PSNR the reference logs, trainers.py:315-317, 334-336).  The fused step hands over the raw sums its loss
+    kernel wrote -- (sum |d|, sum d^2) per render, in a slot of a ring of ``LOSS_RING`` iterations -- and the division by 3 N happens
+    when a value is READ: an iteration enqueues no extra launch for numbers that are looked at every ``summary_freq`` steps.  (Read a
+    StepStats within LOSS_RING iterations of the step that produced it.)"""
+
+    def __init__(self, specular_loss=None, diffuse_loss=None, specular_mse=None, diffuse_mse=None, sums: Optional[Tensor] = None, count: float = 1.0,
+                 has_diffuse: bool = True):
+        self._values = (specular_loss, diffuse_loss, specular_mse, diffuse_mse)
+        self._sums, self._count, self._has_diffuse = sums, float(count), has_diffuse
+
+    def _get(self, i: int, j: int):
+        if self._sums is None:
+            return self._values[i]
+        if i in (1, 3) and not self._has_diffuse:
+            return None
+        return self._sums[j] / self._count
+
+    specular_loss = property(lambda self: self._get(0, 0))
+    specular_mse = property(lambda self: self._get(2, 1))
+    diffuse_loss = property(lambda self: self._get(1, 2))
+    diffuse_mse = property(lambda self: self._get(3, 3))
 
     def psnr(self) -> Dict[str, float]:
         out = {"specular_psnr": float(mse2psnr(self.specular_mse))}
         if self.diffuse_mse is not None:
             out["diffuse_psnr"] = float(mse2psnr(self.diffuse_mse))
         return out
+
+
+LOSS_RING = 4096  # iterations whose loss sums stay readable (StepStats)
 
 
 # owner-computes data parallelism: leave the all-gather of the `rest` parameters in flight across the iteration boundary (RF_OWNER_OVERLAP_PARAMETERS=0
@@ -376,6 +403,11 @@ class TrainStepper:
             n, dev = origins.shape[0], origins.device
         ex = self._executor(n, S, dev)
         st = ex["step"]
+        # the loss sums of this iteration: the next slot of the ring (cleared by the selection launch / a memset of the call)
+        slot = ex["slot"]
+        ex["slot"] = (slot + 1) % LOSS_RING
+        sums = ex["sums_ring"][slot]
+        st.loss_sums_dev = ex["sums_ptr"] + 16 * slot
         if selection is not None:
             intr = dataset.camera_intrinsics
             ids = image_ids.detach().to(dev, torch.int64).contiguous()
@@ -408,8 +440,7 @@ class TrainStepper:
             self._owner_step(ex, st, rf_grid, n, S, dev)
             del keep, jit
             self._grad_clean = True
-            means = ex["sums"] / float(3 * n)
-            return StepStats(means[0], means[2], means[1], means[3])
+            return StepStats(sums=sums, count=3 * n)
         st.phases, st.loss_scale = 0, 1.0
         if self.fuse_optimizer:
             opt.step_count += 1
@@ -434,8 +465,7 @@ class TrainStepper:
                 rfdist.all_reduce_mean_(self.flat.flat_grad)
             opt.step()
             self._grad_clean = False
-        means = ex["sums"] / float(3 * n)
-        return StepStats(means[0], means[2], means[1], means[3])
+        return StepStats(sums=sums, count=3 * n)
 
     def _owner_state(self, ex, device):
         """Persistent state of the owner-computes exchange: who owns which x-slabs of bricks, the ranks' offset tables, where every
@@ -656,11 +686,11 @@ class TrainStepper:
         f32 = dict(dtype=torch.float32, device=device)
         t = {
             "origins": torch.empty((n, 3), **f32), "directions": torch.empty((n, 3), **f32), "pixels": torch.empty((n, 3), **f32),
-            "sums": torch.zeros(4, **f32), "t_vals": ops.t_vals_for(S, device),
+            "sums_ring": torch.zeros((LOSS_RING, 4), **f32), "t_vals": ops.t_vals_for(S, device),
         }
         t["offsets2"] = torch.empty((2, nkeys + 1), dtype=torch.int64, device=device)  # both lists' tables: ONE collective buffer
         step, sel, adam = _lib.RFTrainStep(), _lib.RFRaySelection(), _lib.RFAdamState()
-        step.num_rays, step.num_samples, step.t_vals_dev, step.loss_sums_dev = n, S, t["t_vals"].data_ptr(), t["sums"].data_ptr()
+        step.num_rays, step.num_samples, step.t_vals_dev, step.loss_sums_dev = n, S, t["t_vals"].data_ptr(), t["sums_ring"].data_ptr()
         for i, diffuse in enumerate((False, True)):
             p = {
                 "colour": torch.empty((n, 3), **f32), "depth": torch.empty(n, **f32), "acc": torch.empty(n, **f32), "disparity": torch.empty(n, **f32),
@@ -685,7 +715,7 @@ class TrainStepper:
         adam.exp_avg_second_dev = opt.exp_avg[nd:].data_ptr() if has_second else None
         adam.exp_avg_sq_second_dev = opt.exp_avg_sq[nd:].data_ptr() if has_second else None
         adam.beta1, adam.beta2, adam.eps = opt.betas[0], opt.betas[1], opt.eps
-        self._exec = {"shape": (n, S), "tensors": t, "step": step, "select": sel, "adam": adam, "sums": t["sums"],
+        self._exec = {"shape": (n, S), "tensors": t, "step": step, "select": sel, "adam": adam, "sums_ring": t["sums_ring"], "sums_ptr": t["sums_ring"].data_ptr(), "slot": 0,
                       "origins": t["origins"], "directions": t["directions"], "pixels": t["pixels"]}
         return self._exec
 
