@@ -27,8 +27,26 @@ import os
 import sys
 import time
 
-import numpy as np
-import torch
+
+def host_cpu_quota() -> int:
+    """CPU cores this process may really use: the cgroup's CFS quota (cpu.max = "quota period") when there is one, else
+    os.cpu_count().  The GPU boxes show 256 logical cores under a 16-core quota: OpenMP pools sized by os.cpu_count() (torch's
+    default: 128 threads) burn the quota spinning and the whole cgroup is THROTTLED for tens of milliseconds at a time
+    (cpu.stat: nr_throttled) -- a 40-60 ms stall in the middle of a timed region, and the reason 256-thread CPU baselines collapse."""
+    n = os.cpu_count() or 1
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if quota != "max":
+            n = max(1, min(n, int(int(quota) / int(period))))
+    except Exception:  # noqa: BLE001  (cgroup v1 / no cgroup: keep os.cpu_count())
+        pass
+    return n
+
+
+os.environ.setdefault("OMP_NUM_THREADS", str(host_cpu_quota()))  # (before torch creates its thread pools)
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
@@ -40,6 +58,7 @@ from thr3ed_atom_amd import ops  # noqa: E402
 from thr3ed_atom_amd.trainers import PosedImagesInMemory, TrainStepper  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md)
+HBM_ACHIEVABLE_GBS = 6300.0  # what a streaming kernel measures on it (same guide): the second denominator of the roofline line
 L2_PEAK_TBS = 34.5  # aggregate L2 bandwidth, same guide
 NEAR = float(np.float32(2.0) * 0.9)  # hotdog-like bounds, SURVEY.md 8d
 FAR = float(np.float32(6.0) * 1.1)
@@ -138,24 +157,26 @@ def respawn_under_torchrun(gpus: int):
     os.execv(sys.executable, cmd)
 
 
-def cpu_baseline(grid, rays_cpu, pixels_cpu, num_samples, n_train, n_fwd, threads=0, reps=3):
+def cpu_baseline(grid, rays_cpu, pixels_cpu, num_samples, n_train, n_fwd, threads=0, reps=3, n_full=16384):
     """The oracle's float32 CPU path (the same ATen ops the reference calls) on bounded samples of the same workloads
-    (SURVEY 8d protocol: 1 warm-up + 3 timed repeats, median): cfg3 = specular+diffuse fwd+bwd of ``n_train`` rays, cfg2 = a
-    forward-only chunk of ``n_fwd`` rays."""
+    (SURVEY 8d protocol): cfg3 = specular+diffuse fwd+bwd of ``n_full`` rays -- ONE full training batch, one timed step after a
+    small warm-up (~20 s) -- and, for the spread, the median of ``reps`` repeats on ``n_train`` rays; cfg2 = a forward-only chunk of
+    ``n_fwd`` rays.  Threads = the cores this process may really use (the cgroup quota, host_cpu_quota()), at most 64."""
     from oracle import relu_field_oracle as orc  # checker / baseline only
 
-    # measured on the MI355X host (256 logical cores): 16 threads 4.2e5, 64 threads 3.8e5, 256 threads 0.5e5
-    # ray-samples/s -- the ATen ops of this path do not scale past a few tens of threads, so the default is
-    # capped at 16 (the count actually used is reported as "cores")
-    cores = threads if threads > 0 else min(os.cpu_count() or 1, 16)
+    cores = threads if threads > 0 else min(host_cpu_quota(), 64)
     torch.set_num_threads(cores)
     dens = grid.densities.detach().cpu().clone().requires_grad_(True)
     feat = grid.features.detach().cpu().clone().requires_grad_(True)
     aabb = tuple(tuple(r) for r in grid.aabb)
     rho = grid.expected_density_scale
 
+    def rays_of(n):  # (a leg may hold more rays than the batch handed over: repeat it)
+        reps_ = (n + rays_cpu[0].shape[0] - 1) // rays_cpu[0].shape[0]
+        return rays_cpu[0].repeat(reps_, 1)[:n], rays_cpu[1].repeat(reps_, 1)[:n], pixels_cpu.repeat(reps_, 1)[:n]
+
     def train(n):
-        o, d, px = rays_cpu[0][:n], rays_cpu[1][:n], pixels_cpu[:n]
+        o, d, px = rays_of(n)
         dens.grad = feat.grad = None
         total = 0.0
         for diffuse in (False, True):
@@ -165,44 +186,36 @@ def cpu_baseline(grid, rays_cpu, pixels_cpu, num_samples, n_train, n_fwd, thread
         total.backward()
 
     def forward(n):
-        reps_ = (n + rays_cpu[0].shape[0] - 1) // rays_cpu[0].shape[0]  # (a chunk may hold more rays than one training batch: repeat it)
-        o, d = rays_cpu[0].repeat(reps_, 1)[:n], rays_cpu[1].repeat(reps_, 1)[:n]
+        o, d, _ = rays_of(n)
         with torch.no_grad():
             orc.render(dens, feat, o, d, aabb, NEAR, FAR, num_samples, rho, "relu", white_bkgd=True, t_rand=torch.rand(n, num_samples), interp="aten")
 
-    def timed(fn, n):
+    def timed(fn, n, reps_):
         fn(min(256, n))  # warm-up (thread pool, page-in)
         ts = []
-        for _ in range(reps):
+        for _ in range(reps_):
             t0 = time.perf_counter()
             fn(n)
             ts.append(time.perf_counter() - t0)
         return float(np.median(ts))
 
-    dt_train = timed(train, n_train)
-    dt_fwd = timed(forward, n_fwd) if n_fwd > 0 else None
-    # SURVEY 8d asks for torch.set_num_threads(os.cpu_count()); on a many-core host that is SLOWER for these ATen ops (thread
-    # hand-off dominates), so it is reported beside the default figure, on a smaller sample (one repeat after the warm-up)
-    all_cores = None
-    ncpu = os.cpu_count() or 1
-    if threads <= 0 and ncpu > cores:
-        torch.set_num_threads(ncpu)
-        n_all = max(32, n_train // 32)
-        train(min(16, n_all))
-        t0 = time.perf_counter()
-        train(n_all)
-        dt_all = time.perf_counter() - t0
-        all_cores = {"value": 2 * n_all * num_samples / dt_all, "unit": "ray-samples/s", "cores": ncpu,
-                     "sample": f"one repeat of the same training-step core on {n_all} rays with torch.set_num_threads(os.cpu_count() = {ncpu}); {dt_all:.2f} s"}
-        torch.set_num_threads(cores)
+    dt_train = timed(train, n_train, reps)
+    dt_full = timed(train, n_full, 1) if n_full > 0 else None
+    dt_fwd = timed(forward, n_fwd, reps) if n_fwd > 0 else None
+    value = 2 * n_full * num_samples / dt_full if dt_full else 2 * n_train * num_samples / dt_train
     return {
-        "value": 2 * n_train * num_samples / dt_train,
+        "value": value,
         "unit": "ray-samples/s",
         "cores": cores,
+        "host_cores_visible": os.cpu_count(),
+        "host_cpu_quota_cores": host_cpu_quota(),
         "kind": "port",
-        "sample": f"median of {reps} repeats after 1 warm-up: training-step core (specular+diffuse fwd+bwd, no optimiser) of {n_train} rays x {num_samples} samples "
-        f"on the same 128^3 SH-2 grid, oracle with interp='aten' (F.grid_sample), torch {torch.__version__} CPU fp32; {dt_train:.2f} s/step",
-        "all_host_cores": all_cores,
+        "sample": (f"configs[2] in full: ONE training-step core (specular+diffuse fwd+bwd, no optimiser) of {n_full} rays x {num_samples} samples after a 256-ray warm-up, "
+                   f"{dt_full:.2f} s" if dt_full else f"median of {reps} repeats of the training-step core on {n_train} rays")
+        + f"; same 128^3 SH-2 grid, oracle with interp='aten' (F.grid_sample), torch {torch.__version__} CPU fp32, {cores} threads = the cores this "
+        f"process may use (cgroup quota; os.cpu_count() shows {os.cpu_count()})",
+        "small_batch": {"value": 2 * n_train * num_samples / dt_train, "unit": "ray-samples/s",
+                        "sample": f"median of {reps} repeats after 1 warm-up on {n_train} rays; {dt_train:.2f} s/step"},
         "forward_only": None if dt_fwd is None else {
             "value": n_fwd * num_samples / dt_fwd,
             "unit": "ray-samples/s",
@@ -285,6 +298,7 @@ def main():
     ap.add_argument("--render-frames", type=int, default=5, help="full-frame forward renders timed for fwd_render (0 = skip)")
     ap.add_argument("--highres-frames", type=int, default=5, help="frames timed for the 256^3 / 512-sample configs[4] render (0 = skip)")
     ap.add_argument("--cpu-rays", type=int, default=2048, help="rays of the cpu_baseline training sample (0 = skip the CPU baseline)")
+    ap.add_argument("--cpu-full-rays", type=int, default=16384, help="rays of the cpu_baseline's full training batch (SURVEY 8d cfg3; one timed step, ~20 s; 0 = skip)")
     ap.add_argument("--cpu-fwd-rays", type=int, default=32768, help="rays of the cpu_baseline forward-only chunk (SURVEY 8d: one parallel_rays_chunk_size chunk)")
     ap.add_argument("--dropin-steps", type=int, default=20, help="steps timed for the strict drop-in configuration (0 = skip)")
     ap.add_argument("--storage", choices=["split", "bricked", "reference"], default="split",
@@ -302,7 +316,7 @@ def main():
                     help="data-parallel exchange: owner = owner-computes (record slices all-to-all -> merged brick pass + Adam on the rank's own bricks -> "
                     "parameter all-gather), dense = reduce-scatter of the gradient bucket -> sharded Adam -> all-gather")
     ap.add_argument("--timed-steps", type=int, default=5, help="how many of the --steps record per-kernel HIP events")
-    ap.add_argument("--cpu-threads", type=int, default=0, help="torch CPU threads for cpu_baseline (0 = min(cores, 16))")
+    ap.add_argument("--cpu-threads", type=int, default=0, help="torch CPU threads for cpu_baseline (0 = the cgroup CPU quota, at most 64)")
     args = ap.parse_args()
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ and "RANK" not in os.environ:
@@ -639,7 +653,11 @@ def main():
             "peak": HBM_PEAK_GBS,
             "unit": "GB/s",
             "frac": d["frac_hbm"] if d["frac_hbm"] is not None else d["frac_processed"],
-            "frac_basis": "HBM bytes from the PMC counters (profiles/pmc_traffic.json, sha256-tied to the kernel source) / this run's launch time" if traffic is not None
+            "frac_of_achievable": None if (d["frac_hbm"] if d["frac_hbm"] is not None else d["frac_processed"]) is None
+            else (d["frac_hbm"] if d["frac_hbm"] is not None else d["frac_processed"]) * HBM_PEAK_GBS / HBM_ACHIEVABLE_GBS,
+            "achievable_GBps": HBM_ACHIEVABLE_GBS,
+            "frac_basis": "fabric bytes from the PMC counters (FETCH_SIZE / WRITE_SIZE count at the data fabric: Infinity-Cache hits included, so this is an upper bound of the DRAM traffic; "
+            "profiles/pmc_traffic.json, sha256-tied to the kernel source) / this run's launch time" if traffic is not None
             else ("algorithmic bytes on processed units (profiles/pmc_traffic.json was measured on a different relu_field_kernels.hip: stale, not used)" if pmc_stale
                   else "algorithmic bytes on processed units (no counter entry for this kernel in profiles/pmc_traffic.json)"),
             "traffic": traffic,
@@ -694,7 +712,7 @@ def main():
 
     baseline = None
     if args.cpu_rays > 0:
-        baseline = cpu_baseline(grid, (rays.origins.cpu(), rays.directions.cpu()), pixels.cpu(), S, args.cpu_rays, args.cpu_fwd_rays, args.cpu_threads)
+        baseline = cpu_baseline(grid, (rays.origins.cpu(), rays.directions.cpu()), pixels.cpu(), S, args.cpu_rays, args.cpu_fwd_rays, args.cpu_threads, n_full=args.cpu_full_rays)
         baseline["cfg1_full_frame"] = cfg1_leg(dev, baseline["cores"])
 
     line = {

@@ -469,6 +469,23 @@ def _autograd_uses_bricks(grid, flags: int, n: int, num_samples: int) -> bool:
     return grid.sh_degree >= 2 and n * num_samples >= (1 << 20)
 
 
+# zeroed per-key record counters of the autograd op's binned adjoint: a forward pass takes one, the adjoint that consumes it has its emit
+# launch clear it again (stream order) and hands it back -- no torch.zeros launch per render.  (A forward pass whose adjoint never
+# runs simply keeps its buffer; the pool allocates another.)
+_HIST_POOL: Dict[Tuple[str, int], list] = {}
+
+
+def _take_hist(device, nkeys: int) -> Tensor:
+    pool = _HIST_POOL.setdefault((str(device), int(nkeys)), [])
+    return pool.pop() if pool else torch.zeros(int(nkeys), dtype=torch.int32, device=device)
+
+
+def _return_hist(hist: Tensor) -> None:
+    pool = _HIST_POOL.setdefault((str(hist.device), int(hist.numel())), [])
+    if len(pool) < 8:
+        pool.append(hist)
+
+
 class _ReluFieldRender(torch.autograd.Function):
     @staticmethod
     def forward(ctx, first, second, origins, directions, t_rand, grid: VoxelGrid, num_samples, near, far, flags, need_grad):
@@ -489,7 +506,7 @@ class _ReluFieldRender(torch.autograd.Function):
         key_hist = None
         if need_grad and _autograd_uses_bricks(grid, int(flags), n, int(num_samples)):
             nb = brick_counts(grid, AUTOGRAD_BRICK_SIZE)
-            key_hist = torch.zeros(nb[0] * nb[1] * nb[2] * 8, dtype=torch.int32, device=origins.device)
+            key_hist = _take_hist(origins.device, nb[0] * nb[1] * nb[2] * 8)
         colour, depth, acc, disparity, caches = render_forward_raw(
             grid, origins, directions, keyed if keyed is not None else t_rand, int(num_samples), float(near), float(far), int(flags), bool(need_grad),
             key_hist=key_hist, brick_size=AUTOGRAD_BRICK_SIZE,
@@ -552,8 +569,9 @@ class _ReluFieldRender(torch.autograd.Function):
             bin_offsets(hist, offsets, cursor)
             render_backward_emit_direct_raw(
                 grid, origins, directions, t_rand, ctx.num_samples, ctx.near, ctx.far, ctx.flags, (cache, tcache, stop, cmask),
-                prep(g_colour), prep(g_depth), prep(g_acc), AUTOGRAD_BRICK_SIZE, cursor, records, hist_clear=None,
+                prep(g_colour), prep(g_depth), prep(g_acc), AUTOGRAD_BRICK_SIZE, cursor, records, hist_clear=hist,
             )
+            _return_hist(hist)  # (zero again once the emit launch above has run: every later user is behind it on the stream)
             if bucket is not None and getattr(bucket, "deferred", False) and bucket.matches(first, second):
                 # deferred gradients: the sorted list IS the gradient of this render; the optimizer sums all lists of the iteration
                 bucket.pending.append((records, offsets, diffuse))
