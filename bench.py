@@ -753,7 +753,8 @@ def main():
                         "exchange_fallback_reason": exchange_fallback,  # not None: the owner-computes step failed and the run fell back to the dense exchange
                         "replicas_bit_identical": replicas_ok,  # parameter checksums of all ranks after the timed steps (None on one GPU)
                         "exposed_communication_ms_per_step": ({k: v["avg_ms"] for k, v in kernels.items() if k.startswith("wait:")} if owner else None),
-                        "owner_halves": (stepper._owner or {}).get("H") if owner else None},
+                        "owner_halves": (stepper._owner or {}).get("H") if owner else None,
+                        "owner_workgroups_per_brick": (stepper._owner or {}).get("parts") if owner else None},
         "rays_per_s": world * R * args.steps / elapsed,  # rays of the batch per second (each is rendered twice per step: renders_per_s = 2 x this)
         "final_specular_psnr": stats.psnr()["specular_psnr"],
         "inside_fraction": n_in / (R * S),

@@ -306,6 +306,21 @@ int rf_brick_accumulate_adam(const RFGrid* grid, int32_t brick_size, const RFBri
 int rf_brick_accumulate_adam_range(const RFGrid* grid, int32_t brick_size, const RFBrickList* lists, int32_t num_lists,
                                    const RFAdamState* adam, int32_t first_brick, int32_t num_bricks, void* stream);
 
+/* The owner's pass with SEVERAL workgroups per brick.  With N ranks an owned brick receives N times the records of the single-GPU
+ * case while the launch covers only 1 / N of the bricks: one workgroup per brick leaves most of the machine idle behind the
+ * heaviest bricks (measured at N = 8 on the bench workload: 0.35 ms for the x-slab through the middle of the volume, half of the
+ * 512 workgroup slots unused).  Here `parts` (1..8) workgroups share a brick: workgroup (brick, part) sums the lists l of each kind
+ * with l % parts == part -- the source ranks are dealt out --, the partial accumulator images meet in `scratch_dev`, and the last
+ * workgroup of a brick to arrive adds them and applies Adam (no workgroup waits for another).  scratch_dev: caller-owned,
+ * rf_brick_split_scratch_bytes(grid, num_bricks, parts) bytes, 16-byte aligned, ZERO before the first launch; every launch leaves
+ * its counters zero again (launches that share a scratch buffer must not overlap).  Needs 8^3 bricks and the one-round flush (the
+ * grid tensors below 2^30 elements); RF_ERR_UNSUPPORTED otherwise (use rf_brick_accumulate_adam_range).  (Added to ABI
+ * version 4 compatibly: no existing struct or signature changed.) */
+int64_t rf_brick_split_scratch_bytes(const RFGrid* grid, int32_t num_bricks, int32_t parts);
+int rf_brick_accumulate_adam_split(const RFGrid* grid, int32_t brick_size, const RFBrickList* lists, int32_t num_lists,
+                                   const RFAdamState* adam, int32_t first_brick, int32_t num_bricks, int32_t parts, void* scratch_dev,
+                                   int64_t scratch_bytes, void* stream);
+
 /* VoxelGrid.forward (thre3d_reprs/voxels.py:276-331) as a standalone point query: points_dev [M,3] (any
  * points: zeros padding outside the grid, no AABB mask) -> out_dev [M, F+1] = (F interpolated features in the
  * reference order colour*K + k, activated density).  Bit-for-bit the ATen grid_sample recipe. */

@@ -54,8 +54,12 @@ def _train(stepper, data, steps=3):
     return stepper.flat.flat_param.clone()
 
 
-def _worker(rank, world, port, result_dir, exchange, shard_optimizer, jitter, grid_size=16, halves=1):
+def _worker(rank, world, port, result_dir, exchange, shard_optimizer, jitter, grid_size=16, halves=1, brick_parts=0):
     GRID["G"] = grid_size
+    if brick_parts:
+        import thr3ed_atom_amd.trainers as trainers_module
+
+        trainers_module.OWNER_BRICK_PARTS = brick_parts  # several workgroups per owned brick (rf_brick_accumulate_adam_split)
     os.environ.update(RANK=str(rank), LOCAL_RANK="0", WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     dev = torch.device("cuda", 0)
     torch.cuda.set_device(dev)
@@ -70,6 +74,7 @@ def _worker(rank, world, port, result_dir, exchange, shard_optimizer, jitter, gr
         if exchange == "owner":
             assert stepper.exchange_bytes and stepper.exchange_bytes[-1] > 0 and stepper.owner_records[-1][0] > 0
             assert stepper._owner["H"] == halves, (stepper._owner["H"], halves)  # interleaved ownership: the pipelined step
+            assert stepper._owner["parts"] == (brick_parts or (2 if world >= 4 else 1))
         gathered = [torch.empty_like(dp) for _ in range(world)]
         dist.all_gather(gathered, dp)
         assert all(torch.equal(gathered[0], t) for t in gathered), "replicas diverged"
@@ -98,11 +103,13 @@ def _worker(rank, world, port, result_dir, exchange, shard_optimizer, jitter, gr
     ("owner", True, False, 16, 1), ("owner", True, True, 16, 1),
     ("owner", True, True, 32, 2),  # 4 x-slabs of bricks: rank r owns slabs r and r + 2 -- the interleaved ownership of the pipelined step
     ("owner", True, False, 64, 2),  # 8 x-slabs: two neighbouring slabs per rank and half
+    ("owner", True, True, 32, -2),  # ... with TWO workgroups per owned brick (the source ranks' lists dealt out, partial images merged)
     ("dense", True, False, 16, 1), ("dense", False, True, 16, 1)])
 def test_two_processes_train_data_parallel_on_one_gpu(tmp_path, exchange, shard_optimizer, jitter, grid_size, halves):
     assert torch.cuda.is_available()
     world = 2
-    mp.spawn(_worker, args=(world, _free_port(), str(tmp_path), exchange, shard_optimizer, jitter, grid_size, halves), nprocs=world, join=True)
+    parts = 2 if halves < 0 else 0
+    mp.spawn(_worker, args=(world, _free_port(), str(tmp_path), exchange, shard_optimizer, jitter, grid_size, abs(halves), parts), nprocs=world, join=True)
     assert sorted(os.listdir(tmp_path)) == [f"ok{r}" for r in range(world)]
 
 

@@ -1086,3 +1086,50 @@ def test_paired_launches_equal_one_launch_per_render(hip_device):
         outs.append(json.loads(line[0][len("RESULT "):]))
     np.testing.assert_allclose(np.array(outs[0]["losses"]), np.array(outs[1]["losses"]), rtol=2e-6)
     np.testing.assert_allclose(outs[0]["sums"], outs[1]["sums"], rtol=1e-6)
+
+
+@pytest.mark.parametrize("copies,parts", [(2, 2), (5, 3), (8, 2), (8, 8), (3, 4)])
+def test_split_brick_pass_equals_the_plain_owner_pass(hip_device, copies, parts):
+    """rf_brick_accumulate_adam_split (several workgroups per owned brick: the source ranks' lists dealt out, partial accumulator
+    images merged by the last workgroup to arrive -- across XCDs, inside one launch) == rf_brick_accumulate_adam_range on the same
+    lists and the same optimizer state: parameters and both Adam moments to float32 summation order, the scratch left clean.
+    ``copies`` copies of this GPU's own record lists stand in for the ranks' lists."""
+    G, S, n = 40, 64, 2048
+    F = 27
+    cam = hotdog_like_camera()
+    grid = relu_grid(hip_device, T(hash_uniform((G, G, G, 1), 31)), T(hash_uniform((G, G, G, F), 32)), G, storage="split")
+    cfg = rf.SHVoxGridRenderConfig(S, rf.CameraBounds(cam["near"], cam["far"]), perturb_sampled_points=True, white_bkgd=True)
+    model = rf.VolumetricModel(grid, rf.render_sh_voxel_grid, cfg, device=hip_device)
+    rays = rf.flatten_rays(rf.cast_rays(rf.CameraIntrinsics(48, 48, 66.0), rf.pose_spherical(20.0, -30.0, cam["radius"]), hip_device))[:n]
+    pixels = T(hash_uniform((n, 3), 33, 0.0, 1.0)).to(hip_device)
+    st = TrainStepper(model, n, learning_rate=0.03, fused=True, backward="binned", data_parallel=False)
+    for _ in range(2):
+        st.step_on(rays, pixels)
+    torch.cuda.synchronize()
+    t, opt = st._exec["tensors"], st.optimizer
+    nd = st.flat.flat_gradient_parts()[0].numel()
+    m, v = (opt.exp_avg[:nd], opt.exp_avg[nd:]), (opt.exp_avg_sq[:nd], opt.exp_avg_sq[nd:])
+    lists = [(t["pass0"]["sorted"], t["offsets2"][0], False)] * copies + [(t["pass1"]["sorted"], t["offsets2"][1], True)] * copies
+    assert int(t["offsets2"][0][-1]) > 1000 and int(t["offsets2"][1][-1]) > 1000
+    nb = (G + 7) // 8
+    rng = (nb * nb, 3 * nb * nb)  # x-slabs 1..3 of bricks
+    state0 = (st.flat.flat_param.clone(), opt.exp_avg.clone(), opt.exp_avg_sq.clone())
+
+    def run(split):
+        for dst, src in zip((st.flat.flat_param, opt.exp_avg, opt.exp_avg_sq), state0):
+            dst.copy_(src)
+        ops.brick_accumulate_adam_raw(grid, 8, lists, m, v, 0.03, 0.9, 0.999, 1e-8, 3, brick_range=rng, split=split)
+        torch.cuda.synchronize()
+        return st.flat.flat_param.clone(), opt.exp_avg.clone(), opt.exp_avg_sq.clone()
+
+    ref = run(None)
+    scratch = ops.brick_split_scratch(grid, rng[1], parts)
+    for repeat in range(2):  # (the second launch finds the counters the first one left)
+        got = run((parts, scratch))
+        assert int(scratch.view(torch.int32)[: rng[1] * (1 + parts)].abs().sum()) == 0
+        assert float((got[0] - state0[0]).abs().max()) > 1e-3  # (something was updated)
+        for a, b in zip(got, ref):
+            scale = float(b.abs().max())
+            assert float((a - b).abs().max()) <= 2e-6 * max(scale, 1.0) + 1e-4 * scale * 0 + 3e-6 * scale, (float((a - b).abs().max()), scale)
+    with pytest.raises(RuntimeError):  # too small a scratch is refused before anything is launched
+        ops.brick_accumulate_adam_raw(grid, 8, lists, m, v, 0.03, 0.9, 0.999, 1e-8, 3, brick_range=rng, split=(parts, scratch[: scratch.numel() // 2]))

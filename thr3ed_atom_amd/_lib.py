@@ -54,6 +54,8 @@ EXPORTED_SYMBOLS = [
     "rf_brick_accumulate",
     "rf_brick_accumulate_adam",
     "rf_brick_accumulate_adam_range",
+    "rf_brick_accumulate_adam_split",
+    "rf_brick_split_scratch_bytes",
     "rf_grid_query",
     "rf_grid_query_backward",
     "rf_build_occupancy",
@@ -282,6 +284,8 @@ def load() -> C.CDLL:
     lib.rf_brick_accumulate.argtypes = [C.POINTER(RFGrid), i32, C.POINTER(RFBrickList), i32, vp, vp, i32, vp]
     lib.rf_brick_accumulate_adam.argtypes = [C.POINTER(RFGrid), i32, C.POINTER(RFBrickList), i32, C.POINTER(RFAdamState), vp]
     lib.rf_brick_accumulate_adam_range.argtypes = [C.POINTER(RFGrid), i32, C.POINTER(RFBrickList), i32, C.POINTER(RFAdamState), i32, i32, vp]
+    lib.rf_brick_accumulate_adam_split.argtypes = [C.POINTER(RFGrid), i32, C.POINTER(RFBrickList), i32, C.POINTER(RFAdamState), i32, i32, i32, vp, i64, vp]
+    lib.rf_brick_split_scratch_bytes.argtypes = [C.POINTER(RFGrid), i32, i32]
     lib.rf_train_step.argtypes = [C.POINTER(RFGrid), C.POINTER(RFTrainStep), vp]
     lib.rf_grid_query.argtypes = [C.POINTER(RFGrid), vp, i64, vp, vp]
     lib.rf_grid_query_backward.argtypes = [C.POINTER(RFGrid), vp, i64, vp, vp, vp, vp]
@@ -292,7 +296,7 @@ def load() -> C.CDLL:
     lib.rf_adam_step.argtypes = [vp, vp, vp, vp, i64, f32, f32, f32, f32, i32, i32, vp]
     for name in EXPORTED_SYMBOLS:
         if name not in ("rf_error_string",):
-            getattr(lib, name).restype = C.c_int
+            getattr(lib, name).restype = C.c_int64 if name == "rf_brick_split_scratch_bytes" else C.c_int
     if lib.rf_abi_version() != ABI_VERSION:
         raise RuntimeError(f"{LIB_PATH}: ABI version {lib.rf_abi_version()} != {ABI_VERSION} (stale build? run __graft_entry__.build())")
     lib.rf_abi_struct_size.argtypes = [C.c_int]

@@ -167,6 +167,37 @@ struct __attribute__((packed, aligned(4))) f3u {
 };
 typedef float vf2 __attribute__((ext_vector_type(2)));  // packed pair: v_pk_mul_f32 / v_pk_add_f32
 typedef float vf4 __attribute__((ext_vector_type(4)));  // naturally aligned 16-byte vector (non-temporal builtins)
+// 16-byte accesses with / without the streaming hint (experiment switches RF_NT_*: data written once and read once by the next kernel)
+template <bool NT>
+__device__ __forceinline__ void store_f4(float4* p, float4 v) {
+  if constexpr (NT) {
+    const vf4 t = {v.x, v.y, v.z, v.w};
+    __builtin_nontemporal_store(t, reinterpret_cast<vf4*>(p));
+  } else {
+    *p = v;
+  }
+}
+template <bool NT>
+__device__ __forceinline__ float4 load_f4(const float4* p) {
+  if constexpr (NT) {
+    const vf4 t = __builtin_nontemporal_load(reinterpret_cast<const vf4*>(p));
+    return make_float4(t[0], t[1], t[2], t[3]);
+  } else {
+    return *p;
+  }
+}
+#ifndef RF_NT_RECORD_STORE
+#define RF_NT_RECORD_STORE 1  // measured (A/B, same box): emit 0.0785 -> 0.0768 ms
+#endif
+#ifndef RF_NT_CACHE_STORE
+#define RF_NT_CACHE_STORE 1   // with the load below: forward pair 0.1955 -> 0.192 ms
+#endif
+#ifndef RF_NT_RECORD_LOAD
+#define RF_NT_RECORD_LOAD 0   // (streaming record loads in the brick pass: 0.331 -> 0.349 ms -- slower)
+#endif
+#ifndef RF_NT_CACHE_LOAD
+#define RF_NT_CACHE_LOAD 1
+#endif
 
 // ---------------------------------------------------------------------------------------------
 // wave-level helpers (64 lanes)
@@ -1069,8 +1100,11 @@ __device__ __forceinline__ void render_forward_ray(const GridArgs& g, const RayA
         cv.y = raw_g;
         cv.z = raw_b;
         cv.w = sigma;
-        reinterpret_cast<float4*>(out.cache)[idx] = cv;
-        out.tcache[idx] = T;
+        store_f4<RF_NT_CACHE_STORE>(reinterpret_cast<float4*>(out.cache) + idx, cv);
+        if (RF_NT_CACHE_STORE)
+          __builtin_nontemporal_store(T, out.tcache + idx);
+        else
+          out.tcache[idx] = T;
       }
       my_cmask = (lane == (chunk & (kWave - 1))) ? mask : my_cmask;
       if (out.hist) add_key_runs<false>(out.hist, need ? brick_key(sm.cell.i0, g, out.brick_shift, out.nby, out.nbz) : -1, lane);
@@ -1503,8 +1537,8 @@ __device__ __forceinline__ void render_emit_direct_ray(const GridArgs& g, const 
       const int chunk = max(c0 - u, 0);
       const int s = chunk * kWave + lane;
       const long long idx = cached_slot(ray, r.S, chunk, cm[u], lane);
-      cv[u] = reinterpret_cast<const float4*>(fwd.cache)[idx];
-      Tc[u] = fwd.tcache[idx];
+      cv[u] = load_f4<RF_NT_CACHE_LOAD>(reinterpret_cast<const float4*>(fwd.cache) + idx);
+      Tc[u] = RF_NT_CACHE_LOAD ? __builtin_nontemporal_load(fwd.tcache + idx) : fwd.tcache[idx];
       zq[u] = z_requests(r, s);
     }
 #pragma unroll
@@ -1580,12 +1614,12 @@ __device__ __forceinline__ void render_emit_direct_ray(const GridArgs& g, const 
         const float graw[3] = {(w * gC[0]) * (c[0] * (1.0f - c[0])), (w * gC[1]) * (c[1] * (1.0f - c[1])), (w * gC[2]) * (c[2] * (1.0f - c[2]))};
         float4* dst = gr.sorted + (long long)pos * QE;
         if constexpr (KE == 1) {  // base-channel record: index quad + (density, degree-0 r, g, b) -- nothing left to expand
-          dst[0] = make_float4(ix[u][0], ix[u][1], ix[u][2], 0.0f);
-          dst[1] = make_float4(g_pre * g.rho, graw[0] * kC0, graw[1] * kC0, graw[2] * kC0);
+          store_f4<RF_NT_RECORD_STORE>(dst + 0, make_float4(ix[u][0], ix[u][1], ix[u][2], 0.0f));
+          store_f4<RF_NT_RECORD_STORE>(dst + 1, make_float4(g_pre * g.rho, graw[0] * kC0, graw[1] * kC0, graw[2] * kC0));
         } else {  // compact specular record (48 B): the brick pass multiplies the SH basis of `vdir` in
-          dst[0] = make_float4(ix[u][0], ix[u][1], ix[u][2], g_pre * g.rho);
-          dst[1] = make_float4(graw[0], graw[1], graw[2], vdir[0]);
-          dst[2] = make_float4(vdir[1], vdir[2], 0.0f, 0.0f);
+          store_f4<RF_NT_RECORD_STORE>(dst + 0, make_float4(ix[u][0], ix[u][1], ix[u][2], g_pre * g.rho));
+          store_f4<RF_NT_RECORD_STORE>(dst + 1, make_float4(graw[0], graw[1], graw[2], vdir[0]));
+          store_f4<RF_NT_RECORD_STORE>(dst + 2, make_float4(vdir[1], vdir[2], 0.0f, 0.0f));
         }
       }
     }
@@ -1695,6 +1729,11 @@ struct BrickArgs {
   int stagger;             // development builds (RF_BRICK_PROFILE / RF_BRICK_ABLATE): ablation switches from $RF_BRICK_STAGGER (0x100000 no tile
                            // loop, 0x200000 no lists, 0x400000 no flush)
   AdamArgs adam;           // only read by the ADAM instantiation
+  // SPLIT launches (rf_brick_accumulate_adam_split): `parts` workgroups per brick, workgroup (brick, part) sums the lists l with
+  // l % parts == part of each kind; the partial images meet in `partial`, the last workgroup of a brick to arrive adds them and flushes
+  int parts;
+  float* partial;          // [num_bricks][parts][brick_acc_words] partial accumulator images
+  int* part_state;         // [num_bricks][1 + parts]: arrival counter, then one "wrote an image" flag per part; all zero between launches
 };
 
 
@@ -2207,7 +2246,7 @@ __host__ __device__ inline int gather_lds_words(int B, int C) {
 // leaves a wave 256 registers)
 // ONE_ROUND: the launch is for 8^3-node bricks (the brick edge folds to a constant); with ADAM it also selects the one-round flush
 // (which additionally needs 32-bit byte offsets: the host checks)
-template <int K, bool ADAM, bool ONE_ROUND = false>
+template <int K, bool ADAM, bool ONE_ROUND = false, bool SPLIT = false>
 __global__ __launch_bounds__(kBrickThreads, (K > 9 ? 2 : 4)) void brick_gather_kernel(GridArgs g, BrickArgs a, float* gdens, float* gfeat) {
   constexpr int C = 3 * K + 1;
   constexpr int C4 = (C + 3) / 4 * 4;
@@ -2234,7 +2273,15 @@ __global__ __launch_bounds__(kBrickThreads, (K > 9 ? 2 : 4)) void brick_gather_k
   const int tid = threadIdx.x;
   const int lane = tid & (kWave - 1);
   const int wave = tid >> 6;
-  const int brick = a.brick_first + (int)blockIdx.x;
+  // SPLIT: the `parts` workgroups of a brick are neighbours in the launch (they run side by side)
+  const int parts = SPLIT ? a.parts : 1;
+  const int part = SPLIT ? (int)(blockIdx.x % (unsigned)parts) : 0;
+  const int brick_local = SPLIT ? (int)(blockIdx.x / (unsigned)parts) : (int)blockIdx.x;
+  const int brick = a.brick_first + brick_local;
+  // the lists of a kind this workgroup sums: l = part + ll * parts, ll < lists_of(nl)
+  auto lists_of = [&](int nl) { return SPLIT ? (nl > part ? (nl - part + parts - 1) / parts : 0) : nl; };
+  auto list_index = [&](int ll) { return SPLIT ? part + ll * parts : ll; };
+  const int nwide_p = lists_of(a.nwide), nnarrow_p = lists_of(a.nnarrow);
   const int bz = brick % a.nbz, by = (brick / a.nbz) % a.nby, bx = brick / (a.nbz * a.nby);
   const int X0 = bx << bshift, Y0 = by << bshift, Z0 = bz << bshift;
   // ---- range set-up: waves 0, 1 = the 15 ranges of each full-width list, waves 2, 3 = of each base-channel list; running
@@ -2243,10 +2290,11 @@ __global__ __launch_bounds__(kBrickThreads, (K > 9 ? 2 : 4)) void brick_gather_k
     const int kind = tid >> 7, i = tid & 127;
     int start = 0, cnt = 0;
     if (tid < 256) {
-      const int nl = kind ? a.nnarrow : a.nwide;
+      const int nl = kind ? nnarrow_p : nwide_p;
       if (i < kRangeEntries * nl) {
         const int l = nl == 1 ? 0 : i / kRangeEntries;
-        const long long* offs = nl == 1 ? (kind ? a.narrow[0].offsets : a.wide[0].offsets) : (kind ? a.narrow[l].offsets : a.wide[l].offsets);
+        const int li = list_index(l);
+        const long long* offs = (!SPLIT && nl == 1) ? (kind ? a.narrow[0].offsets : a.wide[0].offsets) : (kind ? a.narrow[li].offsets : a.wide[li].offsets);
         brick_range_entry(a, offs, bx, by, bz, i - l * kRangeEntries, start, cnt);
       }
     }
@@ -2272,8 +2320,8 @@ __global__ __launch_bounds__(kBrickThreads, (K > 9 ? 2 : 4)) void brick_gather_k
   }
   const int total = s_wcum[kMaxRangesKind];
   const int total_d = s_ncum[kMaxRangesKind];
-  const bool any = total > 0 || total_d > 0;
-  if (!any && a.accumulate) return;  // nothing reaches this brick
+  bool any = total > 0 || total_d > 0;
+  if (!SPLIT && !any && a.accumulate) return;  // nothing reaches this brick
   RF_PROF_MARK(0);  // range set-up
 
   // tiles: 2 x 2 x 4 nodes; tile t = (px * npy + py) * npz + pz
@@ -2485,8 +2533,8 @@ __global__ __launch_bounds__(kBrickThreads, (K > 9 ? 2 : 4)) void brick_gather_k
     // own registers per list kind (a conditionally assigned register is merged with a copy, and the copy waits for the load)
     int sri = 0, dri = 0;  // running range index of this thread (its records only move forward), the range's bounds cached
     int rlo = 0, rhi = 0, dlo = 0, dhi = 0;
-    const float4* rptr = a.wide[0].rec;    // list base + (start of the range - its position in the concatenation)
-    const float4* dptr = a.narrow[0].rec;
+    const float4* rptr = a.wide[SPLIT ? min(part, kMaxListsPerKind - 1) : 0].rec;    // list base + (start of the range - its position in the concatenation)
+    const float4* dptr = a.narrow[SPLIT ? min(part, kMaxListsPerKind - 1) : 0].rec;
     float4 w0 = make_float4(0.f, 0.f, 0.f, 0.f), w1 = w0, w2 = w0, d0 = w0, d1 = w0;
     // the range that holds record v of the concatenation: the largest i with cum[i] <= v.  One list (15 ranges, the single-GPU case):
     // the whole table in four independent 16-byte reads and 15 compares -- the walk below is a chain of dependent LDS reads
@@ -2506,28 +2554,28 @@ __global__ __launch_bounds__(kBrickThreads, (K > 9 ? 2 : 4)) void brick_gather_k
       const int nrec = min(kGatherBatch, total - s * kGatherBatch);
       const int v = s * kGatherBatch + min(rec_id, nrec - 1);  // record of the concatenated ranges
       if (v < rlo || v >= rhi) {  // the range of the previous batch's record no longer holds this one
-        sri = range_of(s_wcum, v, a.nwide, sri);
+        sri = range_of(s_wcum, v, nwide_p, sri);
         rlo = s_wcum[sri];
         rhi = s_wcum[sri + 1];
-        rptr = (a.nwide == 1 ? a.wide[0].rec : a.wide[sri / kRangeEntries].rec) + (long long)(s_wstart[sri] - rlo) * QW;
+        rptr = ((!SPLIT && a.nwide == 1) ? a.wide[0].rec : a.wide[list_index(sri / kRangeEntries)].rec) + (long long)(s_wstart[sri] - rlo) * QW;
       }
       const float4* p = rptr + (long long)v * QW;
-      w0 = p[0];
-      w1 = p[1];
-      if constexpr (QW > 2) w2 = p[2];
+      w0 = load_f4<RF_NT_RECORD_LOAD>(p);
+      w1 = load_f4<RF_NT_RECORD_LOAD>(p + 1);
+      if constexpr (QW > 2) w2 = load_f4<RF_NT_RECORD_LOAD>(p + 2);
     };
     auto fetch_narrow = [&](int sd) {
       const int nrec = min(kGatherBatch, total_d - sd * kGatherBatch);
       const int v = sd * kGatherBatch + min(rec_id, nrec - 1);
       if (v < dlo || v >= dhi) {
-        dri = range_of(s_ncum, v, a.nnarrow, dri);
+        dri = range_of(s_ncum, v, nnarrow_p, dri);
         dlo = s_ncum[dri];
         dhi = s_ncum[dri + 1];
-        dptr = (a.nnarrow == 1 ? a.narrow[0].rec : a.narrow[dri / kRangeEntries].rec) + (long long)(s_nstart[dri] - dlo) * QN;
+        dptr = ((!SPLIT && a.nnarrow == 1) ? a.narrow[0].rec : a.narrow[list_index(dri / kRangeEntries)].rec) + (long long)(s_nstart[dri] - dlo) * QN;
       }
       const float4* p = dptr + (long long)v * QN;
-      d0 = p[0];
-      d1 = p[1];
+      d0 = load_f4<RF_NT_RECORD_LOAD>(p);
+      d1 = load_f4<RF_NT_RECORD_LOAD>(p + 1);
     };
     if (nbd > 0) fetch_narrow(0);
     if (nba > 0) fetch_wide(0);
@@ -2575,6 +2623,48 @@ __global__ __launch_bounds__(kBrickThreads, (K > 9 ? 2 : 4)) void brick_gather_k
     }
     __syncthreads();
     RF_PROF_MARK(5);  // accumulator image
+  }
+  if constexpr (SPLIT) {
+    // The parts of a brick meet here.  Every part that summed something writes its image to global memory; the last one to arrive
+    // (arrival counter) adds the others' images to its own and flushes the brick.  Nobody waits for anybody: no spinning, no
+    // assumption about the dispatch order.  The images and flags cross workgroups -- and XCDs, each with an L2 of its own -- inside
+    // ONE launch: they are written and read with device-scope relaxed atomics (sc1 accesses: written through / read past the local
+    // L2) and ordered by vmcnt(0) + the workgroup barrier in front of the counter's atomic.  (A device-scope FENCE instead -- the
+    // textbook last-block pattern -- writes back and invalidates the whole L2 of the XCD per workgroup: measured 0.6 us per
+    // workgroup, serialised: 1.1 ms for 2048 workgroups.)
+    const int words = brick_acc_words(B, C);
+    int* state = a.part_state + (long long)brick_local * (1 + parts);
+    unsigned long long* images = reinterpret_cast<unsigned long long*>(a.partial + (long long)brick_local * parts * words);
+    const int pairs = words / 2;
+    __shared__ int s_arrival;
+    if (any) {
+      unsigned long long* mine = images + (long long)part * pairs;
+      const unsigned long long* src = reinterpret_cast<const unsigned long long*>(acc);
+      for (int i = tid; i < pairs; i += kBrickThreads) __hip_atomic_store(mine + i, src[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (tid == 0) __hip_atomic_store(&state[1 + part], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this thread's stores have been performed at device scope
+    __syncthreads();
+    if (tid == 0) s_arrival = __hip_atomic_fetch_add(&state[0], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __syncthreads();
+    if (s_arrival != parts - 1) return;  // (uniform for the whole workgroup)
+    for (int j = 0; j < parts; ++j) {
+      if (j == part) continue;
+      if (__hip_atomic_load(&state[1 + j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0) continue;  // (uniform)
+      const unsigned long long* other = images + (long long)j * pairs;
+      float2* own = reinterpret_cast<float2*>(acc);
+      for (int i = tid; i < pairs; i += kBrickThreads) {
+        const unsigned long long o = __hip_atomic_load(other + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        float2 v = any ? own[i] : make_float2(0.f, 0.f);
+        v.x += __uint_as_float((uint32_t)o);
+        v.y += __uint_as_float((uint32_t)(o >> 32));
+        own[i] = v;
+      }
+      any = true;
+      __syncthreads();
+    }
+    if (tid <= parts) state[tid] = 0;  // left clean for the next launch
+    __syncthreads();
   }
 #if defined(RF_BRICK_PROFILE) || defined(RF_BRICK_ABLATE)
   if (!(a.stagger & 0x400000))  // (ablation: the batch phases alone)
@@ -3774,7 +3864,7 @@ int rf_scatter_records(const RFGrid* grid, const int16_t* keys_dev, const float*
 int32_t rf_expanded_record_floats(int32_t num_features) { return 4 * record_quads(num_features / 3); }
 
 extern "C++" {
-template <int K, bool ADAM, bool ONE_ROUND = false>
+template <int K, bool ADAM, bool ONE_ROUND = false, bool SPLIT = false>
 static int launch_gather(const GridArgs& g, const BrickArgs& a, int nbricks, float* gd, float* gf, hipStream_t st) {
   const int B = 1 << a.shift;
   const size_t lds = (size_t)gather_lds_words(B, 3 * K + 1) * sizeof(float);
@@ -3783,12 +3873,12 @@ static int launch_gather(const GridArgs& g, const BrickArgs& a, int nbricks, flo
   int dev = 0;
   if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return RF_ERR_LAUNCH;
   if (lds > configured[dev].load(std::memory_order_relaxed)) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&brick_gather_kernel<K, ADAM, ONE_ROUND>),
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&brick_gather_kernel<K, ADAM, ONE_ROUND, SPLIT>),
                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
       return RF_ERR_LAUNCH;
     configured[dev].store(lds, std::memory_order_relaxed);
   }
-  hipLaunchKernelGGL((brick_gather_kernel<K, ADAM, ONE_ROUND>), dim3(nbricks), dim3(kBrickThreads), lds, st, g, a, gd, gf);
+  hipLaunchKernelGGL((brick_gather_kernel<K, ADAM, ONE_ROUND, SPLIT>), dim3(nbricks * (SPLIT ? a.parts : 1)), dim3(kBrickThreads), lds, st, g, a, gd, gf);
   return launch_status();
 }
 }  // extern "C++"
@@ -3818,7 +3908,8 @@ static int check_fused_adam(const RFGrid* grid, const RFAdamState* adam, int K, 
 
 static int brick_accumulate_impl(const RFGrid* grid, int32_t brick_size, const RFBrickList* lists, int32_t num_lists,
                                  float* grad_densities_dev, float* grad_features_dev, int32_t accumulate,
-                                 const RFAdamState* adam, int32_t first_brick, int32_t num_bricks, void* stream) {
+                                 const RFAdamState* adam, int32_t first_brick, int32_t num_bricks, void* stream, int32_t parts = 1,
+                                 void* scratch_dev = nullptr, int64_t scratch_bytes = 0) {
   int rc = check_grid(grid);
   if (rc != RF_OK) return rc;
   if (!lists) return RF_ERR_NULL_POINTER;
@@ -3894,6 +3985,17 @@ static int brick_accumulate_impl(const RFGrid* grid, int32_t brick_size, const R
     }
 #endif
     const bool one_round = a.adam.byte_offsets_fit_32_bits && shift == 3;
+    if (parts > 1) {  // several workgroups per brick (rf_brick_accumulate_adam_split)
+      if (!one_round) return RF_ERR_UNSUPPORTED;
+      if (parts > kMaxListsPerKind || !scratch_dev) return parts > kMaxListsPerKind ? RF_ERR_BAD_SHAPE : RF_ERR_NULL_POINTER;
+      const long long words = brick_acc_words(8, 3 * K + 1);
+      const long long state_bytes = ((long long)nbricks * (1 + parts) * 4 + 255) / 256 * 256;
+      if (scratch_bytes < state_bytes + (long long)nbricks * parts * words * 4 || ((uintptr_t)scratch_dev & 15u)) return RF_ERR_BAD_SHAPE;
+      a.parts = parts;
+      a.part_state = reinterpret_cast<int*>(scratch_dev);
+      a.partial = reinterpret_cast<float*>(reinterpret_cast<char*>(scratch_dev) + state_bytes);
+      return K == 1 ? launch_gather<1, true, true, true>(g, a, nbricks, nullptr, nullptr, st) : launch_gather<9, true, true, true>(g, a, nbricks, nullptr, nullptr, st);
+    }
     switch (K) {
       case 1:
         return one_round ? launch_gather<1, true, true>(g, a, nbricks, nullptr, nullptr, st) : launch_gather<1, true, false>(g, a, nbricks, nullptr, nullptr, st);
@@ -3933,6 +4035,22 @@ int rf_brick_accumulate_adam_range(const RFGrid* grid, int32_t brick_size, const
   if (!adam) return RF_ERR_NULL_POINTER;
   if (num_bricks < 1) return num_bricks == 0 ? RF_OK : RF_ERR_BAD_SHAPE;
   return brick_accumulate_impl(grid, brick_size, lists, num_lists, nullptr, nullptr, 0, adam, first_brick, num_bricks, stream);
+}
+
+int64_t rf_brick_split_scratch_bytes(const RFGrid* grid, int32_t num_bricks, int32_t parts) {
+  if (!grid || num_bricks < 1 || parts < 1 || parts > kMaxListsPerKind) return -1;
+  const int K = grid->num_features / 3;
+  const long long words = brick_acc_words(8, 3 * K + 1);
+  return ((long long)num_bricks * (1 + parts) * 4 + 255) / 256 * 256 + (long long)num_bricks * parts * words * 4;
+}
+
+int rf_brick_accumulate_adam_split(const RFGrid* grid, int32_t brick_size, const RFBrickList* lists, int32_t num_lists,
+                                   const RFAdamState* adam, int32_t first_brick, int32_t num_bricks, int32_t parts, void* scratch_dev,
+                                   int64_t scratch_bytes, void* stream) {
+  if (!adam) return RF_ERR_NULL_POINTER;
+  if (num_bricks < 1) return num_bricks == 0 ? RF_OK : RF_ERR_BAD_SHAPE;
+  if (parts < 1) return RF_ERR_BAD_SHAPE;
+  return brick_accumulate_impl(grid, brick_size, lists, num_lists, nullptr, nullptr, 0, adam, first_brick, num_bricks, stream, parts, scratch_dev, scratch_bytes);
 }
 
 int rf_grid_query(const RFGrid* grid, const float* points_dev, int64_t num_points, float* out_dev, void* stream) {

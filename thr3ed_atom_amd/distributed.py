@@ -40,7 +40,10 @@ def init_from_env(backend: Optional[str] = None) -> tuple:
             backend = os.environ.get("RF_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
         if torch.cuda.is_available():
             torch.cuda.set_device(local_rank)
-        dist.init_process_group(backend=backend, rank=rank, world_size=world)
+        # (a rank that raises while the others sit in a collective must end the job, not hang it for the default 10 minutes)
+        import datetime
+
+        dist.init_process_group(backend=backend, rank=rank, world_size=world, timeout=datetime.timedelta(seconds=int(os.environ.get("RF_DIST_TIMEOUT_S", "300"))))
     return rank, local_rank, world
 
 

@@ -409,13 +409,15 @@ def brick_accumulate_raw(grid: VoxelGrid, brick_size: int, lists, grad_first: Te
 
 
 def brick_accumulate_adam_raw(grid: VoxelGrid, brick_size: int, lists, exp_avg, exp_avg_sq, lr: float, beta1: float, beta2: float,
-                              eps: float, step: int, brick_range=None, rf_grid=None, params=None) -> None:
+                              eps: float, step: int, brick_range=None, rf_grid=None, params=None, split=None) -> None:
     """Enqueue rf_brick_accumulate_adam: the brick pass over ``lists`` (as in ``brick_accumulate_raw``; all renders of the
     iteration -- of all ranks, under data parallelism) with the Adam update of the grid's own tensors applied in the flush.
     ``exp_avg`` / ``exp_avg_sq`` are pairs of tensors shaped like ``grid.kernel_tensors()`` (second entry None when the grid has no
     second tensor).  ``brick_range`` = (first_brick, num_bricks) restricts the pass (and the update) to those bricks.  An entry of
     ``lists`` may give its records as an int (a raw device address) instead of a tensor.  ``rf_grid`` / ``params``: update these
-    tensors (described by this RFGrid) instead of the grid's own -- the split-layout shadow of a reference-storage grid."""
+    tensors (described by this RFGrid) instead of the grid's own -- the split-layout shadow of a reference-storage grid.
+    ``split`` = (parts, scratch): rf_brick_accumulate_adam_split -- ``parts`` workgroups per brick, the lists of each kind dealt out to
+    them, ``scratch`` a zero-initialised uint8 tensor of ``brick_split_scratch_bytes`` bytes (needs ``brick_range``)."""
     lib = _lib.load()
     # (``_tensors``: no wait for parameters a data-parallel step left in flight -- that step orders its launches against them itself)
     first, second = (grid._tensors() if rf_grid is not None else grid.kernel_tensors()) if params is None else params
@@ -431,11 +433,23 @@ def brick_accumulate_adam_raw(grid: VoxelGrid, brick_size: int, lists, exp_avg, 
     if rf_grid is None:
         rf_grid = grid.to_rf_grid()
     with _span(f"brick_accumulate_adam[{'diffuse' if lists[0][2] or grid.sh_degree == 0 else 'sh' + str(grid.sh_degree)}]", dev):
-        if brick_range is None:
+        if split is not None and int(split[0]) > 1:
+            rc = lib.rf_brick_accumulate_adam_split(C.byref(rf_grid), int(brick_size), arr, len(lists), C.byref(st), int(brick_range[0]), int(brick_range[1]),
+                                                    int(split[0]), split[1].data_ptr(), int(split[1].numel()), _stream(dev))
+        elif brick_range is None:
             rc = lib.rf_brick_accumulate_adam(C.byref(rf_grid), int(brick_size), arr, len(lists), C.byref(st), _stream(dev))
         else:
             rc = lib.rf_brick_accumulate_adam_range(C.byref(rf_grid), int(brick_size), arr, len(lists), C.byref(st), int(brick_range[0]), int(brick_range[1]), _stream(dev))
     _lib.check(rc, "rf_brick_accumulate_adam")
+
+
+def brick_split_scratch(grid: VoxelGrid, num_bricks: int, parts: int) -> Tensor:
+    """zero-initialised scratch of rf_brick_accumulate_adam_split for launches over ``num_bricks`` bricks with ``parts`` workgroups each"""
+    first, _ = grid._tensors() if hasattr(grid, "_tensors") else grid.kernel_tensors()
+    n = int(_lib.load().rf_brick_split_scratch_bytes(C.byref(grid.to_rf_grid(wait_parameters=False)), int(num_bricks), int(parts)))
+    if n < 0:
+        raise ValueError("rf_brick_split_scratch_bytes: bad arguments")
+    return torch.zeros(n, dtype=torch.uint8, device=first.device)
 
 
 # How the autograd op computes its adjoint: "atomic" = rf_render_backward (float32 atomic scatter, any configuration), "binned" =

@@ -160,6 +160,11 @@ OWNER_OVERLAP_PARAMETERS = os.environ.get("RF_OWNER_OVERLAP_PARAMETERS", "1") !=
 # owner-computes data parallelism: the x-slabs of bricks are owned in this many interleaved "halves" (1 = one contiguous range per rank):
 # the brick pass of half h + 1 runs while the parameters of half h are all-gathered (TrainStepper._owner_state)
 OWNER_HALVES = int(os.environ.get("RF_OWNER_HALVES", "2"))
+# ... and how many workgroups share one owned brick in the owner's brick pass (rf_brick_accumulate_adam_split; 0 = by world size: 2 from
+# four ranks on).  With N ranks an owned brick receives N times the records while the launch covers 1 / N of the bricks: one workgroup per
+# brick leaves the machine idle behind the heaviest bricks (tools/owner_brick_emulation.py, N = 8: the piece through the middle of the
+# volume 0.35 ms with one workgroup per brick, 0.18 ms with two; 4 and 8 are no faster: the partial images then cost what the split saves)
+OWNER_BRICK_PARTS = int(os.environ.get("RF_OWNER_BRICK_PARTS", "0"))
 
 
 class _ParameterWait:
@@ -506,6 +511,10 @@ class TrainStepper:
             "recv": [[torch.empty((0, widths[k]), dtype=torch.float32, device=device) for _ in range(H)] for k in range(2)],
             "checked": False,
         }
+        parts = OWNER_BRICK_PARTS if OWNER_BRICK_PARTS > 0 else (2 if W >= 4 else 1)
+        ow["parts"] = max(1, min(parts, W, 8))
+        # (one scratch for all halves: their brick passes follow one another on the compute stream)
+        ow["split"] = (ow["parts"], ops.brick_split_scratch(grid, q * nbyz, ow["parts"])) if ow["parts"] > 1 else None
         self._owner = ow
         return ow
 
@@ -636,7 +645,7 @@ class TrainStepper:
                     wk.wait()
             mark(f"wait: record slices of half {h}")
             brick_accumulate_adam_raw(grid, self.brick_size, lists, exp_avg, exp_avg_sq, opt.lr, opt.betas[0], opt.betas[1], opt.eps, opt.step_count,
-                                      brick_range=ow["bricks"][h], rf_grid=rf_grid)
+                                      brick_range=ow["bricks"][h], rf_grid=rf_grid, split=ow["split"])
             mark(f"brick pass + Adam, half {h}")
             if collect:
                 for tag, part in parts:
