@@ -10,7 +10,10 @@ a `RenderProcedure` (thre3d_atom/thre3d_reprs/renderers.py:22-25) that is a drop
 
 `voxel_grid` is the REFERENCE's own VoxelGrid (thre3d_reprs/voxels.py) living on a HIP device; `rays`/`RenderOut` are the
 reference's own types.  The render is differentiable w.r.t. `voxel_grid.densities` / `.features` through a
-torch.autograd.Function (forward = rf_render_forward with the per-sample cache, backward = rf_render_backward).
+torch.autograd.Function: forward = rf_render_forward with the per-sample cache; backward = rf_render_backward (float atomics; any
+configuration) or, for large renders of SH-degree >= 2 grids -- a training batch --, the atomic-free binned adjoint: the forward pass
+counts the gradient records per (brick, flags) key, rf_bin_offsets turns the counts into positions, rf_render_backward_emit_direct
+writes the records there and rf_brick_accumulate sums every 8^3-node brick on chip (0.97 -> 0.40 ms for 16384 x 256 samples at 128^3).
 This file depends on torch, numpy, ctypes and the reference package only -- NOT on the thr3ed_atom_amd Python package.
 
 The one other edit the reference needs: the identity assert of the trainer (modules/trainers.py:116-122) must accept the new
@@ -53,6 +56,15 @@ class RFRenderGrads(C.Structure):
     _fields_ = [("grad_colour_dev", C.c_void_p), ("grad_depth_dev", C.c_void_p), ("grad_acc_dev", C.c_void_p)]
 
 
+class RFBrickList(C.Structure):
+    _fields_ = [("records_sorted_dev", C.c_void_p), ("offsets_dev", C.c_void_p), ("render_diffuse", C.c_int32)]
+
+
+# backward: "auto" = the binned adjoint for SH degree >= 2 and at least 2^20 samples, "atomic", or "binned"
+BACKWARD = os.environ.get("RELU_FIELD_HIP_BACKWARD", "auto")
+BRICK = 8
+
+
 RF_FLAG_WHITE_BKGD, RF_FLAG_RENDER_DIFFUSE, RF_FLAG_AABB_SAMPLING = 1, 2, 4
 RF_DENSITY_RELU, RF_DENSITY_SOFTPLUS, RF_DENSITY_ABS, RF_DENSITY_IDENTITY = 0, 1, 2, 3
 RF_LAYOUT_REFERENCE = 0
@@ -72,6 +84,13 @@ def _library():
         lib.rf_render_backward.restype = C.c_int
         lib.rf_render_backward.argtypes = [C.POINTER(RFGrid), C.POINTER(RFRayBatch), C.c_uint32, C.POINTER(RFRenderOut), C.POINTER(RFRenderGrads),
                                            C.c_void_p, C.c_void_p, C.c_void_p]
+        lib.rf_bin_offsets.restype = lib.rf_render_backward_emit_direct.restype = lib.rf_brick_accumulate.restype = C.c_int
+        lib.rf_expanded_record_floats.restype = C.c_int32
+        lib.rf_expanded_record_floats.argtypes = [C.c_int32]
+        lib.rf_bin_offsets.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p]
+        lib.rf_render_backward_emit_direct.argtypes = [C.POINTER(RFGrid), C.POINTER(RFRayBatch), C.c_uint32, C.POINTER(RFRenderOut), C.POINTER(RFRenderGrads),
+                                                       C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+        lib.rf_brick_accumulate.argtypes = [C.POINTER(RFGrid), C.c_int32, C.POINTER(RFBrickList), C.c_int32, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p]
         if lib.rf_abi_version() != RF_ABI_VERSION:
             raise RuntimeError(f"{_LIB_PATH}: ABI version {lib.rf_abi_version()}, this binding was written for {RF_ABI_VERSION}")
         _lib = lib
@@ -123,9 +142,21 @@ def _describe_grid(voxel_grid, densities, features):
     return g
 
 
+def _use_binned_adjoint(features, n, num_samples):
+    nkeys = 8
+    for d in features.shape[:3]:
+        nkeys *= (int(d) + BRICK - 1) // BRICK
+    if nkeys > (1 << 21) or BACKWARD == "atomic":
+        return 0
+    record_bytes = 4 * int(_library().rf_expanded_record_floats(int(features.shape[-1])))
+    big = int(features.shape[-1]) >= 27 and n * num_samples >= (1 << 20) and n * num_samples * record_bytes <= (1 << 30)
+    return nkeys if (BACKWARD == "binned" or big) else 0
+
+
 class _RenderFunction(torch.autograd.Function):
     """forward: rf_render_forward (+ the per-sample cache when a gradient can be asked for); backward: rf_render_backward
-    into zero-filled gradient tensors -- what autograd does for the reference through ~120 ATen ops."""
+    into zero-filled gradient tensors, or the binned adjoint (see the module docstring) -- what autograd does for the reference
+    through ~120 ATen ops."""
 
     @staticmethod
     def forward(ctx, densities, features, origins, directions, t_vals, t_rand, voxel_grid, num_samples, near, far, flags, need_grad):
@@ -143,6 +174,11 @@ class _RenderFunction(torch.autograd.Function):
             caches = (torch.empty((n, num_samples, 4), dtype=torch.float32, device=dev), torch.empty((n, num_samples), dtype=torch.float32, device=dev),
                       torch.empty((n,), dtype=torch.int32, device=dev), torch.empty((n, (num_samples + 63) // 64), dtype=torch.int64, device=dev))
             out.sample_cache_dev, out.trans_cache_dev, out.stop_cache_dev, out.chunk_mask_dev = (c.data_ptr() for c in caches)
+            nkeys = _use_binned_adjoint(features, n, num_samples)
+            if nkeys:  # the forward pass counts the records of the binned adjoint per (brick, flags) key
+                caches = caches + (torch.zeros(nkeys, dtype=torch.int32, device=dev),)
+                out.key_hist_dev, out.brick_size = caches[-1].data_ptr(), BRICK
+        ctx.binned = len(caches) == 5
         stream = torch.cuda.current_stream(dev).cuda_stream
         _check(lib.rf_render_forward(C.byref(grid), C.byref(rb), flags, C.byref(out), stream), "rf_render_forward")
         ctx.voxel_grid, ctx.args, ctx.need_grad, ctx.has_rand = voxel_grid, (num_samples, near, far, flags), need_grad, t_rand is not None
@@ -157,7 +193,8 @@ class _RenderFunction(torch.autograd.Function):
         lib = _library()
         saved = ctx.saved_tensors
         densities, features, origins, directions, t_vals, cache, tcache, stop, cmask = saved[:9]
-        t_rand = saved[9] if ctx.has_rand else None
+        hist = saved[9] if ctx.binned else None
+        t_rand = saved[-1] if ctx.has_rand else None
         num_samples, near, far, flags = ctx.args
         dev = origins.device
         grid = _describe_grid(ctx.voxel_grid, densities, features)
@@ -166,8 +203,24 @@ class _RenderFunction(torch.autograd.Function):
         fwd = RFRenderOut(None, None, None, None, cache.data_ptr(), tcache.data_ptr(), stop.data_ptr(), cmask.data_ptr(), None, 0)
         keep = [None if g is None else g.detach().to(torch.float32).contiguous() for g in (g_colour, g_depth, g_acc)]
         grads = RFRenderGrads(*[None if g is None else g.data_ptr() for g in keep])
-        grad_d, grad_f = torch.zeros_like(densities), torch.zeros_like(features)  # the library accumulates (+=)
         stream = torch.cuda.current_stream(dev).cuda_stream
+        if hist is not None:
+            diffuse = bool(flags & RF_FLAG_RENDER_DIFFUSE)
+            width = int(lib.rf_expanded_record_floats(3 if diffuse else int(features.shape[-1])))
+            offsets = torch.empty(hist.numel() + 1, dtype=torch.int64, device=dev)
+            cursor = torch.empty(hist.numel(), dtype=torch.int32, device=dev)
+            records = torch.empty((origins.shape[0] * num_samples, width), dtype=torch.float32, device=dev)
+            _check(lib.rf_bin_offsets(hist.data_ptr(), hist.numel(), offsets.data_ptr(), cursor.data_ptr(), stream), "rf_bin_offsets")
+            _check(lib.rf_render_backward_emit_direct(C.byref(grid), C.byref(rb), flags, C.byref(fwd), C.byref(grads), BRICK, cursor.data_ptr(), records.data_ptr(),
+                                                      None, stream), "rf_render_backward_emit_direct")
+            # the brick pass OVERWRITES what its list covers: everything for a specular render; density + degree-0 coefficients for a
+            # render_diffuse pass (the other coefficients get no gradient from it: zero-filled)
+            grad_d = torch.empty_like(densities)
+            grad_f = torch.zeros_like(features) if diffuse and features.shape[-1] > 3 else torch.empty_like(features)
+            lst = RFBrickList(records.data_ptr(), offsets.data_ptr(), int(diffuse))
+            _check(lib.rf_brick_accumulate(C.byref(grid), BRICK, C.byref(lst), 1, grad_d.data_ptr(), grad_f.data_ptr(), 0, stream), "rf_brick_accumulate")
+            return grad_d, grad_f, None, None, None, None, None, None, None, None, None, None
+        grad_d, grad_f = torch.zeros_like(densities), torch.zeros_like(features)  # the library accumulates (+=)
         _check(lib.rf_render_backward(C.byref(grid), C.byref(rb), flags, C.byref(fwd), C.byref(grads), grad_d.data_ptr(), grad_f.data_ptr(), stream),
                "rf_render_backward")
         return grad_d, grad_f, None, None, None, None, None, None, None, None, None, None

@@ -113,7 +113,7 @@ class _ReferenceLikeGrid(torch.nn.Module):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("via", ["binding", "package"])
+@pytest.mark.parametrize("via", ["binding", "binding-binned", "package"])
 @pytest.mark.parametrize("variant", ["relu_spec", "relu_diffuse", "relu_opt", "abs_spec", "softplus_spec"])
 def test_reference_like_module_renders_like_the_reference(hip_device, monkeypatch, via, variant):
     """golden G7 (16^3, SH degree 2): colour / depth / acc and both gradients of L1(colour, target), through
@@ -129,7 +129,9 @@ def test_reference_like_module_renders_like_the_reference(hip_device, monkeypatc
     cfg = rf.SHVoxGridRenderConfig(48, rf.CameraBounds(cam["near"], cam["far"]), perturb_sampled_points=False, white_bkgd=True,
                                    render_diffuse=variant == "relu_diffuse", optimized_sampling=variant == "relu_opt")
     rays = rf.Rays(torch.from_numpy(g7["origins"]).to(hip_device), torch.from_numpy(g7["directions"]).to(hip_device))
-    if via == "binding":
+    if via.startswith("binding"):
+        # ("binding-binned": the atomic-free adjoint the binding picks for training-size renders, forced here on the small one)
+        monkeypatch.setenv("RELU_FIELD_HIP_BACKWARD", "binned" if via == "binding-binned" else "atomic")
         rh = _load_binding(monkeypatch, with_reference=False)
         out = rh.render_sh_voxel_grid_hip(grid, rays, cfg)
     else:
