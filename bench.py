@@ -457,7 +457,7 @@ def main():
             dgrid = make_grid(dev, G, args.sh_degree, seed=42, storage="reference")
             dcfg = rf.SHVoxGridRenderConfig(S, bounds, perturb_sampled_points=True, white_bkgd=True, jitter="torch")
             dmodel = rf.VolumetricModel(dgrid, rf.render_sh_voxel_grid, dcfg, device=dev)
-            dstep = TrainStepper(dmodel, R, learning_rate=0.03, fused=False, ray_selection=selection, backward="atomic", data_parallel=False)
+            dstep = TrainStepper(dmodel, R, learning_rate=0.03, fused=False, ray_selection=selection, data_parallel=False)
             torch.manual_seed(99)
             dbatches = dataset.image_batches(args.images)
             for _ in range(5):

@@ -593,6 +593,10 @@ class _ReluFieldRender(torch.autograd.Function):
                 brick_accumulate_raw(grid, AUTOGRAD_BRICK_SIZE, [(records, offsets, diffuse)], gd, gf, accumulate=not overwrite)
             ctx.key_hist = None  # (a second backward through the same graph would find the counters consumed)
         else:
+            if bucket is not None and getattr(bucket, "deferred", False) and bucket.matches(first, second):
+                # (the optimizer of a deferred bucket consumes record lists only: a gradient scattered into the bucket would be lost)
+                raise RuntimeError("deferred gradients (optim.FlatGrid(deferred=True)): a render can be back-propagated once per optimizer step "
+                                   "(its record counters were consumed by the first backward pass); use FlatGrid(deferred=False) for retained graphs")
             render_backward_raw(
                 grid, origins, directions, t_rand, ctx.num_samples, ctx.near, ctx.far, ctx.flags, (cache, tcache, stop, cmask),
                 prep(g_colour), prep(g_depth), prep(g_acc), gd, gf,

@@ -53,8 +53,15 @@ class FlatGrid:
         from . import distributed as rfdist
         from . import voxels
 
+        # (the flush of the merged brick pass keeps element offsets in 31 bits and the binned adjoint addresses at most 2^18 bricks:
+        # larger grids -- 512^3 at SH degree 2 -- keep the gradient bucket and the atomic adjoint they trained through before)
+        padded_nodes, bricks = 1, 1
+        for dim in grid.grid_dims:
+            padded_nodes *= (dim + 7) // 8 * 8
+            bricks *= (dim + 7) // 8
+        fits = padded_nodes * max(4, grid.num_features - 3) < (1 << 31) and bricks <= (1 << 18) and voxels.shadow_allowed(grid)
         self.deferred = (bool(deferred) and grid.storage == "reference" and (grid.num_features + 1) % 4 == 0 and voxels.SPLIT_SHADOW
-                         and not rfdist._collectives_on())
+                         and not rfdist._collectives_on() and fits)
         self.pending = []  # [(records, offsets, render_diffuse)] of the backward passes since the last zero_grad / step
 
     # ---- protocol used by ops._ReluFieldRender.backward -------------------------------------

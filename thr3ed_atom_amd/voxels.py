@@ -133,8 +133,19 @@ _RF_SHADOW_CACHE: "weakref.WeakKeyDictionary" = weakref.WeakKeyDictionary()
 # of callables per grid that make the CURRENT stream wait for them.  Kept outside the module like the caches above (an RCCL work
 # handle / a HIP event in a module's __dict__ would break copy.deepcopy and torch.save of it).
 _RF_PENDING_PARAMETERS: "weakref.WeakKeyDictionary" = weakref.WeakKeyDictionary()
-# forward passes of reference-storage grids gather from a split-layout shadow (KernelGridInterface.forward_rf_grid)
-SPLIT_SHADOW = True
+# forward passes of reference-storage grids gather from a split-layout shadow (KernelGridInterface.forward_rf_grid): a second copy
+# of the grid, so only up to SHADOW_MAX_BYTES of parameters (512^3 at SH degree 2 would be 15 GB more); $RF_SPLIT_SHADOW=0 turns it off
+import os as _os
+
+SPLIT_SHADOW = _os.environ.get("RF_SPLIT_SHADOW", "1") != "0"
+SHADOW_MAX_BYTES = int(_os.environ.get("RF_SHADOW_MAX_BYTES", str(2 << 30)))
+
+
+def shadow_allowed(grid) -> bool:
+    nodes = 1
+    for dim in grid.grid_dims:
+        nodes *= int(dim)
+    return SPLIT_SHADOW and nodes * (int(grid._num_features) + 1) * 4 <= SHADOW_MAX_BYTES
 
 
 class KernelGridInterface:
@@ -220,9 +231,13 @@ class KernelGridInterface:
         pointers; edits through ``.data`` bypass the version counter: call invalidate_occupancy() after them).  Measured on the
         128^3 / SH-2 training step: diffuse forward 0.288 -> 0.084 ms for a 0.13 ms refresh per optimizer step.  Adjoints are
         unaffected: they produce gradients in the layout of the Parameters."""
-        if self.storage != "reference" or not SPLIT_SHADOW:
+        if self.storage != "reference" or not shadow_allowed(self):
             return self.to_rf_grid(use_occupancy)
         return self._shadow(use_occupancy, refresh=True)[1]
+
+    def release_shadow(self) -> None:
+        """Free the split-layout shadow of a reference-storage grid (it is rebuilt by the next render that wants it)."""
+        _RF_SHADOW_CACHE.pop(self, None)
 
     def _shadow_stamp(self):
         d, f = self.kernel_tensors()
