@@ -681,6 +681,8 @@ class TrainStepper:
             ow["checked"] = True
             grid.wait_for_parameters()
             rfdist.assert_replicas_identical(self.flat.flat_param, "owner-computes exchange, first step")
+            if os.environ.get("RF_OWNER_INJECT_FAILURE") == str(me):  # (test hook: exercises bench.py's fall-back to the dense exchange)
+                raise RuntimeError("injected failure of the owner-computes step (RF_OWNER_INJECT_FAILURE)")
 
     def _executor(self, n: int, S: int, device):
         """Persistent scratch + the ctypes description of one iteration (rebuilt when the batch shape changes)."""
