@@ -1472,6 +1472,11 @@ __global__ __launch_bounds__(kBlock) void render_backward_kernel(GridArgs g, Ray
 // 0.090 / 0.046 ms.  ~2500 instructions per ray remain: issue-bound.
 // Also tried: transposing the records through LDS so that a store instruction writes whole contiguous records instead of 64
 // 16-byte pieces of 64 different lines -- slower (0.113 / 0.078 ms): the L2 merges the partial lines at no cost that matters here.
+// Round 4, DENSE lanes: only a third of the lanes of a chunk pass hold a cached sample (67 records per ray over three or four chunks),
+// so a variant walked a ray's cached samples as one dense list, 64 per pass (lane -> rank among the cached samples -> chunk from
+// the running counts of the chunk masks -> position by an n-th-set-bit search): one or two passes per ray instead of three or four,
+// same results -- and slower, 0.0877 -> 0.093 ms (one pass in flight) / 0.096-0.103 (two): the search is a dependent chain in front
+// of the cache loads, and the kernel is bound by its chains (cache load -> key -> cursor atomic -> store), not by lane occupancy.
 // =============================================================================================
 template <int K, bool DIFFUSE>
 __device__ __forceinline__ void render_emit_direct_ray(const GridArgs& g, const RayArgs& r, const OutArgs& fwd, const GradArgs& gr, uint32_t flags, long long ray,
