@@ -103,6 +103,7 @@ def _worker(rank, world, port, result_dir, exchange, shard_optimizer, jitter, gr
     ("owner", True, False, 16, 1), ("owner", True, True, 16, 1),
     ("owner", True, True, 32, 2),  # 4 x-slabs of bricks: rank r owns slabs r and r + 2 -- the interleaved ownership of the pipelined step
     ("owner", True, False, 64, 2),  # 8 x-slabs: two neighbouring slabs per rank and half
+    ("owner", True, True, 128, 2),  # the BASELINE grid: 16 x-slabs, four per rank and half, 235 MB of parameters gathered in two halves
     ("owner", True, True, 32, -2),  # ... with TWO workgroups per owned brick (the source ranks' lists dealt out, partial images merged)
     ("dense", True, False, 16, 1), ("dense", False, True, 16, 1)])
 def test_two_processes_train_data_parallel_on_one_gpu(tmp_path, exchange, shard_optimizer, jitter, grid_size, halves):
@@ -123,3 +124,51 @@ def test_four_processes_owner_computes_on_one_gpu(tmp_path, grid_size, halves):
     world = 4
     mp.spawn(_worker, args=(world, _free_port(), str(tmp_path), "owner", True, True, grid_size, halves), nprocs=world, join=True)
     assert sorted(os.listdir(tmp_path)) == [f"ok{r}" for r in range(world)]
+
+
+def _trainer_worker(rank, world, port, result_dir):
+    """the whole trainer (two stages, a checkpoint every 7 iterations but a synchronising summary only every 100) under data parallelism:
+    checkpoints are written while parameter all-gathers of the owner-computes step may still be in flight -- state_dict() has to wait
+    for them -- and must hold exactly what every rank holds"""
+    import copy
+    from pathlib import Path
+
+    from thr3ed_atom_amd.trainers import train_sh_vox_grid_vol_mod_with_posed_images
+
+    GRID["G"] = 32
+    os.environ.update(RANK=str(rank), LOCAL_RANK="0", WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dev = torch.device("cuda", 0)
+    torch.cuda.set_device(dev)
+    dist.init_process_group(backend="gloo", rank=rank, world_size=world)
+    try:
+        data, model = _setup(dev, jitter=True)
+        torch.manual_seed(3)  # (global_batch: all ranks draw the same batches and take their own slices)
+        out = Path(result_dir) / f"rank{rank}"
+        trained = train_sh_vox_grid_vol_mod_with_posed_images(
+            model, data, output_dir=out, image_batch_cache_size=4, ray_batch_size=R, num_stages=2, num_iterations_per_stage=15, learning_rate=0.03,
+            lr_decay_steps_per_stage=10, save_freq=7, test_freq=10**6, summary_freq=100, log=lambda *_: None, storage="split", global_batch=True)
+        grid = trained.thre3d_repr
+        copy.deepcopy(grid)  # (nothing un-copyable may be left on the module by the data-parallel step)
+        final = torch.cat([grid.densities.detach().reshape(-1), grid.features.detach().reshape(-1)])
+        gathered = [torch.empty_like(final) for _ in range(world)]
+        dist.all_gather(gathered, final)
+        assert all(torch.equal(gathered[0], t) for t in gathered), "replicas diverged in the trainer"
+        if rank == 0:
+            names = sorted(p.name for p in (out / "saved_models").iterdir())
+            assert "model_final.pth" in names and any(n.startswith("model_stage_2_iter_28") for n in names), names
+            # the last checkpoint of stage 1 == the grid the stage ended with == what an un-distributed reader would load
+            ck = torch.load(out / "saved_models" / "model_final.pth", weights_only=False)
+            sd = ck["thre3d_repr"]["state_dict"]
+            assert torch.equal(sd["_densities"].to(dev), grid.densities.detach()) and torch.equal(sd["_features"].to(dev), grid.features.detach())
+            mid = torch.load(out / "saved_models" / "model_stage_1_iter_14.pth", weights_only=False)["thre3d_repr"]["state_dict"]
+            assert tuple(mid["_densities"].shape) == (16, 16, 16, 1) and bool(torch.isfinite(mid["_features"]).all())
+        open(os.path.join(result_dir, f"ok{rank}"), "w").write("ok")
+    finally:
+        dist.destroy_process_group()
+
+
+def test_trainer_under_data_parallelism_writes_consistent_checkpoints(tmp_path):
+    assert torch.cuda.is_available()
+    world = 2
+    mp.spawn(_trainer_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    assert sorted(n for n in os.listdir(tmp_path) if n.startswith("ok")) == [f"ok{r}" for r in range(world)]
