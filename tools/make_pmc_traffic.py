@@ -37,6 +37,12 @@ BENCH_NAMES = {
     "render_backward_kernel<1, true, 0>": "render_backward[diffuse]",
     "brick_gather_kernel<9, true>": "brick_accumulate_adam[sh2]",
     "brick_gather_kernel<9, true, true>": "brick_accumulate_adam[sh2]",
+    "brick_gather_kernel<9, true, true, false>": "brick_accumulate_adam[sh2]",
+    "brick_gather_kernel<9, true, false, false>": "brick_accumulate_adam[sh2]",
+    "brick_gather_kernel<9, false, true, false>": "brick_accumulate[sh2]",
+    "brick_gather_kernel<9, false, false, false>": "brick_accumulate[sh2]",
+    "brick_gather_kernel<1, false, true, false>": "brick_accumulate[base]",
+    "brick_gather_kernel<1, false, false, false>": "brick_accumulate[base]",
     "brick_gather_kernel<9, true, false>": "brick_accumulate_adam[sh2]",
     "brick_gather_kernel<9, false>": "brick_accumulate[sh2]",
     "brick_gather_kernel<9, false, false>": "brick_accumulate[sh2]",
