@@ -388,6 +388,64 @@ def g11_density_noise():
     save("g11_density_noise.npz", near=np.float64(cam["near"]), far=np.float64(cam["far"]), rho=np.float64(rho), **out)
 
 
+def plugin_tone_map(x):
+    """a non-default radiance_hdr_tone_map (renderers.py:38)"""
+    return torch.sigmoid(2.0 * x) * 0.9 + 0.05
+
+
+def plugin_density2occupancy(densities, deltas):
+    """a non-default density2occupancy (renderers.py:37): saturating, not the physically based exponential"""
+    x = densities * deltas
+    return x / (1.0 + x)
+
+
+def plugin_feature_post(x):
+    return 1.5 * x
+
+
+def g12_plugins():
+    """The plug-in points of the path with NON-default callables (renderers.py:37-38 density2occupancy / radiance_hdr_tone_map,
+    voxels.py:312-322 feature pre- / post-activations, voxels.py:292-309 a density activation pair outside the trainer's three) and the
+    per-sample debug outputs of the accumulator (accumulate.py:96-107, extra_debug_info): outputs and gradients of the reference."""
+    from thre3d_atom.rendering.volumetric.accumulate import accumulate_radiance_density_on_rays
+    from thre3d_atom.rendering.volumetric.render_interface import SampledPointsOnRays
+
+    cam = hotdog_like_camera()
+    bounds = CameraBounds(cam["near"], cam["far"])
+    rho = 100.0 / 3.0
+    dens, feat = procedural_grid((16, 16, 16), 27, 81)
+    o, d = random_rays(96, 94, spread=1.6)
+    rays = Rays(o, d)
+    target = torch.from_numpy(hash_uniform((96, 3), 95, 0.0, 1.0))
+    out = {"origins": o, "directions": d, "target": target}
+    variants = {
+        "tone_d2o": (dict(), dict(density2occupancy=plugin_density2occupancy, radiance_hdr_tone_map=plugin_tone_map)),
+        "feature_acts": (dict(feature_preactivation=torch.tanh, feature_postactivation=plugin_feature_post), dict()),
+        "density_acts": (dict(density_preactivation=torch.tanh, density_postactivation=torch.nn.Softplus(beta=2.0)), dict(render_diffuse=True)),
+    }
+    for tag, (grid_kw, cfg_kw) in variants.items():
+        kw = dict(density_preactivation=torch.nn.Identity(), density_postactivation=torch.nn.ReLU(), expected_density_scale=rho)
+        kw.update(grid_kw)
+        grid = VoxelGrid(densities=dens.clone(), features=feat.clone(), voxel_size=VoxelSize(3.0 / 16, 3.0 / 16, 3.0 / 16), tunable=True, **kw)
+        ckw = dict(num_samples_per_ray=40, camera_bounds=bounds, perturb_sampled_points=False, white_bkgd=True)
+        ckw.update(cfg_kw)
+        res, loss, gd, gf = run_render(grid, rays, SHVoxGridRenderConfig(**ckw), target)
+        out.update({f"{tag}_colour": res.colour, f"{tag}_depth": res.depth, f"{tag}_acc": res.extra["accumulated_weight"],
+                    f"{tag}_disparity": res.extra["disparity"], f"{tag}_loss": loss, f"{tag}_gd": gd, f"{tag}_gf": gf})
+    # the accumulator alone, with its debug outputs and a recorded noise table (the plug-in type AccumulatorFunction, render_interface.py:100)
+    z = torch.from_numpy(hash_uniform((96, 24), 96, 0.0, 1.0)).cumsum(-1) * 0.2 + 2.0
+    processed = torch.from_numpy(hash_uniform((96, 24, 4), 97, -2.0, 2.0))
+    processed[..., -1] = processed[..., -1].clamp(min=0.0) * 8.0
+    torch.manual_seed(778)
+    noise = torch.randn(96, 24) * 0.3
+    torch.manual_seed(778)
+    acc = accumulate_radiance_density_on_rays(SampledPointsOnRays(processed, z), rays, stochastic_density_noise_std=0.3, density2occupancy=plugin_density2occupancy,
+                                              radiance_hdr_tone_map=plugin_tone_map, white_bkgd=False, extra_debug_info=True)
+    out.update({"acc_z": z, "acc_processed": processed, "acc_noise": noise, "acc_colour": acc.colour, "acc_depth": acc.depth})
+    out.update({f"acc_extra_{k}": v for k, v in acc.extra.items()})
+    save("g12_plugins.npz", near=np.float64(cam["near"]), far=np.float64(cam["far"]), rho=np.float64(rho), **out)
+
+
 def g10_single_cube():
     """The reference's only render test scene (thre3d_reprs/tests/test_voxels.py:88-134): a 2x2x2
     grid with +-10 RGB logits on the corners, viewed from the 6 axis directions -- here at
@@ -433,6 +491,7 @@ if __name__ == "__main__":
         "g78": g7_g8_end_to_end,
         "g10": g10_single_cube,
         "g11": g11_density_noise,
+        "g12": g12_plugins,
     }
     for name, fn in jobs.items():
         if not wanted or name in wanted:

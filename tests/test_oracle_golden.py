@@ -234,8 +234,8 @@ NOISE_CASES = [("relu", "relu", {}), ("relu_diffuse_black", "relu", {"render_dif
 
 @pytest.mark.parametrize("tag,mode,over", NOISE_CASES)
 def test_g11_stochastic_density_noise_is_not_usable_in_the_reference(tag, mode, over):
-    """stochastic_density_noise_std != 0 (accumulate.py:58-62) is the one configuration of the path the HIP build refuses
-    (ValueError).  This pins WHY against the reference itself: the noise is added to the ACTIVATED density of every sample,
+    """stochastic_density_noise_std != 0 (accumulate.py:58-62) is not implemented by the fused kernels (the composed path renders
+    it like the reference does: tests/test_hip_composable.py).  This pins WHY it is not worth fusing, against the reference itself: the noise is added to the ACTIVATED density of every sample,
     including the last one, whose interval is 1e10 |d| (accumulate.py:49-55) -- wherever sigma_last + noise < 0 (about half of
     all rays: the last sample usually lies outside the box, sigma = 0) alpha = 1 - exp(+huge) = -inf, and the ray's accumulated
     weight, colour on a white background and loss are non-finite.  The oracle, fed the noise table the reference drew, reproduces

@@ -39,3 +39,17 @@ def test_brick_major_order_matches_the_kernel_index_formula():
     assert torch.equal(unbrick_nodes(b, dims), t)
     # padding nodes are zero and do not leak back
     assert float(b.sum()) == float(t.sum())
+
+
+def test_composed_path_has_no_cpu_side():
+    """thr3ed_atom_amd.composable (the path at the reference's plug-in points) runs on the device only: CPU tensors raise."""
+    import pytest
+    import thr3ed_atom_amd as rf
+    from thr3ed_atom_amd import composable as cp
+
+    rays = rf.Rays(torch.zeros(4, 3), torch.ones(4, 3))
+    with pytest.raises(RuntimeError, match="HIP device"):
+        cp.sample_uniform_points_on_rays(rays, rf.CameraBounds(1.0, 2.0), 8)
+    with pytest.raises(RuntimeError, match="HIP device"):
+        cp.accumulate_radiance_density_on_rays(cp.ProcessedPointsOnRays(torch.zeros(4, 8, 4), torch.zeros(4, 8)), rays)
+    assert rf.render is cp.render and rf.SampledPointsOnRays is cp.SampledPointsOnRays

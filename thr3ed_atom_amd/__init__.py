@@ -35,5 +35,13 @@ from .voxels import (  # noqa: F401
 )
 from .renderers import SHVoxGridRenderConfig, density2occupancy_pb, render_sh_voxel_grid, render_sh_voxel_grid_frame  # noqa: F401
 from .volumetric_model import VolumetricModel, cast_rays, create_volumetric_model_from_saved_model  # noqa: F401
+from .composable import (  # noqa: F401  (the path at the granularity of the reference's plug-in points)
+    SampledPointsOnRays,
+    accumulate_radiance_density_on_rays,
+    process_points_with_sh_voxel_grid,
+    render,
+    sample_aabb_bound_uniform_points_on_rays,
+    sample_uniform_points_on_rays,
+)
 
 __version__ = "0.1.0"

@@ -15,6 +15,12 @@ INFINITY = 1e10
 # RenderOut.extra keys
 EXTRA_DISPARITY = "disparity"
 EXTRA_ACCUMULATED_WEIGHTS = "accumulated_weight"
+# ... the per-sample debug outputs of the accumulator (reference utils/constants.py:14-18, accumulate.py:96-107)
+EXTRA_POINT_DENSITIES = "point_densities"
+EXTRA_POINT_OCCUPANCIES = "point_occupancies"
+EXTRA_SAMPLE_INTERVALS = "deltas"
+EXTRA_POINT_WEIGHTS = "point_weights"
+EXTRA_POINT_DEPTHS = "point_depths"
 
 # checkpoint dictionary keys
 THRE3D_REPR = "thre3d_repr"

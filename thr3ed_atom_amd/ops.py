@@ -636,6 +636,57 @@ class _GridQuery(torch.autograd.Function):
         return gd, gf, None, None
 
 
+class _InterpolateTensors(torch.autograd.Function):
+    """Trilinear interpolation (the bit-exact grid_sample recipe of rf_grid_query) of two EXPLICIT reference-layout tensors
+    [X,Y,Z,1] / [X,Y,Z,F] at points [M,3] of a grid's box: no density scale, no activation -- the building block of the composed
+    path, where arbitrary callables run in torch before and after it.  Differentiable w.r.t. both tensors."""
+
+    @staticmethod
+    def forward(ctx, dens, feat, points, geometry):
+        lib = _lib.load()
+        dens = dens.detach().to(torch.float32).contiguous()
+        feat = feat.detach().to(torch.float32).contiguous()
+        points = points.detach().to(torch.float32).contiguous()
+        _require_hip(points, "points")
+        rf = _lib.RFGrid()
+        C.memmove(C.byref(rf), C.byref(geometry), C.sizeof(_lib.RFGrid))
+        rf.densities_dev, rf.features_dev = dens.data_ptr(), feat.data_ptr()
+        rf.num_features, rf.density_stride, rf.feature_stride = int(feat.shape[-1]), 1, int(feat.shape[-1])
+        rf.layout, rf.density_scale, rf.density_mode, rf.occupancy_dev = _lib.LAYOUTS["reference"], 1.0, _lib.DENSITY_MODES["identity"], None
+        m = points.shape[0]
+        out = torch.empty((m, feat.shape[-1] + 1), dtype=torch.float32, device=points.device)
+        _lib.check(lib.rf_grid_query(C.byref(rf), points.data_ptr(), m, out.data_ptr(), _stream(points.device)), "rf_grid_query")
+        ctx.rf = rf
+        ctx.save_for_backward(dens, feat, points)
+        return out
+
+    @staticmethod
+    def backward(ctx, g_out):
+        dens, feat, points = ctx.saved_tensors
+        g_out = g_out.detach().to(torch.float32).contiguous()
+        gd, gf = torch.zeros_like(dens), torch.zeros_like(feat)
+        _lib.check(_lib.load().rf_grid_query_backward(C.byref(ctx.rf), points.data_ptr(), points.shape[0], g_out.data_ptr(), gd.data_ptr(), gf.data_ptr(),
+                                                      _stream(points.device)), "rf_grid_query_backward")
+        return gd, gf, None, None
+
+
+def interpolate_tensors(grid, dens: Tensor, feat: Tensor, points: Tensor) -> Tensor:
+    """[M, F + 1] = (interp(feat), interp(dens)) at ``points`` inside ``grid``'s box (its dims, AABB and normalisation; its own
+    tensors, density scale and activations are NOT used)."""
+    if tuple(dens.shape[:3]) != tuple(grid.grid_dims) or tuple(feat.shape[:3]) != tuple(grid.grid_dims) or dens.shape[-1] != 1:
+        raise AssertionError("interpolate_tensors: tensors must be [X,Y,Z,1] / [X,Y,Z,F] of the grid's dimensions")
+    g = _lib.RFGrid()
+    for a in range(3):
+        g.dims[a] = grid.grid_dims[a]
+        lo, hi = grid._aabb[a]
+        g.aabb_min[a], g.aabb_max[a] = float(np.float32(lo)), float(np.float32(hi))
+        from .camera import slack_range_map
+
+        scale, bias = slack_range_map((lo, hi))
+        g.norm_scale[a], g.norm_bias[a] = float(scale), float(bias)
+    return _InterpolateTensors.apply(dens, feat, points, g)
+
+
 def grid_query(grid: VoxelGrid, points: Tensor) -> Tensor:
     """[M, 3] points -> [M, F+1] = (interpolated features in the reference order, activated density); differentiable
     w.r.t. the grid (reference VoxelGrid.forward, thre3d_reprs/voxels.py:276-331)."""

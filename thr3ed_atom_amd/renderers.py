@@ -4,10 +4,12 @@
     RenderProcedure = Callable[[Module, Rays, RenderConfig, Optional[int]], RenderOut]
     (renderers.py:22-25; stored and invoked by VolumetricModel, modules/volumetric_model.py:112-114)
 
-``SHVoxGridRenderConfig`` has the reference's fields and defaults (renderers.py:28-45).  The two
-callable fields exist for interface compatibility: only the reference defaults
-(``density2occupancy_pb``, ``torch.sigmoid``) are implemented by the fused kernel, anything else raises
-``ValueError`` (no silent fallback).
+``SHVoxGridRenderConfig`` has the reference's fields and defaults (renderers.py:28-45).  The fused kernels implement the
+reference defaults of the two callable fields (``density2occupancy_pb``, ``torch.sigmoid``), no density noise, and the four
+density-activation pairs of voxels.resolve_density_mode; any other configuration is rendered by the COMPOSED path
+(composable.py: the reference's sampler -> point processor -> accumulator composition with the HIP interpolation in the middle and
+the callables applied by torch, on the device).  The fused training step (trainers.TrainStepper(fused=True)) takes the fused
+configurations only and raises ``ValueError`` otherwise.
 """
 import dataclasses
 from typing import Any, Callable, Optional
@@ -74,6 +76,16 @@ def _check_supported(cfg) -> None:
         raise ValueError("render_sh_voxel_grid (HIP): stochastic_density_noise_std must be 0.0 (the reference's noise path yields non-finite renders)")
 
 
+def fused_kernels_apply(voxel_grid, render_config) -> bool:
+    """True when the fused kernels implement this (grid, config) pair; else ``render_sh_voxel_grid`` composes the render."""
+    try:
+        _check_supported(render_config)
+    except ValueError:
+        return False
+    fn = getattr(voxel_grid, "fused_kernels_apply", None)
+    return True if fn is None else bool(fn())
+
+
 def render_sh_voxel_grid(
     voxel_grid: VoxelGrid,
     rays: Rays,
@@ -92,6 +104,13 @@ def render_sh_voxel_grid(
     "torch" = ``torch.rand(N, S)`` on the rays' device like sample.py:63."""
     # duck typing, like the reference's plug-in contract (renderers.py:22-25 takes "a Module"): this package's VoxelGrid, or any
     # module with the reference VoxelGrid's attribute names -- e.g. the reference's own grid object (TypeError otherwise)
+    if not fused_kernels_apply(voxel_grid, render_config):
+        # non-default plug-ins (density2occupancy, tone map, density noise, activation callables): the composed path
+        from .composable import render_sh_voxel_grid_composed
+
+        if isinstance(t_rand, KeyedJitter):
+            raise ValueError("the composed render path takes a [N, S] t_rand tensor (or draws torch.rand like the reference), not a KeyedJitter")
+        return render_sh_voxel_grid_composed(voxel_grid, rays, render_config, parallel_points_chunk_size, t_rand=t_rand)
     voxel_grid = as_kernel_grid(voxel_grid)
     _check_supported(render_config)
     origins, directions = rays.origins, rays.directions

@@ -23,7 +23,7 @@ from .constants import (
 from . import distributed as rfdist
 from .ops import cast_rays_hip
 from .render_interface import Rays, RenderOut, collate_rendered_output, flatten_rays, reshape_rendered_output
-from .renderers import RenderConfig, RenderProcedure, render_sh_voxel_grid, render_sh_voxel_grid_frame
+from .renderers import RenderConfig, RenderProcedure, render_sh_voxel_grid, render_sh_voxel_grid_frame, fused_kernels_apply
 
 
 def cast_rays(camera_intrinsics: CameraIntrinsics, pose: CameraPose, device=None) -> Rays:
@@ -119,6 +119,7 @@ class VolumetricModel:
         total_rays = int(height) * int(width)
         if (
             self._render_procedure is render_sh_voxel_grid
+            and fused_kernels_apply(self._thre3d_repr, cfg)  # (else: chunk by chunk through the composed path)
             and gpu_render
             and not verbose
             and (not getattr(cfg, "perturb_sampled_points", False) or getattr(cfg, "jitter", "keyed") == "keyed")

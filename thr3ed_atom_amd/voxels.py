@@ -197,6 +197,9 @@ class KernelGridInterface:
         # the descriptor is rebuilt only when something it describes changed (it is on the per-launch host path)
         occ_ptr = self._occupancy.data_ptr() if (use_occupancy and self._occupancy is not None) else None
         mode = self.density_mode
+        if mode is None or not (_is_identity(getattr(self, "_feature_preactivation", None)) and _is_identity(getattr(self, "_feature_postactivation", None))):
+            raise ValueError("the fused HIP kernels implement Identity/ReLU, Identity/Softplus, torch.abs/Identity and Identity/Identity density activations "
+                             "with identity feature activations; this grid's callables need the composed path (thr3ed_atom_amd.composable)")
         key = (d.data_ptr(), None if f is None else f.data_ptr(), occ_ptr, self._aabb, self._expected_density_scale, mode, tuple(d.shape))
         # (kept OUTSIDE the object: a ctypes struct with pointers in a module's __dict__ breaks copy.deepcopy / torch.save of it)
         cached = _RF_GRID_CACHE.get(self)
@@ -342,10 +345,6 @@ class VoxelGrid(Module, KernelGridInterface):
             raise AssertionError(f"features should be [W x D x H x F], got {tuple(features.shape)}")
         if densities.device != features.device:
             raise AssertionError("densities and features are not on the same device")
-        if not (_is_identity(feature_preactivation) and _is_identity(feature_postactivation)):
-            raise ValueError("the HIP render path supports identity feature activations only")
-        if radiance_transfer_function is not None:
-            raise ValueError("radiance_transfer_function is not used on the SH render path")
         super().__init__()
         self._density_preactivation = density_preactivation
         self._density_postactivation = density_postactivation
@@ -356,7 +355,13 @@ class VoxelGrid(Module, KernelGridInterface):
         self._voxel_size = voxel_size
         self._expected_density_scale = expected_density_scale
         self._tunable = tunable
-        self.density_mode = resolve_density_mode(density_preactivation, density_postactivation)
+        # the activation pairs the fused kernels implement (the three the reference's trainer script builds + identity); any other
+        # callables -- and non-identity feature activations / a radiance transfer function -- take the composed path
+        # (composable.py: HIP interpolation of the pre-activated tensors, the callables applied by torch around it)
+        try:
+            self.density_mode = resolve_density_mode(density_preactivation, density_postactivation)
+        except ValueError:
+            self.density_mode = None
 
         densities = densities.detach().to(torch.float32).contiguous()
         features = features.detach().to(torch.float32).contiguous()
@@ -515,12 +520,30 @@ class VoxelGrid(Module, KernelGridInterface):
     def num_features(self) -> int:
         return self._num_features
 
-    def forward(self, points: Tensor, viewdirs: Optional[Tensor] = None) -> Tensor:
-        """[N, 3] -> [N, F+1] = cat(interpolated features, density)  (reference voxels.py:276-331; ``viewdirs`` is
-        only consumed by a radiance transfer function, which this path does not have).  Runs rf_grid_query."""
-        from .ops import grid_query
+    def fused_kernels_apply(self) -> bool:
+        """True when the fused render kernels implement this grid's activations (else: the composed path)."""
+        return self.density_mode is not None and _is_identity(self._feature_preactivation) and _is_identity(self._feature_postactivation)
 
-        return grid_query(self, points)
+    def forward(self, points: Tensor, viewdirs: Optional[Tensor] = None) -> Tensor:
+        """[N, 3] -> [N, F+1] = cat(interpolated features, density)  (reference voxels.py:276-331).  With the activations the
+        kernels implement: one rf_grid_query launch.  Otherwise the reference's composition with the HIP interpolation in the
+        middle: post(interp(pre(D * rho))) | post_f(interp(pre_f(F))), then the radiance transfer function when ``viewdirs`` is given."""
+        from .ops import grid_query, interpolate_tensors
+
+        if self.fused_kernels_apply():
+            out = grid_query(self, points)
+            if self._radiance_transfer_function is None or viewdirs is None:
+                return out
+            feats, dens = out[..., :-1], out[..., -1:]
+        else:
+            pre_d = self._density_preactivation(self.densities * self._expected_density_scale)
+            pre_f = self._feature_preactivation(self.features)
+            both = interpolate_tensors(self, pre_d, pre_f, points)
+            dens = self._density_postactivation(both[..., -1:])
+            feats = self._feature_postactivation(both[..., :-1])
+        if self._radiance_transfer_function is not None and viewdirs is not None:
+            feats = self._radiance_transfer_function(feats, viewdirs)
+        return torch.cat([feats, dens], dim=-1)
 
     def get_config_dict(self) -> Dict[str, Any]:
         return {
