@@ -474,7 +474,7 @@ class TrainStepper:
 
     def _owner_state(self, ex, device):
         """Persistent state of the owner-computes exchange: who owns which x-slabs of bricks, the ranks' offset tables, where every
-        piece's key range starts and ends in them, a pinned host copy of those bounds, the side / communication streams, the receive
+        piece's key range starts and ends in them, a pinned host copy of those bounds, the side stream that fetches it, the receive
         buffers."""
         ow = self._owner
         if ow is not None and ow["ex"] is ex:
