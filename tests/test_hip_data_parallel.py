@@ -37,9 +37,11 @@ def _setup(dev, jitter=False):
     poses = torch.stack([torch.cat([c.rotation, c.translation.reshape(3, 1)], dim=1) for c in cams]).to(dev)
     data = PosedImagesInMemory(images, poses, rf.CameraIntrinsics(24, 24, 33.0), rf.CameraBounds(cam["near"], cam["far"]))
     G = GRID["G"]
+    dims = GRID.get("dims") or (G, G, G)  # (a non-cubic grid: partial bricks along y and z)
+    F = 3 * (GRID.get("deg", DEG) + 1) ** 2
     grid = rf.VoxelGrid(
-        torch.from_numpy(hash_uniform((G, G, G, 1), 901)).to(dev), torch.from_numpy(hash_uniform((G, G, G, F), 900 + F)).to(dev),
-        rf.VoxelSize(3.0 / G, 3.0 / G, 3.0 / G), density_preactivation=torch.nn.Identity(), density_postactivation=torch.nn.ReLU(),
+        torch.from_numpy(hash_uniform((*dims, 1), 901)).to(dev), torch.from_numpy(hash_uniform((*dims, F), 900 + F)).to(dev),
+        rf.VoxelSize(3.0 / dims[0], 3.0 / dims[1], 3.0 / dims[2]), density_preactivation=torch.nn.Identity(), density_postactivation=torch.nn.ReLU(),
         expected_density_scale=100.0 / 3.0, tunable=True, storage="split",
     )
     cfg = rf.SHVoxGridRenderConfig(S, data.camera_bounds, perturb_sampled_points=jitter, white_bkgd=True)
@@ -54,8 +56,9 @@ def _train(stepper, data, steps=3):
     return stepper.flat.flat_param.clone()
 
 
-def _worker(rank, world, port, result_dir, exchange, shard_optimizer, jitter, grid_size=16, halves=1, brick_parts=0):
+def _worker(rank, world, port, result_dir, exchange, shard_optimizer, jitter, grid_size=16, halves=1, brick_parts=0, dims=None, deg=DEG):
     GRID["G"] = grid_size
+    GRID["dims"], GRID["deg"] = dims, deg
     if brick_parts:
         import thr3ed_atom_amd.trainers as trainers_module
 
@@ -68,7 +71,8 @@ def _worker(rank, world, port, result_dir, exchange, shard_optimizer, jitter, gr
         # strong scaling: the ranks split ONE global batch -> the run must equal the single-process run
         # (with the keyed jitter on, rank r must draw the jitter of rays lo..hi of the global batch: KeyedJitter.first_ray)
         data, model = _setup(dev, jitter)
-        stepper = TrainStepper(model, R, learning_rate=0.03, global_batch=True, shard_optimizer=shard_optimizer, exchange=exchange)
+        # (backward="binned": what "auto" picks from SH degree 2 on; the degree-0 case asks for it)
+        stepper = TrainStepper(model, R, learning_rate=0.03, global_batch=True, shard_optimizer=shard_optimizer, exchange=exchange, backward="binned" if deg == 0 else "auto")
         assert stepper.exchange == exchange
         dp = _train(stepper, data)
         if exchange == "owner":
@@ -79,13 +83,13 @@ def _worker(rank, world, port, result_dir, exchange, shard_optimizer, jitter, gr
         dist.all_gather(gathered, dp)
         assert all(torch.equal(gathered[0], t) for t in gathered), "replicas diverged"
         data, model = _setup(dev, jitter)
-        single = _train(TrainStepper(model, R, learning_rate=0.03, data_parallel=False), data)
+        single = _train(TrainStepper(model, R, learning_rate=0.03, data_parallel=False, backward="binned" if deg == 0 else "auto"), data)
         err = float((dp - single).abs().max())
-        moved = float((single - torch.cat([t.reshape(-1) for t in model.thre3d_repr.kernel_tensors()]).detach()).abs().max())
+        moved = float((single - torch.cat([t.reshape(-1) for t in model.thre3d_repr.kernel_tensors() if t is not None]).detach()).abs().max())
         assert err <= 2e-4, f"data-parallel run differs from the single-process run by {err}"
         # weak scaling: every rank draws its own batch; replicas must still agree
         data, model = _setup(dev, jitter)
-        stepper = TrainStepper(model, R // 2, learning_rate=0.03, shard_optimizer=shard_optimizer, exchange=exchange)
+        stepper = TrainStepper(model, R // 2, learning_rate=0.03, shard_optimizer=shard_optimizer, exchange=exchange, backward="binned" if deg == 0 else "auto")
         torch.manual_seed(11 + rank)
         for _ in range(2):
             stepper.step(data, torch.arange(4))
@@ -111,6 +115,16 @@ def test_two_processes_train_data_parallel_on_one_gpu(tmp_path, exchange, shard_
     world = 2
     parts = 2 if halves < 0 else 0
     mp.spawn(_worker, args=(world, _free_port(), str(tmp_path), exchange, shard_optimizer, jitter, grid_size, abs(halves), parts), nprocs=world, join=True)
+    assert sorted(os.listdir(tmp_path)) == [f"ok{r}" for r in range(world)]
+
+
+@pytest.mark.parametrize("deg,dims", [(0, (32, 20, 28)), (2, (32, 12, 44))])
+def test_two_processes_owner_computes_on_odd_grids(tmp_path, deg, dims):
+    """SH degree 0 (one kind of list, the base-channel kernel) and non-cubic grids whose y / z extents are not whole bricks, interleaved
+    halves and two workgroups per owned brick: equal to the single-process run."""
+    assert torch.cuda.is_available()
+    world = 2
+    mp.spawn(_worker, args=(world, _free_port(), str(tmp_path), "owner", True, True, dims[0], 2, 2, dims, deg), nprocs=world, join=True)
     assert sorted(os.listdir(tmp_path)) == [f"ok{r}" for r in range(world)]
 
 
