@@ -14,8 +14,10 @@ What is done the MI355X way instead of translated:
     8 x H x W rays and discarding all but 16384 of them every iteration;
   * gradients accumulate in one flat bucket and Adam is one fused kernel (optim.py); the specular backward of the
     fused step bins per-sample gradient records by 8^3-node brick and sums every brick on chip (MFMA accumulators) without atomics;
-  * with WORLD_SIZE > 1 every rank draws its own ray batch and the bucket is exchanged once per iteration over RCCL:
-    reduce-scatter, Adam on 1/N of the grid per rank, all-gather of the parameters (distributed.py).
+  * with WORLD_SIZE > 1 every rank draws its own ray batch and the ranks exchange gradient RECORDS by owner over RCCL (all-gather of
+    the offset tables -> all-to-all of record slices -> every rank sums its own x-slabs of bricks and applies Adam there -> in-place
+    all-gather of the parameters, pipelined in two interleaved halves: TrainStepper._owner_step); grids the
+    owner step does not cover exchange one flat gradient bucket (reduce-scatter, Adam on 1/N of the grid per rank, all-gather).
 """
 import ctypes as C
 import dataclasses
