@@ -11,17 +11,19 @@ import csv, glob, collections
 f = glob.glob("gpurun_out/gaps/trace/**/*kernel_trace.csv", recursive=True)[0]
 rows = list(csv.DictReader(open(f)))
 rows.sort(key=lambda r: int(r["Start_Timestamp"]))
+def short(n):
+    return n.replace("void ", "").replace("(anonymous namespace)::", "").split("(")[0][:48]
 # the last 30 iterations: find the select kernels
 names = [r["Kernel_Name"] for r in rows]
-idx = [i for i, n in enumerate(names) if n.startswith("select_rays_and_pixels")]
+idx = [i for i, n in enumerate(names) if "select_rays_and_pixels" in n]
 idx = idx[-31:]
 gaps = collections.defaultdict(list); durs = collections.defaultdict(list)
 for a, b in zip(idx[:-1], idx[1:]):
     seq = rows[a:b + 1]
     for x, y in zip(seq[:-1], seq[1:]):
-        key = x["Kernel_Name"][:40] + " -> " + y["Kernel_Name"][:40]
+        key = short(x["Kernel_Name"]) + " -> " + short(y["Kernel_Name"])
         gaps[key].append((int(y["Start_Timestamp"]) - int(x["End_Timestamp"])) / 1e3)
-        durs[x["Kernel_Name"][:60]].append((int(x["End_Timestamp"]) - int(x["Start_Timestamp"])) / 1e3)
+        durs[short(x["Kernel_Name"])].append((int(x["End_Timestamp"]) - int(x["Start_Timestamp"])) / 1e3)
 tot = 0
 for k, v in gaps.items():
     print(f"gap {sum(v)/len(v):8.2f} us  x{len(v)//30}  {k}"); tot += sum(v) / 30
