@@ -30,6 +30,8 @@ extern "C" {
 #endif
 
 #define RF_ABI_VERSION 4
+/* brick_size value for bricks of 4 x 8 x 8 nodes (see the binned backward below) */
+#define RF_BRICK_4X8X8 488
 
 enum {
   RF_OK = 0,
@@ -139,7 +141,7 @@ typedef struct RFRenderOut {
    * backward (see rf_render_backward_emit) into key_hist_dev [8 * nbricks] (added to; clear before the first use), so
    * that rf_render_backward_emit_direct can write their records straight to the final positions. */
   int32_t* key_hist_dev;
-  int32_t brick_size;      /* 4 or 8 (only read when key_hist_dev != NULL)                             */
+  int32_t brick_size;      /* 4, 8 or RF_BRICK_4X8X8 (only read when key_hist_dev != NULL)             */
 } RFRenderOut;
 
 /* Upstream gradients of a render (all [N, ...] device arrays; any may be NULL = zero). */
@@ -206,7 +208,10 @@ int rf_render_backward(const RFGrid* grid, const RFRayBatch* rays, uint32_t flag
  * on chip under exclusive ownership:
  *
  *   key  = ((((bx * 2 + f_x) * NBY + by) * NBZ + bz) << 2) | f_y | f_z << 1;  (bx, by, bz) = the brick (brick_size^3 nodes,
- *          brick_size in {4, 8}) holding the LOWER node of the sample's cell;  f_a = the cell's upper node on axis a belongs
+ *          brick_size in {4, 8}; or RF_BRICK_4X8X8: 4 x 8 x 8 nodes, the bricks of the single-GPU optimizer pass -- four
+ *          256-thread workgroups per CU instead of two 512-thread ones; accepted by the render / emit / offset functions and
+ *          by rf_brick_accumulate_adam and rf_train_step, SH degree 0 or 2, every grid tensor below 2^30 elements)
+ *          holding the LOWER node of the sample's cell;  f_a = the cell's upper node on axis a belongs
  *          to the next brick (so the record also touches that neighbour's nodes).  8 * nbricks keys.  The order is x-slab
  *          major with the x flag directly below the slab index: everything that touches the nodes of the x-slabs [s0, s1)
  *          of bricks is ONE contiguous key range, [key(s0 - 1, f_x = 1), key(s1, f_x = 0)) -- what a data-parallel rank

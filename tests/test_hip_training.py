@@ -1102,7 +1102,7 @@ def test_split_brick_pass_equals_the_plain_owner_pass(hip_device, copies, parts)
     model = rf.VolumetricModel(grid, rf.render_sh_voxel_grid, cfg, device=hip_device)
     rays = rf.flatten_rays(rf.cast_rays(rf.CameraIntrinsics(48, 48, 66.0), rf.pose_spherical(20.0, -30.0, cam["radius"]), hip_device))[:n]
     pixels = T(hash_uniform((n, 3), 33, 0.0, 1.0)).to(hip_device)
-    st = TrainStepper(model, n, learning_rate=0.03, fused=True, backward="binned", data_parallel=False)
+    st = TrainStepper(model, n, learning_rate=0.03, fused=True, backward="binned", data_parallel=False, brick_size=8)  # (owners sum 8^3 bricks)
     for _ in range(2):
         st.step_on(rays, pixels)
     torch.cuda.synchronize()

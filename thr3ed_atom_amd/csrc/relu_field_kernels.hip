@@ -768,14 +768,18 @@ __device__ __forceinline__ float record_channel(int ch, float gdens, const float
 // x-slab major with the x flag directly below the slab index: everything that touches the nodes of the x-slabs [s0, s1) of bricks --
 // the records of those slabs plus the x-flagged records of slab s0 - 1 -- is ONE contiguous key range.  That is what lets a
 // data-parallel rank send an owner of a slab range its share of a sorted list as a single slice (owner-computes exchange).
+// `shift`: log2 of the brick edge; bits 4.. = by how much the x edge's log2 is smaller (brick_geometry: 0 for cubic bricks, 1 for the
+// 4 x 8 x 8 bricks of RF_BRICK_4X8X8).
 __device__ __forceinline__ int brick_key(const int i0[3], const GridArgs& g, int shift, int nby, int nbz) {
   const int dims3[3] = {g.X, g.Y, g.Z};
+  const int syz = shift & 15;
+  const int sh3[3] = {syz - (shift >> 4), syz, syz};
   int b3[3], f3[3];
 #pragma unroll
   for (int a = 0; a < 3; ++a) {
     const int lo = max(i0[a], 0), up = i0[a] + 1;
-    b3[a] = lo >> shift;
-    f3[a] = (up < dims3[a] && (up >> shift) != b3[a]) ? 1 : 0;
+    b3[a] = lo >> sh3[a];
+    f3[a] = (up < dims3[a] && (up >> sh3[a]) != b3[a]) ? 1 : 0;
   }
   // (brick counts are far below 2^24: full-rate 24-bit multiplies)
   return (int)((__umul24(__umul24((unsigned)((b3[0] << 1) | f3[0]), (unsigned)nby) + (unsigned)b3[1], (unsigned)nbz) + (unsigned)b3[2]) << 2) | f3[1] | (f3[2] << 1);
@@ -1776,7 +1780,19 @@ __device__ __forceinline__ void bin_offsets_body(const BinLists& lists, int nkey
   const int t = threadIdx.x, lane = t & (kWave - 1), wave = t >> 6;
   const int seg0 = block * 1024;
   int front = 0;
-  for (int k = t; k < seg0; k += 1024) front += hist[k];
+  {  // (seg0 is a multiple of 1024 keys: whole 16-byte loads, four of them in flight per thread -- 64 segments at 128^3 / 4 x 8 x 8 bricks)
+    const int4* __restrict__ h4 = reinterpret_cast<const int4*>(hist);
+    const int n4 = seg0 >> 2;
+    int k4 = t;
+    for (; k4 + 3 * 1024 < n4; k4 += 4 * 1024) {
+      const int4 a0 = h4[k4], a1 = h4[k4 + 1024], a2 = h4[k4 + 2048], a3 = h4[k4 + 3072];
+      front += (a0.x + a0.y) + (a0.z + a0.w) + (a1.x + a1.y) + (a1.z + a1.w) + (a2.x + a2.y) + (a2.z + a2.w) + (a3.x + a3.y) + (a3.z + a3.w);
+    }
+    for (; k4 < n4; k4 += 1024) {
+      const int4 a0 = h4[k4];
+      front += (a0.x + a0.y) + (a0.z + a0.w);
+    }
+  }
 #pragma unroll
   for (int d = 1; d < kWave; d <<= 1) front += __shfl_xor(front, d);
   const int k = seg0 + t;
@@ -1942,7 +1958,7 @@ __device__ __forceinline__ void brick_range_entry(const BrickArgs& a, const long
 // The last phase of a brick workgroup: the sums of the B^3 owned nodes (LDS accumulators `acc`, node (x, y, z) channel c at
 // x * SX + y * SY + z * CS + c; all zero when `any` is false) go out with plain stores -- or, ADAM, are consumed by the
 // optimizer step on the spot.
-template <int K, bool ADAM, bool ONE_ROUND>
+template <int K, bool ADAM, bool ONE_ROUND, int TH = kBrickThreads>
 __device__ __forceinline__ void brick_flush(const GridArgs& g, const BrickArgs& a, const float* acc, bool any, int X0, int Y0, int Z0,
                                             float* gdens, float* gfeat) {
   constexpr int C = 3 * K + 1;
@@ -1981,7 +1997,8 @@ __device__ __forceinline__ void brick_flush(const GridArgs& g, const BrickArgs& 
       constexpr int U = (QN == 7) ? 4 : 1;
       const AdamArgs& ad = a.adam;
       if constexpr (ONE_ROUND) {  // (host: bricks of 8^3 nodes, every element of the grid tensors below 2^30)
-        // ONE round: thread t takes the base quad of node t (512 nodes) and rest quads t, t + 512, ... of the brick's 3072 -- so that
+        // ONE round: thread t takes the base quad of node t (512 nodes) and rest quads t, t + 512, ... of the brick's 3072 (4 x 8 x 8
+        // bricks, TH = 256: of node t of 256 and rest quads t, t + 256, ... of 1536: the same seven quads per thread) -- so that
         // every load / store instruction of a wave addresses ONE tensor: uniform base (SGPR pair) + a 32-bit byte offset per lane,
         // the same offset for parameter, exp_avg and exp_avg_sq.  7 offsets + 84 data registers: all 21 loads of a thread are in
         // flight before its first store (vmcnt counts loads and stores together, so a second round's first wait would also sit out
@@ -1999,7 +2016,7 @@ __device__ __forceinline__ void brick_flush(const GridArgs& g, const BrickArgs& 
             fz = tid & 7;
             qd = 0;
           } else {
-            const int j = (u - 1) * 512 + tid, col = j / 48, r = j - col * 48;
+            const int j = (u - 1) * TH + tid, col = j / 48, r = j - col * 48;
             fz = r / 6;
             qd = 1 + r - 6 * fz;
             fx = col >> 3;
@@ -2051,14 +2068,14 @@ __device__ __forceinline__ void brick_flush(const GridArgs& g, const BrickArgs& 
         return;
       } else {
       // (bricks of 4^3 nodes, tensors of 2^30 elements and more: two rounds of 4 + 3 quads per thread with per-lane tensor selection)
-      for (int i0 = tid; i0 < nq; i0 += kBrickThreads * U) {
+      for (int i0 = tid; i0 < nq; i0 += TH * U) {
         unsigned int off[U];  // bit 31: rest tensor; 0xffffffff: nothing to do
         float4 p4[U];
         vf4 m4[U], v4[U];
 #pragma unroll
         for (int u = 0; u < U; ++u) {
           int fx, fy, fz, qd;
-          const bool ok = quad_of(i0 + u * kBrickThreads, fx, fy, fz, qd);
+          const bool ok = quad_of(i0 + u * TH, fx, fy, fz, qd);
           const unsigned int lin = ok ? node_lin(g, X0 + fx, Y0 + fy, Z0 + fz) : 0u;
           const unsigned int o = qd == 0 ? lin * (unsigned)g.dstride : (lin * (unsigned)g.fstride + 4u * (unsigned)(qd - 1)) | 0x80000000u;
           off[u] = ok ? o : 0xffffffffu;
@@ -2082,7 +2099,7 @@ __device__ __forceinline__ void brick_flush(const GridArgs& g, const BrickArgs& 
           const bool rest = off[u] >> 31;
           const unsigned int o = off[u] & 0x7fffffffu;
           int fx, fy, fz, qd;
-          quad_of(i0 + u * kBrickThreads, fx, fy, fz, qd);
+          quad_of(i0 + u * TH, fx, fy, fz, qd);
           const float4 gq = any ? *reinterpret_cast<const float4*>(&acc[fx * SX + fy * SY + fz * CS + 4 * qd]) : make_float4(0.f, 0.f, 0.f, 0.f);
           float gg[4] = {gq.x, gq.y, gq.z, gq.w};
           float pn[4] = {p4[u].x, p4[u].y, p4[u].z, p4[u].w};
@@ -2115,7 +2132,7 @@ __device__ __forceinline__ void brick_flush(const GridArgs& g, const BrickArgs& 
       }
       return;
     }
-    for (int i = tid; i < nq; i += kBrickThreads) {
+    for (int i = tid; i < nq; i += TH) {
       int fx, fy, fz, qd;
       if (!quad_of(i, fx, fy, fz, qd)) continue;
       const long long lin = node_lin(g, X0 + fx, Y0 + fy, Z0 + fz);
@@ -2153,7 +2170,7 @@ __device__ __forceinline__ void brick_flush(const GridArgs& g, const BrickArgs& 
     const int run = B * nch;  // floats of one z column in this tensor
     float* out = pass == 0 ? gdens : gfeat;
     const long long ostride = pass == 0 ? g.dstride : g.fstride;
-    for (int i = tid; i < B * B * run; i += kBrickThreads) {
+    for (int i = tid; i < B * B * run; i += TH) {
       const int col = i / run, r = i - col * run;
       const int fz = r / nch, c2 = r - fz * nch;
       const int fx = col >> a.shift, fy = col & (B - 1);
@@ -2226,9 +2243,8 @@ __device__ __forceinline__ void lds_wait(float& a, float& b, float& c, float& d,
   asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a), "+v"(b), "+v"(c), "+v"(d), "+v"(e), "+v"(e2), "+v"(e3), "+v"(f));
 }
 
-// tile tl (0..3) of wave `wave`: interleaved over the waves (a wave's four tiles are spread along x), so that a hot corner of the
-// brick does not land on one wave (0.414 -> 0.409 ms against four consecutive tiles per wave)
-#define RF_TILE_OF(wave, tl) ((tl) * 8 + (wave))
+// tile tl (0..3) of wave `wave` = tl * (waves of the workgroup) + wave: interleaved over the waves (a wave's four tiles are spread along
+// x), so that a hot corner of the brick does not land on one wave (0.414 -> 0.409 ms against four consecutive tiles per wave)
 constexpr int kGatherBatch = 256;  // records per batch (their indices travel as bytes)
 constexpr int kGatherWtab = 24;    // rows of the weight table: 3 axes x local node coordinate 0..7
 // Bank conflicts are what bounds the tile loop (6 LDS reads per instruction): table rows are kGatherBatch + 4 words apart, so that
@@ -2240,10 +2256,12 @@ constexpr int kGatherRow = kGatherBatch + 4;
 __host__ __device__ constexpr int gather_record_words(int C4) { return C4 + 8; }
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
-__host__ __device__ inline int gather_lds_words(int B, int C) {
+// (BX = 4: the 4 x 8 x 8 bricks of 256-thread workgroups -- batches of 128 records, an image of 4 slabs)
+__host__ __device__ inline int gather_lds_words(int B, int C, int BX = 8) {
   const int C4 = (C + 3) / 4 * 4;
-  const int batch = kGatherBatch * gather_record_words(C4) + kGatherRow * kGatherWtab;  // per-channel rows, weight table
-  const int image = brick_acc_words(B, C);
+  const int gb = BX == 4 ? kGatherBatch / 2 : kGatherBatch;
+  const int batch = gb * gather_record_words(C4) + (gb + 4) * kGatherWtab;  // per-channel rows, weight table
+  const int image = BX == 4 ? 4 * brick_slab_stride(B, C) + 64 : brick_acc_words(B, C);
   return batch > image ? batch : image;
 }
 
@@ -2251,8 +2269,17 @@ __host__ __device__ inline int gather_lds_words(int B, int C) {
 // leaves a wave 256 registers)
 // ONE_ROUND: the launch is for 8^3-node bricks (the brick edge folds to a constant); with ADAM it also selects the one-round flush
 // (which additionally needs 32-bit byte offsets: the host checks)
-template <int K, bool ADAM, bool ONE_ROUND = false, bool SPLIT = false>
-__global__ __launch_bounds__(kBrickThreads, (K > 9 ? 2 : 4)) void brick_gather_kernel(GridArgs g, BrickArgs a, float* gdens, float* gfeat) {
+// BX = 4 (RF_BRICK_4X8X8, the single-GPU optimizer pass): bricks of 4 x 8 x 8 nodes, summed by 256-thread workgroups in batches of 128
+// records -- 16 tiles, four per wave as in the 8^3 case, half the LDS: FOUR workgroups per CU instead of two.  The pass is bound by the
+// latencies of a workgroup's serial phases (ranges -> first records -> tile loops -> flush), and twice the workgroups hide twice as
+// many of them; the price is one more brick face across x (a record is read 1.58 x instead of 1.42 x) and twice the keys.
+template <int K, bool ADAM, bool ONE_ROUND = false, bool SPLIT = false, int BX = 8>
+__global__ __launch_bounds__(BX == 4 ? kBrickThreads / 2 : kBrickThreads, (K > 9 ? 2 : 4)) void brick_gather_kernel(GridArgs g, BrickArgs a, float* gdens, float* gfeat) {
+  static_assert(BX == 8 || (BX == 4 && ADAM && ONE_ROUND && !SPLIT), "4 x 8 x 8 bricks: the one-round optimizer flush only");
+  constexpr int TH = BX == 4 ? kBrickThreads / 2 : kBrickThreads;  // threads of the workgroup
+  constexpr int NWV = TH / 64;                                     // its waves: four tiles each
+  constexpr int GB = TH / 2;                                       // records per batch (two threads per record)
+  constexpr int GROW = GB + 4;                                     // words of a weight-table row (GROW)
   constexpr int C = 3 * K + 1;
   constexpr int C4 = (C + 3) / 4 * 4;
   constexpr int QW = record_quads(K);      // quads of a full-width record in HBM
@@ -2260,13 +2287,12 @@ __global__ __launch_bounds__(kBrickThreads, (K > 9 ? 2 : 4)) void brick_gather_k
   constexpr int NT = (C4 + 15) / 16;       // 16-channel blocks per tile
   static_assert(NT == 1 || NT == 2 || NT == 4, "one, two or four 16-channel blocks (SH degree 0 / base lists, 1-2, 3)");
   constexpr int CS = C4;
-  constexpr int NW = kGatherBatch / 64;    // mask words per tile
-  static_assert(2 * kGatherBatch == kBrickThreads, "two threads per record of a batch");
+  constexpr int NW = GB / 64;    // mask words per tile
   extern __shared__ __attribute__((aligned(16))) float acc[];  // first the batch buffers, in the end the accumulator image the flush reads
-  float* rows = acc;                                            // [kGatherBatch][RW] per-channel values of the batch's records
-  float* wtab = acc + kGatherBatch * gather_record_words(C4);   // [3][8][kGatherRow]: axis, local node coordinate, record
-  __shared__ uint32_t s_tmask[kGatherBatch];                   // record -> bit t: it touches tile t
-  __shared__ unsigned char s_list[32][kGatherBatch + 24];      // tile -> its records (+ padding of the last instructions, + read-ahead slack)
+  float* rows = acc;                                            // [GB][RW] per-channel values of the batch's records
+  float* wtab = acc + GB * gather_record_words(C4);   // [3][8][GROW]: axis, local node coordinate, record
+  __shared__ uint32_t s_tmask[GB];                   // record -> bit t: it touches tile t
+  __shared__ unsigned char s_list[4 * NWV][GB + 24];      // tile -> its records (+ padding of the last instructions, + read-ahead slack)
   __shared__ __attribute__((aligned(16))) int s_wstart[kMaxRangesKind], s_wcum[kMaxRangesKind + 8];  // ranges of the full-width lists: first record, running count
   __shared__ __attribute__((aligned(16))) int s_nstart[kMaxRangesKind], s_ncum[kMaxRangesKind + 8];  // ... of the base-channel lists of a mixed call
   __shared__ int s_part[4];
@@ -2288,7 +2314,7 @@ __global__ __launch_bounds__(kBrickThreads, (K > 9 ? 2 : 4)) void brick_gather_k
   auto list_index = [&](int ll) { return SPLIT ? part + ll * parts : ll; };
   const int nwide_p = lists_of(a.nwide), nnarrow_p = lists_of(a.nnarrow);
   const int bz = brick % a.nbz, by = (brick / a.nbz) % a.nby, bx = brick / (a.nbz * a.nby);
-  const int X0 = bx << bshift, Y0 = by << bshift, Z0 = bz << bshift;
+  const int X0 = bx << (BX == 4 ? 2 : bshift), Y0 = by << bshift, Z0 = bz << bshift;
   // ---- range set-up: waves 0, 1 = the 15 ranges of each full-width list, waves 2, 3 = of each base-channel list; running
   // counts by wave scan (empty ranges stay in the tables with zero length: the record -> range walk skips them)
   {
@@ -2331,7 +2357,7 @@ __global__ __launch_bounds__(kBrickThreads, (K > 9 ? 2 : 4)) void brick_gather_k
 
   // tiles: 2 x 2 x 4 nodes; tile t = (px * npy + py) * npz + pz
   const int npz = B >> 2, npy = B >> 1;
-  const int ntiles = (B * B * B) >> 4;
+  const int ntiles = BX == 4 ? 16 : (B * B * B) >> 4;
   const int mi = lane & 15;  // node of this lane inside a tile (A operand row / accumulator row group)
   const int mdx = mi >> 3, mdy = (mi >> 2) & 1, mdz = mi & 3;
   const int kk = lane >> 4;  // which of the 4 records of an instruction this lane feeds
@@ -2344,10 +2370,10 @@ __global__ __launch_bounds__(kBrickThreads, (K > 9 ? 2 : 4)) void brick_gather_k
     for (int nt = 0; nt < NT; ++nt) accr[tl][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
 
   if (any) {
-    const int nba = (total + kGatherBatch - 1) / kGatherBatch, nbd = (total_d + kGatherBatch - 1) / kGatherBatch;
+    const int nba = (total + GB - 1) / GB, nbd = (total_d + GB - 1) / GB;
     uint32_t wprev = 0x00ffffffu;  // the lower nodes (c + 1, one byte per axis) this thread's record of the previous batch had; 0xff = none
-    const int rec_id = tid & (kGatherBatch - 1);  // this thread's record of every batch; the two threads of a record split its channels
-    const int half = tid >> 8;
+    const int rec_id = tid & (GB - 1);  // this thread's record of every batch; the two threads of a record split its channels
+    const int half = tid >= GB;
 
     // -- the thread's part of the record pass: the record's column of the weight table and the set of tiles it touches (first
     // thread of the record), and its row of per-channel values.  A full-width record of an SH grid arrives COMPACT -- d density,
@@ -2363,8 +2389,8 @@ __global__ __launch_bounds__(kBrickThreads, (K > 9 ? 2 : 4)) void brick_gather_k
         for (int ax = 0; ax < 3; ++ax) {  // un-write the previous batch's entries (same thread, same column)
           const int c1 = (int)((wprev >> (8 * ax)) & 0xffu);  // c + 1
           if (c1 != 0xff) {
-            if (c1 >= 1) wcol[(ax * 8 + c1 - 1) * kGatherRow] = 0.0f;
-            if (c1 < B) wcol[(ax * 8 + c1) * kGatherRow] = 0.0f;
+            if (c1 >= 1) wcol[(ax * 8 + c1 - 1) * GROW] = 0.0f;
+            if (c1 < (BX == 4 && ax == 0 ? 4 : B)) wcol[(ax * 8 + c1) * GROW] = 0.0f;
           }
         }
         if (rec_id < nrec) {
@@ -2379,11 +2405,11 @@ __global__ __launch_bounds__(kBrickThreads, (K > 9 ? 2 : 4)) void brick_gather_k
             const int sh = ax == 2 ? 2 : 1;
             uint32_t bits = 0;
             if (c >= 0) {
-              wcol[(ax * 8 + c) * kGatherRow] = (fl + 1.0f) - idx[ax];  // same arithmetic as locate()
+              wcol[(ax * 8 + c) * GROW] = (fl + 1.0f) - idx[ax];  // same arithmetic as locate()
               bits |= 1u << (c >> sh);
             }
-            if (c + 1 < B) {
-              wcol[(ax * 8 + c + 1) * kGatherRow] = idx[ax] - fl;
+            if (c + 1 < (BX == 4 && ax == 0 ? 4 : B)) {
+              wcol[(ax * 8 + c + 1) * GROW] = idx[ax] - fl;
               bits |= 1u << ((c + 1) >> sh);
             }
             pb[ax] = bits;
@@ -2445,27 +2471,27 @@ __global__ __launch_bounds__(kBrickThreads, (K > 9 ? 2 : 4)) void brick_gather_k
         const uint32_t tmv = s_tmask[wd * 64 + lane] >> wave;
 #pragma unroll
         for (int tl = 0; tl < 4; ++tl) {
-          const bool hit = (tmv >> (8 * tl)) & 1u;
+          const bool hit = (tmv >> (NWV * tl)) & 1u;
           const unsigned long long m = __ballot(hit);
           const int pos = cnt[tl] + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0));
-          if (hit) s_list[RF_TILE_OF(wave, tl)][pos] = (unsigned char)(wd * 64 + lane);
+          if (hit) s_list[(tl * NWV + wave)][pos] = (unsigned char)(wd * 64 + lane);
           cnt[tl] += __popcll(m);
         }
       }
 #pragma unroll
       for (int tl = 0; tl < 4; ++tl)
-        if (lane < 8) s_list[RF_TILE_OF(wave, tl)][cnt[tl] + lane] = 0;  // pad the last instructions with a record that exists
+        if (lane < 8) s_list[(tl * NWV + wave)][cnt[tl] + lane] = 0;  // pad the last instructions with a record that exists
       // ... and multiplies them into the tiles' accumulators, four records per instruction, two instructions' operands in flight
 #pragma unroll
       for (int tl = 0; tl < 4; ++tl) {
-        const int t = RF_TILE_OF(wave, tl);
+        const int t = (tl * NWV + wave);
         const int n = cnt[tl];
         if (t < ntiles && n > 0 && !no_tiles) {
           const int pz = t % npz, py = (t / npz) % npy, px = t / (npz * npy);
           // this lane's three entries of a record's weight-table column, as byte offsets from the record's own
-          const float* wx = wtab + (2 * px + mdx) * kGatherRow;
-          const float* wy = wtab + (8 + 2 * py + mdy) * kGatherRow;
-          const float* wz = wtab + (16 + 4 * pz + mdz) * kGatherRow;
+          const float* wx = wtab + (2 * px + mdx) * GROW;
+          const float* wy = wtab + (8 + 2 * py + mdy) * GROW;
+          const float* wz = wtab + (16 + 4 * pz + mdz) * GROW;
           const float* gbase = rows + (WIDE ? jj : (jj & 3));  // (base-channel rows: lanes 4..15 re-read channels 0..3)
           // software pipeline: the record index of instruction q + 2 and the operands of instruction q + 1 are requested before
           // instruction q is issued; an iteration waits once, at its top, for requests that are a whole iteration old
@@ -2556,8 +2582,8 @@ __global__ __launch_bounds__(kBrickThreads, (K > 9 ? 2 : 4)) void brick_gather_k
       return i;
     };
     auto fetch_wide = [&](int s) {
-      const int nrec = min(kGatherBatch, total - s * kGatherBatch);
-      const int v = s * kGatherBatch + min(rec_id, nrec - 1);  // record of the concatenated ranges
+      const int nrec = min(GB, total - s * GB);
+      const int v = s * GB + min(rec_id, nrec - 1);  // record of the concatenated ranges
       if (v < rlo || v >= rhi) {  // the range of the previous batch's record no longer holds this one
         sri = range_of(s_wcum, v, nwide_p, sri);
         rlo = s_wcum[sri];
@@ -2570,8 +2596,8 @@ __global__ __launch_bounds__(kBrickThreads, (K > 9 ? 2 : 4)) void brick_gather_k
       if constexpr (QW > 2) w2 = load_f4<RF_NT_RECORD_LOAD>(p + 2);
     };
     auto fetch_narrow = [&](int sd) {
-      const int nrec = min(kGatherBatch, total_d - sd * kGatherBatch);
-      const int v = sd * kGatherBatch + min(rec_id, nrec - 1);
+      const int nrec = min(GB, total_d - sd * GB);
+      const int v = sd * GB + min(rec_id, nrec - 1);
       if (v < dlo || v >= dhi) {
         dri = range_of(s_ncum, v, nnarrow_p, dri);
         dlo = s_ncum[dri];
@@ -2586,10 +2612,10 @@ __global__ __launch_bounds__(kBrickThreads, (K > 9 ? 2 : 4)) void brick_gather_k
     if (nba > 0) fetch_wide(0);
     // (behind the first batches' loads:) the weight table starts zero-filled; a record's thread clears the entries of the previous
     // batch before it writes new ones
-    for (int i = tid; i < kGatherRow * kGatherWtab / 4; i += kBrickThreads) reinterpret_cast<float4*>(wtab)[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int i = tid; i < GROW * kGatherWtab / 4; i += TH) reinterpret_cast<float4*>(wtab)[i] = make_float4(0.f, 0.f, 0.f, 0.f);
     __syncthreads();
     for (int s = 0; s < nba; ++s) {
-      const int nrec = min(kGatherBatch, total - s * kGatherBatch);
+      const int nrec = min(GB, total - s * GB);
       if constexpr (K > 1)
         stage(Yes{}, w0, w1, w2, nrec);
       else
@@ -2600,7 +2626,7 @@ __global__ __launch_bounds__(kBrickThreads, (K > 9 ? 2 : 4)) void brick_gather_k
       process(Yes{}, nrec);
     }
     for (int sd = 0; sd < nbd; ++sd) {
-      const int nrec = min(kGatherBatch, total_d - sd * kGatherBatch);
+      const int nrec = min(GB, total_d - sd * GB);
       stage(No{}, d0, d1, d1, nrec);
       RF_PROF_MARK(1);
       fetch_narrow(min(sd + 1, nbd - 1));
@@ -2611,7 +2637,7 @@ __global__ __launch_bounds__(kBrickThreads, (K > 9 ? 2 : 4)) void brick_gather_k
     // 4 (lane >> 4) + e of the tile, channel 16 nt + (lane & 15)
 #pragma unroll
     for (int tl = 0; tl < 4; ++tl) {
-      const int t = RF_TILE_OF(wave, tl);
+      const int t = (tl * NWV + wave);
       if (t < ntiles) {
         const int pz = t % npz, py = (t / npz) % npy, px = t / (npz * npy);
 #pragma unroll
@@ -2645,7 +2671,7 @@ __global__ __launch_bounds__(kBrickThreads, (K > 9 ? 2 : 4)) void brick_gather_k
     if (any) {
       unsigned long long* mine = images + (long long)part * pairs;
       const unsigned long long* src = reinterpret_cast<const unsigned long long*>(acc);
-      for (int i = tid; i < pairs; i += kBrickThreads) __hip_atomic_store(mine + i, src[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      for (int i = tid; i < pairs; i += TH) __hip_atomic_store(mine + i, src[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       if (tid == 0) __hip_atomic_store(&state[1 + part], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this thread's stores have been performed at device scope
@@ -2658,7 +2684,7 @@ __global__ __launch_bounds__(kBrickThreads, (K > 9 ? 2 : 4)) void brick_gather_k
       if (__hip_atomic_load(&state[1 + j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0) continue;  // (uniform)
       const unsigned long long* other = images + (long long)j * pairs;
       float2* own = reinterpret_cast<float2*>(acc);
-      for (int i = tid; i < pairs; i += kBrickThreads) {
+      for (int i = tid; i < pairs; i += TH) {
         const unsigned long long o = __hip_atomic_load(other + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         float2 v = any ? own[i] : make_float2(0.f, 0.f);
         v.x += __uint_as_float((uint32_t)o);
@@ -2674,7 +2700,7 @@ __global__ __launch_bounds__(kBrickThreads, (K > 9 ? 2 : 4)) void brick_gather_k
 #if defined(RF_BRICK_PROFILE) || defined(RF_BRICK_ABLATE)
   if (!(a.stagger & 0x400000))  // (ablation: the batch phases alone)
 #endif
-  brick_flush<K, ADAM, ONE_ROUND>(g, a, acc, any, X0, Y0, Z0, gdens, gfeat);
+  brick_flush<K, ADAM, ONE_ROUND, TH>(g, a, acc, any, X0, Y0, Z0, gdens, gfeat);
   RF_PROF_MARK(4);  // flush (stores issued, not necessarily retired)
   RF_PROF_END();
 }
@@ -3585,12 +3611,15 @@ int rf_ray_aabb_bounds(const float* origins_dev, const float* directions_dev, in
 
 // short_keys: the (brick, flags) key must fit a positive 16-bit sort key (per-slot key arrays of rf_render_backward_emit);
 // the fused binning only needs the counters to be addressable (2^21 keys = grids up to 512^3 at 8^3 bricks)
+// *shift: log2 of the brick edge; for the 4 x 8 x 8 bricks of RF_BRICK_4X8X8 bit 4 is set as well (brick_key: the x edge is half as long)
 static int brick_geometry(const RFGrid* grid, int brick_size, int* shift, int nb[3], bool short_keys) {
-  if (brick_size != 4 && brick_size != 8) return RF_ERR_UNSUPPORTED;
-  *shift = (brick_size == 4) ? 2 : 3;
+  if (brick_size != 4 && brick_size != 8 && brick_size != RF_BRICK_4X8X8) return RF_ERR_UNSUPPORTED;
+  const bool slab4 = brick_size == RF_BRICK_4X8X8;
+  *shift = (brick_size == 4) ? 2 : (slab4 ? (3 | (1 << 4)) : 3);
   long long total = 1;
   for (int a = 0; a < 3; ++a) {
-    nb[a] = (grid->dims[a] + brick_size - 1) / brick_size;
+    const int edge = slab4 ? (a == 0 ? 4 : 8) : brick_size;
+    nb[a] = (grid->dims[a] + edge - 1) / edge;
     total *= nb[a];
   }
   return (total * 8 - 1 <= (short_keys ? 0x7fffLL : (1LL << 21) - 1)) ? RF_OK : RF_ERR_UNSUPPORTED;
@@ -3869,21 +3898,22 @@ int rf_scatter_records(const RFGrid* grid, const int16_t* keys_dev, const float*
 int32_t rf_expanded_record_floats(int32_t num_features) { return 4 * record_quads(num_features / 3); }
 
 extern "C++" {
-template <int K, bool ADAM, bool ONE_ROUND = false, bool SPLIT = false>
+template <int K, bool ADAM, bool ONE_ROUND = false, bool SPLIT = false, int BX = 8>
 static int launch_gather(const GridArgs& g, const BrickArgs& a, int nbricks, float* gd, float* gf, hipStream_t st) {
   const int B = 1 << a.shift;
-  const size_t lds = (size_t)gather_lds_words(B, 3 * K + 1) * sizeof(float);
+  const size_t lds = (size_t)gather_lds_words(B, 3 * K + 1, BX) * sizeof(float);
   if (lds > 150 * 1024) return RF_ERR_UNSUPPORTED;
   static std::atomic<size_t> configured[64];
   int dev = 0;
   if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return RF_ERR_LAUNCH;
   if (lds > configured[dev].load(std::memory_order_relaxed)) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&brick_gather_kernel<K, ADAM, ONE_ROUND, SPLIT>),
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&brick_gather_kernel<K, ADAM, ONE_ROUND, SPLIT, BX>),
                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
       return RF_ERR_LAUNCH;
     configured[dev].store(lds, std::memory_order_relaxed);
   }
-  hipLaunchKernelGGL((brick_gather_kernel<K, ADAM, ONE_ROUND, SPLIT>), dim3(nbricks * (SPLIT ? a.parts : 1)), dim3(kBrickThreads), lds, st, g, a, gd, gf);
+  hipLaunchKernelGGL((brick_gather_kernel<K, ADAM, ONE_ROUND, SPLIT, BX>), dim3(nbricks * (SPLIT ? a.parts : 1)), dim3(BX == 4 ? kBrickThreads / 2 : kBrickThreads), lds, st, g, a,
+                     gd, gf);
   return launch_status();
 }
 }  // extern "C++"
@@ -3926,6 +3956,8 @@ static int brick_accumulate_impl(const RFGrid* grid, int32_t brick_size, const R
   int shift, nb[3];
   rc = brick_geometry(grid, brick_size, &shift, nb, false);
   if (rc != RF_OK) return rc;
+  const bool slab4 = (shift >> 4) != 0;  // RF_BRICK_4X8X8
+  shift &= 15;
   // lists: the full-width ones first, then the base-channel lists of render_diffuse passes (on a degree-0 grid, or when every list
   // is a render_diffuse list, there is one kind only and the pass runs on the 4 base channels)
   BrickArgs a = {};
@@ -3990,6 +4022,10 @@ static int brick_accumulate_impl(const RFGrid* grid, int32_t brick_size, const R
     }
 #endif
     const bool one_round = a.adam.byte_offsets_fit_32_bits && shift == 3;
+    if (slab4) {  // 4 x 8 x 8 bricks: the 256-thread workgroups of the single-GPU optimizer pass
+      if (!one_round || parts > 1 || (K != 1 && K != 9)) return RF_ERR_UNSUPPORTED;
+      return K == 1 ? launch_gather<1, true, true, false, 4>(g, a, nbricks, nullptr, nullptr, st) : launch_gather<9, true, true, false, 4>(g, a, nbricks, nullptr, nullptr, st);
+    }
     if (parts > 1) {  // several workgroups per brick (rf_brick_accumulate_adam_split)
       if (!one_round) return RF_ERR_UNSUPPORTED;
       if (parts > kMaxListsPerKind || !scratch_dev) return parts > kMaxListsPerKind ? RF_ERR_BAD_SHAPE : RF_ERR_NULL_POINTER;
@@ -4008,6 +4044,7 @@ static int brick_accumulate_impl(const RFGrid* grid, int32_t brick_size, const R
         return one_round ? launch_gather<9, true, true>(g, a, nbricks, nullptr, nullptr, st) : launch_gather<9, true, false>(g, a, nbricks, nullptr, nullptr, st);
     }
   }
+  if (slab4) return RF_ERR_UNSUPPORTED;  // (gradient tensors: cubic bricks)
   switch (K) {
     case 1:
       return shift == 3 ? launch_gather<1, false, true>(g, a, nbricks, grad_densities_dev, grad_features_dev, st)

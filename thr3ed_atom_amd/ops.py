@@ -289,8 +289,15 @@ def render_backward_raw(grid: VoxelGrid, origins: Tensor, directions: Tensor, t_
 NO_BRICK = 0x7FFF
 
 
+BRICK_4X8X8 = 488  # RF_BRICK_4X8X8 of relu_field.h: bricks of 4 x 8 x 8 nodes (the single-GPU optimizer pass)
+
+
+def brick_edges(brick_size: int) -> Tuple[int, int, int]:
+    return (4, 8, 8) if int(brick_size) == BRICK_4X8X8 else (int(brick_size),) * 3
+
+
 def brick_counts(grid: VoxelGrid, brick_size: int) -> Tuple[int, int, int]:
-    return tuple((d + brick_size - 1) // brick_size for d in grid.grid_dims)
+    return tuple((d + e - 1) // e for d, e in zip(grid.grid_dims, brick_edges(brick_size)))
 
 
 def render_backward_emit_raw(grid: VoxelGrid, origins: Tensor, directions: Tensor, t_rand: Optional[Tensor], num_samples: int,

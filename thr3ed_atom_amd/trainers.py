@@ -36,6 +36,7 @@ from . import distributed as rfdist
 from .camera import CameraBounds, CameraIntrinsics, compute_thre3d_grid_sizes, mse2psnr, scale_camera_intrinsics
 from .constants import CAMERA_BOUNDS, CAMERA_INTRINSICS, HEMISPHERICAL_RADIUS
 from .ops import (
+    BRICK_4X8X8,
     brick_accumulate_adam_raw,
     brick_accumulate_raw,
     brick_counts,
@@ -201,8 +202,12 @@ class TrainStepper:
         merge_bricks: Optional[bool] = None,
         fuse_optimizer: Optional[bool] = None,
         exchange: str = "auto",
+        brick_size: Optional[int] = None,
     ):
-        """``ray_selection``: "randperm" draws torch.randperm over all B*H*W pixels exactly like the reference
+        """``brick_size``: 8 or 4 (cubic bricks of the binned backward) or ops.BRICK_4X8X8; None = $RF_BRICK_SIZE, else 4 x 8 x 8 for the
+        single-process step with Adam in the brick flush and 8 otherwise.
+
+        ``ray_selection``: "randperm" draws torch.randperm over all B*H*W pixels exactly like the reference
         (utils/misc.py:123) and keeps the first ``ray_batch_size``; "keyed" draws the same kind of sample
         (distinct, uniformly random pixels) with one fused kernel (rf_select_rays_and_pixels) keyed from torch's
         CPU generator -- no 5-million-key sort per iteration."""
@@ -230,7 +235,8 @@ class TrainStepper:
         # contiguous slice of it, so that N ranks reproduce the single-GPU iteration up to float summation order.
         # Default (False) = weak scaling: every rank draws its own ``ray_batch_size`` rays.
         self.global_batch = bool(global_batch)
-        self.brick_size = int(os.environ.get("RF_BRICK_SIZE", "8"))  # (experiments: 4)
+        brick_size_given = brick_size is not None or "RF_BRICK_SIZE" in os.environ
+        self.brick_size = int(brick_size) if brick_size is not None else int(os.environ.get("RF_BRICK_SIZE", "8"))
         self._bins = None
         self._exec = None
         self.step_events = None  # an ops.StepEvents: the next rf_train_step call records its per-launch HIP events there
@@ -297,6 +303,11 @@ class TrainStepper:
         self.fuse_optimizer = can_fuse if fuse_optimizer is None else bool(fuse_optimizer)
         if self.fuse_optimizer and not can_fuse:
             raise ValueError("fuse_optimizer needs a merged brick pass on a single process, split or bricked storage, SH degree 0 or 2 and fewer than 2^31 elements per grid tensor")
+        # one process, Adam in the flush: bricks of 4 x 8 x 8 nodes -- four 256-thread workgroups per CU sum them instead of two
+        # 512-thread ones (RF_BRICK_4X8X8; the flush needs its 32-bit byte offsets: every grid tensor below 2^30 elements)
+        if (not brick_size_given and single and self.fuse_optimizer and self.exchange != "owner" and grid.num_features in (3, 27)
+                and padded_nodes <= (1 << 24) and padded_nodes * max(4, grid.num_features - 3) < (1 << 30)):
+            self.brick_size = BRICK_4X8X8
 
     def select(self, dataset: PosedImagesInMemory, image_ids: Tensor):
         """Synchronous random subset of rays and pixels of the given images

@@ -60,7 +60,11 @@ lib.rf_debug_brick_profile(out, 0)
 brick_ms = sum(e.elapsed_ms()["brick_accumulate"] for e in events) / steps
 print(f"brick pass of this instrumented build: {brick_ms:.4f} ms per launch ($RF_BRICK_STAGGER = {os.environ.get('RF_BRICK_STAGGER', '0')})")
 names = ["range set-up", "batch: wait for loads + LDS stores + barrier", "batch: barriers after record pass / tiles", "batch: lists + tiles (MFMA), wave 0", "flush / optimizer", "accumulator image", "batch: issue of the next loads", "batch: record pass, wave 0"]
-nb = 4096 * steps
+from thr3ed_atom_amd.ops import brick_counts  # noqa: E402
+
+_nb = brick_counts(grid, stepper.brick_size)
+nb = _nb[0] * _nb[1] * _nb[2] * steps
+print('bricks per launch', nb // steps, 'brick_size', stepper.brick_size)
 tot = sum(out[i] for i in range(len(names)))
 for i, nm in enumerate(names):
     print(f"{nm:34s} {out[i] / nb:10.0f} ticks per brick   {100.0 * out[i] / max(tot, 1):5.1f} %")

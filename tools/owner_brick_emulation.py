@@ -17,7 +17,7 @@ pose_mat = torch.stack([torch.cat([p.rotation, p.translation], dim=1) for p in p
 data = PosedImagesInMemory(images, pose_mat, intr, bounds)
 grid = bench.make_grid(dev, 128, 2, seed=42, storage="split")
 model = rf.VolumetricModel(grid, rf.render_sh_voxel_grid, rf.SHVoxGridRenderConfig(256, bounds, perturb_sampled_points=True, white_bkgd=True), device=dev)
-st = TrainStepper(model, 16384, 0.03)
+st = TrainStepper(model, 16384, 0.03, brick_size=8)  # (owners sum 8^3 bricks)
 batches = data.image_batches(8)
 for _ in range(12): st.step(data, next(batches))
 torch.cuda.synchronize()
