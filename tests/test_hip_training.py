@@ -1088,6 +1088,56 @@ def test_paired_launches_equal_one_launch_per_render(hip_device):
     np.testing.assert_allclose(outs[0]["sums"], outs[1]["sums"], rtol=1e-6)
 
 
+@pytest.mark.parametrize("dims,deg,storage", [((40, 40, 40), 2, "split"), ((38, 41, 43), 2, "split"), ((21, 30, 26), 0, "split"), ((42, 24, 40), 2, "bricked")])
+def test_bricks_of_4x8x8_nodes_equal_cubic_bricks(hip_device, dims, deg, storage):
+    """RF_BRICK_4X8X8 (the default of the single-process fused step: 256-thread workgroups on bricks of 4 x 8 x 8 nodes, twice the
+    keys) against brick_size 8 -- same rays, same jitter keys: the record lists hold the same records (per-key order aside), and
+    parameters and both Adam moments agree to float32 summation order after three iterations; grids whose x extent is no multiple of
+    4 (partial bricks), SH degree 0 (one list kind) and the bricked node order included.  Also the lists summed into gradient
+    TENSORS (rf_brick_accumulate, the deferred bucket's materialize()) for both brick shapes."""
+    X, Y, Z = dims
+    F = 3 * (deg + 1) ** 2
+    S, n = 64, 2048
+    cam = hotdog_like_camera()
+    cfg = rf.SHVoxGridRenderConfig(S, rf.CameraBounds(cam["near"], cam["far"]), perturb_sampled_points=True, white_bkgd=True)
+    rays = rf.flatten_rays(rf.cast_rays(rf.CameraIntrinsics(48, 48, 66.0), rf.pose_spherical(20.0, -30.0, cam["radius"]), hip_device))[:n]
+    pixels = T(hash_uniform((n, 3), 33, 0.0, 1.0)).to(hip_device)
+    results, lists_of = [], []
+    for brick_size in (8, ops.BRICK_4X8X8):
+        grid = rf.VoxelGrid(T(hash_uniform((X, Y, Z, 1), 31)).to(hip_device), T(hash_uniform((X, Y, Z, F), 32)).to(hip_device), rf.VoxelSize(3.0 / X, 3.0 / Y, 3.0 / Z),
+                            density_preactivation=torch.nn.Identity(), density_postactivation=torch.nn.ReLU(), expected_density_scale=100.0 / 3.0,
+                            tunable=True, storage=storage)
+        model = rf.VolumetricModel(grid, rf.render_sh_voxel_grid, cfg, device=hip_device)
+        st = TrainStepper(model, n, learning_rate=0.03, fused=True, backward="binned", data_parallel=False, brick_size=brick_size)
+        assert st.fuse_optimizer and st.brick_size == brick_size
+        torch.manual_seed(5)  # (the jitter keys of the renders come from torch's CPU generator)
+        for _ in range(3):
+            st.step_on(rays, pixels)
+        torch.cuda.synchronize()
+        t = st._exec["tensors"]
+        nrec = [int(t["offsets2"][k][-1]) for k in range(2)]
+        assert nrec[0] > 1000 and nrec[1] > 1000
+        lists_of.append((grid, brick_size, [(t["pass0"]["sorted"], t["offsets2"][0], False), (t["pass1"]["sorted"], t["offsets2"][1], True)], nrec))
+        results.append((st.flat.flat_param.clone(), st.optimizer.exp_avg.clone(), st.optimizer.exp_avg_sq.clone()))
+    assert lists_of[0][3] == lists_of[1][3]  # the same samples emit records
+    for a, b in zip(results[0], results[1]):
+        scale = float(a.abs().max())
+        assert float((a - b).abs().max()) <= 5e-6 * max(scale, 1e-30) + (2e-5 if a is results[0][0] else 0.0), (float((a - b).abs().max()), scale)
+    # the lists of the last iteration as gradient tensors: 4 x 8 x 8 bricks == cubic bricks (each on its own grid's lists)
+    grads = []
+    for grid, brick_size, lists, _ in lists_of:
+        first, second = grid.kernel_tensors()
+        gd, gf = torch.full_like(first, 7.0), (None if second is None else torch.full_like(second, 7.0))
+        ops.brick_accumulate_raw(grid, brick_size, lists, gd, gf, accumulate=False)
+        torch.cuda.synchronize()
+        grads.append((gd, gf))
+    for a, b in zip(grads[0], grads[1]):
+        if a is None:
+            continue
+        scale = float(a.abs().max())
+        assert scale > 0 and float((a - b).abs().max()) <= 2e-5 * scale, (float((a - b).abs().max()), scale)
+
+
 @pytest.mark.parametrize("copies,parts", [(2, 2), (5, 3), (8, 2), (8, 8), (3, 4)])
 def test_split_brick_pass_equals_the_plain_owner_pass(hip_device, copies, parts):
     """rf_brick_accumulate_adam_split (several workgroups per owned brick: the source ranks' lists dealt out, partial accumulator

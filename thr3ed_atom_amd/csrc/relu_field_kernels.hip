@@ -1958,7 +1958,7 @@ __device__ __forceinline__ void brick_range_entry(const BrickArgs& a, const long
 // The last phase of a brick workgroup: the sums of the B^3 owned nodes (LDS accumulators `acc`, node (x, y, z) channel c at
 // x * SX + y * SY + z * CS + c; all zero when `any` is false) go out with plain stores -- or, ADAM, are consumed by the
 // optimizer step on the spot.
-template <int K, bool ADAM, bool ONE_ROUND, int TH = kBrickThreads>
+template <int K, bool ADAM, bool ONE_ROUND, int TH = kBrickThreads, int BX = 8>
 __device__ __forceinline__ void brick_flush(const GridArgs& g, const BrickArgs& a, const float* acc, bool any, int X0, int Y0, int Z0,
                                             float* gdens, float* gfeat) {
   constexpr int C = 3 * K + 1;
@@ -1972,7 +1972,7 @@ __device__ __forceinline__ void brick_flush(const GridArgs& g, const BrickArgs& 
     // split layout, whole float4s: base [X,Y,Z,4] = channels 0..3 of a node, rest [X,Y,Z,C-4] = channels 4..C-1
     constexpr int QN = C / 4;  // float4s per node
     constexpr int QR = QN > 1 ? QN - 1 : 1;
-    const int nq = B * B * B * QN;
+    const int nq = (BX == 4 ? 4 : B) * B * B * QN;  // (BX = 4: bricks of 4 x 8 x 8 nodes -- four x columns)
     // i -> (column (x, y), quad group, z, quad) with the quads of one tensor contiguous along z
     auto quad_of = [&](int i, int& fx, int& fy, int& fz, int& qd) -> bool {
       const int col = (i >> a.shift) / QN, r = i - col * (B * QN);  // (division by a constant)
@@ -2170,7 +2170,7 @@ __device__ __forceinline__ void brick_flush(const GridArgs& g, const BrickArgs& 
     const int run = B * nch;  // floats of one z column in this tensor
     float* out = pass == 0 ? gdens : gfeat;
     const long long ostride = pass == 0 ? g.dstride : g.fstride;
-    for (int i = tid; i < B * B * run; i += TH) {
+    for (int i = tid; i < (BX == 4 ? 4 : B) * B * run; i += TH) {
       const int col = i / run, r = i - col * run;
       const int fz = r / nch, c2 = r - fz * nch;
       const int fx = col >> a.shift, fy = col & (B - 1);
@@ -2275,7 +2275,7 @@ __host__ __device__ inline int gather_lds_words(int B, int C, int BX = 8) {
 // many of them; the price is one more brick face across x (a record is read 1.58 x instead of 1.42 x) and twice the keys.
 template <int K, bool ADAM, bool ONE_ROUND = false, bool SPLIT = false, int BX = 8>
 __global__ __launch_bounds__(BX == 4 ? kBrickThreads / 2 : kBrickThreads, (K > 9 ? 2 : 4)) void brick_gather_kernel(GridArgs g, BrickArgs a, float* gdens, float* gfeat) {
-  static_assert(BX == 8 || (BX == 4 && ADAM && ONE_ROUND && !SPLIT), "4 x 8 x 8 bricks: the one-round optimizer flush only");
+  static_assert(BX == 8 || (BX == 4 && ONE_ROUND && !SPLIT), "4 x 8 x 8 bricks: 8-node y and z edges, one workgroup per brick");
   constexpr int TH = BX == 4 ? kBrickThreads / 2 : kBrickThreads;  // threads of the workgroup
   constexpr int NWV = TH / 64;                                     // its waves: four tiles each
   constexpr int GB = TH / 2;                                       // records per batch (two threads per record)
@@ -2700,7 +2700,7 @@ __global__ __launch_bounds__(BX == 4 ? kBrickThreads / 2 : kBrickThreads, (K > 9
 #if defined(RF_BRICK_PROFILE) || defined(RF_BRICK_ABLATE)
   if (!(a.stagger & 0x400000))  // (ablation: the batch phases alone)
 #endif
-  brick_flush<K, ADAM, ONE_ROUND, TH>(g, a, acc, any, X0, Y0, Z0, gdens, gfeat);
+  brick_flush<K, ADAM, ONE_ROUND, TH, BX>(g, a, acc, any, X0, Y0, Z0, gdens, gfeat);
   RF_PROF_MARK(4);  // flush (stores issued, not necessarily retired)
   RF_PROF_END();
 }
@@ -4044,7 +4044,11 @@ static int brick_accumulate_impl(const RFGrid* grid, int32_t brick_size, const R
         return one_round ? launch_gather<9, true, true>(g, a, nbricks, nullptr, nullptr, st) : launch_gather<9, true, false>(g, a, nbricks, nullptr, nullptr, st);
     }
   }
-  if (slab4) return RF_ERR_UNSUPPORTED;  // (gradient tensors: cubic bricks)
+  if (slab4) {  // 4 x 8 x 8 bricks into gradient tensors: SH degree 0 / 2 (the lists of a deferred gradient bucket, summed on demand)
+    if (K != 1 && K != 9) return RF_ERR_UNSUPPORTED;
+    return K == 1 ? launch_gather<1, false, true, false, 4>(g, a, nbricks, grad_densities_dev, grad_features_dev, st)
+                  : launch_gather<9, false, true, false, 4>(g, a, nbricks, grad_densities_dev, grad_features_dev, st);
+  }
   switch (K) {
     case 1:
       return shift == 3 ? launch_gather<1, false, true>(g, a, nbricks, grad_densities_dev, grad_features_dev, st)

@@ -470,8 +470,14 @@ AUTOGRAD_BINNED_MAX_BYTES = 1 << 30
 AUTOGRAD_BRICK_SIZE = 8
 
 
+def _autograd_brick_size(grid) -> int:
+    """Bricks of the binned adjoint's record lists: the deferred bucket's choice (optim.FlatGrid.brick_size) when it consumes them."""
+    bucket = getattr(grid, "_grad_bucket", None)
+    return int(getattr(bucket, "brick_size", AUTOGRAD_BRICK_SIZE)) if getattr(bucket, "deferred", False) else AUTOGRAD_BRICK_SIZE
+
+
 def _autograd_uses_bricks(grid, flags: int, n: int, num_samples: int) -> bool:
-    nb = brick_counts(grid, AUTOGRAD_BRICK_SIZE)
+    nb = brick_counts(grid, _autograd_brick_size(grid))
     deferred = getattr(getattr(grid, "_grad_bucket", None), "deferred", False)
     if nb[0] * nb[1] * nb[2] * 8 > (1 << 21):
         if deferred:
@@ -525,14 +531,15 @@ class _ReluFieldRender(torch.autograd.Function):
             if tuple(t_rand.shape) != (n, num_samples):
                 raise ValueError(f"t_rand must be [{n}, {num_samples}], got {tuple(t_rand.shape)}")
         key_hist = None
+        brick_size = _autograd_brick_size(grid)
         if need_grad and _autograd_uses_bricks(grid, int(flags), n, int(num_samples)):
-            nb = brick_counts(grid, AUTOGRAD_BRICK_SIZE)
+            nb = brick_counts(grid, brick_size)
             key_hist = _take_hist(origins.device, nb[0] * nb[1] * nb[2] * 8)
         colour, depth, acc, disparity, caches = render_forward_raw(
             grid, origins, directions, keyed if keyed is not None else t_rand, int(num_samples), float(near), float(far), int(flags), bool(need_grad),
-            key_hist=key_hist, brick_size=AUTOGRAD_BRICK_SIZE,
+            key_hist=key_hist, brick_size=brick_size,
         )
-        ctx.grid, ctx.flags, ctx.keyed, ctx.key_hist = grid, int(flags), keyed, key_hist
+        ctx.grid, ctx.flags, ctx.keyed, ctx.key_hist, ctx.brick_size = grid, int(flags), keyed, key_hist, brick_size
         ctx.num_samples, ctx.near, ctx.far = int(num_samples), float(near), float(far)
         ctx.has_rand = t_rand is not None
         ctx.has_second = second is not None
@@ -590,12 +597,14 @@ class _ReluFieldRender(torch.autograd.Function):
             bin_offsets(hist, offsets, cursor)
             render_backward_emit_direct_raw(
                 grid, origins, directions, t_rand, ctx.num_samples, ctx.near, ctx.far, ctx.flags, (cache, tcache, stop, cmask),
-                prep(g_colour), prep(g_depth), prep(g_acc), AUTOGRAD_BRICK_SIZE, cursor, records, hist_clear=hist,
+                prep(g_colour), prep(g_depth), prep(g_acc), ctx.brick_size, cursor, records, hist_clear=hist,
             )
             _return_hist(hist)  # (zero again once the emit launch above has run: every later user is behind it on the stream)
-            if bucket is not None and getattr(bucket, "deferred", False) and bucket.matches(first, second):
+            if bucket is not None and getattr(bucket, "deferred", False) and bucket.matches(first, second) and ctx.brick_size == bucket.brick_size:
                 # deferred gradients: the sorted list IS the gradient of this render; the optimizer sums all lists of the iteration
                 bucket.pending.append((records, offsets, diffuse))
+            elif ctx.brick_size != AUTOGRAD_BRICK_SIZE:
+                raise RuntimeError("the grid's deferred gradient bucket was replaced between forward and backward")
             else:
                 brick_accumulate_raw(grid, AUTOGRAD_BRICK_SIZE, [(records, offsets, diffuse)], gd, gf, accumulate=not overwrite)
             ctx.key_hist = None  # (a second backward through the same graph would find the counters consumed)

@@ -16,6 +16,8 @@ checkpoints are unchanged.
 """
 from typing import Optional, Tuple
 
+import os
+
 import torch
 from torch import Tensor
 
@@ -63,6 +65,12 @@ class FlatGrid:
         self.deferred = (bool(deferred) and grid.storage == "reference" and (grid.num_features + 1) % 4 == 0 and voxels.SPLIT_SHADOW
                          and not rfdist._collectives_on() and fits)
         self.pending = []  # [(records, offsets, render_diffuse)] of the backward passes since the last zero_grad / step
+        # bricks of the record lists: 4 x 8 x 8 nodes (ops.BRICK_4X8X8: four 256-thread workgroups per CU in the optimizer's brick pass)
+        # where its one-round flush applies -- SH degree 0 or 2, every shadow tensor below 2^30 elements --, else 8^3
+        from .ops import AUTOGRAD_BRICK_SIZE, BRICK_4X8X8
+
+        small = padded_nodes <= (1 << 24) and padded_nodes * max(4, grid.num_features - 3) < (1 << 30) and bricks * 2 * 8 <= (1 << 21)
+        self.brick_size = BRICK_4X8X8 if (self.deferred and grid.num_features in (3, 27) and small and "RF_BRICK_SIZE" not in os.environ) else AUTOGRAD_BRICK_SIZE
 
     # ---- protocol used by ops._ReluFieldRender.backward -------------------------------------
     def matches(self, first: Tensor, second: Optional[Tensor]) -> bool:
@@ -88,13 +96,13 @@ class FlatGrid:
     def materialize(self) -> Tensor:
         """deferred mode: sum the pending record lists into ``flat_grad`` (reference layout; overwrites it) -- for inspection, the
         optimizer does not need it."""
-        from .ops import AUTOGRAD_BRICK_SIZE, brick_accumulate_raw
+        from .ops import brick_accumulate_raw
 
         if self.deferred and self.pending:
             lists = sorted(self.pending, key=lambda l: bool(l[2]))  # full-width lists first
             if all(l[2] for l in lists) and self.grid.num_features != 3:
                 self.flat_grad.zero_()  # (render_diffuse lists only cover the base channels)
-            brick_accumulate_raw(self.grid, AUTOGRAD_BRICK_SIZE, lists, self._gd, self._gf, accumulate=False)
+            brick_accumulate_raw(self.grid, self.brick_size, lists, self._gd, self._gf, accumulate=False)
         return self.flat_grad
 
     def zero_grad(self) -> None:
@@ -156,7 +164,7 @@ class FusedAdam:
 
     def _deferred_step(self) -> None:
         """All record lists of the iteration -> ONE merged brick pass with Adam in its flush on the split shadow -> Parameters."""
-        from .ops import AUTOGRAD_BRICK_SIZE, brick_accumulate_adam_raw
+        from .ops import brick_accumulate_adam_raw
 
         flat, grid = self.flat, self.flat.grid
         if not flat.pending:
@@ -170,7 +178,7 @@ class FusedAdam:
             z = lambda t: None if t is None else torch.zeros_like(t)
             self._split_moments = ((z(sh["base"]), z(sh["rest"])), (z(sh["base"]), z(sh["rest"])))
         m, v = self._split_moments
-        brick_accumulate_adam_raw(grid, AUTOGRAD_BRICK_SIZE, lists, m, v, self.lr, self.betas[0], self.betas[1], self.eps, self.step_count,
+        brick_accumulate_adam_raw(grid, flat.brick_size, lists, m, v, self.lr, self.betas[0], self.betas[1], self.eps, self.step_count,
                                   rf_grid=rf_grid, params=(sh["base"], sh["rest"]))
         grid.adopt_shadow()
         flat.pending = []
