@@ -1138,6 +1138,38 @@ def test_bricks_of_4x8x8_nodes_equal_cubic_bricks(hip_device, dims, deg, storage
         assert scale > 0 and float((a - b).abs().max()) <= 2e-5 * scale, (float((a - b).abs().max()), scale)
 
 
+def test_bricks_of_4x8x8_nodes_at_256_cubed(hip_device):
+    """The largest grid the 4 x 8 x 8 brick pass takes (2^24 nodes: the one-round flush's 24-bit node indices, 524288 keys): two
+    iterations against cubic bricks, parameters and moments to float32 summation order."""
+    G, F, S, n = 256, 27, 128, 4096
+    cam = hotdog_like_camera()
+    cfg = rf.SHVoxGridRenderConfig(S, rf.CameraBounds(cam["near"], cam["far"]), perturb_sampled_points=True, white_bkgd=True)
+    rays = rf.flatten_rays(rf.cast_rays(rf.CameraIntrinsics(64, 64, 88.0), rf.pose_spherical(20.0, -30.0, cam["radius"]), hip_device))[:n]
+    pixels = T(hash_uniform((n, 3), 33, 0.0, 1.0)).to(hip_device)
+    gen = torch.Generator(device=hip_device).manual_seed(11)
+    dens0 = torch.rand((G, G, G, 1), generator=gen, device=hip_device) * 2.0 - 1.0
+    feat0 = torch.rand((G, G, G, F), generator=gen, device=hip_device) * 2.0 - 1.0
+    results = []
+    for brick_size in (8, ops.BRICK_4X8X8):
+        grid = rf.VoxelGrid(dens0.clone(), feat0.clone(), rf.VoxelSize(3.0 / G, 3.0 / G, 3.0 / G), density_preactivation=torch.nn.Identity(),
+                            density_postactivation=torch.nn.ReLU(), expected_density_scale=100.0 / 3.0, tunable=True, storage="split")
+        model = rf.VolumetricModel(grid, rf.render_sh_voxel_grid, cfg, device=hip_device)
+        st = TrainStepper(model, n, learning_rate=0.03, fused=True, backward="binned", data_parallel=False, brick_size=brick_size)
+        assert st.fuse_optimizer
+        torch.manual_seed(5)
+        for _ in range(2):
+            st.step_on(rays, pixels)
+        torch.cuda.synchronize()
+        results.append((st.flat.flat_param.clone(), st.optimizer.exp_avg.clone(), st.optimizer.exp_avg_sq.clone()))
+        st.flat.detach()
+        del st, model, grid
+        torch.cuda.empty_cache()
+    for k, (a, b) in enumerate(zip(results[0], results[1])):
+        scale = float(a.abs().max())
+        assert float((a - b).abs().max()) <= 5e-6 * scale + (2e-5 if k == 0 else 0.0), (k, float((a - b).abs().max()), scale)
+    assert float(results[0][1].abs().max()) > 0  # (gradients arrived)
+
+
 @pytest.mark.parametrize("copies,parts", [(2, 2), (5, 3), (8, 2), (8, 8), (3, 4)])
 def test_split_brick_pass_equals_the_plain_owner_pass(hip_device, copies, parts):
     """rf_brick_accumulate_adam_split (several workgroups per owned brick: the source ranks' lists dealt out, partial accumulator
