@@ -665,8 +665,11 @@ def main():
             "frac_processed": d["frac_processed"],
             "algorithmic_bytes_processed": d["algorithmic_bytes_processed"],
             "units_processed": {"records_specular": rec_spec, "records_diffuse": rec_diff, "in_aabb_samples": n_in, "nominal_samples": R * S, "parameters": nparam},
-            "note": "brick pass: both renders' gradient records summed per 8^3-node brick in MFMA accumulators (no atomics)"
-            + (", Adam applied in the flush (no gradient tensor in HBM)" if fused_opt else "") + "; two workgroups per CU (LDS), phases of a workgroup serialise: see DESIGN section 4",
+            "note": "brick pass: both renders' gradient records summed per brick ("
+            + ("4 x 8 x 8 nodes, four 256-thread workgroups per CU" if getattr(stepper, "brick_size", 8) == rf.ops.BRICK_4X8X8 else "8^3 nodes, two 512-thread workgroups per CU")
+            + ") in MFMA accumulators (no atomics)" + (", Adam applied in the flush (no gradient tensor in HBM)" if fused_opt else "")
+            + "; bound by the latencies of a workgroup's serial phases: see DESIGN section 4",
+            "brick_size": int(getattr(stepper, "brick_size", 8)),
             "traffic_source": pmc.get("_source"),
             "traffic_stale": bool(pmc_stale),
             "by_kernel": by_kernel,
