@@ -1138,6 +1138,41 @@ def test_bricks_of_4x8x8_nodes_equal_cubic_bricks(hip_device, dims, deg, storage
         assert scale > 0 and float((a - b).abs().max()) <= 2e-5 * scale, (float((a - b).abs().max()), scale)
 
 
+def test_auto_backward_policy(hip_device, monkeypatch):
+    """backward="auto" (the default): the atomic adjoint on the first grids of a progressive schedule -- fewer than 256 bricks of 8^3
+    nodes: a handful of brick workgroups would sum the whole batch's records --, the binned one with the optimizer in the brick flush
+    from there on; and the two agree on a grid at the boundary after a few iterations (losses to rounding, parameters to Adam's
+    tolerance)."""
+    monkeypatch.delenv("RF_AUTO_BINNED_MIN_BRICKS", raising=False)
+    cam = hotdog_like_camera()
+    S, n, F = 48, 2048, 27
+    cfg = rf.SHVoxGridRenderConfig(S, rf.CameraBounds(cam["near"], cam["far"]), perturb_sampled_points=True, white_bkgd=True)
+    rays = rf.flatten_rays(rf.cast_rays(rf.CameraIntrinsics(48, 48, 66.0), rf.pose_spherical(20.0, -30.0, cam["radius"]), hip_device))[:n]
+    pixels = T(hash_uniform((n, 3), 33, 0.0, 1.0)).to(hip_device)
+    picked, results = {}, {}
+    for G in (16, 48, 56):
+        for backward in ("auto", "binned", "atomic"):
+            if backward != "auto" and G != 48:
+                continue
+            grid = relu_grid(hip_device, T(hash_uniform((G, G, G, 1), 31)), T(hash_uniform((G, G, G, F), 32)), G, storage="split")
+            model = rf.VolumetricModel(grid, rf.render_sh_voxel_grid, cfg, device=hip_device)
+            st = TrainStepper(model, n, learning_rate=0.03, data_parallel=False, backward=backward)
+            if backward == "auto":
+                picked[G] = (st.backward, st.fuse_optimizer)
+            if G == 48:
+                torch.manual_seed(9)
+                losses = []
+                for _ in range(3):
+                    s_ = st.step_on(rays, pixels)
+                    losses.append((s_.specular_loss.item(), s_.diffuse_loss.item()))
+                results[backward] = (losses, st.flat.flat_param.clone())
+    assert picked[16] == ("atomic", False) and picked[48] == ("atomic", False) and picked[56] == ("binned", True)  # 8 / 216 / 343 bricks
+    np.testing.assert_allclose(np.array(results["binned"][0]), np.array(results["atomic"][0]), rtol=2e-5)
+    np.testing.assert_allclose(np.array(results["auto"][0]), np.array(results["atomic"][0]), rtol=2e-5)
+    err = (results["binned"][1] - results["atomic"][1]).abs()
+    assert float((err <= 2e-5).float().mean()) >= 0.999 and float(err.max()) <= 0.03 * 2 * 3 + 1e-6
+
+
 def test_bricks_of_4x8x8_nodes_at_256_cubed(hip_device):
     """The largest grid the 4 x 8 x 8 brick pass takes (2^24 nodes: the one-round flush's 24-bit node indices, 524288 keys): two
     iterations against cubic bricks, parameters and moments to float32 summation order."""

@@ -61,7 +61,10 @@ class FlatGrid:
         for dim in grid.grid_dims:
             padded_nodes *= (dim + 7) // 8 * 8
             bricks *= (dim + 7) // 8
-        fits = padded_nodes * max(4, grid.num_features - 3) < (1 << 31) and bricks <= (1 << 18) and voxels.shadow_allowed(grid)
+        # (and, like TrainStepper(backward="auto"), fewer than 256 bricks keep the atomic adjoint: a handful of brick workgroups would sum
+        # the whole batch's records -- $RF_AUTO_BINNED_MIN_BRICKS, 0 in the tests)
+        fits = (padded_nodes * max(4, grid.num_features - 3) < (1 << 31) and int(os.environ.get("RF_AUTO_BINNED_MIN_BRICKS", "256")) <= bricks <= (1 << 18)
+                and voxels.shadow_allowed(grid))
         self.deferred = (bool(deferred) and grid.storage == "reference" and (grid.num_features + 1) % 4 == 0 and voxels.SPLIT_SHADOW
                          and not rfdist._collectives_on() and fits)
         self.pending = []  # [(records, offsets, render_diffuse)] of the backward passes since the last zero_grad / step

@@ -255,8 +255,14 @@ class TrainStepper:
         self.flat = FlatGrid(grid, deferred=not self.fused and not (self.data_parallel and rfdist._collectives_on()))
         self.optimizer = FusedAdam(self.flat, lr=learning_rate, betas=(0.9, 0.999))
         if backward == "auto":
-            nb = brick_counts(grid, self.brick_size)
-            backward = "binned" if (self.fused and grid.sh_degree >= 2 and nb[0] * nb[1] * nb[2] * 8 <= (1 << 21)) else "atomic"
+            # binned from 256 bricks of 8^3 nodes on: the brick pass has one workgroup per brick, and on the first grids of a progressive
+            # schedule a handful of workgroups would sum two million records (16^3: 2.26 ms per iteration against 0.79 ms with the atomic
+            # adjoint, whose targets then sit in L2; 32^3: 1.13 / 0.49; 64^3: 0.37 / 0.44; 128^3: 0.50 / 1.33 -- tools/small_grid_steps.py)
+            # ($RF_AUTO_BINNED_MIN_BRICKS: the tests run the binned machinery on small grids -- tests/conftest.py sets 0)
+            nb = brick_counts(grid, 8)
+            bricks = nb[0] * nb[1] * nb[2]
+            min_bricks = int(os.environ.get("RF_AUTO_BINNED_MIN_BRICKS", "256"))
+            backward = "binned" if (self.fused and grid.sh_degree >= 2 and min_bricks <= bricks and bricks * 16 <= (1 << 21)) else "atomic"
         self.backward = backward
         # merge_bricks (binned, non-deterministic steps with the diffuse regulariser): BOTH renders emit their records first and
         # ONE brick pass sums them (the 4-channel diffuse records in the first channel columns of the same accumulators), so
