@@ -43,6 +43,162 @@ def host_cpu_quota() -> int:
     return n
 
 
+# =====================================================================================================================================
+# Multi-GPU runs are supervised.  Launched as one rank of N > 1 (torch.distributed.run's environment), this process does not join the
+# process group itself: it becomes the SUPERVISOR of its rank and runs the benchmark in a child process, so that a configuration that
+# hangs (a collective one rank never enters, an ordering bug of in-flight all-gathers) or dies still ends in a labelled JSON line:
+#
+#   attempt 0   what the command asks for (default: the owner-computes exchange, pipelined in interleaved halves, parameter all-gathers
+#               in flight across the iteration boundary, several workgroups per owned brick, ProcessGroup entry points without wrappers)
+#   attempt 1   owner-computes, conservative: one contiguous ownership range per rank, every all-gather waited for at the end of its
+#               iteration, torch.distributed's public collectives only, one workgroup per brick
+#   attempt 2   --exchange dense: reduce-scatter -> sharded Adam -> all-gather of the flat bucket (public collectives only)
+#
+# Every attempt VALIDATES itself before anything is timed (the first iterations compare the replicas' parameter checksums) under a
+# watchdog: once all ranks are ready, the validation has RF_BENCH_VALIDATE_TIMEOUT_S (30) seconds; the timed region and the final
+# replica check RF_BENCH_RUN_TIMEOUT_S (300).  A rank whose child dies, fails its validation or runs out of time says so in a marker
+# file of the run's directory (shared by the N supervisors of the node); every supervisor then kills its child and all move on to the
+# next attempt together, on a rendezvous port of its own.  The line printed by the attempt that completes carries
+# ``distributed.exchange_fallback_reason`` = why the earlier ones were abandoned.  (The reference has no multi-GPU code to mirror:
+# the step being wrapped is one device's loss.backward(); optimizer.step(), modules/trainers.py:338-341.)
+# =====================================================================================================================================
+EXIT_FALLBACK = 75  # a worker's "this configuration failed its validation on some rank; all ranks agreed; try the next one"
+
+ATTEMPTS = [
+    ("as asked", {}, []),
+    ("owner-computes, conservative (contiguous ownership, no all-gather left in flight, public collectives, one workgroup per brick)",
+     {"RF_OWNER_HALVES": "1", "RF_OWNER_OVERLAP_PARAMETERS": "0", "RF_DIST_FAST": "0", "RF_OWNER_BRICK_PARTS": "1"}, []),
+    ("dense exchange (reduce-scatter -> sharded Adam -> all-gather)", {"RF_DIST_FAST": "0"}, ["--exchange", "dense"]),
+]
+
+
+def _mark(name: str, text: str = "") -> None:
+    """worker side: leave a marker of this rank's progress in the run directory (no-op without a supervisor)"""
+    d = os.environ.get("RF_BENCH_RUN_DIR")
+    if d and os.environ.get("RF_BENCH_WORKER"):
+        path = os.path.join(d, f"a{os.environ.get('RF_BENCH_ATTEMPT', '0')}.r{os.environ.get('RANK', '0')}.{name}")
+        with open(path + ".tmp", "w") as fh:
+            fh.write(text)
+        os.replace(path + ".tmp", path)
+
+
+def supervise(argv) -> int:
+    import glob
+    import signal
+    import socket
+    import subprocess
+
+    rank, world = int(os.environ.get("RANK", "0")), int(os.environ["WORLD_SIZE"])
+    run_dir = os.environ.get("RF_BENCH_RUN_DIR") or f"/tmp/rf_bench_{os.environ.get('MASTER_PORT', '0')}_{os.getppid()}"
+    os.makedirs(run_dir, exist_ok=True)
+    validate_s = float(os.environ.get("RF_BENCH_VALIDATE_TIMEOUT_S", "30"))
+    ready_s = float(os.environ.get("RF_BENCH_READY_TIMEOUT_S", "600"))
+    run_s = float(os.environ.get("RF_BENCH_RUN_TIMEOUT_S", "300"))
+    attempts = list(range(len(ATTEMPTS)))
+    if "--exchange" in argv and argv[argv.index("--exchange") + 1] == "dense":
+        attempts = [2]
+    reasons = []
+
+    def say(msg):
+        print(f"[bench supervisor, rank {rank}] {msg}", file=sys.stderr, flush=True)
+
+    def files(k, kind):
+        return sorted(glob.glob(os.path.join(run_dir, f"a{k}.r*.{kind}")))
+
+    def write(k, kind, text):
+        path = os.path.join(run_dir, f"a{k}.r{rank}.{kind}")
+        with open(path + ".tmp", "w") as fh:
+            fh.write(text)
+        os.replace(path + ".tmp", path)
+
+    for pos, k in enumerate(attempts):
+        label, env_add, arg_add = ATTEMPTS[k]
+        last = pos == len(attempts) - 1
+        # a rendezvous of its own per attempt: rank 0's supervisor picks a free port, the others read it
+        port_file = os.path.join(run_dir, f"a{k}.port")
+        if rank == 0:
+            with socket.socket() as sk:
+                sk.bind(("127.0.0.1", 0))
+                port = sk.getsockname()[1]
+            with open(port_file + ".tmp", "w") as fh:
+                fh.write(str(port))
+            os.replace(port_file + ".tmp", port_file)
+        t_wait = time.time()
+        while not os.path.exists(port_file):
+            if time.time() - t_wait > 120.0:
+                say(f"attempt {k}: no rendezvous port from rank 0's supervisor")
+                return 1
+            time.sleep(0.05)
+        port = int(open(port_file).read())
+        env = dict(os.environ)
+        env.update(env_add)
+        env.update({"RF_BENCH_WORKER": "1", "RF_BENCH_ATTEMPT": str(k), "RF_BENCH_RUN_DIR": run_dir, "RF_BENCH_LAST_ATTEMPT": "1" if last else "0",
+                    "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": str(port), "TORCHELASTIC_USE_AGENT_STORE": "False"})
+        if reasons:
+            env["RF_BENCH_FALLBACK_REASON"] = " | ".join(reasons)
+        if pos > 0 and not os.environ.get("RF_INJECT_IN_ALL_ATTEMPTS"):  # (the test hooks break the first attempt only)
+            for name in ("RF_OWNER_INJECT_HANG", "RF_OWNER_INJECT_FAILURE"):
+                env.pop(name, None)
+        # (RF_BENCH_WORKER_CMD: tests/test_bench_supervisor.py drives this protocol on the CPU with a stand-in worker)
+        worker = os.environ["RF_BENCH_WORKER_CMD"].split() if os.environ.get("RF_BENCH_WORKER_CMD") else [sys.executable, os.path.abspath(__file__)]
+        child = subprocess.Popen(worker + list(argv) + arg_add, env=env)
+        t_spawn = time.time()
+        t_ready = t_valid = None
+        verdict = None  # None: running; "next": abandon this attempt; int: return code to leave with
+        while verdict is None:
+            time.sleep(0.1)
+            rc = child.poll()
+            now = time.time()
+            committed = len(files(k, "done")) == world  # timed region + final replica check passed on every rank: no way back
+            if rc is not None and (committed or rc != 0):
+                if committed:
+                    verdict = rc
+                elif rc == EXIT_FALLBACK and not last:
+                    verdict = "next"
+                else:
+                    write(k, "dead", f"rank {rank}: worker exited with code {rc}")
+                    verdict = rc if last else "next"
+                break
+            # (a worker that left with 0 before every rank was done -- it cannot, its last act is a barrier -- is treated like a running
+            # one: the attempt counts only when ALL ranks are done)
+            if committed:
+                continue
+            bad = files(k, "dead") + files(k, "timeout") + files(k, "fail")
+            if bad:
+                verdict = "next" if not last else 1
+                break
+            if t_ready is None:
+                if len(files(k, "ready")) == world:
+                    t_ready = now
+                elif now - t_spawn > ready_s:
+                    write(k, "timeout", f"rank {rank}: not all ranks ready {ready_s:.0f} s after the workers were started")
+            elif t_valid is None:
+                if len(files(k, "valid")) == world:
+                    t_valid = now
+                elif now - t_ready > validate_s:
+                    write(k, "timeout", f"rank {rank}: validation steps not finished {validate_s:.0f} s after all ranks were ready (a hang)")
+            elif now - t_valid > run_s:
+                write(k, "timeout", f"rank {rank}: timed region not finished {run_s:.0f} s after the validation")
+        if child.poll() is None:
+            child.send_signal(signal.SIGKILL)
+            child.wait()
+        if verdict == "next" or (isinstance(verdict, int) and verdict != 0 and not last):
+            why = "; ".join(open(f).read().strip() for f in files(k, "fail") + files(k, "timeout") + files(k, "dead")) or "abandoned"
+            reasons.append(f"attempt {k} [{label}]: {why}")
+            say(f"attempt {k} [{label}] abandoned: {why}")
+            # all supervisors leave the attempt before anyone starts the next one (their children must be gone: GPU memory, ports)
+            write(k, "left", "")
+            t_wait = time.time()
+            while len(files(k, "left")) < world and time.time() - t_wait < 60.0:
+                time.sleep(0.05)
+            continue
+        return int(verdict)
+    return 1
+
+
+if __name__ == "__main__" and int(os.environ.get("WORLD_SIZE", "1")) > 1 and not os.environ.get("RF_BENCH_WORKER") and not os.environ.get("RF_BENCH_NO_SUPERVISOR"):
+    sys.exit(supervise(sys.argv[1:]))
+
 os.environ.setdefault("OMP_NUM_THREADS", str(host_cpu_quota()))  # (before torch creates its thread pools)
 
 import numpy as np  # noqa: E402
@@ -258,30 +414,31 @@ def cfg1_leg(dev, cores, reps=3):
             "gpu_ray_samples_per_s": n / gpu_s, "max_abs_colour_difference_gpu_vs_cpu": float((gpu.reshape(-1, 3) - ref).abs().max())}
 
 
-def time_frames(fn, frames):
-    """median of per-frame wall times (sync before and after every frame)"""
+def time_frames(fn, frames, kernel=None):
+    """median of per-frame wall times (sync before and after every frame).  With ``kernel`` (the name of a launch): also the median
+    of that launch's HIP-event time over THE SAME frames (ops.KernelTimer: events on the launch stream, inside the timed call) and
+    its launches per frame -- returned as (wall seconds, kernel ms, launches).  A kernel cannot outlast the synchronised call that
+    contains it: the two medians come from the same frames so that the line keeps that order."""
     fn()  # warm-up
-    ts = []
+    ts, ks, launches = [], [], 0
     for _ in range(frames):
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        fn()
-        torch.cuda.synchronize()
-        ts.append(time.perf_counter() - t0)
+        timer = ops.KernelTimer() if kernel else None
+        ops.KERNEL_TIMER = timer
+        try:
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            fn()
+            torch.cuda.synchronize()
+            ts.append(time.perf_counter() - t0)
+        finally:
+            ops.KERNEL_TIMER = None
+        if kernel:
+            rec = timer.summary()[kernel]
+            ks.append(rec["total_ms"])
+            launches = rec["launches"]
+    if kernel:
+        return float(np.median(ts)), float(np.median(ks)), launches
     return float(np.median(ts))
-
-
-def kernel_ms(fn, name):
-    """HIP-event time of the launch called ``name`` inside one call of ``fn`` (ops.KernelTimer, events on the launch stream)"""
-    timer = ops.KernelTimer()
-    ops.KERNEL_TIMER = timer
-    try:
-        fn()
-        torch.cuda.synchronize()
-    finally:
-        ops.KERNEL_TIMER = None
-    rec = timer.summary()
-    return rec[name]["total_ms"], rec[name]["launches"]
 
 
 def main():
@@ -316,6 +473,8 @@ def main():
                     help="data-parallel exchange: owner = owner-computes (record slices all-to-all -> merged brick pass + Adam on the rank's own bricks -> "
                     "parameter all-gather), dense = reduce-scatter of the gradient bucket -> sharded Adam -> all-gather")
     ap.add_argument("--timed-steps", type=int, default=5, help="how many of the --steps record per-kernel HIP events")
+    ap.add_argument("--second-point-rays", type=int, default=32768, help="rays per GPU of the second weak-scaling point timed behind the windows (0 = skip)")
+    ap.add_argument("--windows", type=int, default=9, help="further windows of --steps steps timed behind the official one (ms_per_step_windows)")
     ap.add_argument("--cpu-threads", type=int, default=0, help="torch CPU threads for cpu_baseline (0 = the cgroup CPU quota, at most 64)")
     args = ap.parse_args()
 
@@ -338,7 +497,13 @@ def main():
     dev = torch.device("cuda", local_rank)
     torch.cuda.set_device(dev)
     backend = torch.distributed.get_backend() if torch.distributed.is_initialized() else None
-    rccl_world = torch.distributed.get_world_size() if torch.distributed.is_initialized() else 1
+    rccl_world = 1
+    if torch.distributed.is_initialized():  # counted by a collective, not read from the environment: every rank adds a one
+        ones = torch.ones(1, device=dev, dtype=torch.float32)
+        torch.distributed.all_reduce(ones)
+        rccl_world = int(round(float(ones.item())))
+        if rccl_world != world:
+            raise SystemExit(f"--gpus {world} but an all-reduce of ones over the process group gives {rccl_world}")
 
     H = W = args.image_size
     focal = 1111.111 * (W / 800.0)
@@ -380,8 +545,7 @@ def main():
         for leg, rho in (("init_field", None), ("traversal", 0.25)):
             g2 = grid if rho is None else make_grid(dev, G, args.sh_degree, seed=42, storage=args.storage, rho=rho)
             m2 = rf.VolumetricModel(g2, rf.render_sh_voxel_grid, cfg, device=dev)
-            dt = time_frames(lambda: m2.render(pose, intr), args.render_frames)
-            kms, launches = kernel_ms(lambda: m2.render(pose, intr), kname)
+            dt, kms, launches = time_frames(lambda: m2.render(pose, intr), args.render_frames, kernel=kname)
             # units really processed: samples whose features are gathered = in-box, positive density, T != 0; counted by a
             # save-forward of a ray subset is not possible at frame size, so the record predicate is evaluated on the device
             # by the training-style forward of a 65536-ray sample of the frame and scaled
@@ -493,24 +657,49 @@ def main():
                             merge_bricks=False if exchange == "dense" and (world > 1 or args.dp_style_step) else None, exchange=exchange)
 
     stepper = make_stepper(args.exchange)
-    exchange_fallback = None
+    exchange_fallback = os.environ.get("RF_BENCH_FALLBACK_REASON")  # (the supervisor's: why earlier attempts were abandoned)
+    supervised = bool(os.environ.get("RF_BENCH_WORKER")) and os.environ.get("RF_BENCH_LAST_ATTEMPT") != "1"
     torch.manual_seed(1234 + rank)  # every rank draws its own rays
     batches = dataset.image_batches(args.images)
-    if world > 1 and stepper.exchange == "owner":
-        # the owner-computes exchange validates itself on its first step (replica checksum); should it raise on ANY rank -- a
-        # collective RCCL refuses, diverged replicas -- ALL ranks fall back to the dense exchange (reduce-scatter -> sharded Adam ->
-        # all-gather) on a freshly initialised grid, and the line says so: a multi-GPU run always yields a valid, labelled number
+    validation_steps = 0
+    if world > 1:
+        # VALIDATION, before anything is timed: the first iterations of the exchange with the replicas compared after each (the
+        # owner-computes step does it itself on its first RF_OWNER_CHECK_STEPS = 3 iterations: the all-gathers left in flight across
+        # the iteration boundary are first consumed by the second).  Should it raise on ANY rank -- a collective RCCL refuses,
+        # diverged replicas -- all ranks agree on it through an all-reduce and leave this configuration together: under the
+        # supervisor (top of this file) with EXIT_FALLBACK, so that the next, more conservative attempt starts in fresh processes;
+        # unsupervised by falling back to the dense exchange on a freshly initialised grid right here.  A rank that HANGS instead is
+        # the supervisor's business (its watchdog starts when every rank has written `ready`).  The line says which it was.
+        from thr3ed_atom_amd.trainers import OWNER_CHECK_STEPS
+
+        torch.distributed.barrier()
+        torch.cuda.synchronize()
+        _mark("ready")
         failed, reason = 0, None
+        validation_steps = max(1, OWNER_CHECK_STEPS) if stepper.exchange == "owner" else 1
         try:
-            stepper.step(dataset, next(batches))
+            for _ in range(validation_steps):
+                stepper.step(dataset, next(batches))
             torch.cuda.synchronize()
+            if stepper.exchange != "owner":
+                rfdist.assert_replicas_identical(stepper.flat.flat_param, "dense exchange, first iteration")
         except Exception as exc:  # noqa: BLE001
             failed, reason = 1, f"{type(exc).__name__}: {exc}"
+            if supervised:
+                # said at once: the other ranks may already sit in the next iteration's collectives, where the all-reduce below never
+                # meets them -- the supervisors see the marker, end every rank's worker and move on with the real reason
+                _mark("fail", f"rank {rank}: {reason}")
         flag = torch.tensor([failed], device=dev, dtype=torch.int32)
         torch.distributed.all_reduce(flag, op=torch.distributed.ReduceOp.MAX)
         if int(flag.item()):
-            exchange_fallback = reason or "the owner-computes step failed on another rank"
-            print(f"[rank {rank}] owner-computes exchange failed ({exchange_fallback}); falling back to --exchange dense", file=sys.stderr)
+            why = reason or "the validation steps failed on another rank"
+            print(f"[rank {rank}] {stepper.exchange} exchange failed its validation ({why})", file=sys.stderr, flush=True)
+            if supervised or stepper.exchange != "owner":
+                if not failed:
+                    _mark("fail", f"rank {rank}: {why}")
+                torch.distributed.barrier()
+                os._exit(EXIT_FALLBACK if supervised else 1)
+            exchange_fallback = why
             stepper.flat.detach()
             del stepper
             grid = make_grid(dev, G, args.sh_degree, seed=42, storage=args.storage)
@@ -518,9 +707,11 @@ def main():
             stepper = make_stepper("dense")
             torch.manual_seed(1234 + rank)
             batches = dataset.image_batches(args.images)
+            validation_steps = 0
+        _mark("valid")
     owner = stepper.exchange == "owner"
     executor = stepper.fused and stepper.merged_bricks and args.ray_selection == "keyed" and not owner
-    for _ in range(args.warmup - (1 if (world > 1 and owner) else 0)):  # (the owner-computes step's self-check above was the first warm-up step)
+    for _ in range(max(0, args.warmup - validation_steps)):  # (the validation steps above were the first warm-up steps)
         stepper.step(dataset, next(batches))
     # per-kernel HIP events on `--timed-steps` of the timed steps, recorded by the library between its own launches
     timer_stride = max(1, args.steps // max(1, args.timed_steps))
@@ -560,13 +751,54 @@ def main():
     exchange_bytes = 0
     if owner and stepper.exchange_bytes:  # measured: record slices + offset tables + parameter chunks this rank sent, mean of the last steps
         exchange_bytes = int(np.mean(stepper.exchange_bytes))
+    # ---- more windows of the same K steps, behind the official one (which is what the driver's command fixes: steps W .. W + K from
+    # the initialisation).  The official window is ~13 ms of GPU time: box-to-box and run-to-run spread is the size of a "kept" win,
+    # so the line also says what the following windows took.  (The field gets sparser as it trains: later windows are a little
+    # lighter by the data -- they are reported beside `ms_per_step`, never instead of it.)
+    window_ms = []
+    for _ in range(max(0, args.windows)):
+        if world > 1:
+            torch.distributed.barrier()
+        torch.cuda.synchronize()
+        tw = time.perf_counter()
+        for _i in range(args.steps):
+            stepper.step(dataset, next(batches))
+        torch.cuda.synchronize()
+        if world > 1:
+            torch.distributed.barrier()
+        window_ms.append((time.perf_counter() - tw) / args.steps * 1e3)
+    # ---- a second weak-scaling point: the same step on --second-point-rays rays per GPU.  The data-parallel exchange moves the MODEL
+    # every iteration (205 MB of parameters per rank at N = 8) whatever the batch is, so the scaling ratio depends on the per-GPU
+    # batch: DESIGN section 7 projects < 6 x at 16384 rays per GPU and > 6 x at 32768.  Every N prints both, the ratio is the driver's.
+    second = None
+    if args.second_point_rays > 0:
+        R2 = args.second_point_rays
+        stepper.ray_batch_size = R2  # (the step's persistent scratch is rebuilt for the new batch shape on the first of these iterations)
+        for _ in range(max(3, min(args.warmup, 5))):
+            stepper.step(dataset, next(batches))
+        if world > 1:
+            torch.distributed.barrier()
+        torch.cuda.synchronize()
+        t2 = time.perf_counter()
+        for _ in range(args.steps):
+            stepper.step(dataset, next(batches))
+        torch.cuda.synchronize()
+        if world > 1:
+            torch.distributed.barrier()
+        second = time.perf_counter() - t2
+        stepper.ray_batch_size = R
     replicas_ok = None
     if world > 1:
         model.thre3d_repr.wait_for_parameters()
         replicas_ok = bool(rfdist.replicas_identical(stepper.flat.flat_param))  # every rank must hold the same parameters after the timed steps
-        te = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        if not replicas_ok and supervised:  # (a collective result: every rank sees the same) -> the next attempt
+            _mark("fail", f"rank {rank}: the replicas' parameters differ after the timed steps")
+            torch.distributed.barrier()
+            os._exit(EXIT_FALLBACK)
+        te = torch.tensor([elapsed, second or 0.0] + window_ms, device=dev, dtype=torch.float64)
         torch.distributed.all_reduce(te, op=torch.distributed.ReduceOp.MAX)
-        elapsed = float(te.item())
+        elapsed, second, window_ms = float(te[0].item()), (float(te[1].item()) if second else None), [float(x) for x in te[2:].tolist()]
+        _mark("done")
         if not owner:  # reduce-scatter + all-gather (or all-reduce) of the flat bucket: 2 (N-1)/N x bucket bytes sent per rank per step
             exchange_bytes = int(2 * (world - 1) / world * stepper.flat.flat_grad.numel() * 4)
         # every rank leaves the group together, BEFORE rank 0 starts its single-process reporting legs
@@ -645,22 +877,26 @@ def main():
         dom = max(alg, key=lambda kname: kernels[kname]["avg_ms"])
         d = by_kernel[dom]
         traffic = d["counter_bytes_per_launch"]
-        achieved_bytes = traffic if traffic is not None else d["algorithmic_bytes_processed"]
+        # `frac` = ALGORITHMIC bytes of the launch (the compulsory HBM bytes on the units it really processed, counted on the device in
+        # this run) / this run's launch time / 8 TB/s: reproducible from the run alone.  The counter figure (fabric bytes of a separate
+        # rocprofv3 --pmc run of this command, profiles/pmc_traffic.json, tied to the kernel source by hash) is `traffic` and
+        # `frac_fabric_counters`: traffic well above the algorithmic bytes = wasted re-reads.
         roofline = {
             "kernel": names.get(dom, dom),
             "bound": "hbm",
-            "achieved": achieved_bytes / 1e9 / (d["avg_launch_ms"] / 1e3),
+            "achieved": d["algorithmic_bytes_processed"] / 1e9 / (d["avg_launch_ms"] / 1e3),
             "peak": HBM_PEAK_GBS,
             "unit": "GB/s",
-            "frac": d["frac_hbm"] if d["frac_hbm"] is not None else d["frac_processed"],
-            "frac_of_achievable": None if (d["frac_hbm"] if d["frac_hbm"] is not None else d["frac_processed"]) is None
-            else (d["frac_hbm"] if d["frac_hbm"] is not None else d["frac_processed"]) * HBM_PEAK_GBS / HBM_ACHIEVABLE_GBS,
+            "frac": d["frac_processed"],
+            "frac_of_achievable": None if d["frac_processed"] is None else d["frac_processed"] * HBM_PEAK_GBS / HBM_ACHIEVABLE_GBS,
             "achievable_GBps": HBM_ACHIEVABLE_GBS,
-            "frac_basis": "fabric bytes from the PMC counters (FETCH_SIZE / WRITE_SIZE count at the data fabric: Infinity-Cache hits included, so this is an upper bound of the DRAM traffic; "
-            "profiles/pmc_traffic.json, sha256-tied to the kernel source) / this run's launch time" if traffic is not None
-            else ("algorithmic bytes on processed units (profiles/pmc_traffic.json was measured on a different relu_field_kernels.hip: stale, not used)" if pmc_stale
-                  else "algorithmic bytes on processed units (no counter entry for this kernel in profiles/pmc_traffic.json)"),
+            "frac_basis": "algorithmic (compulsory) HBM bytes of the launch on the units it really processed -- records read once + 24 B per parameter for the brick pass with Adam "
+            "in its flush, counted on the device in this run -- / this run's HIP-event launch time / the 8 TB/s peak",
             "traffic": traffic,
+            "traffic_over_algorithmic": None if traffic is None else traffic / d["algorithmic_bytes_processed"],
+            "frac_fabric_counters": d["frac_hbm"],
+            "frac_fabric_counters_basis": None if traffic is None else "fabric bytes from the PMC counters (2 x FETCH_SIZE + WRITE_SIZE sectors at the data fabric, Infinity-Cache hits included: an upper "
+            "bound of the DRAM traffic; profiles/pmc_traffic.json, sha256-tied to the kernel source) / this run's launch time",
             "avg_launch_ms": d["avg_launch_ms"],
             "frac_processed": d["frac_processed"],
             "algorithmic_bytes_processed": d["algorithmic_bytes_processed"],
@@ -726,6 +962,16 @@ def main():
         "steps": args.steps,
         "warmup": args.warmup,
         "ms_per_step": ms_per_step,
+        "ms_per_step_windows": None if not window_ms else {
+            "min": float(np.min(window_ms)), "median": float(np.median(window_ms)), "max": float(np.max(window_ms)), "windows": len(window_ms), "steps_per_window": args.steps,
+            "first_step": args.warmup + args.steps,
+            "note": "further windows of the same length timed back to back BEHIND the official one (ms_per_step = steps warmup .. warmup + steps from the initialisation, "
+                    "what the driver's command fixes); the field gets sparser as it trains, so later windows are a little lighter by the data"},
+        "second_weak_scaling_point": None if not second else {
+            "rays_per_gpu_per_step": args.second_point_rays, "ms_per_step": second / args.steps * 1e3, "value": world * 2 * args.second_point_rays * S * args.steps / second,
+            "unit": "ray-samples/s", "steps": args.steps,
+            "note": "the same iteration on a larger per-GPU batch, timed behind the windows (max over ranks, barriers on both sides): the exchange moves the model, not the "
+                    "batch, so the N-GPU ratio grows with the per-GPU batch (DESIGN section 7)"},
         "host_issue_ms_per_step": host_issue / args.steps * 1e3,
         "kernel_timer_steps": len(timed_idx),
         "higher_is_better": True,

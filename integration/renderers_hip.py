@@ -60,8 +60,10 @@ class RFBrickList(C.Structure):
     _fields_ = [("records_sorted_dev", C.c_void_p), ("offsets_dev", C.c_void_p), ("render_diffuse", C.c_int32)]
 
 
-# backward: "auto" = the binned adjoint for SH degree >= 2 and at least 2^20 samples, "atomic", or "binned"
+# backward: "auto" = the binned adjoint for SH degree >= 2, at least 2^20 samples and at least RELU_FIELD_HIP_MIN_BRICKS (256) bricks of
+# 8^3 nodes -- the measured crossover, see _use_binned_adjoint --, else float atomics; "atomic" / "binned" force one
 BACKWARD = os.environ.get("RELU_FIELD_HIP_BACKWARD", "auto")
+MIN_BRICKS = int(os.environ.get("RELU_FIELD_HIP_MIN_BRICKS", "256"))
 BRICK = 8
 
 
@@ -149,7 +151,11 @@ def _use_binned_adjoint(features, n, num_samples):
     if nkeys > (1 << 21) or BACKWARD == "atomic":
         return 0
     record_bytes = 4 * int(_library().rf_expanded_record_floats(int(features.shape[-1])))
-    big = int(features.shape[-1]) >= 27 and n * num_samples >= (1 << 20) and n * num_samples * record_bytes <= (1 << 30)
+    # "auto": the binned adjoint from 2^20 samples on a degree >= 2 grid of at least 256 bricks (measured crossover on one MI355X,
+    # fwd+bwd of 16384 x 256 samples: 128^3 0.50 ms binned / 1.33 atomic, 64^3 0.37 / 0.44, 32^3 1.13 / 0.49, 16^3 2.26 / 0.79 --
+    # on a small grid a handful of brick workgroups would sum every record, while the atomic adjoint's targets sit in L2)
+    big = (int(features.shape[-1]) >= 27 and n * num_samples >= (1 << 20) and n * num_samples * record_bytes <= (1 << 30)
+           and nkeys // 8 >= MIN_BRICKS)
     return nkeys if (BACKWARD == "binned" or big) else 0
 
 

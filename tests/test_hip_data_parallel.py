@@ -186,3 +186,49 @@ def test_trainer_under_data_parallelism_writes_consistent_checkpoints(tmp_path):
     world = 2
     mp.spawn(_trainer_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
     assert sorted(n for n in os.listdir(tmp_path) if n.startswith("ok")) == [f"ok{r}" for r in range(world)]
+
+
+# ---- bench.py --gpus N: the supervised multi-GPU run (top of bench.py) --------------------------------------------------------------
+def _bench_two_ranks(extra_env, timeout=900):
+    """``python bench.py --gpus 2`` the way the driver launches N > 1 -- it re-executes itself as two ranks under torch.distributed.run,
+    every rank a supervisor with the benchmark in a child process -- on ONE GPU over gloo (RF_SINGLE_DEVICE / RF_DIST_BACKEND), small
+    workload.  Returns (completed process, the JSON lines it printed)."""
+    import json
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, PYTHONPATH=root, RF_SINGLE_DEVICE="1", RF_DIST_BACKEND="gloo", RF_BENCH_VALIDATE_TIMEOUT_S="20", **extra_env)
+    for name in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "RF_BENCH_WORKER", "RF_BENCH_RUN_DIR"):
+        env.pop(name, None)
+    cmd = [sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "3", "--windows", "1", "--second-point-rays", "8192", "--grid", "64", "--rays", "4096",
+           "--samples", "64", "--image-size", "200", "--cpu-rays", "0", "--render-frames", "0", "--highres-frames", "0", "--dropin-steps", "0"]
+    r = subprocess.run(cmd, cwd=root, env=env, capture_output=True, text=True, timeout=timeout)
+    return r, [json.loads(ln) for ln in r.stdout.splitlines() if ln.startswith("{")]
+
+
+def test_bench_two_ranks_supervised(hip_device):
+    """The undisturbed run: attempt 0 (owner-computes, interleaved halves, all-gathers in flight across the iteration boundary)
+    validates itself on its first three iterations and is the configuration that gets timed; the world size in the line is counted
+    by a collective."""
+    r, lines = _bench_two_ranks({})
+    assert r.returncode == 0 and len(lines) == 1, (r.returncode, r.stdout[-1500:], r.stderr[-3000:])
+    d = lines[0]["distributed"]
+    assert lines[0]["n_gpus"] == 2 and d["world_size_seen_by_collectives"] == 2 and d["exchange"] == "owner" and d["owner_halves"] == 2
+    assert d["exchange_fallback_reason"] is None and d["replicas_bit_identical"] is True
+    assert lines[0]["ms_per_step_windows"]["windows"] == 1 and lines[0]["second_weak_scaling_point"]["rays_per_gpu_per_step"] == 8192
+
+
+@pytest.mark.parametrize("inject", ["hang", "failure", "death"])
+def test_bench_two_ranks_watchdog_falls_back(hip_device, inject):
+    """A rank that HANGS in its second iteration (the first that consumes all-gathers left in flight), one that RAISES in its first,
+    one whose process DIES: the watchdog / the agreed failure flag / the exit code end attempt 0 on every rank, and the next attempt --
+    owner-computes in its conservative configuration, fresh processes, a rendezvous of its own -- yields the line, labelled with why."""
+    hook = {"hang": {"RF_OWNER_INJECT_HANG": "1:2"}, "failure": {"RF_OWNER_INJECT_FAILURE": "1"}, "death": {"RF_OWNER_INJECT_HANG": "1:2", "RF_OWNER_INJECT_DEATH": "1"}}[inject]
+    r, lines = _bench_two_ranks(hook)
+    assert r.returncode == 0 and len(lines) == 1, (r.returncode, r.stdout[-1500:], r.stderr[-3000:])
+    d = lines[0]["distributed"]
+    assert lines[0]["n_gpus"] == 2 and d["exchange"] == "owner" and d["owner_halves"] == 1 and d["replicas_bit_identical"] is True
+    why = d["exchange_fallback_reason"]
+    assert why and "attempt 0" in why, why
+    assert {"hang": "a hang", "failure": "injected failure", "death": "exited with code"}[inject] in why, why

@@ -125,8 +125,21 @@ def _follow(kind, storage, dev, g, dens0, feat0, checks=None):
     return run, grid, np.array(rel)
 
 
-@pytest.mark.parametrize("kind,storage", [("fused", "split"), ("fused", "bricked"), ("autograd", "reference"), ("torch_optim", "reference")])
-def test_g9b_trained_field_through_the_stage_transition(hip_device, kind, storage):
+# ``policy``: which adjoint / optimizer machinery backward="auto" and optim.FlatGrid(deferred) pick per stage.  tests/conftest.py sets
+# RF_AUTO_BINNED_MIN_BRICKS=0 (binned records + brick pass + Adam in the flush on EVERY grid); "production" removes the override -- the
+# shipped default: atomic adjoint + rf_adam_step below 256 bricks, i.e. on both grids of this schedule (8 and 27 bricks of 8^3 nodes),
+# what a CLI user gets on the 16^3 / 32^3 stages of the reference's schedule (modules/trainers.py:125-152); "switch" puts the
+# threshold BETWEEN the two stages (atomic at 12^3, binned with Adam in the flush at 24^3): the change of machinery at a stage
+# boundary that the reference's 16^3 -> 128^3 schedule makes at its third stage.
+_POLICY_MIN_BRICKS = {"binned-on-every-grid": "0", "production": None, "switch": "20"}
+
+
+@pytest.mark.parametrize("kind,storage,policy", [
+    ("fused", "split", "binned-on-every-grid"), ("fused", "bricked", "binned-on-every-grid"), ("autograd", "reference", "binned-on-every-grid"),
+    ("torch_optim", "reference", "binned-on-every-grid"),
+    ("fused", "split", "production"), ("autograd", "reference", "production"), ("torch_optim", "reference", "production"),
+    ("fused", "split", "switch"), ("autograd", "reference", "switch")])
+def test_g9b_trained_field_through_the_stage_transition(hip_device, monkeypatch, kind, storage, policy):
     """What float32 allows to be asserted, and what it does not.  Adam turns rounding-level differences of near-zero gradients into
     full-size steps and the L1 loss flips the sign of a pixel's gradient at |error| ~ 1e-7, so two float32 evaluations of this
     schedule drift apart chaotically: G9b holds 12 re-runs of the REFERENCE ITSELF from initial parameters moved by one ulp --
@@ -137,6 +150,10 @@ def test_g9b_trained_field_through_the_stage_transition(hip_device, kind, storag
       * the transition: rf_upsample_grid on the reference's stage-1 parameters == the reference's up-scaled grid, bit for bit;
       * after stage 2: a trained field (> 22 dB; here ~42 dB) inside the range of the reference's own runs (the distribution is
         compared in test_g9b_final_psnr_distribution_is_the_references)."""
+    if _POLICY_MIN_BRICKS[policy] is None:
+        monkeypatch.delenv("RF_AUTO_BINNED_MIN_BRICKS", raising=False)
+    else:
+        monkeypatch.setenv("RF_AUTO_BINNED_MIN_BRICKS", _POLICY_MIN_BRICKS[policy])
     g = load_golden("g9b_trainer_stages.npz")
     G, deg, hw, n_img, n_rays, iters, S, stages, eval_S, seed0 = (int(v) for v in g["config"])
     F = 3 * (deg + 1) ** 2
@@ -145,8 +162,12 @@ def test_g9b_trained_field_through_the_stage_transition(hip_device, kind, storag
     gd_ref, gf_ref = oracle_gradient_of_step1(g)
     checkpoints = [int(c) for c in g["checkpoints"]]
     seen = {}
+    machinery = []  # per stage: what the policy picked
 
     def checks(step, grid, run):
+        if step in (0, iters) and kind != "torch_optim":
+            st = run.stepper
+            machinery.append(("binned" if (st.backward == "binned" or st.flat.deferred) else "atomic", bool(st.fuse_optimizer or st.flat.deferred)))
         if step == 0:
             # Adam's first update is lr * sign(g) wherever |g| >> eps: every parameter with a gradient that is not summation noise
             # (|g| > 1e-6; the L1 gradients of this batch are ~1e-4) must agree with the reference's to 2e-5 -- ALL of them
@@ -179,6 +200,9 @@ def test_g9b_trained_field_through_the_stage_transition(hip_device, kind, storag
 
     run, grid, rel = _follow(kind, storage, dev, g, T(hash_uniform((g0, g0, g0, 1), 901)), T(hash_uniform((g0, g0, g0, F), 900 + F)), checks)
     assert sorted(seen) == checkpoints and seen[100][1] > 30.0  # (PSNR within 0.01 dB after 100 equal steps, at 30 dB)
+    if kind != "torch_optim":  # the machinery the policy is meant to pick, per stage (binned adjoint?, Adam inside the brick flush?)
+        want = {"binned-on-every-grid": [("binned", True)] * 2, "production": [("atomic", False)] * 2, "switch": [("atomic", False), ("binned", True)]}[policy]
+        assert machinery == want, (machinery, want)
     # per-step losses: tight while the trajectories coincide, inside (a multiple of) the reference's own spread afterwards
     ref_rel = np.abs(g["rerun_specular_loss"] / g["specular_loss"][None] - 1.0)
     assert rel[:3].max() <= 2e-5 and rel[:100].max() <= 2e-3, (rel[:3].max(), rel[:100].max())

@@ -34,10 +34,16 @@ def relu_grid(dev, dens, feat, G, rho=100.0 / 3.0, tunable=True, storage="refere
     )
 
 
+@pytest.mark.parametrize("policy", ["binned-on-every-grid", "production"])
 @pytest.mark.parametrize("fused", [True, False])
 @pytest.mark.parametrize("storage", ["reference", "split", "bricked"])
-def test_g9_reference_trainer_trajectory(hip_device, storage, fused):
-    """TrainStepper fed the batches the REAL reference trainer selected reproduces its losses and parameters."""
+def test_g9_reference_trainer_trajectory(hip_device, monkeypatch, storage, fused, policy):
+    """TrainStepper fed the batches the REAL reference trainer selected reproduces its losses and parameters.  ``policy``:
+    tests/conftest.py keeps the binned machinery on every grid; "production" removes that override, so that the path a user gets --
+    backward="auto": the atomic adjoint + rf_adam_step on this 16^3 grid (8 bricks < 256) -- follows the reference trainer too
+    (modules/trainers.py:278-341)."""
+    if policy == "production":
+        monkeypatch.delenv("RF_AUTO_BINNED_MIN_BRICKS", raising=False)
     g = load_golden("g9_trainer_trajectory.npz")
     G, deg, hw, n_img, n_rays, steps, S = (int(v) for v in g["config"])
     F = 3 * (deg + 1) ** 2
@@ -45,6 +51,8 @@ def test_g9_reference_trainer_trajectory(hip_device, storage, fused):
     cfg = rf.SHVoxGridRenderConfig(S, rf.CameraBounds(float(g["near"]), float(g["far"])), perturb_sampled_points=False, white_bkgd=True)
     model = rf.VolumetricModel(grid, rf.render_sh_voxel_grid, cfg, device=hip_device)
     stepper = TrainStepper(model, n_rays, learning_rate=float(g["lr"]), fused=fused)
+    if policy == "production":
+        assert stepper.backward == "atomic" and not stepper.fuse_optimizer and not stepper.flat.deferred
     for it in range(steps):
         rays = rf.Rays(T(g["origins"][it]).to(hip_device), T(g["directions"][it]).to(hip_device))
         stats = stepper.step_on(rays, T(g["pixels"][it]).to(hip_device))

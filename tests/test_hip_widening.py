@@ -127,12 +127,14 @@ def test_test_set_psnr_loop_against_the_oracle(hip_device):
 
 
 def test_bench_line_contract(hip_device):
-    """bench.py the way the driver runs it (fewer steps): ONE JSON line with the contract's keys, the roofline object priced on
-    counter bytes (a fraction in (0, 1]), the CPU baseline measured by the oracle, nothing above the HBM peak anywhere."""
+    """bench.py the way the driver runs it (fewer steps): ONE JSON line with the contract's keys, the roofline object priced on the
+    launch's algorithmic bytes (a fraction in (0, 1]; the counter bytes beside it), the CPU baseline measured by the oracle, nothing
+    above the HBM peak anywhere, and the line consistent with itself: no launch longer than the step it is part of, no kernel longer
+    than the synchronised frame call that contains it."""
     import json
 
     r = _run([os.path.join(REPO_ROOT, "bench.py"), "--gpus", "1", "--steps", "3", "--warmup", "2", "--cpu-rays", "256", "--cpu-fwd-rays", "512",
-              "--render-frames", "1", "--highres-frames", "0", "--dropin-steps", "2"], timeout=900)
+              "--render-frames", "1", "--highres-frames", "0", "--dropin-steps", "2", "--second-point-rays", "20000"], timeout=900)
     lines = [ln for ln in r.stdout.strip().splitlines() if ln.startswith("{")]
     assert len(lines) == 1, r.stdout[-2000:]
     line = json.loads(lines[0])
@@ -146,6 +148,19 @@ def test_bench_line_contract(hip_device):
     roof = line["roofline"]
     assert roof["bound"] == "hbm" and roof["unit"] == "GB/s" and roof["peak"] == 8000.0
     assert 0.0 < roof["frac"] <= 1.0 and abs(roof["frac"] - roof["achieved"] / roof["peak"]) < 1e-9
+    assert roof["frac"] == roof["frac_processed"]  # run-only figure first; the counter-based one is `frac_fabric_counters`
+    assert roof["frac_fabric_counters"] is None or 0.0 < roof["frac_fabric_counters"] <= 1.0
+    for name, rec in line["kernels"].items():
+        assert rec["avg_ms"] <= line["ms_per_step"], (name, rec, line["ms_per_step"])
+    assert sum(rec["avg_ms"] for rec in line["kernels"].values()) <= 1.05 * line["ms_per_step"] + 0.05
+    for leg in ("init_field", "traversal"):
+        fr = line["fwd_render"][leg]
+        assert fr["kernel_ms_per_frame"] <= 1.02 * fr["ms_per_frame"], (leg, fr["kernel_ms_per_frame"], fr["ms_per_frame"])
+    sp = line["second_weak_scaling_point"]
+    assert sp["rays_per_gpu_per_step"] == 20000 and sp["ms_per_step"] > 0
+    np.testing.assert_allclose(sp["value"], 2 * 20000 * 256 / (sp["ms_per_step"] * 1e-3), rtol=1e-6)
+    win = line["ms_per_step_windows"]
+    assert win["windows"] == 9 and win["steps_per_window"] == 3 and 0.0 < win["min"] <= win["median"] <= win["max"]
     # the counter table is tied to the kernel source by hash: a stale table is never used (the fraction is then priced on the algorithmic bytes)
     assert (roof["traffic"] is None and roof["traffic_stale"]) or (roof["traffic"] > 0 and not roof["traffic_stale"])
     for rec in roof["by_kernel"].values():

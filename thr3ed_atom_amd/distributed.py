@@ -229,6 +229,9 @@ def exchange_slices(send: list, recv: list, async_op: bool = False):
 # always asynchronously: the collective is ordered after the work already enqueued on the CURRENT stream and runs on the backend's own
 # stream; ``work.wait()`` makes the then-current stream wait for it.  RCCL only; arguments are checked on the first calls.
 _FAST = {"group": None, "ag": None, "a2a": None, "checks": 64}
+# RF_DIST_FAST=0: the owner-computes step goes through torch.distributed's public functions only (all_gather_into_tensor with a staging
+# copy, all_to_all) -- the conservative configuration bench.py falls back to before it gives up on the owner-computes exchange
+FAST_COLLECTIVES = os.environ.get("RF_DIST_FAST", "1") != "0"
 
 
 def _fast_group():

@@ -9,6 +9,7 @@ the boundary as raw device pointers; PyTorch is only the allocator and the strea
 Nothing here computes on the CPU and nothing falls back: CPU tensors or a missing library raise.
 """
 import ctypes as C
+import os
 from typing import Dict, NamedTuple, Optional, Tuple
 
 import numpy as np
@@ -492,6 +493,11 @@ def _autograd_uses_bricks(grid, flags: int, n: int, num_samples: int) -> bool:
     # the binned adjoint allocates one worst-case record list per backward (48 B per sample slot): above AUTOGRAD_BINNED_MAX_BYTES
     # the atomic kernel, which needs no scratch, is used instead (user code that fitted before keeps fitting)
     if n * num_samples * 4 * expanded_record_floats(grid) > AUTOGRAD_BINNED_MAX_BYTES:
+        return False
+    # (and, like TrainStepper(backward="auto") and optim.FlatGrid(deferred): below 256 bricks of 8^3 nodes a handful of brick workgroups
+    # would sum the whole render's records -- 16^3: 2.26 ms per iteration binned against 0.79 ms atomic, tools/small_grid_steps.py)
+    nb8 = brick_counts(grid, 8)
+    if nb8[0] * nb8[1] * nb8[2] < int(os.environ.get("RF_AUTO_BINNED_MIN_BRICKS", "256")):
         return False
     return grid.sh_degree >= 2 and n * num_samples >= (1 << 20)
 

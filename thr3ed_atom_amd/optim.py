@@ -39,7 +39,7 @@ class FlatGrid:
         self.grid = grid
         self._d, self._f = d, f
         nd, nf = d.numel(), (0 if f is None else f.numel())
-        self.flat_param = torch.empty(nd + nf, dtype=torch.float32, device=d.device)
+        self._flat_param = torch.empty(nd + nf, dtype=torch.float32, device=d.device)
         self.flat_param[:nd].copy_(d.detach().reshape(-1))
         d.data = self.flat_param[:nd].view(d.shape)
         self.flat_grad = torch.zeros_like(self.flat_param)
@@ -74,6 +74,15 @@ class FlatGrid:
 
         small = padded_nodes <= (1 << 24) and padded_nodes * max(4, grid.num_features - 3) < (1 << 30) and bricks * 2 * 8 <= (1 << 21)
         self.brick_size = BRICK_4X8X8 if (self.deferred and grid.num_features in (3, 27) and small and "RF_BRICK_SIZE" not in os.environ) else AUTOGRAD_BRICK_SIZE
+
+    @property
+    def flat_param(self) -> Tensor:
+        """The flat parameter buffer (first tensor | second tensor).  Under the owner-computes data-parallel step the parameter
+        all-gathers of an iteration stay in flight after ``step()`` returns: like every accessor of the VoxelGrid, this one makes the
+        current stream wait for them first, so that a reader (a clone for a test, a checksum, a checkpoint) never sees torn
+        parameters.  (The step itself works on ``_flat_param``.)"""
+        self.grid.wait_for_parameters()
+        return self._flat_param
 
     # ---- protocol used by ops._ReluFieldRender.backward -------------------------------------
     def matches(self, first: Tensor, second: Optional[Tensor]) -> bool:

@@ -127,20 +127,38 @@ class StepStats:
     """Losses of one iteration as 0-d device tensors: ``specular_loss`` / ``diffuse_loss`` (mean L1) and ``specular_mse`` /
     ``diffuse_mse`` (for the PSNR the reference logs, trainers.py:315-317, 334-336).  The fused step hands over the raw sums its loss
     kernel wrote -- (sum |d|, sum d^2) per render, in a slot of a ring of ``LOSS_RING`` iterations -- and the division by 3 N happens
-    when a value is READ: an iteration enqueues no extra launch for numbers that are looked at every ``summary_freq`` steps.  (Read a
-    StepStats within LOSS_RING iterations of the step that produced it.)"""
+    when a value is READ: an iteration enqueues no extra launch for numbers that are looked at every ``summary_freq`` steps.  The ring
+    slot is re-used LOSS_RING iterations later: a StepStats read after that RAISES instead of returning another iteration's sums
+    (``ring`` = (the executor's step counter, the step that produced this object)); ``materialize()`` copies the four sums out of
+    the ring (one small launch) for code that keeps a history of StepStats objects."""
 
     def __init__(self, specular_loss=None, diffuse_loss=None, specular_mse=None, diffuse_mse=None, sums: Optional[Tensor] = None, count: float = 1.0,
-                 has_diffuse: bool = True):
+                 has_diffuse: bool = True, ring=None):
         self._values = (specular_loss, diffuse_loss, specular_mse, diffuse_mse)
         self._sums, self._count, self._has_diffuse = sums, float(count), has_diffuse
+        self._ring = ring  # (executor dict holding "serial", serial of the producing step) or None
+
+    def _live_sums(self) -> Tensor:
+        if self._ring is not None:
+            ex, serial = self._ring
+            if ex["serial"] - serial >= LOSS_RING:
+                raise RuntimeError(f"this StepStats was produced {ex['serial'] - serial} iterations ago: its slot of the loss ring ({LOSS_RING} iterations) "
+                                   "has been re-used -- read it earlier or keep StepStats.materialize() of it")
+        return self._sums
+
+    def materialize(self) -> "StepStats":
+        """Detach from the ring: the four sums are copied now (in stream order), the object stays valid for ever."""
+        if self._sums is not None and self._ring is not None:
+            self._sums = self._live_sums().clone()
+            self._ring = None
+        return self
 
     def _get(self, i: int, j: int):
         if self._sums is None:
             return self._values[i]
         if i in (1, 3) and not self._has_diffuse:
             return None
-        return self._sums[j] / self._count
+        return self._live_sums()[j] / self._count
 
     specular_loss = property(lambda self: self._get(0, 0))
     specular_mse = property(lambda self: self._get(2, 1))
@@ -168,6 +186,9 @@ OWNER_HALVES = int(os.environ.get("RF_OWNER_HALVES", "2"))
 # brick leaves the machine idle behind the heaviest bricks (tools/owner_brick_emulation.py, N = 8: the piece through the middle of the
 # volume 0.35 ms with one workgroup per brick, 0.18 ms with two; 4 and 8 are no faster: the partial images then cost what the split saves)
 OWNER_BRICK_PARTS = int(os.environ.get("RF_OWNER_BRICK_PARTS", "0"))
+# ... and on how many of a run's first iterations the replicas' parameters are compared (a float64 checksum all-gathered, one device
+# synchronisation each; bench.py validates a multi-GPU configuration on them before it times anything)
+OWNER_CHECK_STEPS = int(os.environ.get("RF_OWNER_CHECK_STEPS", "3"))
 
 
 class _ParameterWait:
@@ -430,6 +451,7 @@ class TrainStepper:
         # the loss sums of this iteration: the next slot of the ring (cleared by the selection launch / a memset of the call)
         slot = ex["slot"]
         ex["slot"] = (slot + 1) % LOSS_RING
+        ex["serial"] = serial = ex.get("serial", 0) + 1
         sums = ex["sums_ring"][slot]
         st.loss_sums_dev = ex["sums_ptr"] + 16 * slot
         if selection is not None:
@@ -464,7 +486,7 @@ class TrainStepper:
             self._owner_step(ex, st, rf_grid, n, S, dev)
             del keep, jit
             self._grad_clean = True
-            return StepStats(sums=sums, count=3 * n)
+            return StepStats(sums=sums, count=3 * n, ring=(ex, serial))
         st.phases, st.loss_scale = 0, 1.0
         if self.fuse_optimizer:
             opt.step_count += 1
@@ -489,7 +511,7 @@ class TrainStepper:
                 rfdist.all_reduce_mean_(self.flat.flat_grad)
             opt.step()
             self._grad_clean = False
-        return StepStats(sums=sums, count=3 * n)
+        return StepStats(sums=sums, count=3 * n, ring=(ex, serial))
 
     def _owner_state(self, ex, device):
         """Persistent state of the owner-computes exchange: who owns which x-slabs of bricks, the ranks' offset tables, where every
@@ -528,7 +550,7 @@ class TrainStepper:
             "bounds_host": torch.empty((W, 2, 2 * H * W), dtype=torch.int64).pin_memory(),
             "side": torch.cuda.Stream(device), "forward_done": ev(), "ready": ev(),
             "recv": [[torch.empty((0, widths[k]), dtype=torch.float32, device=device) for _ in range(H)] for k in range(2)],
-            "checked": False,
+            "checked": 0,  # iterations whose replicas have been compared (the first OWNER_CHECK_STEPS of a run)
         }
         parts = OWNER_BRICK_PARTS if OWNER_BRICK_PARTS > 0 else (2 if W >= 4 else 1)
         ow["parts"] = max(1, min(parts, W, 8))
@@ -559,7 +581,7 @@ class TrainStepper:
         # a 1-rank group (bench.py --dp-style-step, tests) has nothing to exchange: the record exchange and the parameter all-gather
         # are skipped unless RF_OWNER_FORCE_COLLECTIVES asks for the calls themselves to be exercised (tests do)
         collect = W > 1 or bool(os.environ.get("RF_OWNER_FORCE_COLLECTIVES"))
-        fast = collect and rfdist.fast_path()
+        fast = collect and rfdist.fast_path() and rfdist.FAST_COLLECTIVES
         lib, grid, opt = _lib.load(), self.vol_mod.thre3d_repr, self.optimizer
         main = torch.cuda.current_stream(dev)
         main_ptr = main.cuda_stream
@@ -657,7 +679,7 @@ class TrainStepper:
         tick()  # [3] exchanges issued
         exp_avg = (opt.exp_avg[:nd], opt.exp_avg[nd:] if has_second else None)
         exp_avg_sq = (opt.exp_avg_sq[:nd], opt.exp_avg_sq[nd:] if has_second else None)
-        parts = (("base", self.flat.flat_param[:nd]), ("rest", self.flat.flat_param[nd:] if has_second else None))
+        parts = (("base", self.flat._flat_param[:nd]), ("rest", self.flat._flat_param[nd:] if has_second else None))
         for h, lists, pending in issue:
             for wk in pending:  # the brick pass of this half waits for its two exchanges
                 if wk is not None:
@@ -675,7 +697,7 @@ class TrainStepper:
                     wk = rfdist.fast_all_gather_in_place(half) if fast else rfdist.all_gather_chunks_(half, async_op=True)
                     new_waits.append(_ParameterWait(wk, tag))
         tick()  # [4] brick passes + parameter all-gathers issued
-        sent += (W - 1) * (self.flat.flat_param.numel() // W) * 4
+        sent += (W - 1) * (self.flat._flat_param.numel() // W) * 4
         if collect:
             if OWNER_OVERLAP_PARAMETERS:
                 # left in flight: the next reader of the grid waits for them (VoxelGrid.wait_for_parameters) -- the next iteration
@@ -694,14 +716,21 @@ class TrainStepper:
         if ht is not None:
             tick()  # [5] end of the host side
             self.host_timing.append([b_ - a_ for a_, b_ in zip(ht[:-1], ht[1:])])
-        if collect and not ow["checked"]:
-            # FIRST step of a run: the replicas must hold the same parameters (a wrong slice, a lost record or a torn all-gather shows
-            # here, not as a silently diverging run).  One device synchronisation, once.
-            ow["checked"] = True
+        if collect and ow["checked"] < OWNER_CHECK_STEPS:
+            # The FIRST iterations of a run: the replicas must hold the same parameters (a wrong slice, a lost record or a torn
+            # all-gather shows here, not as a silently diverging run).  Three of them, not one: the all-gathers left in flight across
+            # the iteration boundary are first consumed -- `base` in front of the diffuse chain, `rest` in front of the specular
+            # forward pass -- by the SECOND iteration, so an ordering bug of that overlap cannot show after the first.  One device
+            # synchronisation each.
+            ow["checked"] += 1
             grid.wait_for_parameters()
-            rfdist.assert_replicas_identical(self.flat.flat_param, "owner-computes exchange, first step")
-            if os.environ.get("RF_OWNER_INJECT_FAILURE") == str(me):  # (test hook: exercises bench.py's fall-back to the dense exchange)
+            rfdist.assert_replicas_identical(self.flat.flat_param, f"owner-computes exchange, iteration {ow['checked']} of the run")
+            if ow["checked"] == 1 and os.environ.get("RF_OWNER_INJECT_FAILURE") == str(me):  # (test hook: exercises bench.py's fall-back to the dense exchange)
                 raise RuntimeError("injected failure of the owner-computes step (RF_OWNER_INJECT_FAILURE)")
+            if os.environ.get("RF_OWNER_INJECT_HANG") == f"{me}:{ow['checked']}":  # (test hook "rank:iteration": bench.py's watchdog)
+                if os.environ.get("RF_OWNER_INJECT_DEATH"):
+                    os._exit(41)
+                time.sleep(3600.0)
 
     def _executor(self, n: int, S: int, device):
         """Persistent scratch + the ctypes description of one iteration (rebuilt when the batch shape changes)."""

@@ -9,7 +9,7 @@ TAG=${1:-r03}
 OUT=$ROOT/gpurun_out/prof_$TAG
 rm -rf $OUT; mkdir -p $OUT
 python $ROOT/bench.py --steps 20 --warmup 5 > $OUT/bench_default_line.json 2> $OUT/bench_default.err
-ARGS="--steps 20 --warmup 5 --cpu-rays 0 --dropin-steps 0 --highres-frames 0 --render-frames 1"
+ARGS="--steps 20 --warmup 5 --cpu-rays 0 --dropin-steps 0 --highres-frames 0 --render-frames 1 --windows 0 --second-point-rays 0"
 cd /tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python $ROOT/bench.py $ARGS > $OUT/trace.json 2> $OUT/trace.err
 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/fetch -- python $ROOT/bench.py $ARGS > /dev/null 2> $OUT/fetch.err
@@ -18,6 +18,6 @@ rocprofv3 --pmc TCC_HIT_sum TCC_MISS_sum --kernel-trace --output-format csv -d $
 cd $ROOT
 python tools/summarize_rocprof.py $OUT/trace > $OUT/kernel_stats.md
 python tools/summarize_pmc.py $OUT/fetch $OUT/write $OUT/tcc > $OUT/pmc.md
-python tools/make_pmc_traffic.py $OUT/fetch $OUT/write --gt-frames 8 --frames-per-leg 3 --bench-args "$ARGS" > $OUT/pmc_traffic.json
+python tools/make_pmc_traffic.py $OUT/fetch $OUT/write --gt-frames 8 --frames-per-leg 2 --bench-args "$ARGS" > $OUT/pmc_traffic.json
 find $OUT -name "*.csv" -size +3M -delete
 cat $OUT/kernel_stats.md | head -30; cat $OUT/pmc.md; du -sh $OUT; python tools/benchsum.py $OUT/bench_default_line.json
