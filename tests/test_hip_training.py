@@ -1258,3 +1258,24 @@ def test_split_brick_pass_equals_the_plain_owner_pass(hip_device, copies, parts)
             assert float((a - b).abs().max()) <= 2e-6 * max(scale, 1.0) + 1e-4 * scale * 0 + 3e-6 * scale, (float((a - b).abs().max()), scale)
     with pytest.raises(RuntimeError):  # too small a scratch is refused before anything is launched
         ops.brick_accumulate_adam_raw(grid, 8, lists, m, v, 0.03, 0.9, 0.999, 1e-8, 3, brick_range=rng, split=(parts, scratch[: scratch.numel() // 2]))
+
+
+def test_l1_loss_with_mse_equals_torch(hip_device):
+    """ops.l1_loss_with_mse (one launch, a torch.autograd.Function) against torch.nn.functional.l1_loss / mse_loss and their autograd,
+    which the reference's trainer calls (modules/trainers.py:311-317): values, the gradient incl. sign(0) = 0, an upstream factor."""
+    n = 5000
+    colour = T(hash_uniform((n, 3), 71, 0.0, 1.0)).to(hip_device)
+    target = T(hash_uniform((n, 3), 72, 0.0, 1.0)).to(hip_device)
+    colour[:7] = target[:7]  # exact zeros of the difference
+    for _ in range(3):  # (several slots of the sums ring)
+        a = colour.clone().requires_grad_(True)
+        b = colour.clone().requires_grad_(True)
+        loss, mse = ops.l1_loss_with_mse(a, target)
+        ref = torch.nn.functional.l1_loss(b, target)
+        np.testing.assert_allclose(loss.item(), ref.item(), rtol=2e-6)
+        np.testing.assert_allclose(mse.item(), torch.nn.functional.mse_loss(b.detach(), target).item(), rtol=2e-6)
+        assert not mse.requires_grad
+        (2.5 * loss).backward()
+        (2.5 * ref).backward()
+        assert torch.equal(a.grad[:7], torch.zeros_like(a.grad[:7]))
+        np.testing.assert_allclose(a.grad.cpu().numpy(), b.grad.cpu().numpy(), rtol=1e-6, atol=0.0)

@@ -738,6 +738,52 @@ def l1_loss_grad_hip(colour: Tensor, target: Tensor, sums: Tensor, scale: float 
     return grad
 
 
+# zeroed (sum |d|, sum d^2) slots for l1_loss_with_mse: handed out one after the other, the whole ring cleared once per turn -- no
+# torch.zeros launch per loss (a tiny launch still costs ~5 us of GPU time between two 100 us kernels)
+_L1_SUMS_RING: Dict[str, list] = {}
+_L1_RING_SLOTS = 1024
+
+
+def _l1_sums_slot(device) -> Tensor:
+    st = _L1_SUMS_RING.setdefault(str(device), [None, _L1_RING_SLOTS])
+    if st[1] >= _L1_RING_SLOTS:
+        # (a fresh ring per turn: slots handed out earlier may still be referenced by losses somebody kept)
+        st[0], st[1] = torch.zeros((_L1_RING_SLOTS, 2), dtype=torch.float32, device=device), 0
+    st[1] += 1
+    return st[0][st[1] - 1]
+
+
+class _L1LossWithMSE(torch.autograd.Function):
+    """mean |colour - target| (differentiable w.r.t. colour) and mean (colour - target)^2 (for the PSNR the reference logs,
+    modules/trainers.py:311-317) in ONE launch of rf_l1_loss_grad, which also leaves d loss / d colour for the backward pass: what
+    torch.nn.functional.l1_loss + mse_loss and their autograd graph do in ~14 launches."""
+
+    @staticmethod
+    def forward(ctx, colour, target):
+        colour_c = colour.detach().to(torch.float32).contiguous()
+        target_c = target.detach().to(colour_c.device, torch.float32).contiguous()
+        if colour_c.shape != target_c.shape or colour_c.dim() != 2 or colour_c.shape[1] != 3:
+            raise ValueError(f"l1_loss_with_mse takes [N, 3] colours and targets, got {tuple(colour.shape)} and {tuple(target.shape)}")
+        sums = _l1_sums_slot(colour_c.device)
+        grad = l1_loss_grad_hip(colour_c, target_c, sums)
+        ctx.save_for_backward(grad)
+        means = sums * (1.0 / float(colour_c.numel()))
+        loss, mse = means[0], means[1]
+        ctx.mark_non_differentiable(mse)
+        return loss, mse
+
+    @staticmethod
+    def backward(ctx, g_loss, _g_mse):
+        (grad,) = ctx.saved_tensors
+        return grad * g_loss, None
+
+
+def l1_loss_with_mse(colour: Tensor, target: Tensor) -> Tuple[Tensor, Tensor]:
+    """(mean L1 loss -- differentiable w.r.t. ``colour`` --, mean squared error) of [N, 3] colours against their targets, one launch."""
+    _require_hip(colour, "colour")
+    return _L1LossWithMSE.apply(colour, target)
+
+
 def relu_field_render(
     grid: VoxelGrid,
     origins: Tensor,

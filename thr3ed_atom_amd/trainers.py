@@ -29,7 +29,7 @@ from typing import Callable, Dict, Iterator, List, Optional
 import numpy as np
 import torch
 from torch import Tensor
-from torch.nn.functional import l1_loss, mse_loss
+from torch.nn.functional import mse_loss
 
 from . import _lib, ops
 from . import distributed as rfdist
@@ -391,15 +391,16 @@ class TrainStepper:
         if t_rand is not None:
             raise ValueError("t_rand is only taken by the fused step (pass t_rand= to render_sh_voxel_grid on the autograd path)")
         self.optimizer.zero_grad()
+        # the reference's loss lines (modules/trainers.py:311-317, 329-336: l1_loss for the gradient, mse_loss for the logged PSNR) as
+        # ONE launch per render: ops.l1_loss_with_mse, a torch.autograd.Function like the render op itself
         spec = vol_mod.render_rays(rays).colour
-        total = l1_loss(spec, pixels)
+        total, spec_mse = ops.l1_loss_with_mse(spec, pixels)
         spec_loss, diff_loss, diff_mse = total.detach(), None, None
-        spec_mse = mse_loss(spec.detach(), pixels)
         if self.diffuse:
             diff = vol_mod.render_rays(rays, render_diffuse=True).colour
-            dl = l1_loss(diff, pixels)
+            dl, diff_mse = ops.l1_loss_with_mse(diff, pixels)
             total = total + dl
-            diff_loss, diff_mse = dl.detach(), mse_loss(diff.detach(), pixels)
+            diff_loss = dl.detach()
         total.backward()
         if self.data_parallel:
             rfdist.all_reduce_mean_(self.flat.flat_grad)
