@@ -300,6 +300,18 @@ typedef struct RFAdamState {
 int rf_brick_accumulate_adam(const RFGrid* grid, int32_t brick_size, const RFBrickList* lists, int32_t num_lists,
                              const RFAdamState* adam, void* stream);
 
+/* The same pass (whole grid, brick_size == RF_BRICK_4X8X8) for a grid held in the REFERENCE's two tensors whose forward passes run
+ * from a split-layout shadow: `grid` / `adam` describe the shadow (RF_LAYOUT_SPLIT, F in {3, 27}), and the flush writes every
+ * updated parameter a second time, in the reference's own layout -- mirror_densities_dev [X,Y,Z,1], mirror_features_dev [X,Y,Z,F]
+ * with feature index = colour * K + k (thre3d_atom/thre3d_reprs/voxels.py:70-71, rendering/volumetric/process.py:61,66), both
+ * contiguous and 16-byte aligned -- so that the nn.Parameters a reference user holds stay in sync with the shadow without a
+ * re-layout launch (rf_convert_grid: 235 MB read + 235 MB written per iteration at 128^3 / SH degree 2; here +235 MB written out
+ * of LDS).  Grid dims must be multiples of (4, 8, 8); RF_ERR_UNSUPPORTED otherwise (use rf_brick_accumulate_adam, then
+ * rf_convert_grid).  This is what optimizer.step() of modules/trainers.py:341 becomes for the strict drop-in.  (Added to ABI
+ * version 4 compatibly: no existing struct or signature changed.) */
+int rf_brick_accumulate_adam_mirror(const RFGrid* grid, int32_t brick_size, const RFBrickList* lists, int32_t num_lists,
+                                    const RFAdamState* adam, float* mirror_densities_dev, float* mirror_features_dev, void* stream);
+
 /* The same pass restricted to the bricks [first_brick, first_brick + num_bricks) (brick id = (bx * NBY + by) * NBZ + bz): the
  * OWNER-COMPUTES step of data-parallel training.  The reference trains on one device (modules/trainers.py:338-341 is its
  * loss.backward(); optimizer.step()); with N ranks each rank owns a range of x-slabs of bricks, receives from every rank the

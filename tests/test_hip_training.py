@@ -1279,3 +1279,42 @@ def test_l1_loss_with_mse_equals_torch(hip_device):
         (2.5 * ref).backward()
         assert torch.equal(a.grad[:7], torch.zeros_like(a.grad[:7]))
         np.testing.assert_allclose(a.grad.cpu().numpy(), b.grad.cpu().numpy(), rtol=1e-6, atol=0.0)
+
+
+@pytest.mark.parametrize("dims,deg", [((16, 16, 16), 2), ((20, 24, 32), 2), ((16, 16, 16), 0), ((12, 16, 16), 2)])
+def test_mirror_flush_keeps_the_parameters_in_sync(hip_device, monkeypatch, dims, deg):
+    """The strict drop-in's optimizer step (optim.FusedAdam on deferred record lists of a reference-storage grid): the brick flush
+    that updates the split shadow writes the Parameters' own layout as well (rf_brick_accumulate_adam_mirror) -- bit for bit what
+    the separate re-layout launch wrote before ($RF_MIRROR_FLUSH=0), for both tensors, both SH degrees it covers and non-cubic grids."""
+    from thr3ed_atom_amd import optim
+
+    F = 3 * (deg + 1) ** 2
+    cam = hotdog_like_camera()
+    cfg = rf.SHVoxGridRenderConfig(48, rf.CameraBounds(cam["near"], cam["far"]), perturb_sampled_points=False, white_bkgd=True)
+    rays = rf.flatten_rays(rf.cast_rays(rf.CameraIntrinsics(32, 32, 44.0), rf.pose_spherical(20.0, -30.0, cam["radius"]), hip_device))
+    pixels = T(hash_uniform((len(rays), 3), 33, 0.0, 1.0)).to(hip_device)
+    out = []
+    for mirror in (True, False):
+        monkeypatch.setattr(optim, "MIRROR_FLUSH", mirror)
+        grid = rf.VoxelGrid(T(hash_uniform((*dims, 1), 31)).to(hip_device), T(hash_uniform((*dims, F), 32)).to(hip_device), rf.VoxelSize(3.0 / dims[0], 3.0 / dims[1], 3.0 / dims[2]),
+                            density_preactivation=torch.nn.Identity(), density_postactivation=torch.nn.ReLU(), expected_density_scale=100.0 / 3.0, tunable=True)
+        model = rf.VolumetricModel(grid, rf.render_sh_voxel_grid, cfg, device=hip_device)
+        st = TrainStepper(model, len(rays), learning_rate=0.03, fused=False, data_parallel=False)
+        assert st.flat.deferred
+        applies = ops.mirror_flush_applies(grid, st.flat.brick_size, grid.densities.data, grid.features.data)
+        assert applies == (dims[0] % 4 == 0 and dims[1] % 8 == 0 and dims[2] % 8 == 0)
+        for _ in range(3):
+            st.step_on(rays, pixels)
+        torch.cuda.synchronize()
+        # the Parameters == the shadow the next forward pass renders from (converted back by the library)
+        sh, _ = grid._shadow(refresh=False)
+        base, rest = sh["base"], sh["rest"]
+        assert torch.equal(grid.densities.detach()[..., 0], base[..., 0])
+        K = F // 3
+        feat = grid.features.detach().reshape(*dims, 3, K)
+        assert torch.equal(feat[..., 0], base[..., 1:4])
+        if K > 1:
+            assert torch.equal(feat[..., 1:], rest.reshape(*dims, 3, K - 1))
+        out.append((grid.densities.detach().clone(), grid.features.detach().clone()))
+        st.flat.detach()
+    assert torch.equal(out[0][0], out[1][0]) and torch.equal(out[0][1], out[1][1])

@@ -53,6 +53,7 @@ EXPORTED_SYMBOLS = [
     "rf_scatter_records",
     "rf_brick_accumulate",
     "rf_brick_accumulate_adam",
+    "rf_brick_accumulate_adam_mirror",
     "rf_brick_accumulate_adam_range",
     "rf_brick_accumulate_adam_split",
     "rf_brick_split_scratch_bytes",
@@ -284,6 +285,7 @@ def load() -> C.CDLL:
     lib.rf_brick_accumulate.argtypes = [C.POINTER(RFGrid), i32, C.POINTER(RFBrickList), i32, vp, vp, i32, vp]
     lib.rf_brick_accumulate_adam.argtypes = [C.POINTER(RFGrid), i32, C.POINTER(RFBrickList), i32, C.POINTER(RFAdamState), vp]
     lib.rf_brick_accumulate_adam_range.argtypes = [C.POINTER(RFGrid), i32, C.POINTER(RFBrickList), i32, C.POINTER(RFAdamState), i32, i32, vp]
+    lib.rf_brick_accumulate_adam_mirror.argtypes = [C.POINTER(RFGrid), i32, C.POINTER(RFBrickList), i32, C.POINTER(RFAdamState), vp, vp, vp]
     lib.rf_brick_accumulate_adam_split.argtypes = [C.POINTER(RFGrid), i32, C.POINTER(RFBrickList), i32, C.POINTER(RFAdamState), i32, i32, i32, vp, i64, vp]
     lib.rf_brick_split_scratch_bytes.argtypes = [C.POINTER(RFGrid), i32, i32]
     lib.rf_train_step.argtypes = [C.POINTER(RFGrid), C.POINTER(RFTrainStep), vp]

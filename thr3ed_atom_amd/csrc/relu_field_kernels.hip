@@ -1962,9 +1962,16 @@ __device__ __forceinline__ void brick_range_entry(const BrickArgs& a, const long
 // The last phase of a brick workgroup: the sums of the B^3 owned nodes (LDS accumulators `acc`, node (x, y, z) channel c at
 // x * SX + y * SY + z * CS + c; all zero when `any` is false) go out with plain stores -- or, ADAM, are consumed by the
 // optimizer step on the spot.
-template <int K, bool ADAM, bool ONE_ROUND, int TH = kBrickThreads, int BX = 8>
+// MIRROR (ADAM, ONE_ROUND, 4 x 8 x 8 bricks, grid dims multiples of the brick): the updated parameters ALSO go out in the reference's
+// own layout -- densities [X,Y,Z,1] at `gdens`, features [X,Y,Z,3K] (index = colour * K + k, process.py:61,66) at `gfeat` -- so that the
+// Parameters of a reference-storage grid whose split shadow this pass updates stay in sync without a re-layout launch (81 us per
+// iteration of the strict drop-in step: 235 MB read + 235 MB written; here 235 MB written out of LDS).  Every thread parks its
+// updated quads in the accumulator image, in place of the gradient quads it alone consumed; a z column of 8 nodes is then 8 * 3K
+// consecutive floats of the feature tensor = 2 * 3K whole 16-byte stores (the column starts at a multiple of 8 nodes).
+template <int K, bool ADAM, bool ONE_ROUND, int TH = kBrickThreads, int BX = 8, bool MIRROR = false>
 __device__ __forceinline__ void brick_flush(const GridArgs& g, const BrickArgs& a, const float* acc, bool any, int X0, int Y0, int Z0,
                                             float* gdens, float* gfeat) {
+  static_assert(!MIRROR || (ADAM && ONE_ROUND && BX == 4), "the mirror write-out rides on the one-round optimizer flush of 4 x 8 x 8 bricks");
   constexpr int C = 3 * K + 1;
   constexpr int CS = (C + 3) / 4 * 4;
   const int B = ONE_ROUND ? 8 : (1 << a.shift);  // (ONE_ROUND: the host launches it for 8^3 bricks only -- strides fold to constants)
@@ -2068,6 +2075,33 @@ __device__ __forceinline__ void brick_flush(const GridArgs& g, const BrickArgs& 
           *reinterpret_cast<float4*>(pb + bo[u]) = make_float4(pn[0], pn[1], pn[2], pn[3]);
           __builtin_nontemporal_store(mn, reinterpret_cast<vf4*>(mb + bo[u]));
           __builtin_nontemporal_store(vn, reinterpret_cast<vf4*>(vb + bo[u]));
+          if constexpr (MIRROR) *reinterpret_cast<float4*>(const_cast<float*>(&acc[lds_at[u]])) = make_float4(pn[0], pn[1], pn[2], pn[3]);
+        }
+        if constexpr (MIRROR) {
+          __syncthreads();
+          constexpr int F = 3 * K, FQ = 2 * F, CQ = FQ + 2;  // float4s of a column of 8 nodes: features, + 2 of densities
+          for (int i = tid; i < 32 * CQ; i += TH) {
+            const int col = i / CQ, r = i - col * CQ;
+            const int fx = col >> 3, fy = col & 7;
+            const float* img = acc + fx * SX + fy * SY;
+            const unsigned int lin0 = node_lin(g, X0 + fx, Y0 + fy, Z0);
+            float v[4];
+            if (r < FQ) {
+#pragma unroll
+              for (int t = 0; t < 4; ++t) {
+                const int e = 4 * r + t;
+                const int nz = e / F, f = e - nz * F;
+                const int colour = f / K, k = f - colour * K;
+                v[t] = img[nz * CS + (k == 0 ? 1 + colour : 4 + colour * (K - 1) + (k - 1))];
+              }
+              *reinterpret_cast<float4*>(gfeat + (size_t)(__umul24(lin0, (unsigned)F) + 4u * (unsigned)r)) = make_float4(v[0], v[1], v[2], v[3]);
+            } else {
+              const int z0 = 4 * (r - FQ);
+#pragma unroll
+              for (int t = 0; t < 4; ++t) v[t] = img[(z0 + t) * CS];
+              *reinterpret_cast<float4*>(gdens + (size_t)(lin0 + (unsigned)z0)) = make_float4(v[0], v[1], v[2], v[3]);
+            }
+          }
         }
         return;
       } else {
@@ -2277,7 +2311,7 @@ __host__ __device__ inline int gather_lds_words(int B, int C, int BX = 8) {
 // records -- 16 tiles, four per wave as in the 8^3 case, half the LDS: FOUR workgroups per CU instead of two.  The pass is bound by the
 // latencies of a workgroup's serial phases (ranges -> first records -> tile loops -> flush), and twice the workgroups hide twice as
 // many of them; the price is one more brick face across x (a record is read 1.58 x instead of 1.42 x) and twice the keys.
-template <int K, bool ADAM, bool ONE_ROUND = false, bool SPLIT = false, int BX = 8>
+template <int K, bool ADAM, bool ONE_ROUND = false, bool SPLIT = false, int BX = 8, bool MIRROR = false>
 __global__ __launch_bounds__(BX == 4 ? kBrickThreads / 2 : kBrickThreads, (K > 9 ? 2 : 4)) void brick_gather_kernel(GridArgs g, BrickArgs a, float* gdens, float* gfeat) {
   static_assert(BX == 8 || (BX == 4 && ONE_ROUND && !SPLIT), "4 x 8 x 8 bricks: 8-node y and z edges, one workgroup per brick");
   constexpr int TH = BX == 4 ? kBrickThreads / 2 : kBrickThreads;  // threads of the workgroup
@@ -2704,7 +2738,7 @@ __global__ __launch_bounds__(BX == 4 ? kBrickThreads / 2 : kBrickThreads, (K > 9
 #if defined(RF_BRICK_PROFILE) || defined(RF_BRICK_ABLATE)
   if (!(a.stagger & 0x400000))  // (ablation: the batch phases alone)
 #endif
-  brick_flush<K, ADAM, ONE_ROUND, TH, BX>(g, a, acc, any, X0, Y0, Z0, gdens, gfeat);
+  brick_flush<K, ADAM, ONE_ROUND, TH, BX, MIRROR>(g, a, acc, any, X0, Y0, Z0, gdens, gfeat);
   RF_PROF_MARK(4);  // flush (stores issued, not necessarily retired)
   RF_PROF_END();
 }
@@ -3992,7 +4026,7 @@ int rf_scatter_records(const RFGrid* grid, const int16_t* keys_dev, const float*
 int32_t rf_expanded_record_floats(int32_t num_features) { return 4 * record_quads(num_features / 3); }
 
 extern "C++" {
-template <int K, bool ADAM, bool ONE_ROUND = false, bool SPLIT = false, int BX = 8>
+template <int K, bool ADAM, bool ONE_ROUND = false, bool SPLIT = false, int BX = 8, bool MIRROR = false>
 static int launch_gather(const GridArgs& g, const BrickArgs& a, int nbricks, float* gd, float* gf, hipStream_t st) {
   const int B = 1 << a.shift;
   const size_t lds = (size_t)gather_lds_words(B, 3 * K + 1, BX) * sizeof(float);
@@ -4001,12 +4035,12 @@ static int launch_gather(const GridArgs& g, const BrickArgs& a, int nbricks, flo
   int dev = 0;
   if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return RF_ERR_LAUNCH;
   if (lds > configured[dev].load(std::memory_order_relaxed)) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&brick_gather_kernel<K, ADAM, ONE_ROUND, SPLIT, BX>),
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&brick_gather_kernel<K, ADAM, ONE_ROUND, SPLIT, BX, MIRROR>),
                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
       return RF_ERR_LAUNCH;
     configured[dev].store(lds, std::memory_order_relaxed);
   }
-  hipLaunchKernelGGL((brick_gather_kernel<K, ADAM, ONE_ROUND, SPLIT, BX>), dim3(nbricks * (SPLIT ? a.parts : 1)), dim3(BX == 4 ? kBrickThreads / 2 : kBrickThreads), lds, st, g, a,
+  hipLaunchKernelGGL((brick_gather_kernel<K, ADAM, ONE_ROUND, SPLIT, BX, MIRROR>), dim3(nbricks * (SPLIT ? a.parts : 1)), dim3(BX == 4 ? kBrickThreads / 2 : kBrickThreads), lds, st, g, a,
                      gd, gf);
   return launch_status();
 }
@@ -4118,8 +4152,16 @@ static int brick_accumulate_impl(const RFGrid* grid, int32_t brick_size, const R
     const bool one_round = a.adam.byte_offsets_fit_32_bits && shift == 3;
     if (slab4) {  // 4 x 8 x 8 bricks: the 256-thread workgroups of the single-GPU optimizer pass
       if (!one_round || parts > 1 || (K != 1 && K != 9)) return RF_ERR_UNSUPPORTED;
+      if (grad_densities_dev) {  // rf_brick_accumulate_adam_mirror: the updated parameters also in the reference layout
+        if (!grad_features_dev || (grid->dims[0] & 3) || (grid->dims[1] & 7) || (grid->dims[2] & 7) || g.bricked || first_brick != 0 || nbricks != nb[0] * nb[1] * nb[2])
+          return RF_ERR_UNSUPPORTED;
+        if ((reinterpret_cast<uintptr_t>(grad_densities_dev) | reinterpret_cast<uintptr_t>(grad_features_dev)) & 15u) return RF_ERR_BAD_SHAPE;
+        return K == 1 ? launch_gather<1, true, true, false, 4, true>(g, a, nbricks, grad_densities_dev, grad_features_dev, st)
+                      : launch_gather<9, true, true, false, 4, true>(g, a, nbricks, grad_densities_dev, grad_features_dev, st);
+      }
       return K == 1 ? launch_gather<1, true, true, false, 4>(g, a, nbricks, nullptr, nullptr, st) : launch_gather<9, true, true, false, 4>(g, a, nbricks, nullptr, nullptr, st);
     }
+    if (grad_densities_dev) return RF_ERR_UNSUPPORTED;  // (the mirror write-out exists for the 4 x 8 x 8 pass only)
     if (parts > 1) {  // several workgroups per brick (rf_brick_accumulate_adam_split)
       if (!one_round) return RF_ERR_UNSUPPORTED;
       if (parts > kMaxListsPerKind || !scratch_dev) return parts > kMaxListsPerKind ? RF_ERR_BAD_SHAPE : RF_ERR_NULL_POINTER;
@@ -4168,6 +4210,13 @@ int rf_brick_accumulate_adam(const RFGrid* grid, int32_t brick_size, const RFBri
                              const RFAdamState* adam, void* stream) {
   if (!adam) return RF_ERR_NULL_POINTER;
   return brick_accumulate_impl(grid, brick_size, lists, num_lists, nullptr, nullptr, 0, adam, 0, 0, stream);
+}
+
+int rf_brick_accumulate_adam_mirror(const RFGrid* grid, int32_t brick_size, const RFBrickList* lists, int32_t num_lists,
+                                    const RFAdamState* adam, float* mirror_densities_dev, float* mirror_features_dev, void* stream) {
+  if (!adam || !mirror_densities_dev || !mirror_features_dev) return RF_ERR_NULL_POINTER;
+  if (brick_size != RF_BRICK_4X8X8) return RF_ERR_UNSUPPORTED;
+  return brick_accumulate_impl(grid, brick_size, lists, num_lists, mirror_densities_dev, mirror_features_dev, 0, adam, 0, 0, stream);
 }
 
 int rf_brick_accumulate_adam_range(const RFGrid* grid, int32_t brick_size, const RFBrickList* lists, int32_t num_lists,

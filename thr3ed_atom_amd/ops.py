@@ -417,7 +417,7 @@ def brick_accumulate_raw(grid: VoxelGrid, brick_size: int, lists, grad_first: Te
 
 
 def brick_accumulate_adam_raw(grid: VoxelGrid, brick_size: int, lists, exp_avg, exp_avg_sq, lr: float, beta1: float, beta2: float,
-                              eps: float, step: int, brick_range=None, rf_grid=None, params=None, split=None) -> None:
+                              eps: float, step: int, brick_range=None, rf_grid=None, params=None, split=None, mirror=None) -> None:
     """Enqueue rf_brick_accumulate_adam: the brick pass over ``lists`` (as in ``brick_accumulate_raw``; all renders of the
     iteration -- of all ranks, under data parallelism) with the Adam update of the grid's own tensors applied in the flush.
     ``exp_avg`` / ``exp_avg_sq`` are pairs of tensors shaped like ``grid.kernel_tensors()`` (second entry None when the grid has no
@@ -425,7 +425,9 @@ def brick_accumulate_adam_raw(grid: VoxelGrid, brick_size: int, lists, exp_avg, 
     ``lists`` may give its records as an int (a raw device address) instead of a tensor.  ``rf_grid`` / ``params``: update these
     tensors (described by this RFGrid) instead of the grid's own -- the split-layout shadow of a reference-storage grid.
     ``split`` = (parts, scratch): rf_brick_accumulate_adam_split -- ``parts`` workgroups per brick, the lists of each kind dealt out to
-    them, ``scratch`` a zero-initialised uint8 tensor of ``brick_split_scratch_bytes`` bytes (needs ``brick_range``)."""
+    them, ``scratch`` a zero-initialised uint8 tensor of ``brick_split_scratch_bytes`` bytes (needs ``brick_range``).
+    ``mirror`` = (densities [X,Y,Z,1], features [X,Y,Z,F]): rf_brick_accumulate_adam_mirror -- the flush also writes the updated
+    parameters in the reference layout into these tensors (see ``mirror_flush_applies``)."""
     lib = _lib.load()
     # (``_tensors``: no wait for parameters a data-parallel step left in flight -- that step orders its launches against them itself)
     first, second = (grid._tensors() if rf_grid is not None else grid.kernel_tensors()) if params is None else params
@@ -441,7 +443,9 @@ def brick_accumulate_adam_raw(grid: VoxelGrid, brick_size: int, lists, exp_avg, 
     if rf_grid is None:
         rf_grid = grid.to_rf_grid()
     with _span(f"brick_accumulate_adam[{'diffuse' if lists[0][2] or grid.sh_degree == 0 else 'sh' + str(grid.sh_degree)}]", dev):
-        if split is not None and int(split[0]) > 1:
+        if mirror is not None:
+            rc = lib.rf_brick_accumulate_adam_mirror(C.byref(rf_grid), int(brick_size), arr, len(lists), C.byref(st), mirror[0].data_ptr(), mirror[1].data_ptr(), _stream(dev))
+        elif split is not None and int(split[0]) > 1:
             rc = lib.rf_brick_accumulate_adam_split(C.byref(rf_grid), int(brick_size), arr, len(lists), C.byref(st), int(brick_range[0]), int(brick_range[1]),
                                                     int(split[0]), split[1].data_ptr(), int(split[1].numel()), _stream(dev))
         elif brick_range is None:
@@ -449,6 +453,14 @@ def brick_accumulate_adam_raw(grid: VoxelGrid, brick_size: int, lists, exp_avg, 
         else:
             rc = lib.rf_brick_accumulate_adam_range(C.byref(rf_grid), int(brick_size), arr, len(lists), C.byref(st), int(brick_range[0]), int(brick_range[1]), _stream(dev))
     _lib.check(rc, "rf_brick_accumulate_adam")
+
+
+def mirror_flush_applies(grid, brick_size: int, densities: Tensor, features: Tensor) -> bool:
+    """True when rf_brick_accumulate_adam_mirror takes this grid: 4 x 8 x 8 bricks, dims multiples of the brick, the two reference-layout
+    tensors contiguous float32 at 16-byte aligned addresses."""
+    X, Y, Z = grid.grid_dims
+    return (int(brick_size) == BRICK_4X8X8 and X % 4 == 0 and Y % 8 == 0 and Z % 8 == 0 and features is not None
+            and all(t.is_contiguous() and t.dtype == torch.float32 and t.data_ptr() % 16 == 0 for t in (densities, features)))
 
 
 def brick_split_scratch(grid: VoxelGrid, num_bricks: int, parts: int) -> Tensor:

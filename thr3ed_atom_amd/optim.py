@@ -25,6 +25,11 @@ from .ops import adam_step_hip
 from .voxels import VoxelGrid
 
 
+# deferred optimizer steps on a reference-storage grid: let the brick flush write the Parameters' own layout beside the split shadow
+# ($RF_MIRROR_FLUSH=0: update the shadow only and re-lay it out into the Parameters with a launch of its own -- A/B runs)
+MIRROR_FLUSH = os.environ.get("RF_MIRROR_FLUSH", "1") != "0"
+
+
 class FlatGrid:
     def __init__(self, grid: VoxelGrid, deferred: bool = False):
         """``deferred`` (opt-in; reference storage, SH degree 0 or 2, single process): the autograd op does not sum its gradient
@@ -176,7 +181,7 @@ class FusedAdam:
 
     def _deferred_step(self) -> None:
         """All record lists of the iteration -> ONE merged brick pass with Adam in its flush on the split shadow -> Parameters."""
-        from .ops import brick_accumulate_adam_raw
+        from .ops import brick_accumulate_adam_raw, mirror_flush_applies
 
         flat, grid = self.flat, self.flat.grid
         if not flat.pending:
@@ -190,9 +195,13 @@ class FusedAdam:
             z = lambda t: None if t is None else torch.zeros_like(t)
             self._split_moments = ((z(sh["base"]), z(sh["rest"])), (z(sh["base"]), z(sh["rest"])))
         m, v = self._split_moments
+        # the flush updates the shadow AND writes the Parameters' own (reference) layout where it can (rf_brick_accumulate_adam_mirror);
+        # else one re-layout launch copies the shadow into the Parameters afterwards (81 us at 128^3 / SH degree 2)
+        d, f = grid.kernel_tensors()
+        mirror = (d.data, f.data) if (MIRROR_FLUSH and mirror_flush_applies(grid, flat.brick_size, d.data, f.data)) else None
         brick_accumulate_adam_raw(grid, flat.brick_size, lists, m, v, self.lr, self.betas[0], self.betas[1], self.eps, self.step_count,
-                                  rf_grid=rf_grid, params=(sh["base"], sh["rest"]))
-        grid.adopt_shadow()
+                                  rf_grid=rf_grid, params=(sh["base"], sh["rest"]), mirror=mirror)
+        grid.adopt_shadow(relayout=mirror is None)
         flat.pending = []
 
 

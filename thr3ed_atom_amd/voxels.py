@@ -271,13 +271,15 @@ class KernelGridInterface:
                 sh["stamp"] = stamp
         return sh, g
 
-    def adopt_shadow(self) -> None:
+    def adopt_shadow(self, relayout: bool = True) -> None:
         """The split shadow is the newer copy (an optimizer updated it in place): re-layout it into the Parameters (raw-pointer
-        write: their version counters do not move) and mark the two as in sync."""
+        write: their version counters do not move) and mark the two as in sync.  ``relayout=False``: the optimizer pass has written
+        the Parameters itself (rf_brick_accumulate_adam_mirror) -- only the bookkeeping is left."""
         d, _ = self.kernel_tensors()
         sh, g = self._shadow(refresh=False)
-        real = self.to_rf_grid()
-        _lib.check(_lib.load().rf_convert_grid(C.byref(g), C.byref(real), torch.cuda.current_stream(d.device).cuda_stream), "rf_convert_grid")
+        if relayout:
+            real = self.to_rf_grid()
+            _lib.check(_lib.load().rf_convert_grid(C.byref(g), C.byref(real), torch.cuda.current_stream(d.device).cuda_stream), "rf_convert_grid")
         self.invalidate_occupancy()  # the densities changed
         sh["stamp"] = self._shadow_stamp()
 
