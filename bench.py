@@ -617,9 +617,9 @@ def main():
     # ---- strict drop-in: reference storage, torch.autograd.Function ops, torch.randperm selection, torch.rand jitter ----
     dropin = None
     if args.dropin_steps > 0 and rank == 0 and world == 1:
-        def dropin_leg(selection):
+        def dropin_leg(selection, jitter="keyed"):
             dgrid = make_grid(dev, G, args.sh_degree, seed=42, storage="reference")
-            dcfg = rf.SHVoxGridRenderConfig(S, bounds, perturb_sampled_points=True, white_bkgd=True, jitter="torch")
+            dcfg = rf.SHVoxGridRenderConfig(S, bounds, perturb_sampled_points=True, white_bkgd=True, jitter=jitter)
             dmodel = rf.VolumetricModel(dgrid, rf.render_sh_voxel_grid, dcfg, device=dev)
             dstep = TrainStepper(dmodel, R, learning_rate=0.03, fused=False, ray_selection=selection, data_parallel=False)
             torch.manual_seed(99)
@@ -638,14 +638,18 @@ def main():
             return dt
 
         dt = dropin_leg("keyed")
-        dt_randperm = dropin_leg("randperm")
+        dt_rand = dropin_leg("keyed", jitter="torch")
+        dt_randperm = dropin_leg("randperm", jitter="torch")
         dropin = {
-            "workload": "the same iteration the way a reference user gets it: VoxelGrid in the reference's two tensors (forward passes gather from its split-layout shadow, "
-            "gradients in the Parameters' layout), render_sh_voxel_grid as a torch.autograd.Function (rf_render_forward / binned adjoint), torch.rand jitter, L1 via autograd, "
-            "fused Adam; the batch = distinct uniformly random pixels by the keyed bijection (the law of torch.randperm(P)[:R] without sorting 5.12 M keys)",
+            "workload": "the same iteration the way a reference user gets it: VoxelGrid in the reference's two tensors (its nn.Parameters; forward passes gather from a split-layout "
+            "shadow), render_sh_voxel_grid as a torch.autograd.Function per render (rf_render_forward / binned adjoint as record lists), SHVoxGridRenderConfig defaults (stratified "
+            "jitter drawn inside the kernel from a per-call key: the law of torch.rand(N, S) without the tensor), the trainer's L1 + MSE lines as one autograd.Function launch per render, "
+            "FusedAdam.step = ONE brick pass with Adam in its flush that writes the shadow AND the Parameters' own layout; the batch = distinct uniformly random pixels by the keyed "
+            "bijection (the law of torch.randperm(P)[:R] without sorting 5.12 M keys)",
             "ms_per_step": dt * 1e3,
             "ray_samples_per_s": 2 * R * S / dt,
-            "ms_per_step_with_torch_randperm_selection": dt_randperm * 1e3,
+            "ms_per_step_with_torch_rand_jitter": dt_rand * 1e3,
+            "ms_per_step_with_torch_rand_jitter_and_torch_randperm_selection": dt_randperm * 1e3,
             "steps": args.dropin_steps,
             "warmup": 5,
         }
