@@ -157,6 +157,14 @@ struct GradArgs {
 
 constexpr short kNoBrick = -1;  // sorts in front of every (brick, flags) key
 
+#ifdef RF_EXP_TICKET
+// Development build (tools/exp_ticket.sh): the forward pass's per-key counter atomic made RETURNING, its result --
+// the sample's rank inside its key class -- parked per cached sample; the adjoint's record position is then offsets[key] + rank, a plain
+// load, and its returning cursor atomic disappears.  The rank buffers ([2][N * S] ints, specular / diffuse) are handed over through
+// rf_exp_set_ticket_buffers so that the experiment needs no ABI change.
+__device__ int* g_exp_ticket[2];
+#endif
+
 
 // 16-byte load/store at 4-byte alignment (a corner's 27 features start at a multiple of 108 B)
 struct __attribute__((packed, aligned(4))) f4u {
@@ -1115,7 +1123,14 @@ __device__ __forceinline__ void render_forward_ray(const GridArgs& g, const RayA
           out.tcache[idx] = T;
       }
       my_cmask = (lane == (chunk & (kWave - 1))) ? mask : my_cmask;
+#ifdef RF_EXP_TICKET
+      if (out.hist) {
+        const int rank = add_key_runs<true>(out.hist, need ? brick_key(sm.cell.i0, g, out.brick_shift, out.nby, out.nbz) : -1, lane);
+        if (need) g_exp_ticket[DIFFUSE ? 1 : 0][ray * (long long)r.S + chunk * kWave + slot] = rank;
+      }
+#else
       if (out.hist) add_key_runs<false>(out.hist, need ? brick_key(sm.cell.i0, g, out.brick_shift, out.nby, out.nbz) : -1, lane);
+#endif
     }
     wave_lds_fence();
     if (T_carry == 0.0f) break;  // every later weight is exactly 0
@@ -1526,6 +1541,9 @@ __device__ __forceinline__ void render_emit_direct_ray(const GridArgs& g, const 
   for (int c0 = nchunks - 1; c0 >= 0; c0 -= G) {
     float4 cv[G];
     float Tc[G], zz[G], zn[G];
+#ifdef RF_EXP_TICKET
+    int tk[G];
+#endif
     unsigned long long cm[G];
     // -- A0: the masks of the cached samples of chunks c0, c0 - 1, ...: a chunk without any is skipped
 #pragma unroll
@@ -1552,6 +1570,9 @@ __device__ __forceinline__ void render_emit_direct_ray(const GridArgs& g, const 
       const long long idx = cached_slot(ray, r.S, chunk, cm[u], lane);
       cv[u] = load_f4<RF_NT_CACHE_LOAD>(reinterpret_cast<const float4*>(fwd.cache) + idx);
       Tc[u] = RF_NT_CACHE_LOAD ? __builtin_nontemporal_load(fwd.tcache + idx) : fwd.tcache[idx];
+#ifdef RF_EXP_TICKET
+      tk[u] = g_exp_ticket[DIFFUSE ? 1 : 0][idx];
+#endif
       zq[u] = z_requests(r, s);
     }
 #pragma unroll
@@ -1580,6 +1601,10 @@ __device__ __forceinline__ void render_emit_direct_ray(const GridArgs& g, const 
       ix[u][2] = sm.cell.idx[2];
       counted[u] = (cm[u] >> lane) & 1ull;
       const int key = counted[u] ? brick_key(sm.cell.i0, g, gr.brick_shift, gr.nby, gr.nbz) : -1;
+#ifdef RF_EXP_TICKET
+      base_[u] = gr.cursor[max(key, 0)];  // (never advanced in this build: the start of the key class)
+      continue;
+#endif
       // one atomic per RUN of equal keys (add_key_runs, split: the returned base is only combined in phase B)
       const bool active = key >= 0;
       const int prev = __shfl_up(key, 1);
@@ -1621,7 +1646,11 @@ __device__ __forceinline__ void render_emit_direct_ray(const GridArgs& g, const 
         g_pre = g_sigma * (1.0f - exp_fast(-sigma));  // softplus'(x) = sigmoid(x) = 1 - exp(-softplus(x))
       else
         g_pre = g_sigma;
+#ifdef RF_EXP_TICKET
+      const int pos = base_[u] + tk[u];
+#else
       const int pos = __shfl(base_[u], hl_[u]) + (lane - hl_[u]);
+#endif
       if (have) {
         // (a counted sample is inside the box; its record is written even when its gradient happens to vanish)
         const float graw[3] = {(w * gC[0]) * (c[0] * (1.0f - c[0])), (w * gC[1]) * (c[1] * (1.0f - c[1])), (w * gC[2]) * (c[2] * (1.0f - c[2]))};
@@ -3740,6 +3769,13 @@ static int brick_geometry(const RFGrid* grid, int brick_size, int* shift, int nb
   return (total * 8 - 1 <= (short_keys ? 0x7fffLL : (1LL << 21) - 1)) ? RF_OK : RF_ERR_UNSUPPORTED;
 }
 
+#ifdef RF_EXP_TICKET
+int rf_exp_set_ticket_buffers(int* specular_dev, int* diffuse_dev) {
+  int* h[2] = {specular_dev, diffuse_dev};
+  return hipMemcpyToSymbol(HIP_SYMBOL(g_exp_ticket), h, sizeof(h)) == hipSuccess ? RF_OK : RF_ERR_LAUNCH;
+}
+#endif
+
 #ifdef RF_EXP_GATHER
 // development builds only (see exp_gather_sorted_kernel)
 int rf_exp_gather_sorted(const RFGrid* grid, const float* records_sorted_dev, const int64_t* offsets_dev, int32_t brick_size, float* out_rgb_dev, void* stream) {
@@ -4394,6 +4430,21 @@ int rf_adam_step(float* param_dev, float* grad_dev, float* exp_avg_dev, float* e
 }
 
 int rf_train_step(const RFGrid* grid, const RFTrainStep* step, void* stream) {
+#ifdef RF_EXP_TICKET
+  {  // (development build: the rank buffers of the experiment, grown on demand)
+    static int* bufs[2] = {nullptr, nullptr};
+    static long long cap = 0;
+    const long long need = step ? (long long)step->num_rays * step->num_samples : 0;
+    if (need > cap) {
+      for (int i = 0; i < 2; ++i) {
+        if (bufs[i]) (void)hipFree(bufs[i]);
+        if (hipMalloc(&bufs[i], (size_t)need * sizeof(int)) != hipSuccess) return RF_ERR_LAUNCH;
+      }
+      cap = need;
+      if (rf_exp_set_ticket_buffers(bufs[0], bufs[1]) != RF_OK) return RF_ERR_LAUNCH;
+    }
+  }
+#endif
   if (!grid || !step) return RF_ERR_NULL_POINTER;
   if (step->num_rays == 0) return RF_OK;
   if (!step->origins_dev || !step->directions_dev || !step->pixels_dev || !step->loss_sums_dev) return RF_ERR_NULL_POINTER;
