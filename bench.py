@@ -65,9 +65,9 @@ def host_cpu_quota() -> int:
 EXIT_FALLBACK = 75  # a worker's "this configuration failed its validation on some rank; all ranks agreed; try the next one"
 
 ATTEMPTS = [
-    ("as asked", {}, []),
+    ("as asked: owner-computes, pipelined", {"RF_OWNER_PIPELINED": "1"}, []),
     ("owner-computes, conservative (contiguous ownership, no all-gather left in flight, public collectives, one workgroup per brick)",
-     {"RF_OWNER_HALVES": "1", "RF_OWNER_OVERLAP_PARAMETERS": "0", "RF_DIST_FAST": "0", "RF_OWNER_BRICK_PARTS": "1"}, []),
+     {"RF_OWNER_PIPELINED": "0", "RF_OWNER_HALVES": "1", "RF_OWNER_OVERLAP_PARAMETERS": "0", "RF_DIST_FAST": "0", "RF_OWNER_BRICK_PARTS": "1"}, []),
     ("dense exchange (reduce-scatter -> sharded Adam -> all-gather)", {"RF_DIST_FAST": "0"}, ["--exchange", "dense"]),
 ]
 

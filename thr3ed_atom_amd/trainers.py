@@ -178,6 +178,20 @@ LOSS_RING = 4096  # iterations whose loss sums stay readable (StepStats)
 # owner-computes data parallelism: leave the all-gather of the `rest` parameters in flight across the iteration boundary (RF_OWNER_OVERLAP_PARAMETERS=0
 # makes every iteration wait for it at its end instead)
 OWNER_OVERLAP_PARAMETERS = os.environ.get("RF_OWNER_OVERLAP_PARAMETERS", "1") != "0"
+# The PIPELINED form of the owner-computes step (interleaved halves, all-gathers in flight across the iteration boundary, several
+# workgroups per owned brick, ProcessGroup entry points without wrappers) has run under RCCL with ONE rank only (no multi-GPU box in
+# any round; every multi-rank test goes through gloo, where collectives complete on return).  Until a multi-GPU run has validated it,
+# a multi-rank RCCL group gets the CONSERVATIVE form by default -- one contiguous ownership range per rank, every all-gather waited
+# for at the end of its iteration, one workgroup per brick, torch.distributed's public collectives -- and $RF_OWNER_PIPELINED=1 opts
+# in (bench.py's first, supervised and self-validating attempt does).  Other backends (gloo: the tests) keep the pipelined form.
+OWNER_PIPELINED = os.environ.get("RF_OWNER_PIPELINED")
+
+
+def owner_pipelined() -> bool:
+    if OWNER_PIPELINED is not None:
+        return OWNER_PIPELINED != "0"
+    multi_rank_rccl = torch.distributed.is_available() and torch.distributed.is_initialized() and torch.distributed.get_backend() == "nccl" and torch.distributed.get_world_size() > 1
+    return not multi_rank_rccl
 # owner-computes data parallelism: the x-slabs of bricks are owned in this many interleaved "halves" (1 = one contiguous range per rank):
 # the brick pass of half h + 1 runs while the parameters of half h are all-gathered (TrainStepper._owner_state)
 OWNER_HALVES = int(os.environ.get("RF_OWNER_HALVES", "2"))
@@ -530,7 +544,8 @@ class TrainStepper:
         # order; piece p = h W + r (half h, rank r) = the slabs [p q, (p + 1) q).  Half h of every parameter tensor is one contiguous
         # chunk made of the W ranks' pieces in rank order -- what an in-place all-gather wants -- so the parameters of half 0 travel
         # while the brick pass of half 1 still runs.  H = 1 is the plain contiguous split.
-        H = OWNER_HALVES if (OWNER_HALVES > 1 and nb[0] % (OWNER_HALVES * W) == 0) else 1
+        pipelined = owner_pipelined()
+        H = OWNER_HALVES if (pipelined and OWNER_HALVES > 1 and nb[0] % (OWNER_HALVES * W) == 0) else 1
         q = nb[0] // (H * W)
         assert q >= 1 and q * H * W == nb[0]
         # everything that touches the nodes of piece p is the key range [key(slab p q - 1, f_x = 1), key(slab (p + 1) q, f_x = 0))
@@ -553,7 +568,8 @@ class TrainStepper:
             "recv": [[torch.empty((0, widths[k]), dtype=torch.float32, device=device) for _ in range(H)] for k in range(2)],
             "checked": 0,  # iterations whose replicas have been compared (the first OWNER_CHECK_STEPS of a run)
         }
-        parts = OWNER_BRICK_PARTS if OWNER_BRICK_PARTS > 0 else (2 if W >= 4 else 1)
+        parts = OWNER_BRICK_PARTS if OWNER_BRICK_PARTS > 0 else (2 if (W >= 4 and pipelined) else 1)
+        ow["pipelined"] = pipelined
         ow["parts"] = max(1, min(parts, W, 8))
         # (one scratch for all halves: their brick passes follow one another on the compute stream)
         ow["split"] = (ow["parts"], ops.brick_split_scratch(grid, q * nbyz, ow["parts"])) if ow["parts"] > 1 else None
@@ -582,7 +598,7 @@ class TrainStepper:
         # a 1-rank group (bench.py --dp-style-step, tests) has nothing to exchange: the record exchange and the parameter all-gather
         # are skipped unless RF_OWNER_FORCE_COLLECTIVES asks for the calls themselves to be exercised (tests do)
         collect = W > 1 or bool(os.environ.get("RF_OWNER_FORCE_COLLECTIVES"))
-        fast = collect and rfdist.fast_path() and rfdist.FAST_COLLECTIVES
+        fast = collect and rfdist.fast_path() and rfdist.FAST_COLLECTIVES and ow["pipelined"]
         lib, grid, opt = _lib.load(), self.vol_mod.thre3d_repr, self.optimizer
         main = torch.cuda.current_stream(dev)
         main_ptr = main.cuda_stream
@@ -700,7 +716,7 @@ class TrainStepper:
         tick()  # [4] brick passes + parameter all-gathers issued
         sent += (W - 1) * (self.flat._flat_param.numel() // W) * 4
         if collect:
-            if OWNER_OVERLAP_PARAMETERS:
+            if OWNER_OVERLAP_PARAMETERS and ow["pipelined"]:
                 # left in flight: the next reader of the grid waits for them (VoxelGrid.wait_for_parameters) -- the next iteration
                 # piece by piece: `base` in front of its diffuse chain, `rest` only in front of its specular forward pass
                 for w_ in new_waits:
