@@ -1190,6 +1190,250 @@ __global__ __launch_bounds__(kBlock, RF_FWD_WAVES) void render_forward_pair_kern
   }
 }
 
+// =============================================================================================
+// frame render, ray PACKETS: one wavefront = the 8 x 8 pixel tile of a posed-camera frame, lanes = rays, all of them at the SAME
+// sample index s (VolumetricModel.render, modules/volumetric_model.py:143-172; inference only).
+//
+// The per-ray kernel above walks one ray per wave with lanes = samples: every lane gathers its own 8 corners (8 L1 look-ups per
+// sample for the base records, 48 more per sample that needs its features), and on a coherent frame it is bound by vector-ALU issue
+// (81 % busy) with the L1's line look-up rate as the co-limit -- although the 64 rays of a pixel tile at one
+// sample index sit within ~2.5 voxels of each other and ask for the same few nodes.  Here the wave fetches the NEIGHBOURHOOD once:
+// per step the 64 lanes load one node each of a 4 x 4 x 4-node window (16-byte base record + 96-byte rest record, 7 loads per lane
+// whatever the lanes need) into LDS, and every lane interpolates its own sample from LDS (8 + 48 ds_read_b128).  Compositing is the
+// lane's own sequential recurrence T <- T (1 - alpha) -- torch.cumprod's order (accumulate.py:66-67) -- with no cross-lane scan.
+// The window: origin = per-axis minimum of the lanes' lower nodes, pulled towards an anchor lane so that the anchor is always
+// covered; lanes whose cell does not fit take part in another round with a window of their own (a tile that straddles more
+// than three cells on an axis: fine grids, grazing views, per-ray AABB bounds).  Per-sample arithmetic -- z, point, cell, weights,
+// the density's separately rounded products in ATen's corner order, the fused colour sums in the per-ray kernel's order, alpha,
+// sigmoid -- is the per-ray kernel's, value for value; only the order in which a ray's weighted samples are ADDED differs
+// (sequential here, per-lane partial sums + a butterfly there), so the two kernels agree to summation order, not bit for bit.
+// A pixel's result does not depend on the other pixels of its tile or on how a frame is cut into calls.
+// Split / bricked storage with near addressing, SH degree 2 (REST) or the base record alone (degree 0, render_diffuse).
+// =============================================================================================
+#ifndef RF_TILE_WAVES
+#define RF_TILE_WAVES 4
+#endif
+__device__ __forceinline__ int wave_min_i32(int x) {
+  auto step = [](int v, auto ctrl_tag, auto mask_tag) {
+    constexpr int CTRL = decltype(ctrl_tag)::value, MASK = decltype(mask_tag)::value;
+    return min(v, __builtin_amdgcn_update_dpp(v, v, CTRL, MASK, 0xf, false));
+  };
+  x = step(x, std::integral_constant<int, kDppRowShr1>{}, std::integral_constant<int, 0xf>{});
+  x = step(x, std::integral_constant<int, kDppRowShr2>{}, std::integral_constant<int, 0xf>{});
+  x = step(x, std::integral_constant<int, kDppRowShr4>{}, std::integral_constant<int, 0xf>{});
+  x = step(x, std::integral_constant<int, kDppRowShr8>{}, std::integral_constant<int, 0xf>{});
+  x = step(x, std::integral_constant<int, kDppRowBcast15>{}, std::integral_constant<int, 0xa>{});
+  x = step(x, std::integral_constant<int, kDppRowBcast31>{}, std::integral_constant<int, 0xc>{});
+  return __builtin_amdgcn_readlane(x, kWave - 1);
+}
+
+template <bool REST>
+__global__ __launch_bounds__(kBlock, RF_TILE_WAVES) void render_frame_tile_kernel(GridArgs g, RayArgs r, OutArgs out, uint32_t flags, int row0, int tile_rows,
+                                                                                  int tiles_x) {
+  constexpr int K = 9, KR = 8;
+  __shared__ __attribute__((aligned(16))) float4 s_base[kWavesPerBlock][kWave];
+  __shared__ __attribute__((aligned(16))) float4 s_rest[kWavesPerBlock][REST ? kWave * 6 : 1];
+  const int lane = threadIdx.x & (kWave - 1);
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int tile = (int)blockIdx.x * kWavesPerBlock + wave;
+  const int ty = tile / tiles_x, tx = tile - ty * tiles_x;
+  if (ty >= tile_rows) return;
+  float4* my_base = s_base[wave];
+  float4* my_rest = s_rest[wave];
+
+  // ---- this lane's ray: pixel (i, j), cast_rays fused (utils/misc.py:12-50) -- lanes off the frame or outside the pixel range of
+  // the call compute on a clamped pixel and never write
+  const int i_raw = row0 + ty * 8 + (lane >> 3), j_raw = tx * 8 + (lane & 7);
+  const int i = min(i_raw, r.H - 1), j = min(j_raw, r.W - 1);
+  const long long pidx = (long long)i * r.W + j;
+  const long long ray = pidx - r.ray0;
+  const bool lane_valid = i_raw < r.H && j_raw < r.W && ray >= 0 && ray < r.n;
+  RayState st;
+  {
+    const float R[9] = {r.pose[0], r.pose[1], r.pose[2], r.pose[4], r.pose[5], r.pose[6], r.pose[8], r.pose[9], r.pose[10]};
+    pixel_ray(i, j, r.H, r.W, r.focal, R, st.d);
+    st.o[0] = r.pose[3];
+    st.o[1] = r.pose[7];
+    st.o[2] = r.pose[11];
+    st.jseed = r.jitter ? jitter_ray_seed(r.jkey, pidx) : 0u;
+    st.dnorm = sqrtf((st.d[0] * st.d[0] + st.d[1] * st.d[1]) + st.d[2] * st.d[2]);
+    st.near = r.near;
+    st.far = r.far;
+    if (flags & RF_FLAG_AABB_SAMPLING) {
+      float t0, t1;
+      ray_box(st.o, st.d, g.amin, g.amax, r.near, r.far, t0, t1);
+      st.near = t0;
+      st.far = t1;
+    }
+  }
+  const bool white = flags & RF_FLAG_WHITE_BKGD;
+  const bool use_occ = (flags & RF_FLAG_OCCUPANCY_SKIP) && g.occ != nullptr;
+  float Y[16];
+  if constexpr (REST) sh_basis<K>(st.d[0] / st.dnorm, st.d[1] / st.dnorm, st.d[2] / st.dnorm, Y);  // v = d / |d| (process.py:53)
+  const BoxSpan span = box_span(st, r, g);
+
+  float T = 1.0f;
+  float part_c[3] = {0.f, 0.f, 0.f};
+  float part_acc = 0.f, part_depth = 0.f;
+  float z_cur = 0.0f;
+  bool z_ready = false;
+  const int dims3[3] = {g.X, g.Y, g.Z};
+  const unsigned int dsb = (unsigned int)g.dstride * 4u, fsb = (unsigned int)g.fstride * 4u;
+
+  for (int s = 0; s < r.S; ++s) {
+    // ---- can any ray of the tile be inside the box at this sample index?  (the per-ray kernel's margins: slab interval of the ray,
+    // one stratum of jitter; a sample outside contributes exactly nothing -- sigma = 0, alpha = 0, w = 0, T unchanged)
+    {
+      const float zc = z_uniform(st.near, st.far, r.tvals[s]);
+      const bool maybe = lane_valid && span.hits && !(zc + span.zpad < span.t_in - span.margin || zc - span.zpad > span.t_out + span.margin);
+      if (__ballot(maybe) == 0ull) {
+        z_ready = false;
+        continue;
+      }
+    }
+    if (!z_ready) z_cur = z_of(st, r, ray, s);
+    const float z_next = z_of(st, r, ray, s + 1);
+    const Sample sm = sample_at(st, r, g, s, z_cur, z_next);
+    z_cur = z_next;
+    z_ready = true;
+    bool live = lane_valid && sm.inside;
+    if (use_occ && live) live = cell_occupied(sm.cell, g);
+    float sigma = 0.0f;
+    float raw[3] = {0.f, 0.f, 0.f};
+    bool need = false;
+    if (__ballot(live) != 0ull) {
+      // the lane's cell in (clamped) node coordinates: lower node c0, step to the upper node e (0 where clamping collapses the two),
+      // per-axis weights with out-of-grid nodes forced to 0 -- corners_of's rules
+      int c0[3], e[3];
+      float aw[3][2];
+#pragma unroll
+      for (int a = 0; a < 3; ++a) {
+        const int i0 = sm.cell.i0[a];
+        const bool ok0 = i0 >= 0, ok1 = i0 + 1 < dims3[a];
+        c0[a] = max(i0, 0);
+        e[a] = (ok0 && ok1) ? 1 : 0;
+        aw[a][0] = ok0 ? sm.cell.w0[a] : 0.0f;
+        aw[a][1] = ok1 ? sm.cell.w1[a] : 0.0f;
+      }
+      const float wxy[4] = {aw[0][0] * aw[1][0], aw[0][1] * aw[1][0], aw[0][0] * aw[1][1], aw[0][1] * aw[1][1]};  // [dx + 2 dy]
+      float w[8];
+#pragma unroll
+      for (int k = 0; k < 8; ++k) w[k] = wxy[k & 3] * aw[2][k >> 2];
+      bool pending = live;
+      while (true) {
+        const unsigned long long pm = __ballot(pending);
+        if (pm == 0ull) break;
+        const int anchor = (pm >> 27) & 1ull ? 27 : __builtin_ctzll(pm);  // the tile's centre ray when it is still waiting, else the first one that is
+        int O[3];
+#pragma unroll
+        for (int a = 0; a < 3; ++a) {
+          const int lo = wave_min_i32(pending ? c0[a] : 0x7fffffff);
+          O[a] = max(lo, __builtin_amdgcn_readlane(c0[a], anchor) - 2);
+        }
+        // ---- the 4 x 4 x 4-node window, one node per lane: global -> registers -> LDS
+        {
+          const int nx = min(O[0] + (lane >> 4), g.X - 1), ny = min(O[1] + ((lane >> 2) & 3), g.Y - 1), nz = min(O[2] + (lane & 3), g.Z - 1);
+          const unsigned int lin = node_lin(g, nx, ny, nz);
+          const float4 b = *reinterpret_cast<const float4*>(g.base + (size_t)(g.dens_off + __umul24(lin, dsb)));
+          if constexpr (REST) {
+            const char* rp = g.base + (size_t)(g.feat_off + __umul24(lin, fsb));
+            float4 q[6];
+#pragma unroll
+            for (int t = 0; t < 6; ++t) q[t] = *reinterpret_cast<const float4*>(rp + 16 * t);
+#pragma unroll
+            for (int t = 0; t < 6; ++t) my_rest[lane * 6 + t] = q[t];
+          }
+          my_base[lane] = b;
+        }
+        wave_lds_fence();
+        const int l0[3] = {c0[0] - O[0], c0[1] - O[1], c0[2] - O[2]};
+        // (O is the minimum over the pending lanes unless the anchor pulled it up: then the lanes below it wait for another round)
+        const bool covered = pending && l0[0] >= 0 && l0[1] >= 0 && l0[2] >= 0 && l0[0] + e[0] <= 3 && l0[1] + e[1] <= 3 && l0[2] + e[2] <= 3;
+        if (covered) {
+          const int n0 = (l0[0] * 4 + l0[1]) * 4 + l0[2];
+          const int ex = e[0] * 16, ey = e[1] * 4, ez = e[2];
+          int nk[8];
+#pragma unroll
+          for (int k = 0; k < 8; ++k) nk[k] = n0 + ((k & 1) ? ex : 0) + ((k & 2) ? ey : 0) + ((k & 4) ? ez : 0);
+          // density in the reference's operation order (separately rounded products, ATen's corner order); degree-0 colour fused
+          float acc = 0.0f, cb = 0.0f;
+          vf2 crg = {0.f, 0.f};
+#pragma unroll
+          for (int k = 0; k < 8; ++k) {
+            const float4 t = my_base[nk[k]];
+            float v = t.x * g.rho;
+            if (g.mode == RF_DENSITY_ABS) v = fabsf(v);
+            acc = acc + v * w[k];
+            const vf2 rg = {t.y, t.z}, wk = {w[k], w[k]};
+            crg = __builtin_elementwise_fma(rg, wk, crg);
+            cb = __builtin_fmaf(t.w, w[k], cb);
+          }
+          sigma = density_post(acc, g.mode);
+          raw[0] = kC0 * crg.x;
+          raw[1] = kC0 * crg.y;
+          raw[2] = kC0 * cb;
+          need = (T != 0.0f) && !(g.mode == RF_DENSITY_RELU && sigma == 0.0f);
+          if constexpr (REST) {
+            if (need) {
+              // rest coefficients: element c * 8 + (k - 1), each summed over the corners with fused multiply-adds in corner order,
+              // then basis * sum and the per-ray kernel's grouping: ((p1 + p2) + (p3 + p4)) + ((p5 + p6) + (p7 + p8)) per colour
+              vf2 a2[12];
+#pragma unroll
+              for (int t = 0; t < 12; ++t) a2[t] = vf2{0.f, 0.f};
+#pragma unroll
+              for (int k = 0; k < 8; ++k) {
+                const vf2 wk = {w[k], w[k]};
+#pragma unroll
+                for (int t = 0; t < 6; ++t) {
+                  const float4 v = my_rest[nk[k] * 6 + t];
+                  a2[2 * t] = __builtin_elementwise_fma(vf2{v.x, v.y}, wk, a2[2 * t]);
+                  a2[2 * t + 1] = __builtin_elementwise_fma(vf2{v.z, v.w}, wk, a2[2 * t + 1]);
+                }
+              }
+#pragma unroll
+              for (int c = 0; c < 3; ++c) {
+                float p[KR];
+#pragma unroll
+                for (int jj = 0; jj < KR; ++jj) {
+                  const int el = c * KR + jj;
+                  const float av = (el & 1) ? a2[el >> 1].y : a2[el >> 1].x;
+                  p[jj] = Y[1 + jj] * av;
+                }
+                const float d0 = (p[0] + p[1]) + (p[2] + p[3]), d1 = (p[4] + p[5]) + (p[6] + p[7]);
+                raw[c] = raw[c] + (d1 + d0);
+              }
+            }
+          }
+        }
+        wave_lds_fence();  // (the next round overwrites the window)
+        pending = pending && !covered;
+      }
+    }
+    // ---- compositing, this ray's own recurrence (accumulate.py:63-88)
+    const float alpha = 1.0f - exp_fast(-(sigma * sm.delta));
+    const float wgt = alpha * T;
+    if (need) {
+      part_c[0] += wgt * sigmoidf_(raw[0]);
+      part_c[1] += wgt * sigmoidf_(raw[1]);
+      part_c[2] += wgt * sigmoidf_(raw[2]);
+    }
+    part_acc += wgt;
+    part_depth += wgt * sm.z;
+    T = T * (1.0f - alpha);
+    if (__ballot(lane_valid && T != 0.0f) == 0ull) break;  // every later weight of every ray of the tile is exactly 0
+  }
+  if (lane_valid) {
+    const float bg = white ? (1.0f - part_acc) : 0.0f;
+    out.colour[ray * 3 + 0] = white ? part_c[0] + bg : part_c[0];
+    out.colour[ray * 3 + 1] = white ? part_c[1] + bg : part_c[1];
+    out.colour[ray * 3 + 2] = white ? part_c[2] + bg : part_c[2];
+    out.depth[ray] = part_depth;
+    out.acc[ray] = part_acc;
+    const float q = part_depth / part_acc;  // 0/0 = NaN propagates like torch.maximum (accumulate.py:85-88)
+    out.disparity[ray] = 1.0f / ((q != q) ? q : fmaxf(kZeroPlus, q));
+  }
+}
+
 // The cached samples of a chunk (forward pass, SAVE): lane l of the adjoint handles sample 64 c + l like the forward pass did; its
 // cache entry, if bit l of the chunk's mask is set, is entry rank(l) = popcount(mask below l) of the chunk's slots.  Lanes without
 // an entry load entry 0 of the chunk (a line the wave touches anyway; a load under a lane condition would be followed by a
@@ -3819,6 +4063,37 @@ int rf_render_forward(const RFGrid* grid, const RFRayBatch* rays, uint32_t flags
   hipStream_t st = (hipStream_t)stream;
   const bool diffuse = flags & RF_FLAG_RENDER_DIFFUSE;
   const int K = grid->num_features / 3;
+  // frames of a posed camera (rays generated in-kernel, inference only): ray packets -- one wave per 8 x 8 pixel tile
+  // (render_frame_tile_kernel).  $RF_FRAME_TILES=0: the per-ray kernel for these calls too (A/B runs, tests).
+  if (rays->camera && !save && g.layout == RF_LAYOUT_SPLIT && g.near32 && (K == 9 || K == 1) && g.Z >= 4 && g.Y >= 4 && g.X >= 4) {
+    // ... where a tile's rays stay within ~2 voxels of each other at the volume's centre (8 pixels x distance / focal length against
+    // the smallest voxel edge): beyond that the 4 x 4 x 4-node window has to be moved several times per step and the per-ray
+    // kernel wins (measured: 800 x 800 at 128^3, footprint 1.3 voxels: 2.0 against 2.8 ms; at 256^3, 2.6 voxels: 8.7 against
+    // 2.9 ms without the occupancy mask, 1.97 against 2.05 with it).  $RF_FRAME_TILES = 1 / 0 forces / forbids the tile kernel.
+    const char* tiles_env = getenv("RF_FRAME_TILES");
+    bool tiles = tiles_env ? atoi(tiles_env) != 0 : false;
+    if (!tiles_env) {
+      float dist2 = 0.0f, vmin = 1e30f;
+      for (int a = 0; a < 3; ++a) {
+        const float c = 0.5f * (g.amin[a] + g.amax[a]) - rays->camera->pose[4 * a + 3];
+        dist2 += c * c;
+        const int dim = a == 0 ? g.X : (a == 1 ? g.Y : g.Z);
+        vmin = fminf(vmin, (g.amax[a] - g.amin[a]) / (float)dim);
+      }
+      tiles = 8.0f * sqrtf(dist2) / rays->camera->focal <= 2.0f * vmin;
+    }
+    if (tiles) {
+      const int W = rays->camera->width;
+      const int row0 = (int)(rays->first_ray / W), row1 = (int)((rays->first_ray + rays->num_rays - 1) / W);
+      const int tile_rows = (row1 - row0) / 8 + 1, tiles_x = (W + 7) / 8;
+      const unsigned tblocks = (unsigned)(((long long)tile_rows * tiles_x + kWavesPerBlock - 1) / kWavesPerBlock);
+      if (K == 9 && !diffuse)
+        hipLaunchKernelGGL((render_frame_tile_kernel<true>), dim3(tblocks), dim3(kBlock), 0, st, g, r, o, flags, row0, tile_rows, tiles_x);
+      else
+        hipLaunchKernelGGL((render_frame_tile_kernel<false>), dim3(tblocks), dim3(kBlock), 0, st, g, r, o, flags, row0, tile_rows, tiles_x);
+      return launch_status();
+    }
+  }
   if (diffuse || K == 1)
     launch_forward<1, true>(save, blocks, st, g, r, o, flags);
   else if (K == 4)
