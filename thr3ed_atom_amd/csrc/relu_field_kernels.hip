@@ -1227,49 +1227,184 @@ __device__ __forceinline__ int wave_min_i32(int x) {
   return __builtin_amdgcn_readlane(x, kWave - 1);
 }
 
+// a lane's cell in (clamped) node coordinates -- corners_of's rules: lower node c0, step e to the upper node (0 where clamping
+// collapses the two), the 8 trilinear weights with out-of-grid nodes forced to 0
+struct TileCell {
+  int c0[3], e[3];
+  float w[8];
+};
+__device__ __forceinline__ TileCell tile_cell(const Cell& c, const GridArgs& g) {
+  const int dims3[3] = {g.X, g.Y, g.Z};
+  TileCell t;
+  float aw[3][2];
+#pragma unroll
+  for (int a = 0; a < 3; ++a) {
+    const int i0 = c.i0[a];
+    const bool ok0 = i0 >= 0, ok1 = i0 + 1 < dims3[a];
+    t.c0[a] = max(i0, 0);
+    t.e[a] = (ok0 && ok1) ? 1 : 0;
+    aw[a][0] = ok0 ? c.w0[a] : 0.0f;
+    aw[a][1] = ok1 ? c.w1[a] : 0.0f;
+  }
+  const float wxy[4] = {aw[0][0] * aw[1][0], aw[0][1] * aw[1][0], aw[0][0] * aw[1][1], aw[0][1] * aw[1][1]};  // [dx + 2 dy]
+#pragma unroll
+  for (int k = 0; k < 8; ++k) t.w[k] = wxy[k & 3] * aw[2][k >> 2];
+  return t;
+}
+
+// origin of the 4 x 4 x 4-node window for the lanes that still wait: the per-axis minimum of their lower nodes, pulled up towards an
+// anchor lane (the tile's centre ray while it waits, else the first waiting one) so that the anchor's cell always fits
+__device__ __forceinline__ void tile_window_origin(bool pending, unsigned long long pm, const int c0[3], int O[3]) {
+  const int anchor = ((pm >> 27) & 1ull) ? 27 : __builtin_ctzll(pm);
+#pragma unroll
+  for (int a = 0; a < 3; ++a) {
+    const int lo = wave_min_i32(pending ? c0[a] : 0x7fffffff);
+    O[a] = max(lo, __builtin_amdgcn_readlane(c0[a], anchor) - 2);
+  }
+}
+
+// the window in registers, one node per lane (node O + (lane >> 4, (lane >> 2) & 3, lane & 3), clamped into the grid).  (Named
+// members filled in place, no arrays, no struct copies: the compiler keeps an aggregate that is assigned under a condition in scratch
+// memory.)
+struct TileWindow {
+  vf4 b, q0, q1, q2, q3, q4, q5;  // (native vectors: HIP's float4 is a class with a union inside, which kept these in scratch memory)
+};
+__device__ __forceinline__ unsigned int tile_window_node(const GridArgs& g, const int O[3], int lane) {
+  const int nx = min(O[0] + (lane >> 4), g.X - 1), ny = min(O[1] + ((lane >> 2) & 3), g.Y - 1), nz = min(O[2] + (lane & 3), g.Z - 1);
+  return node_lin(g, nx, ny, nz);
+}
+__device__ __forceinline__ void tile_window_load_base(TileWindow& wdw, const GridArgs& g, unsigned int lin) {
+  wdw.b = *reinterpret_cast<const vf4*>(g.base + (size_t)(g.dens_off + __umul24(lin, (unsigned int)g.dstride * 4u)));
+}
+__device__ __forceinline__ void tile_window_load_rest(TileWindow& wdw, const GridArgs& g, unsigned int lin) {
+  const char* rp = g.base + (size_t)(g.feat_off + __umul24(lin, (unsigned int)g.fstride * 4u));
+  wdw.q0 = *reinterpret_cast<const vf4*>(rp);
+  wdw.q1 = *reinterpret_cast<const vf4*>(rp + 16);
+  wdw.q2 = *reinterpret_cast<const vf4*>(rp + 32);
+  wdw.q3 = *reinterpret_cast<const vf4*>(rp + 48);
+  wdw.q4 = *reinterpret_cast<const vf4*>(rp + 64);
+  wdw.q5 = *reinterpret_cast<const vf4*>(rp + 80);
+}
+__device__ __forceinline__ void tile_window_store_rest(const TileWindow& wdw, vf4* my_rest, int lane) {
+  vf4* d = my_rest + lane * 6;
+  d[0] = wdw.q0;
+  d[1] = wdw.q1;
+  d[2] = wdw.q2;
+  d[3] = wdw.q3;
+  d[4] = wdw.q4;
+  d[5] = wdw.q5;
+}
+
+// the lanes whose cell lies inside the window interpolate their sample from LDS -- first the base record (density, degree-0 colour);
+// returns whether this lane was one of them, and in `nk` the window slots of its 8 corners
+__device__ __forceinline__ bool tile_interpolate_base(bool pending, const TileCell& tc, const int O[3], const vf4* my_base, const GridArgs& g, float T, int nk[8],
+                                                      float& sigma, float raw[3], bool& need) {
+  const int l0[3] = {tc.c0[0] - O[0], tc.c0[1] - O[1], tc.c0[2] - O[2]};
+  // (O is the minimum over the waiting lanes unless the anchor pulled it up: then the lanes below it wait for another round)
+  const bool covered = pending && l0[0] >= 0 && l0[1] >= 0 && l0[2] >= 0 && l0[0] + tc.e[0] <= 3 && l0[1] + tc.e[1] <= 3 && l0[2] + tc.e[2] <= 3;
+  const int n0 = (l0[0] * 4 + l0[1]) * 4 + l0[2];
+  const int ex = tc.e[0] * 16, ey = tc.e[1] * 4, ez = tc.e[2];
+#pragma unroll
+  for (int k = 0; k < 8; ++k) nk[k] = n0 + ((k & 1) ? ex : 0) + ((k & 2) ? ey : 0) + ((k & 4) ? ez : 0);
+  if (covered) {
+    // density in the reference's operation order (separately rounded products, ATen's corner order); degree-0 colour fused
+    float acc = 0.0f, cb = 0.0f;
+    vf2 crg = {0.f, 0.f};
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      const vf4 t = my_base[nk[k]];
+      float v = t[0] * g.rho;
+      if (g.mode == RF_DENSITY_ABS) v = fabsf(v);
+      acc = acc + v * tc.w[k];
+      const vf2 rg = {t[1], t[2]}, wk = {tc.w[k], tc.w[k]};
+      crg = __builtin_elementwise_fma(rg, wk, crg);
+      cb = __builtin_fmaf(t[3], tc.w[k], cb);
+    }
+    sigma = density_post(acc, g.mode);
+    raw[0] = kC0 * crg.x;
+    raw[1] = kC0 * crg.y;
+    raw[2] = kC0 * cb;
+    need = (T != 0.0f) && !(g.mode == RF_DENSITY_RELU && sigma == 0.0f);
+  }
+  return covered;
+}
+// ... then, for the lanes that need their colour, the 24 rest coefficients: element c * 8 + (k - 1), each summed over the corners with
+// fused multiply-adds in corner order, then basis * sum and the per-ray kernel's grouping ((p1 + p2) + (p3 + p4)) + ((p5 + p6) + (p7 + p8))
+__device__ __forceinline__ void tile_interpolate_rest(const TileCell& tc, const int nk[8], const vf4* my_rest, const float Y[16], float raw[3]) {
+  constexpr int KR = 8;
+  vf2 a2[12];
+#pragma unroll
+  for (int t = 0; t < 12; ++t) a2[t] = vf2{0.f, 0.f};
+#pragma unroll
+  for (int k = 0; k < 8; ++k) {
+    const vf2 wk = {tc.w[k], tc.w[k]};
+#pragma unroll
+    for (int t = 0; t < 6; ++t) {
+      const vf4 v = my_rest[nk[k] * 6 + t];
+      a2[2 * t] = __builtin_elementwise_fma(vf2{v[0], v[1]}, wk, a2[2 * t]);
+      a2[2 * t + 1] = __builtin_elementwise_fma(vf2{v[2], v[3]}, wk, a2[2 * t + 1]);
+    }
+  }
+#pragma unroll
+  for (int c = 0; c < 3; ++c) {
+    float p[KR];
+#pragma unroll
+    for (int jj = 0; jj < KR; ++jj) {
+      const int el = c * KR + jj;
+      const float av = (el & 1) ? a2[el >> 1].y : a2[el >> 1].x;
+      p[jj] = Y[1 + jj] * av;
+    }
+    const float d0 = (p[0] + p[1]) + (p[2] + p[3]), d1 = (p[4] + p[5]) + (p[6] + p[7]);
+    raw[c] = raw[c] + (d1 + d0);
+  }
+}
+
+// this lane's ray of the tile: pixel (i, j), cast_rays fused (utils/misc.py:12-50) -- lanes off the frame or outside the pixel
+// range of the call compute on a clamped pixel and never write
+__device__ __forceinline__ RayState tile_ray(const GridArgs& g, const RayArgs& r, uint32_t flags, int i, int j) {
+  RayState st;
+  const float R[9] = {r.pose[0], r.pose[1], r.pose[2], r.pose[4], r.pose[5], r.pose[6], r.pose[8], r.pose[9], r.pose[10]};
+  pixel_ray(i, j, r.H, r.W, r.focal, R, st.d);
+  st.o[0] = r.pose[3];
+  st.o[1] = r.pose[7];
+  st.o[2] = r.pose[11];
+  st.jseed = r.jitter ? jitter_ray_seed(r.jkey, (long long)i * r.W + j) : 0u;
+  st.dnorm = sqrtf((st.d[0] * st.d[0] + st.d[1] * st.d[1]) + st.d[2] * st.d[2]);
+  st.near = r.near;
+  st.far = r.far;
+  if (flags & RF_FLAG_AABB_SAMPLING) {
+    float t0, t1;
+    ray_box(st.o, st.d, g.amin, g.amax, r.near, r.far, t0, t1);
+    st.near = t0;
+    st.far = t1;
+  }
+  return st;
+}
+
+// (A variant pipelined over the sample index -- the window of sample s + 1 requested into registers before sample s is interpolated, two
+// waves per SIMD with up to 256 registers each -- measured SLOWER: 2.54 against 2.01 ms per 800 x 800 x 256 frame; at four waves per SIMD it
+// spills 176 registers.  Four resident waves hide the window's round trip better than one wave's own prefetch.)
 template <bool REST>
-__global__ __launch_bounds__(kBlock, RF_TILE_WAVES) void render_frame_tile_kernel(GridArgs g, RayArgs r, OutArgs out, uint32_t flags, int row0, int tile_rows,
-                                                                                  int tiles_x) {
-  constexpr int K = 9, KR = 8;
-  __shared__ __attribute__((aligned(16))) float4 s_base[kWavesPerBlock][kWave];
-  __shared__ __attribute__((aligned(16))) float4 s_rest[kWavesPerBlock][REST ? kWave * 6 : 1];
+__global__ __launch_bounds__(kBlock, RF_TILE_WAVES) void render_frame_tile_kernel(GridArgs g, RayArgs r, OutArgs out, uint32_t flags, int row0, int tile_rows, int tiles_x) {
+  __shared__ __attribute__((aligned(16))) vf4 s_base[kWavesPerBlock][kWave];
+  __shared__ __attribute__((aligned(16))) vf4 s_rest[kWavesPerBlock][REST ? kWave * 6 : 1];
   const int lane = threadIdx.x & (kWave - 1);
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int tile = (int)blockIdx.x * kWavesPerBlock + wave;
   const int ty = tile / tiles_x, tx = tile - ty * tiles_x;
   if (ty >= tile_rows) return;
-  float4* my_base = s_base[wave];
-  float4* my_rest = s_rest[wave];
+  vf4* my_base = s_base[wave];
+  vf4* my_rest = s_rest[wave];
 
-  // ---- this lane's ray: pixel (i, j), cast_rays fused (utils/misc.py:12-50) -- lanes off the frame or outside the pixel range of
-  // the call compute on a clamped pixel and never write
   const int i_raw = row0 + ty * 8 + (lane >> 3), j_raw = tx * 8 + (lane & 7);
   const int i = min(i_raw, r.H - 1), j = min(j_raw, r.W - 1);
-  const long long pidx = (long long)i * r.W + j;
-  const long long ray = pidx - r.ray0;
+  const long long ray = ((long long)i * r.W + j) - r.ray0;
   const bool lane_valid = i_raw < r.H && j_raw < r.W && ray >= 0 && ray < r.n;
-  RayState st;
-  {
-    const float R[9] = {r.pose[0], r.pose[1], r.pose[2], r.pose[4], r.pose[5], r.pose[6], r.pose[8], r.pose[9], r.pose[10]};
-    pixel_ray(i, j, r.H, r.W, r.focal, R, st.d);
-    st.o[0] = r.pose[3];
-    st.o[1] = r.pose[7];
-    st.o[2] = r.pose[11];
-    st.jseed = r.jitter ? jitter_ray_seed(r.jkey, pidx) : 0u;
-    st.dnorm = sqrtf((st.d[0] * st.d[0] + st.d[1] * st.d[1]) + st.d[2] * st.d[2]);
-    st.near = r.near;
-    st.far = r.far;
-    if (flags & RF_FLAG_AABB_SAMPLING) {
-      float t0, t1;
-      ray_box(st.o, st.d, g.amin, g.amax, r.near, r.far, t0, t1);
-      st.near = t0;
-      st.far = t1;
-    }
-  }
+  const RayState st = tile_ray(g, r, flags, i, j);
   const bool white = flags & RF_FLAG_WHITE_BKGD;
   const bool use_occ = (flags & RF_FLAG_OCCUPANCY_SKIP) && g.occ != nullptr;
   float Y[16];
-  if constexpr (REST) sh_basis<K>(st.d[0] / st.dnorm, st.d[1] / st.dnorm, st.d[2] / st.dnorm, Y);  // v = d / |d| (process.py:53)
+  if constexpr (REST) sh_basis<9>(st.d[0] / st.dnorm, st.d[1] / st.dnorm, st.d[2] / st.dnorm, Y);  // v = d / |d| (process.py:53)
   const BoxSpan span = box_span(st, r, g);
 
   float T = 1.0f;
@@ -1277,8 +1412,7 @@ __global__ __launch_bounds__(kBlock, RF_TILE_WAVES) void render_frame_tile_kerne
   float part_acc = 0.f, part_depth = 0.f;
   float z_cur = 0.0f;
   bool z_ready = false;
-  const int dims3[3] = {g.X, g.Y, g.Z};
-  const unsigned int dsb = (unsigned int)g.dstride * 4u, fsb = (unsigned int)g.fstride * 4u;
+  bool rest_hot = true;  // (wave-uniform) did the previous step with live lanes need colours?
 
   for (int s = 0; s < r.S; ++s) {
     // ---- can any ray of the tile be inside the box at this sample index?  (the per-ray kernel's margins: slab interval of the ray,
@@ -1301,113 +1435,44 @@ __global__ __launch_bounds__(kBlock, RF_TILE_WAVES) void render_frame_tile_kerne
     float sigma = 0.0f;
     float raw[3] = {0.f, 0.f, 0.f};
     bool need = false;
-    if (__ballot(live) != 0ull) {
-      // the lane's cell in (clamped) node coordinates: lower node c0, step to the upper node e (0 where clamping collapses the two),
-      // per-axis weights with out-of-grid nodes forced to 0 -- corners_of's rules
-      int c0[3], e[3];
-      float aw[3][2];
-#pragma unroll
-      for (int a = 0; a < 3; ++a) {
-        const int i0 = sm.cell.i0[a];
-        const bool ok0 = i0 >= 0, ok1 = i0 + 1 < dims3[a];
-        c0[a] = max(i0, 0);
-        e[a] = (ok0 && ok1) ? 1 : 0;
-        aw[a][0] = ok0 ? sm.cell.w0[a] : 0.0f;
-        aw[a][1] = ok1 ? sm.cell.w1[a] : 0.0f;
-      }
-      const float wxy[4] = {aw[0][0] * aw[1][0], aw[0][1] * aw[1][0], aw[0][0] * aw[1][1], aw[0][1] * aw[1][1]};  // [dx + 2 dy]
-      float w[8];
-#pragma unroll
-      for (int k = 0; k < 8; ++k) w[k] = wxy[k & 3] * aw[2][k >> 2];
-      bool pending = live;
-      while (true) {
-        const unsigned long long pm = __ballot(pending);
-        if (pm == 0ull) break;
-        const int anchor = (pm >> 27) & 1ull ? 27 : __builtin_ctzll(pm);  // the tile's centre ray when it is still waiting, else the first one that is
+    bool pending = live;
+    unsigned long long pm = __ballot(pending);
+    if (pm != 0ull) {
+      const TileCell tc = tile_cell(sm.cell, g);
+      bool step_needs_rest = false;
+      do {
         int O[3];
-#pragma unroll
-        for (int a = 0; a < 3; ++a) {
-          const int lo = wave_min_i32(pending ? c0[a] : 0x7fffffff);
-          O[a] = max(lo, __builtin_amdgcn_readlane(c0[a], anchor) - 2);
-        }
-        // ---- the 4 x 4 x 4-node window, one node per lane: global -> registers -> LDS
-        {
-          const int nx = min(O[0] + (lane >> 4), g.X - 1), ny = min(O[1] + ((lane >> 2) & 3), g.Y - 1), nz = min(O[2] + (lane & 3), g.Z - 1);
-          const unsigned int lin = node_lin(g, nx, ny, nz);
-          const float4 b = *reinterpret_cast<const float4*>(g.base + (size_t)(g.dens_off + __umul24(lin, dsb)));
-          if constexpr (REST) {
-            const char* rp = g.base + (size_t)(g.feat_off + __umul24(lin, fsb));
-            float4 q[6];
-#pragma unroll
-            for (int t = 0; t < 6; ++t) q[t] = *reinterpret_cast<const float4*>(rp + 16 * t);
-#pragma unroll
-            for (int t = 0; t < 6; ++t) my_rest[lane * 6 + t] = q[t];
-          }
-          my_base[lane] = b;
-        }
+        tile_window_origin(pending, pm, tc.c0, O);
+        // the 4 x 4 x 4-node window, one node per lane: global -> registers -> LDS.  The 96-byte rest records travel with the base
+        // records when the previous step of this tile needed colours (`rest_hot`: they are needed in contiguous regions), else
+        // only once the interpolated densities say that a lane of this round does -- empty space costs one 16-byte load per lane
+        const unsigned int lin = tile_window_node(g, O, lane);
+        TileWindow wdw;
+        tile_window_load_base(wdw, g, lin);
+        const bool with_rest = REST && rest_hot;  // (wave-uniform)
+        if (with_rest) tile_window_load_rest(wdw, g, lin);
+        my_base[lane] = wdw.b;
+        if (with_rest) tile_window_store_rest(wdw, my_rest, lane);
         wave_lds_fence();
-        const int l0[3] = {c0[0] - O[0], c0[1] - O[1], c0[2] - O[2]};
-        // (O is the minimum over the pending lanes unless the anchor pulled it up: then the lanes below it wait for another round)
-        const bool covered = pending && l0[0] >= 0 && l0[1] >= 0 && l0[2] >= 0 && l0[0] + e[0] <= 3 && l0[1] + e[1] <= 3 && l0[2] + e[2] <= 3;
-        if (covered) {
-          const int n0 = (l0[0] * 4 + l0[1]) * 4 + l0[2];
-          const int ex = e[0] * 16, ey = e[1] * 4, ez = e[2];
-          int nk[8];
-#pragma unroll
-          for (int k = 0; k < 8; ++k) nk[k] = n0 + ((k & 1) ? ex : 0) + ((k & 2) ? ey : 0) + ((k & 4) ? ez : 0);
-          // density in the reference's operation order (separately rounded products, ATen's corner order); degree-0 colour fused
-          float acc = 0.0f, cb = 0.0f;
-          vf2 crg = {0.f, 0.f};
-#pragma unroll
-          for (int k = 0; k < 8; ++k) {
-            const float4 t = my_base[nk[k]];
-            float v = t.x * g.rho;
-            if (g.mode == RF_DENSITY_ABS) v = fabsf(v);
-            acc = acc + v * w[k];
-            const vf2 rg = {t.y, t.z}, wk = {w[k], w[k]};
-            crg = __builtin_elementwise_fma(rg, wk, crg);
-            cb = __builtin_fmaf(t.w, w[k], cb);
-          }
-          sigma = density_post(acc, g.mode);
-          raw[0] = kC0 * crg.x;
-          raw[1] = kC0 * crg.y;
-          raw[2] = kC0 * cb;
-          need = (T != 0.0f) && !(g.mode == RF_DENSITY_RELU && sigma == 0.0f);
-          if constexpr (REST) {
-            if (need) {
-              // rest coefficients: element c * 8 + (k - 1), each summed over the corners with fused multiply-adds in corner order,
-              // then basis * sum and the per-ray kernel's grouping: ((p1 + p2) + (p3 + p4)) + ((p5 + p6) + (p7 + p8)) per colour
-              vf2 a2[12];
-#pragma unroll
-              for (int t = 0; t < 12; ++t) a2[t] = vf2{0.f, 0.f};
-#pragma unroll
-              for (int k = 0; k < 8; ++k) {
-                const vf2 wk = {w[k], w[k]};
-#pragma unroll
-                for (int t = 0; t < 6; ++t) {
-                  const float4 v = my_rest[nk[k] * 6 + t];
-                  a2[2 * t] = __builtin_elementwise_fma(vf2{v.x, v.y}, wk, a2[2 * t]);
-                  a2[2 * t + 1] = __builtin_elementwise_fma(vf2{v.z, v.w}, wk, a2[2 * t + 1]);
-                }
-              }
-#pragma unroll
-              for (int c = 0; c < 3; ++c) {
-                float p[KR];
-#pragma unroll
-                for (int jj = 0; jj < KR; ++jj) {
-                  const int el = c * KR + jj;
-                  const float av = (el & 1) ? a2[el >> 1].y : a2[el >> 1].x;
-                  p[jj] = Y[1 + jj] * av;
-                }
-                const float d0 = (p[0] + p[1]) + (p[2] + p[3]), d1 = (p[4] + p[5]) + (p[6] + p[7]);
-                raw[c] = raw[c] + (d1 + d0);
-              }
+        int nk[8];
+        const bool covered = tile_interpolate_base(pending, tc, O, my_base, g, T, nk, sigma, raw, need);
+        if constexpr (REST) {
+          const bool mine = covered && need;
+          if (__ballot(mine) != 0ull) {
+            step_needs_rest = true;
+            if (!with_rest) {
+              tile_window_load_rest(wdw, g, lin);
+              tile_window_store_rest(wdw, my_rest, lane);
+              wave_lds_fence();
             }
+            if (mine) tile_interpolate_rest(tc, nk, my_rest, Y, raw);
           }
         }
         wave_lds_fence();  // (the next round overwrites the window)
         pending = pending && !covered;
-      }
+        pm = __ballot(pending);
+      } while (pm != 0ull);  // lanes whose cell did not fit take part in another round, with a window of their own
+      rest_hot = step_needs_rest;
     }
     // ---- compositing, this ray's own recurrence (accumulate.py:63-88)
     const float alpha = 1.0f - exp_fast(-(sigma * sm.delta));
@@ -4067,9 +4132,10 @@ int rf_render_forward(const RFGrid* grid, const RFRayBatch* rays, uint32_t flags
   // (render_frame_tile_kernel).  $RF_FRAME_TILES=0: the per-ray kernel for these calls too (A/B runs, tests).
   if (rays->camera && !save && g.layout == RF_LAYOUT_SPLIT && g.near32 && (K == 9 || K == 1) && g.Z >= 4 && g.Y >= 4 && g.X >= 4) {
     // ... where a tile's rays stay within ~2 voxels of each other at the volume's centre (8 pixels x distance / focal length against
-    // the smallest voxel edge): beyond that the 4 x 4 x 4-node window has to be moved several times per step and the per-ray
-    // kernel wins (measured: 800 x 800 at 128^3, footprint 1.3 voxels: 2.0 against 2.8 ms; at 256^3, 2.6 voxels: 8.7 against
-    // 2.9 ms without the occupancy mask, 1.97 against 2.05 with it).  $RF_FRAME_TILES = 1 / 0 forces / forbids the tile kernel.
+    // the smallest voxel edge; 3 voxels with the occupancy mask, whose live lanes are few): beyond that the 4 x 4 x 4-node window has
+    // to be moved several times per step and the per-ray kernel wins.  Measured, 800 x 800: 128^3 / 256 samples (1.3 voxels) 1.78
+    // against 2.80 ms; 256^3 / 512 samples (2.6 voxels) 1.70 against 2.05 ms with the mask, 3.12 against 2.90 ms without.
+    // $RF_FRAME_TILES = 1 / 0 forces / forbids the tile kernel.
     const char* tiles_env = getenv("RF_FRAME_TILES");
     bool tiles = tiles_env ? atoi(tiles_env) != 0 : false;
     if (!tiles_env) {
@@ -4080,7 +4146,7 @@ int rf_render_forward(const RFGrid* grid, const RFRayBatch* rays, uint32_t flags
         const int dim = a == 0 ? g.X : (a == 1 ? g.Y : g.Z);
         vmin = fminf(vmin, (g.amax[a] - g.amin[a]) / (float)dim);
       }
-      tiles = 8.0f * sqrtf(dist2) / rays->camera->focal <= 2.0f * vmin;
+      tiles = 8.0f * sqrtf(dist2) / rays->camera->focal <= (((flags & RF_FLAG_OCCUPANCY_SKIP) && grid->occupancy_dev) ? 3.0f : 2.0f) * vmin;
     }
     if (tiles) {
       const int W = rays->camera->width;
