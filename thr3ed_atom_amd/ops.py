@@ -752,12 +752,13 @@ def l1_loss_grad_hip(colour: Tensor, target: Tensor, sums: Tensor, scale: float 
 
 # zeroed (sum |d|, sum d^2) slots for l1_loss_with_mse: handed out one after the other, the whole ring cleared once per turn -- no
 # torch.zeros launch per loss (a tiny launch still costs ~5 us of GPU time between two 100 us kernels)
-_L1_SUMS_RING: Dict[str, list] = {}
+_L1_SUMS_RING: Dict[Tuple[str, int], list] = {}
 _L1_RING_SLOTS = 1024
 
 
 def _l1_sums_slot(device) -> Tensor:
-    st = _L1_SUMS_RING.setdefault(str(device), [None, _L1_RING_SLOTS])
+    # (one ring per stream: a ring is zeroed by a launch on the stream that creates it)
+    st = _L1_SUMS_RING.setdefault((str(device), torch.cuda.current_stream(device).cuda_stream), [None, _L1_RING_SLOTS])
     if st[1] >= _L1_RING_SLOTS:
         # (a fresh ring per turn: slots handed out earlier may still be referenced by losses somebody kept)
         st[0], st[1] = torch.zeros((_L1_RING_SLOTS, 2), dtype=torch.float32, device=device), 0
