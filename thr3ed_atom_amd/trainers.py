@@ -174,9 +174,6 @@ class StepStats:
 
 LOSS_RING = 4096  # iterations whose loss sums stay readable (StepStats)
 
-# autograd-driven steps (TrainStepper(fused=False)): the diffuse render, its loss and its adjoint on a side stream (step_on)
-DROPIN_STREAMS = os.environ.get("RF_DROPIN_STREAMS", "1") != "0"
-
 
 # owner-computes data parallelism: leave the all-gather of the `rest` parameters in flight across the iteration boundary (RF_OWNER_OVERLAP_PARAMETERS=0
 # makes every iteration wait for it at its end instead)
@@ -410,39 +407,17 @@ class TrainStepper:
         self.optimizer.zero_grad()
         # the reference's loss lines (modules/trainers.py:311-317, 329-336: l1_loss for the gradient, mse_loss for the logged PSNR) as
         # ONE launch per render: ops.l1_loss_with_mse, a torch.autograd.Function like the render op itself.
-        # The two renders of an iteration are independent of each other until their losses are added (:306-330): the diffuse render
-        # and its loss are issued on a SIDE STREAM, so that its forward kernel shares the machine with the specular one (what the fused
-        # step's paired launch does: 0.178 + 0.074 ms one after the other, 0.21 ms together) -- and so do the two adjoints, since
-        # autograd runs a backward node on the stream of its forward (and joins the streams at the end of backward()).
-        # Ordering: the side stream waits for everything enqueued so far (batch selection, the previous optimizer step, the shadow of
-        # a reference-storage grid brought up to date) before its render; the main stream waits for the side stream before it adds
-        # the losses.  Single process only ($RF_DROPIN_STREAMS=0: one stream, for A/B runs).
-        two_streams = self.diffuse and DROPIN_STREAMS and rays.origins.is_cuda and not (self.data_parallel and rfdist._collectives_on())
-        if two_streams:
-            dev = rays.origins.device
-            if getattr(self, "_side_stream", None) is None:
-                self._side_stream = torch.cuda.Stream(dev)
-            main, side = torch.cuda.current_stream(dev), self._side_stream
-            if hasattr(grid, "forward_rf_grid"):
-                grid.forward_rf_grid(use_occupancy=bool(cfg.use_occupancy_mask))  # (a stale shadow is refreshed here, on the main stream)
-            side.wait_stream(main)
+        # (The diffuse render, its loss and its adjoint on a side stream -- so that the two forward kernels and the two adjoints share
+        # the machine like the fused step's paired launches -- measured no gain: 0.822 against 0.812 ms per iteration; each kernel
+        # fills the machine by itself.  docs/experiments.md D.)
         spec = vol_mod.render_rays(rays).colour
-        if two_streams:
-            with torch.cuda.stream(side):
-                diff = vol_mod.render_rays(rays, render_diffuse=True).colour
-                dl, diff_mse = ops.l1_loss_with_mse(diff, pixels)
         total, spec_mse = ops.l1_loss_with_mse(spec, pixels)
-        spec_loss, diff_loss, diff_mse_ = total.detach(), None, None
-        if two_streams:
-            main.wait_stream(side)
-            total = total + dl
-            diff_loss, diff_mse_ = dl.detach(), diff_mse
-        elif self.diffuse:
+        spec_loss, diff_loss, diff_mse = total.detach(), None, None
+        if self.diffuse:
             diff = vol_mod.render_rays(rays, render_diffuse=True).colour
-            dl, diff_mse_ = ops.l1_loss_with_mse(diff, pixels)
+            dl, diff_mse = ops.l1_loss_with_mse(diff, pixels)
             total = total + dl
             diff_loss = dl.detach()
-        diff_mse = diff_mse_
         total.backward()
         if self.data_parallel:
             rfdist.all_reduce_mean_(self.flat.flat_grad)
