@@ -414,6 +414,19 @@ def cfg1_leg(dev, cores, reps=3):
             "gpu_ray_samples_per_s": n / gpu_s, "max_abs_colour_difference_gpu_vs_cpu": float((gpu.reshape(-1, 3) - ref).abs().max())}
 
 
+def frame_kernel_of(grid, intr, use_mask):
+    """which kernel rf_render_forward picks for a frame of this camera (its dispatch rule restated: ray packets where an 8 x 8 pixel
+    tile's footprint at the volume's centre stays within 2 voxels -- 3 with the occupancy mask --, $RF_FRAME_TILES overrides)"""
+    env = os.environ.get("RF_FRAME_TILES")
+    if env is not None:
+        tiles = int(env) != 0
+    else:
+        voxel = min((hi - lo) / d for (lo, hi), d in zip(grid.aabb, grid.grid_dims))
+        tiles = 8.0 * RADIUS / float(intr.focal) <= (3.0 if use_mask else 2.0) * voxel
+    tiles = tiles and grid.sh_degree in (0, 2)
+    return "render_frame_tile_kernel (ray packets: one wave per 8x8 pixel tile, window staged through LDS)" if tiles else "render_forward_kernel (one wave per ray)"
+
+
 def time_frames(fn, frames, kernel=None):
     """median of per-frame wall times (sync before and after every frame).  With ``kernel`` (the name of a launch): also the median
     of that launch's HIP-event time over THE SAME frames (ops.KernelTimer: events on the launch stream, inside the timed call) and
@@ -561,6 +574,7 @@ def main():
             counter = pmc.get(f"{kname}:{leg}", {}).get("hbm_bytes_per_launch")
             legs[leg] = {
                 "density_scale": g2.expected_density_scale,
+                "frame_kernel": frame_kernel_of(g2, intr, False),
                 "ms_per_frame": dt * 1e3,
                 "ray_samples_per_s": H * W * S / dt,
                 "rays_per_s": H * W / dt,
@@ -570,7 +584,9 @@ def main():
                 "algorithmic_GB_processed": alg / 1e9,
                 # a coherent frame re-uses every cell across neighbouring rays and the 235 MB grid sits in the 32 MB of L2 + 256 MB
                 # of Infinity Cache: the gathers are served on-die, so the algorithmic bytes are priced against the L2 ceiling
-                # (34.5 TB/s aggregate, MI355X_MICROARCH.md) -- the HBM side is the counter figure below
+                # (34.5 TB/s aggregate, MI355X_MICROARCH.md) -- the HBM side is the counter figure below.  (The ray-packet kernel does
+                # not move these bytes through L2 at all: a tile fetches its neighbourhood once per step and the per-sample gathers
+                # are LDS reads; the figure is then an EFFECTIVE rate on SURVEY 8d's per-sample byte model, comparable across rounds.)
                 "effective_TBps_processed": alg / 1e12 / (kms / 1e3),
                 "frac_of_l2_peak_processed": alg / 1e12 / (kms / 1e3) / L2_PEAK_TBS,
                 "counter_GB_per_launch": None if counter is None else counter / 1e9,
@@ -603,6 +619,7 @@ def main():
         occ_bits = int(sum(bin(w & 0xFFFFFFFF).count("1") for w in hg.occupancy.cpu().tolist()))
         highres = {
             "workload": f"configs[4]: 256^3 SH-{args.sh_degree} sparse ReLU field, {H}x{W}, 512 jittered samples/ray, VolumetricModel.render (one launch per frame)",
+            "frame_kernel_no_mask": frame_kernel_of(hg, intr, False), "frame_kernel_occupancy_mask": frame_kernel_of(hg, intr, True),
             "ms_per_frame_no_mask": times[False] * 1e3,
             "ms_per_frame_occupancy_mask": times[True] * 1e3,
             "ray_samples_per_s_occupancy_mask": H * W * 512 / times[True],
