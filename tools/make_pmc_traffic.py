@@ -39,6 +39,14 @@ BENCH_NAMES = {
     "brick_gather_kernel<9, true, true>": "brick_accumulate_adam[sh2]",
     "brick_gather_kernel<9, true, true, false>": "brick_accumulate_adam[sh2]",
     "brick_gather_kernel<9, true, true, false, 4>": "brick_accumulate_adam[sh2]",
+    "brick_gather_kernel<9, true, true, false, 4, false>": "brick_accumulate_adam[sh2]",
+    "brick_gather_kernel<9, true, true, false, 4, true>": "brick_accumulate_adam_mirror[sh2]",
+    "brick_gather_kernel<9, true, true, false, 8, false>": "brick_accumulate_adam[sh2]",
+    "brick_gather_kernel<9, true, false, false, 8, false>": "brick_accumulate_adam[sh2]",
+    "brick_gather_kernel<9, false, true, false, 8, false>": "brick_accumulate[sh2]",
+    "brick_gather_kernel<9, false, false, false, 8, false>": "brick_accumulate[sh2]",
+    "brick_gather_kernel<1, false, true, false, 8, false>": "brick_accumulate[base]",
+    "brick_gather_kernel<1, false, false, false, 8, false>": "brick_accumulate[base]",
     "brick_gather_kernel<9, true, true, false, 8>": "brick_accumulate_adam[sh2]",
     "brick_gather_kernel<9, true, false, false, 8>": "brick_accumulate_adam[sh2]",
     "brick_gather_kernel<9, false, true, false, 8>": "brick_accumulate[sh2]",

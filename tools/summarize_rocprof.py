@@ -14,7 +14,7 @@ import sys
 
 def short(name: str) -> str:
     name = re.sub(r"\(anonymous namespace\)::", "", name)
-    m = re.match(r"(?:void )?((?:render_(?:forward|backward|emit_direct)|brick_gather|brick_accumulate|scatter_records|expand_records)_kernel<[^>]*>)", name)
+    m = re.match(r"(?:void )?((?:render_(?:forward|backward|emit_direct|frame_tile)|brick_gather|brick_accumulate|scatter_records|expand_records)_kernel<[^>]*>)", name)
     if m:
         return m.group(1)
     m = re.match(r"(?:void )?([A-Za-z_0-9:]+)", name)
