@@ -12,6 +12,7 @@ import pytest
 import torch
 
 import thr3ed_atom_amd as rf
+from thr3ed_atom_amd import ops
 from thr3ed_atom_amd.trainers import TrainStepper
 from thr3ed_atom_amd.voxels import unpack_split
 from oracle import relu_field_oracle as orc
@@ -181,6 +182,45 @@ def test_full_size_depth_within_float64_anchored_band(hip_device):
         band = (ref32[key].double() - ref64[key]).abs() + 1e-5
         assert bool(((ours.cpu().double() - ref64[key]).abs() <= band).all()), key
     np.testing.assert_allclose(out.colour.cpu().numpy(), ref32["colour"].numpy(), rtol=0, atol=1e-5)
+
+
+@pytest.mark.parametrize("G,S,mask", [(128, 256, False), (256, 512, True)])
+def test_ray_packet_frame_against_oracle_at_baseline_size(hip_device, monkeypatch, G, S, mask):
+    """The frame path bench.py times for configs[1] (128^3, 800x800x256) and configs[4] (256^3 sparse, 512 samples, occupancy mask) --
+    VolumetricModel.render's one-launch frame, served by the ray-packet kernel there (the library's own dispatch: asserted through
+    bench.frame_kernel_of's restatement of it) -- on a band of eight pixel rows through the middle of the frame, with the keyed jitter
+    on: colour / accumulated weight against the oracle (fed the jitter table oracle.keyed_jitter derives from the same key) at 1e-5,
+    depth under the float64-anchored rule; and the same band from the per-ray kernel agrees to summation order."""
+    import bench
+
+    monkeypatch.delenv("RF_FRAME_TILES", raising=False)
+    cam = hotdog_like_camera()
+    grid, dens, feat = _uniform_grid(hip_device, G, 27, 11 if mask else 42, "split", sparse=mask)
+    intr = rf.CameraIntrinsics(800, 800, 1111.111)
+    assert bench.frame_kernel_of(grid, intr, mask).startswith("render_frame_tile_kernel")
+    pose = rf.pose_spherical(30.0, -30.0, cam["radius"])
+    first, n = 396 * 800, 8 * 800
+    cfg = rf.SHVoxGridRenderConfig(S, rf.CameraBounds(cam["near"], cam["far"]), perturb_sampled_points=True, white_bkgd=True, use_occupancy_mask=mask)
+    torch.manual_seed(21)
+    band = rf.render_sh_voxel_grid_frame(grid, intr, pose, cfg, first_ray=first, num_rays=n)
+    torch.manual_seed(21)
+    key = ops.draw_jitter_key()  # the key the frame call drew
+    monkeypatch.setenv("RF_FRAME_TILES", "0")
+    torch.manual_seed(21)
+    per_ray = rf.render_sh_voxel_grid_frame(grid, intr, pose, cfg, first_ray=first, num_rays=n)
+    assert float((band.colour - per_ray.colour).abs().max()) <= 2e-6 and float((band.depth - per_ray.depth).abs().max()) <= 2e-5
+    rays = rf.flatten_rays(rf.cast_rays(intr, pose, hip_device))[first : first + n]
+    t_rand = T(orc.keyed_jitter(key, first, n, S))
+    aabb = orc.make_aabb((G,) * 3, (3.0 / G,) * 3)
+    with torch.no_grad():
+        ref = orc.render(dens, feat, rays.origins.cpu(), rays.directions.cpu(), aabb, cam["near"], cam["far"], S, RHO, "relu", white_bkgd=True, t_rand=t_rand, interp="aten")
+        ref64 = orc.render(dens.double(), feat.double(), rays.origins.cpu().double(), rays.directions.cpu().double(), aabb, cam["near"], cam["far"], S, RHO, "relu",
+                           white_bkgd=True, t_rand=t_rand.double())
+    np.testing.assert_allclose(band.colour.cpu().numpy(), ref["colour"].numpy(), rtol=0, atol=1e-5)
+    np.testing.assert_allclose(band.extra["accumulated_weight"].cpu().numpy(), ref["acc"].numpy(), rtol=0, atol=1e-5)
+    tol = (ref["depth"].double() - ref64["depth"]).abs() + 1e-5
+    assert bool(((band.depth.cpu().double() - ref64["depth"]).abs() <= tol).all())
+    assert float(band.colour.min()) < 0.9  # (the band crosses the volume)
 
 
 def test_one_call_step_equals_the_launch_by_launch_step(hip_device):
