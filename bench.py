@@ -414,17 +414,29 @@ def cfg1_leg(dev, cores, reps=3):
             "gpu_ray_samples_per_s": n / gpu_s, "max_abs_colour_difference_gpu_vs_cpu": float((gpu.reshape(-1, 3) - ref).abs().max())}
 
 
-def frame_kernel_of(grid, intr, use_mask):
-    """which kernel rf_render_forward picks for a frame of this camera (its dispatch rule restated: ray packets where an 8 x 8 pixel
-    tile's footprint at the volume's centre stays within 2 voxels -- 3 with the occupancy mask --, $RF_FRAME_TILES overrides)"""
-    env = os.environ.get("RF_FRAME_TILES")
-    if env is not None:
-        tiles = int(env) != 0
-    else:
-        voxel = min((hi - lo) / d for (lo, hi), d in zip(grid.aabb, grid.grid_dims))
-        tiles = 8.0 * RADIUS / float(intr.focal) <= (3.0 if use_mask else 2.0) * voxel
-    tiles = tiles and grid.sh_degree in (0, 2)
-    return "render_frame_tile_kernel (ray packets: one wave per 8x8 pixel tile, window staged through LDS)" if tiles else "render_forward_kernel (one wave per ray)"
+def frame_kernel_of(grid, intr, use_mask, pose=None):
+    """which kernel rf_render_forward picks for a frame of this camera: asked of the library itself (rf_frame_render_kernel, the
+    host-side restatement-free dispatch rule: ray packets where an 8 x 8 pixel tile's footprint at the volume's centre stays within
+    2 voxels -- 3 with the occupancy mask --, $RF_FRAME_TILES overrides)"""
+    import ctypes as C
+
+    from thr3ed_atom_amd import _lib
+
+    pose = pose if pose is not None else rf.pose_spherical(30.0, -30.0, RADIUS)
+    cam = _lib.RFCamera()
+    cam.height, cam.width, cam.focal = int(intr.height), int(intr.width), float(np.float32(intr.focal))
+    rot, trans = pose.rotation.detach().cpu().reshape(3, 3), pose.translation.detach().cpu().reshape(3)
+    for a in range(3):
+        for b in range(3):
+            cam.pose[4 * a + b] = float(rot[a, b])
+        cam.pose[4 * a + 3] = float(trans[a])
+    if use_mask and not grid.occupancy_current():
+        grid.build_occupancy()
+    rf_grid = grid.forward_rf_grid(use_occupancy=bool(use_mask))
+    flags = ops.render_flags(True, False, False, bool(use_mask))
+    rc = _lib.load().rf_frame_render_kernel(C.byref(rf_grid), C.byref(cam), int(flags))
+    _lib.check(min(rc, 0), "rf_frame_render_kernel")
+    return "render_frame_tile_kernel (ray packets: one wave per 8x8 pixel tile, window staged through LDS)" if rc == 1 else "render_forward_kernel (one wave per ray)"
 
 
 def time_frames(fn, frames, kernel=None):

@@ -164,6 +164,15 @@ int rf_abi_struct_size(int which);
 int rf_cast_rays(int32_t height, int32_t width, float focal, const float* rotation_host,
                  const float* translation_host, float* origins_dev, float* directions_dev, void* stream);
 
+/* Which kernel rf_render_forward uses for a frame of this camera (RFRayBatch.camera set, no sample cache; the frame loop of
+ * modules/volumetric_model.py:143-172): 1 = ray packets (one wavefront per 8 x 8 pixel tile, the tile's 4 x 4 x 4-node neighbourhood
+ * staged through LDS once per sample index), 0 = one wavefront per ray; negative = error code.  The packet kernel is chosen where a
+ * tile's footprint at the volume's centre stays within 2 voxels (3 with RF_FLAG_OCCUPANCY_SKIP and a mask), on split / bricked
+ * storage of SH degree 0 / 2; $RF_FRAME_TILES = 1 / 0 in the environment forces / forbids it.  Both kernels compute a pixel with the
+ * same per-sample arithmetic and differ in the order a ray's weighted samples are added (<= 2e-6 on colours).  Host-side only: no
+ * device access.  (Added to ABI version 4 compatibly: no existing struct or signature changed.) */
+int rf_frame_render_kernel(const RFGrid* grid, const RFCamera* camera, uint32_t flags);
+
 /* The training-iteration ray source (modules/trainers.py:281-303): rays of the selected pixels only.
  * pixel_index_dev[r] indexes the concatenation of B images: b*H*W + i*W + j; poses_dev is [B, 3, 4]
  * (rotation | translation) on the device. */

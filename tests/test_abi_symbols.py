@@ -153,3 +153,53 @@ def test_product_path_raises_without_gpu_tensors():
     rays = rf.Rays(torch.zeros(3, 3), torch.ones(3, 3))
     with pytest.raises(RuntimeError, match="no CPU fallback"):
         rf.render_sh_voxel_grid(grid, rays, cfg)
+
+
+def test_frame_kernel_dispatch_rule_needs_no_gpu(lib, monkeypatch):
+    """rf_frame_render_kernel (host-side only): frames go to the ray-packet kernel where an 8 x 8 pixel tile's footprint at the
+    volume's centre is at most 2 voxels (3 with the occupancy mask) on split storage of SH degree 0 / 2, else to the per-ray kernel;
+    $RF_FRAME_TILES overrides where the packet kernel exists.  The bench configurations: configs[1] -> packets, configs[4] -> packets
+    only with the mask."""
+    import ctypes as C
+
+    monkeypatch.delenv("RF_FRAME_TILES", raising=False)
+
+    def grid_of(G, F=27, layout="split", occ=False):
+        g = _lib.RFGrid()
+        g.densities_dev, g.features_dev = 1 << 20, (1 << 20) + G * G * G * 16
+        for a in range(3):
+            g.dims[a] = G
+            g.aabb_min[a], g.aabb_max[a] = -1.5, 1.5
+            g.norm_scale[a], g.norm_bias[a] = 1.0 / 1.5, 0.0
+        g.num_features = F
+        split = layout != "reference"
+        g.density_stride, g.feature_stride = (4, F - 3) if split else (1, F)
+        g.layout = _lib.LAYOUTS[layout]
+        g.density_scale, g.density_mode = 1.0, 0
+        g.occupancy_dev = (1 << 19) if occ else None
+        return g
+
+    def cam_of(focal, dist=4.0311, hw=800):
+        c = _lib.RFCamera()
+        c.height, c.width, c.focal = hw, hw, focal
+        for i, v in enumerate((1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, dist)):  # identity rotation, camera on the z axis
+            c.pose[i] = float(v)
+        return c
+
+    def choice(g, c, flags=0):
+        return lib.rf_frame_render_kernel(C.byref(g), C.byref(c), flags)
+
+    cam = cam_of(1111.111)
+    assert choice(grid_of(128), cam) == 1                                   # configs[1]: 1.24 voxels
+    assert choice(grid_of(256), cam) == 0                                   # configs[4] without the mask: 2.48 voxels
+    assert choice(grid_of(256, occ=True), cam, _lib.FLAG_OCCUPANCY_SKIP) == 1  # ... with it
+    assert choice(grid_of(256, occ=True), cam, 0) == 0                      # (a mask that the render does not use)
+    assert choice(grid_of(128), cam_of(88.9)) == 0                          # a 64-pixel camera: a tile spans many voxels
+    assert choice(grid_of(128, layout="reference"), cam) == 0               # no packet kernel for the reference layout
+    assert choice(grid_of(128, F=12), cam) == 0                             # ... nor for SH degree 1
+    assert choice(grid_of(64, F=3), cam_of(1111.111)) == 1                  # degree 0: the base-record instantiation
+    monkeypatch.setenv("RF_FRAME_TILES", "0")
+    assert choice(grid_of(128), cam) == 0
+    monkeypatch.setenv("RF_FRAME_TILES", "1")
+    assert choice(grid_of(256), cam) == 1 and choice(grid_of(128, layout="reference"), cam) == 0
+    assert lib.rf_frame_render_kernel(C.byref(grid_of(128)), None, 0) == -1

@@ -44,6 +44,7 @@ EXPORTED_SYMBOLS = [
     "rf_select_rays_and_pixels",
     "rf_ray_aabb_bounds",
     "rf_render_forward",
+    "rf_frame_render_kernel",
     "rf_render_backward",
     "rf_render_backward_emit",
     "rf_expand_records",
@@ -261,6 +262,7 @@ def load() -> C.CDLL:
     lib.rf_select_rays_and_pixels.argtypes = [i32, i32, f32, vp, vp, i32, vp, C.c_uint64, i64, i64, vp, vp, vp, vp, vp]
     lib.rf_ray_aabb_bounds.argtypes = [vp, vp, i64, f32, f32, fp, fp, vp, vp, vp]
     lib.rf_render_forward.argtypes = [C.POINTER(RFGrid), C.POINTER(RFRayBatch), u32, C.POINTER(RFRenderOut), vp]
+    lib.rf_frame_render_kernel.argtypes = [C.POINTER(RFGrid), C.POINTER(RFCamera), u32]
     lib.rf_render_backward.argtypes = [
         C.POINTER(RFGrid),
         C.POINTER(RFRayBatch),

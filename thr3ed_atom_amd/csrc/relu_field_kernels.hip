@@ -4098,6 +4098,35 @@ int rf_exp_gather_sorted(const RFGrid* grid, const float* records_sorted_dev, co
 }
 #endif
 
+// Which kernel renders a frame of a posed camera (RFRayBatch.camera, no sample cache): ray packets -- one wave per 8 x 8 pixel tile,
+// render_frame_tile_kernel -- where a tile's rays stay within ~2 voxels of each other at the volume's centre (8 pixels x distance /
+// focal length against the smallest voxel edge; 3 voxels with the occupancy mask, whose live lanes are few): beyond that the
+// 4 x 4 x 4-node window has to be moved several times per step and the per-ray kernel wins.  Measured, 800 x 800: 128^3 / 256 samples
+// (1.3 voxels) 1.78 against 2.80 ms; 256^3 / 512 samples (2.6 voxels) 1.70 against 2.05 ms with the mask, 3.12 against 2.90 ms without.
+// The packet kernel exists for split / bricked storage with near addressing and SH degree 0 / 2.  $RF_FRAME_TILES = 1 / 0 forces /
+// forbids it where it exists (A/B runs, tests).
+static bool frame_uses_packets(const RFGrid* grid, const GridArgs& g, const RFCamera* cam, uint32_t flags) {
+  const int K = grid->num_features / 3;
+  if (!(g.layout == RF_LAYOUT_SPLIT && g.near32 && (K == 9 || K == 1) && g.Z >= 4 && g.Y >= 4 && g.X >= 4)) return false;
+  if (const char* e = getenv("RF_FRAME_TILES")) return atoi(e) != 0;
+  float dist2 = 0.0f, vmin = 1e30f;
+  for (int a = 0; a < 3; ++a) {
+    const float c = 0.5f * (g.amin[a] + g.amax[a]) - cam->pose[4 * a + 3];
+    dist2 += c * c;
+    const int dim = a == 0 ? g.X : (a == 1 ? g.Y : g.Z);
+    vmin = fminf(vmin, (g.amax[a] - g.amin[a]) / (float)dim);
+  }
+  return 8.0f * sqrtf(dist2) / cam->focal <= (((flags & RF_FLAG_OCCUPANCY_SKIP) && grid->occupancy_dev) ? 3.0f : 2.0f) * vmin;
+}
+
+int rf_frame_render_kernel(const RFGrid* grid, const RFCamera* camera, uint32_t flags) {
+  int rc = check_grid(grid);
+  if (rc != RF_OK) return rc;
+  if (!camera) return RF_ERR_NULL_POINTER;
+  if (camera->height < 1 || camera->width < 1 || !(camera->focal > 0.0f)) return RF_ERR_BAD_SHAPE;
+  return frame_uses_packets(grid, to_args(grid), camera, flags) ? 1 : 0;
+}
+
 int rf_render_forward(const RFGrid* grid, const RFRayBatch* rays, uint32_t flags, const RFRenderOut* out,
                       void* stream) {
   int rc = check_grid(grid);
@@ -4128,26 +4157,9 @@ int rf_render_forward(const RFGrid* grid, const RFRayBatch* rays, uint32_t flags
   hipStream_t st = (hipStream_t)stream;
   const bool diffuse = flags & RF_FLAG_RENDER_DIFFUSE;
   const int K = grid->num_features / 3;
-  // frames of a posed camera (rays generated in-kernel, inference only): ray packets -- one wave per 8 x 8 pixel tile
-  // (render_frame_tile_kernel).  $RF_FRAME_TILES=0: the per-ray kernel for these calls too (A/B runs, tests).
-  if (rays->camera && !save && g.layout == RF_LAYOUT_SPLIT && g.near32 && (K == 9 || K == 1) && g.Z >= 4 && g.Y >= 4 && g.X >= 4) {
-    // ... where a tile's rays stay within ~2 voxels of each other at the volume's centre (8 pixels x distance / focal length against
-    // the smallest voxel edge; 3 voxels with the occupancy mask, whose live lanes are few): beyond that the 4 x 4 x 4-node window has
-    // to be moved several times per step and the per-ray kernel wins.  Measured, 800 x 800: 128^3 / 256 samples (1.3 voxels) 1.78
-    // against 2.80 ms; 256^3 / 512 samples (2.6 voxels) 1.70 against 2.05 ms with the mask, 3.12 against 2.90 ms without.
-    // $RF_FRAME_TILES = 1 / 0 forces / forbids the tile kernel.
-    const char* tiles_env = getenv("RF_FRAME_TILES");
-    bool tiles = tiles_env ? atoi(tiles_env) != 0 : false;
-    if (!tiles_env) {
-      float dist2 = 0.0f, vmin = 1e30f;
-      for (int a = 0; a < 3; ++a) {
-        const float c = 0.5f * (g.amin[a] + g.amax[a]) - rays->camera->pose[4 * a + 3];
-        dist2 += c * c;
-        const int dim = a == 0 ? g.X : (a == 1 ? g.Y : g.Z);
-        vmin = fminf(vmin, (g.amax[a] - g.amin[a]) / (float)dim);
-      }
-      tiles = 8.0f * sqrtf(dist2) / rays->camera->focal <= (((flags & RF_FLAG_OCCUPANCY_SKIP) && grid->occupancy_dev) ? 3.0f : 2.0f) * vmin;
-    }
+  // frames of a posed camera (rays generated in-kernel, inference only): ray packets where frame_uses_packets() says so
+  if (rays->camera && !save) {
+    const bool tiles = frame_uses_packets(grid, g, rays->camera, flags);
     if (tiles) {
       const int W = rays->camera->width;
       const int row0 = (int)(rays->first_ray / W), row1 = (int)((rays->first_ray + rays->num_rays - 1) / W);
