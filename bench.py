@@ -183,14 +183,16 @@ def supervise(argv) -> int:
             child.send_signal(signal.SIGKILL)
             child.wait()
         if verdict == "next" or (isinstance(verdict, int) and verdict != 0 and not last):
-            why = "; ".join(open(f).read().strip() for f in files(k, "fail") + files(k, "timeout") + files(k, "dead")) or "abandoned"
-            reasons.append(f"attempt {k} [{label}]: {why}")
-            say(f"attempt {k} [{label}] abandoned: {why}")
             # all supervisors leave the attempt before anyone starts the next one (their children must be gone: GPU memory, ports)
             write(k, "left", "")
             t_wait = time.time()
             while len(files(k, "left")) < world and time.time() - t_wait < 60.0:
                 time.sleep(0.05)
+            # (read behind that barrier: every rank's supervisor has written what it saw -- the rank that died, the peers whose
+            # collectives broke on it)
+            why = "; ".join(open(f).read().strip() for f in files(k, "dead") + files(k, "timeout") + files(k, "fail")) or "abandoned"
+            reasons.append(f"attempt {k} [{label}]: {why}")
+            say(f"attempt {k} [{label}] abandoned: {why}")
             continue
         return int(verdict)
     return 1

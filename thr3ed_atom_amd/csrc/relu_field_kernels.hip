@@ -1208,7 +1208,7 @@ __global__ __launch_bounds__(kBlock, RF_FWD_WAVES) void render_forward_pair_kern
 // sigmoid -- is the per-ray kernel's, value for value; only the order in which a ray's weighted samples are ADDED differs
 // (sequential here, per-lane partial sums + a butterfly there), so the two kernels agree to summation order, not bit for bit.
 // A pixel's result does not depend on the other pixels of its tile or on how a frame is cut into calls.
-// Split / bricked storage with near addressing, SH degree 2 (REST) or the base record alone (degree 0, render_diffuse).
+// Split / bricked storage, SH degree 2 (REST) or the base record alone (degree 0, render_diffuse).
 // =============================================================================================
 #ifndef RF_TILE_WAVES
 #define RF_TILE_WAVES 4
@@ -1273,11 +1273,12 @@ __device__ __forceinline__ unsigned int tile_window_node(const GridArgs& g, cons
   const int nx = min(O[0] + (lane >> 4), g.X - 1), ny = min(O[1] + ((lane >> 2) & 3), g.Y - 1), nz = min(O[2] + (lane & 3), g.Z - 1);
   return node_lin(g, nx, ny, nz);
 }
+// (general 64-bit addresses: one record per lane and round, not eight per sample -- the two tensors need not share a 4 GB window)
 __device__ __forceinline__ void tile_window_load_base(TileWindow& wdw, const GridArgs& g, unsigned int lin) {
-  wdw.b = *reinterpret_cast<const vf4*>(g.base + (size_t)(g.dens_off + __umul24(lin, (unsigned int)g.dstride * 4u)));
+  wdw.b = *reinterpret_cast<const vf4*>(g.dens + (size_t)lin * (size_t)g.dstride);
 }
 __device__ __forceinline__ void tile_window_load_rest(TileWindow& wdw, const GridArgs& g, unsigned int lin) {
-  const char* rp = g.base + (size_t)(g.feat_off + __umul24(lin, (unsigned int)g.fstride * 4u));
+  const char* rp = reinterpret_cast<const char*>(g.feat + (size_t)lin * (size_t)g.fstride);
   wdw.q0 = *reinterpret_cast<const vf4*>(rp);
   wdw.q1 = *reinterpret_cast<const vf4*>(rp + 16);
   wdw.q2 = *reinterpret_cast<const vf4*>(rp + 32);
@@ -4103,11 +4104,11 @@ int rf_exp_gather_sorted(const RFGrid* grid, const float* records_sorted_dev, co
 // focal length against the smallest voxel edge; 3 voxels with the occupancy mask, whose live lanes are few): beyond that the
 // 4 x 4 x 4-node window has to be moved several times per step and the per-ray kernel wins.  Measured, 800 x 800: 128^3 / 256 samples
 // (1.3 voxels) 1.78 against 2.80 ms; 256^3 / 512 samples (2.6 voxels) 1.70 against 2.05 ms with the mask, 3.12 against 2.90 ms without.
-// The packet kernel exists for split / bricked storage with near addressing and SH degree 0 / 2.  $RF_FRAME_TILES = 1 / 0 forces /
+// The packet kernel exists for split / bricked storage and SH degree 0 / 2.  $RF_FRAME_TILES = 1 / 0 forces /
 // forbids it where it exists (A/B runs, tests).
 static bool frame_uses_packets(const RFGrid* grid, const GridArgs& g, const RFCamera* cam, uint32_t flags) {
   const int K = grid->num_features / 3;
-  if (!(g.layout == RF_LAYOUT_SPLIT && g.near32 && (K == 9 || K == 1) && g.Z >= 4 && g.Y >= 4 && g.X >= 4)) return false;
+  if (!(g.layout == RF_LAYOUT_SPLIT && (K == 9 || K == 1) && g.Z >= 4 && g.Y >= 4 && g.X >= 4 && (g.dstride & 3) == 0 && (K == 1 || (g.fstride & 3) == 0))) return false;
   if (const char* e = getenv("RF_FRAME_TILES")) return atoi(e) != 0;
   float dist2 = 0.0f, vmin = 1e30f;
   for (int a = 0; a < 3; ++a) {
