@@ -56,6 +56,10 @@ class RFRenderGrads(C.Structure):
     _fields_ = [("grad_colour_dev", C.c_void_p), ("grad_depth_dev", C.c_void_p), ("grad_acc_dev", C.c_void_p)]
 
 
+class RFCamera(C.Structure):
+    _fields_ = [("height", C.c_int32), ("width", C.c_int32), ("focal", C.c_float), ("pose", C.c_float * 12)]
+
+
 class RFBrickList(C.Structure):
     _fields_ = [("records_sorted_dev", C.c_void_p), ("offsets_dev", C.c_void_p), ("render_diffuse", C.c_int32)]
 
@@ -69,7 +73,8 @@ BRICK = 8
 
 RF_FLAG_WHITE_BKGD, RF_FLAG_RENDER_DIFFUSE, RF_FLAG_AABB_SAMPLING = 1, 2, 4
 RF_DENSITY_RELU, RF_DENSITY_SOFTPLUS, RF_DENSITY_ABS, RF_DENSITY_IDENTITY = 0, 1, 2, 3
-RF_LAYOUT_REFERENCE = 0
+RF_LAYOUT_REFERENCE, RF_LAYOUT_SPLIT = 0, 1
+RF_FLAG_JITTER_KEYED = 16
 
 _lib = None
 
@@ -256,4 +261,83 @@ def render_sh_voxel_grid_hip(voxel_grid, rays: Rays, render_config, parallel_poi
     # (grad mode is off inside Function.forward: whether the per-sample cache is needed is decided here)
     need_grad = torch.is_grad_enabled() and (densities.requires_grad or features.requires_grad)
     colour, depth, acc, disparity = _RenderFunction.apply(densities, features, origins, directions, t_vals, t_rand, voxel_grid, s, near, far, flags, need_grad)
+    return RenderOut(colour=colour, depth=depth, extra={EXTRA_DISPARITY: disparity, EXTRA_ACCUMULATED_WEIGHTS: acc})
+
+
+# ---- whole frames (modules/volumetric_model.py:143-172) in ONE launch --------------------------------------------------------------
+# The frame loop of VolumetricModel.render -- cast_rays, slices of parallel_rays_chunk_size, one procedure call per chunk, concatenate
+# -- as one library call: rays and stratified jitter are generated inside the kernel (RFRayBatch.camera), and on frames whose 8 x 8
+# pixel tiles stay within ~2 voxels the library renders RAY PACKETS (rf_frame_render_kernel says which kernel a frame gets).  The
+# packet kernel gathers from a split-layout copy of the grid (base [X,Y,Z,4] = density + degree-0 coefficients, rest [X,Y,Z,F-3]):
+# rf_convert_grid makes it, once per change of the grid's tensors (data pointers / in-place version counters).
+import weakref
+
+_FRAME_SHADOWS = weakref.WeakKeyDictionary()
+
+
+def _split_shadow(voxel_grid, densities, features, reference_grid):
+    f = int(features.shape[-1])
+    stamp = (densities.data_ptr(), features.data_ptr(), densities._version, features._version, tuple(features.shape))
+    sh = _FRAME_SHADOWS.get(voxel_grid)
+    if sh is None or sh["shape"] != tuple(features.shape) or sh["base"].device != features.device:
+        dims = tuple(features.shape[:3])
+        sh = {"shape": tuple(features.shape), "stamp": None, "base": torch.empty(dims + (4,), dtype=torch.float32, device=features.device),
+              "rest": torch.empty(dims + (f - 3,), dtype=torch.float32, device=features.device) if f > 3 else None}
+        _FRAME_SHADOWS[voxel_grid] = sh
+    g = RFGrid()
+    C.memmove(C.byref(g), C.byref(reference_grid), C.sizeof(RFGrid))
+    g.densities_dev, g.features_dev = sh["base"].data_ptr(), None if sh["rest"] is None else sh["rest"].data_ptr()
+    g.density_stride, g.feature_stride, g.layout = 4, f - 3, RF_LAYOUT_SPLIT
+    if sh["stamp"] != stamp:
+        lib = _library()
+        lib.rf_convert_grid.argtypes = [C.POINTER(RFGrid), C.POINTER(RFGrid), C.c_void_p]
+        _check(lib.rf_convert_grid(C.byref(reference_grid), C.byref(g), torch.cuda.current_stream(features.device).cuda_stream), "rf_convert_grid")
+        sh["stamp"] = stamp
+    return g, sh
+
+
+def render_frame_hip(voxel_grid, camera_intrinsics, camera_pose, render_config, first_ray=0, num_rays=None) -> RenderOut:
+    """The pixels [first_ray, first_ray + num_rays) (row-major; default: the whole frame) of a posed camera in one launch: what
+    VolumetricModel.render (modules/volumetric_model.py:143-172) computes chunk by chunk.  ``camera_intrinsics`` = (height, width,
+    focal), ``camera_pose`` = (rotation [3,3], translation [3,1]) like utils/imaging_utils.py:17-30.  Inference only.  With
+    ``perturb_sampled_points`` the stratified jitter is drawn inside the kernel from a per-call key taken from torch's CPU generator
+    (the law of sample.py:63's torch.rand(N, S), no tensor).  A whole frame comes back as [H, W, .] tensors, a pixel range flat."""
+    if render_config.density2occupancy.__name__ != "density2occupancy_pb" or render_config.radiance_hdr_tone_map is not torch.sigmoid:
+        raise ValueError("render_frame_hip: only density2occupancy_pb / torch.sigmoid are implemented")
+    if render_config.stochastic_density_noise_std != 0.0:
+        raise ValueError("render_frame_hip: stochastic_density_noise_std must be 0.0")
+    densities, features = voxel_grid.densities.detach(), voxel_grid.features.detach()
+    if not (densities.is_cuda and densities.is_contiguous() and features.is_contiguous() and densities.dtype == features.dtype == torch.float32):
+        raise RuntimeError("the VoxelGrid's tensors must be contiguous float32 on the HIP device")
+    lib, dev = _library(), features.device
+    height, width, focal = (int(camera_intrinsics[0]), int(camera_intrinsics[1]), float(np.float32(camera_intrinsics[2])))
+    n = height * width - int(first_ray) if num_rays is None else int(num_rays)
+    cam = RFCamera()
+    cam.height, cam.width, cam.focal = height, width, focal
+    rot = torch.as_tensor(camera_pose[0]).detach().to("cpu", torch.float32).reshape(3, 3)
+    trans = torch.as_tensor(camera_pose[1]).detach().to("cpu", torch.float32).reshape(3)
+    for i in range(3):
+        for j in range(3):
+            cam.pose[4 * i + j] = float(rot[i, j])
+        cam.pose[4 * i + 3] = float(trans[i])
+    grid = _describe_grid(voxel_grid, densities, features)
+    keep = None
+    if int(features.shape[-1]) in (3, 27):  # (the layouts the packet kernel gathers from; other degrees: the per-ray kernel on the grid's own tensors)
+        grid, keep = _split_shadow(voxel_grid, densities, features, grid)
+    s = int(render_config.num_samples_per_ray)
+    t_vals = torch.linspace(0.0, 1.0, s, dtype=torch.float32).to(dev)
+    flags = (RF_FLAG_WHITE_BKGD if render_config.white_bkgd else 0) | (RF_FLAG_RENDER_DIFFUSE if render_config.render_diffuse else 0) | (
+        RF_FLAG_AABB_SAMPLING if render_config.optimized_sampling else 0)
+    rb = RFRayBatch(None, None, n, s, float(np.float32(render_config.camera_bounds.near)), float(np.float32(render_config.camera_bounds.far)),
+                    t_vals.data_ptr(), None, 0, int(first_ray), C.cast(C.pointer(cam), C.c_void_p))
+    if render_config.perturb_sampled_points:
+        rb.jitter_key = int(torch.randint(-(2**63), 2**63 - 1, (1,), dtype=torch.int64).item()) & 0xFFFFFFFFFFFFFFFF
+        flags |= RF_FLAG_JITTER_KEYED
+    colour = torch.empty((n, 3), dtype=torch.float32, device=dev)
+    depth, acc, disparity = (torch.empty((n, 1), dtype=torch.float32, device=dev) for _ in range(3))
+    out = RFRenderOut(colour.data_ptr(), depth.data_ptr(), acc.data_ptr(), disparity.data_ptr(), None, None, None, None, None, 0)
+    _check(lib.rf_render_forward(C.byref(grid), C.byref(rb), flags, C.byref(out), torch.cuda.current_stream(dev).cuda_stream), "rf_render_forward")
+    del keep
+    if int(first_ray) == 0 and n == height * width:
+        colour, depth, acc, disparity = (t.reshape(height, width, -1) for t in (colour, depth, acc, disparity))
     return RenderOut(colour=colour, depth=depth, extra={EXTRA_DISPARITY: disparity, EXTRA_ACCUMULATED_WEIGHTS: acc})

@@ -56,7 +56,7 @@ def test_binding_struct_mirrors_match_the_library(monkeypatch):
     rh = _load_binding(monkeypatch, with_reference=False)
     lib = rh._library()
     lib.rf_abi_struct_size.argtypes = [C.c_int]
-    for which, mirror in ((0, rh.RFGrid), (1, rh.RFRayBatch), (2, rh.RFRenderOut), (3, rh.RFRenderGrads)):
+    for which, mirror in ((0, rh.RFGrid), (1, rh.RFRayBatch), (2, rh.RFRenderOut), (3, rh.RFRenderGrads), (4, rh.RFBrickList), (6, rh.RFCamera)):
         assert lib.rf_abi_struct_size(which) == C.sizeof(mirror) == C.sizeof(_lib.ABI_STRUCTS[which])
     assert lib.rf_abi_struct_size(99) == -1
     for which, mirror in enumerate(_lib.ABI_STRUCTS):  # the package's own mirrors (also checked at load time)
@@ -143,3 +143,38 @@ def test_reference_like_module_renders_like_the_reference(hip_device, monkeypatc
     for ours, key in ((grid.densities.grad, f"{variant}_gd"), (grid.features.grad, f"{variant}_gf")):
         ref = g7[key]
         np.testing.assert_allclose(ours.cpu().numpy(), ref, rtol=2e-4, atol=2e-6 * np.abs(ref).max())
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("tiles", ["1", "0"])
+def test_binding_frame_entry_equals_the_ray_list_procedure(hip_device, monkeypatch, tiles):
+    """integration/renderers_hip.py::render_frame_hip -- VolumetricModel.render's frame loop (modules/volumetric_model.py:143-172) as
+    one library call on the reference's own grid type: rays generated in-kernel, the grid gathered from a split-layout copy that
+    rf_convert_grid keeps in step with the module's tensors, ray packets ($RF_FRAME_TILES=1) or the per-ray kernel (=0) -- against the
+    binding's own ray-list procedure on cast_rays' rays (summation order), whole frame and a pixel range, and after an in-place edit
+    of the grid (the copy must follow)."""
+    import thr3ed_atom_amd as rf
+
+    cam = hotdog_like_camera()
+    dens, feat = procedural_grid((16, 16, 16), 27, 81)
+    grid = _ReferenceLikeGrid(dens.to(hip_device), feat.to(hip_device), (3.0 / 16,) * 3, (0.0, 0.0, 0.0), torch.nn.Identity(), torch.nn.ReLU(), 100.0 / 3.0).to(hip_device)
+    cfg = rf.SHVoxGridRenderConfig(48, rf.CameraBounds(cam["near"], cam["far"]), perturb_sampled_points=False, white_bkgd=True)
+    intr = rf.CameraIntrinsics(37, 45, 70.0)
+    pose = rf.pose_spherical(25.0, -35.0, cam["radius"])
+    rays = rf.flatten_rays(rf.cast_rays(intr, pose, hip_device))
+    monkeypatch.setenv("RF_FRAME_TILES", tiles)
+    rh = _load_binding(monkeypatch, with_reference=False)
+    for edit in (False, True):
+        if edit:
+            with torch.no_grad():
+                grid._densities.mul_(0.5)  # (in place: the version counter moves, the split copy has to be refreshed)
+        with torch.no_grad():
+            ref = rh.render_sh_voxel_grid_hip(grid, rays, cfg)
+            frame = rh.render_frame_hip(grid, tuple(intr), (pose.rotation, pose.translation), cfg)
+            part = rh.render_frame_hip(grid, tuple(intr), (pose.rotation, pose.translation), cfg, first_ray=300, num_rays=500)
+        assert frame.colour.shape == (37, 45, 3) and frame.depth.shape == (37, 45, 1)
+        assert float((frame.colour.reshape(-1, 3) - ref.colour).abs().max()) <= 2e-6
+        assert float((frame.depth.reshape(-1, 1) - ref.depth).abs().max()) <= 2e-5
+        assert float((frame.extra["accumulated_weight"].reshape(-1, 1) - ref.extra["accumulated_weight"]).abs().max()) <= 2e-6
+        assert torch.equal(part.colour, frame.colour.reshape(-1, 3)[300:800]) and torch.equal(part.depth, frame.depth.reshape(-1, 1)[300:800])
+    assert float(frame.colour.min()) < 0.95
