@@ -111,6 +111,18 @@ def supervise(argv) -> int:
             fh.write(text)
         os.replace(path + ".tmp", path)
 
+    # a supervisor that is told to stop (the launcher's timeout, ^C) takes its worker with it: no orphan keeps a GPU busy
+    current = {"child": None}
+
+    def stop(signum, _frame):
+        child_ = current["child"]
+        if child_ is not None and child_.poll() is None:
+            child_.send_signal(signal.SIGKILL)
+        os._exit(128 + signum)
+
+    for sig in (signal.SIGTERM, signal.SIGINT, signal.SIGHUP):
+        signal.signal(sig, stop)
+
     for pos, k in enumerate(attempts):
         label, env_add, arg_add = ATTEMPTS[k]
         last = pos == len(attempts) - 1
@@ -142,6 +154,7 @@ def supervise(argv) -> int:
         # (RF_BENCH_WORKER_CMD: tests/test_bench_supervisor.py drives this protocol on the CPU with a stand-in worker)
         worker = os.environ["RF_BENCH_WORKER_CMD"].split() if os.environ.get("RF_BENCH_WORKER_CMD") else [sys.executable, os.path.abspath(__file__)]
         child = subprocess.Popen(worker + list(argv) + arg_add, env=env)
+        current["child"] = child
         t_spawn = time.time()
         t_ready = t_valid = None
         verdict = None  # None: running; "next": abandon this attempt; int: return code to leave with

@@ -23,6 +23,9 @@ def barrier(kind):  # (like a collective: returns when every rank got there, nev
         time.sleep(0.05)
 
 
+if os.environ.get("FAKE_PID_DIR"):
+    with open(os.path.join(os.environ["FAKE_PID_DIR"], f"pid.{k}.{r}"), "w") as fh:
+        fh.write(str(os.getpid()))
 assert os.environ["RF_BENCH_WORKER"] == "1" and os.environ["TORCHELASTIC_USE_AGENT_STORE"] == "False" and int(os.environ["MASTER_PORT"]) > 0
 time.sleep(0.2 * r)
 mark("ready")

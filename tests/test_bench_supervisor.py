@@ -44,3 +44,31 @@ def test_explicit_dense_exchange_is_a_single_attempt(tmp_path):
     rcs, lines, err = _run("ok", tmp_path, argv=("--exchange", "dense"))
     assert rcs == [0, 0] and len(lines) == 1 and lines[0]["attempt"] == 2, (rcs, lines, err)
     assert lines[0]["argv"].count("--exchange") == 2  # (the user's and the attempt's own: argparse keeps the last, both say dense)
+
+
+def test_a_stopped_supervisor_takes_its_worker_with_it(tmp_path):
+    """SIGTERM to the supervisors (a launcher's timeout): the workers are killed, nothing is left running."""
+    import signal
+    import time
+
+    env = dict(os.environ, WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT="29998", RF_BENCH_RUN_DIR=str(tmp_path), FAKE_MODE="hang",
+               RF_BENCH_WORKER_CMD=f"{sys.executable} {os.path.join(ROOT, 'tests', 'fake_bench_worker.py')}", RF_BENCH_VALIDATE_TIMEOUT_S="60",
+               RF_BENCH_RUN_TIMEOUT_S="60", RF_BENCH_READY_TIMEOUT_S="60", FAKE_PID_DIR=str(tmp_path))
+    env.pop("RF_BENCH_WORKER", None)
+    procs = [subprocess.Popen([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2"], env=dict(env, RANK=str(r), LOCAL_RANK=str(r))) for r in range(2)]
+    deadline = time.time() + 30
+    while time.time() < deadline and len(list(tmp_path.glob("a0.r*.ready"))) < 2:
+        time.sleep(0.1)
+    pids = [int(f.read_text()) for f in tmp_path.glob("pid.*")]
+    assert len(pids) == 2
+    for p in procs:
+        p.send_signal(signal.SIGTERM)
+    for p in procs:
+        assert p.wait(timeout=20) == 128 + signal.SIGTERM
+    time.sleep(0.5)
+    for pid in pids:  # gone, or a zombie waiting for the container's init to reap it -- not running
+        try:
+            state = open(f"/proc/{pid}/stat").read().rsplit(")", 1)[1].split()[0]
+        except FileNotFoundError:
+            state = "gone"
+        assert state in ("gone", "Z"), (pid, state)
