@@ -200,6 +200,7 @@ class _RenderFunction(torch.autograd.Function):
         ctx.voxel_grid, ctx.args, ctx.need_grad, ctx.has_rand = voxel_grid, (num_samples, near, far, flags), need_grad, t_rand is not None
         ctx.save_for_backward(densities, features, origins, directions, t_vals, *caches, *(() if t_rand is None else (t_rand,)))
         ctx.mark_non_differentiable(disparity)
+        ctx.set_materialize_grads(False)  # (unused outputs' gradients arrive as None, not as zero tensors filled per render)
         return colour, depth, acc, disparity
 
     @staticmethod

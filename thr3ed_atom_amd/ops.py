@@ -569,6 +569,9 @@ class _ReluFieldRender(torch.autograd.Function):
             saved.append(t_rand)
         ctx.save_for_backward(*saved)
         ctx.mark_non_differentiable(disparity)
+        # (outputs the loss does not use -- depth, accumulated weight in every reference use -- arrive as None in backward instead of
+        # zero tensors autograd would fill per render: two [N, 1] fill launches each, ~20 us of GPU time per training iteration)
+        ctx.set_materialize_grads(False)
         return colour, depth, acc, disparity
 
     @staticmethod
@@ -783,10 +786,13 @@ class _L1LossWithMSE(torch.autograd.Function):
         means = sums * (1.0 / float(colour_c.numel()))
         loss, mse = means[0], means[1]
         ctx.mark_non_differentiable(mse)
+        ctx.set_materialize_grads(False)
         return loss, mse
 
     @staticmethod
     def backward(ctx, g_loss, _g_mse):
+        if g_loss is None:
+            return None, None
         (grad,) = ctx.saved_tensors
         return grad * g_loss, None
 
