@@ -89,11 +89,18 @@ def supervise(argv) -> int:
     import subprocess
 
     rank, world = int(os.environ.get("RANK", "0")), int(os.environ["WORLD_SIZE"])
-    run_dir = os.environ.get("RF_BENCH_RUN_DIR") or f"/tmp/rf_bench_{os.environ.get('MASTER_PORT', '0')}_{os.getppid()}"
+    # one directory per RUN, shared by the node's supervisors: named after the launcher they all descend from -- its pid AND its start
+    # time (a recycled pid + port cannot resurrect another run's markers)
+    try:
+        launcher_start = open(f"/proc/{os.getppid()}/stat").read().rsplit(")", 1)[1].split()[19]
+    except Exception:  # noqa: BLE001
+        launcher_start = "0"
+    run_dir = os.environ.get("RF_BENCH_RUN_DIR") or f"/tmp/rf_bench_{os.environ.get('MASTER_PORT', '0')}_{os.getppid()}_{launcher_start}"
     os.makedirs(run_dir, exist_ok=True)
     validate_s = float(os.environ.get("RF_BENCH_VALIDATE_TIMEOUT_S", "30"))
     ready_s = float(os.environ.get("RF_BENCH_READY_TIMEOUT_S", "600"))
     run_s = float(os.environ.get("RF_BENCH_RUN_TIMEOUT_S", "300"))
+    report_s = float(os.environ.get("RF_BENCH_REPORT_TIMEOUT_S", "1200"))
     attempts = list(range(len(ATTEMPTS)))
     if "--exchange" in argv and argv[argv.index("--exchange") + 1] == "dense":
         attempts = [2]
@@ -158,6 +165,7 @@ def supervise(argv) -> int:
         t_spawn = time.time()
         t_ready = t_valid = None
         verdict = None  # None: running; "next": abandon this attempt; int: return code to leave with
+        committed, t_commit = False, None
         while verdict is None:
             time.sleep(0.1)
             rc = child.poll()
@@ -175,6 +183,11 @@ def supervise(argv) -> int:
             # (a worker that left with 0 before every rank was done -- it cannot, its last act is a barrier -- is treated like a running
             # one: the attempt counts only when ALL ranks are done)
             if committed:
+                t_commit = t_commit or now
+                if now - t_commit > report_s:  # (the reporting legs behind the timed region are local work of minutes at most)
+                    say(f"attempt {k}: worker still running {report_s:.0f} s after every rank was done -- ended")
+                    verdict = 1
+                    break
                 continue
             bad = files(k, "dead") + files(k, "timeout") + files(k, "fail")
             if bad:
@@ -195,6 +208,10 @@ def supervise(argv) -> int:
         if child.poll() is None:
             child.send_signal(signal.SIGKILL)
             child.wait()
+        if committed and isinstance(verdict, int):
+            # every rank finished the timed region and the replica check: this attempt IS the run, whatever the exit code of a rank's
+            # reporting legs (a crash there must not send one supervisor into another attempt that nobody else joins)
+            return int(verdict)
         if verdict == "next" or (isinstance(verdict, int) and verdict != 0 and not last):
             # all supervisors leave the attempt before anyone starts the next one (their children must be gone: GPU memory, ports)
             write(k, "left", "")
@@ -481,6 +498,164 @@ def time_frames(fn, frames, kernel=None):
     return float(np.median(ts))
 
 
+def multi_gpu_forward_legs(args, dev, rank, world, intr, bounds):
+    """``north_star``: forward throughput "reported at 1/2/4/8 GPUs".  Every rank takes part (the reference's counterpart is one device's
+    loop over a frame's chunks, modules/volumetric_model.py:143-172; rays are independent, the grid is replicated):
+
+      frame_parallel   rank r renders ITS OWN pose (r-th view of an orbit), whole frames, nothing exchanged: the throughput form
+                       (a test-set evaluation, a turntable video) -- value = N frames per max-over-ranks frame time;
+      sharded_frame    ONE pose, ``VolumetricModel.render(data_parallel=True)``: every rank renders its shard_range of the pixels and
+                       the [n, 6] results are all-gathered -- the latency form; also timed without the gather (each rank keeps its rows).
+
+    configs[1] (the grid of the fwd_render leg: same seed, same field) and configs[4] (256^3 sparse field, 512 samples, occupancy mask).
+    Timed like the step: barrier + synchronize on both sides, max over ranks.  Returns {"fwd_render": {...}, "highres_render": {...}}."""
+    import torch.distributed as dist
+
+    H, W = int(intr.height), int(intr.width)
+
+    def timed(fn, frames):
+        fn()  # warm-up (and the first use of a collective shape)
+        dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(frames):
+            fn()
+        torch.cuda.synchronize()
+        dist.barrier()
+        t = torch.tensor([(time.perf_counter() - t0) / frames], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return float(t.item())
+
+    def legs(model, S_, frames, **over):
+        own_pose = rf.pose_spherical(30.0 + 360.0 / world * rank, -30.0, RADIUS)
+        pose = rf.pose_spherical(30.0, -30.0, RADIUS)
+        lo, hi = rfdist.shard_range(H * W)
+        dt_fp = timed(lambda: model.render(own_pose, intr, **over), frames)
+        dt_sh = timed(lambda: model.render(pose, intr, data_parallel=True, **over), frames)
+        from thr3ed_atom_amd.renderers import render_sh_voxel_grid_frame
+
+        cfg_ = model._update_render_config(model.render_config, over)
+        dt_rows = timed(lambda: render_sh_voxel_grid_frame(model.thre3d_repr, intr, pose, cfg_, first_ray=lo, num_rays=hi - lo), frames)
+        # the sharded frame IS the single-GPU frame (jitter off for the comparison; every rank checks the frame it ended up with)
+        a = model.render(pose, intr, data_parallel=True, perturb_sampled_points=False, **over)
+        b = model.render(pose, intr, perturb_sampled_points=False, **over)
+        same = torch.tensor([int(torch.equal(a.colour, b.colour) and torch.equal(a.depth, b.depth))], device=dev, dtype=torch.int32)
+        dist.all_reduce(same, op=dist.ReduceOp.MIN)
+        return {
+            "frame_parallel": {"what": f"rank r renders its own pose (view r of a {world}-view orbit), whole {H}x{W} frames, no exchange; max over ranks", "ms_per_frame_per_gpu": dt_fp * 1e3,
+                               "frames_per_s": world / dt_fp, "rays_per_s": world * H * W / dt_fp, "ray_samples_per_s": world * H * W * S_ / dt_fp},
+            "sharded_frame": {"what": "ONE pose, VolumetricModel.render(data_parallel=True): every rank renders its contiguous shard of the pixels, one all-gather of the [n, 6] results "
+                              "(every rank ends up with the whole frame); max over ranks", "ms_per_frame": dt_sh * 1e3, "rays_per_s": H * W / dt_sh, "ray_samples_per_s": H * W * S_ / dt_sh,
+                              "ms_per_frame_without_the_gather": dt_rows * 1e3, "equals_single_gpu_frame_bit_for_bit": bool(int(same.item()))},
+            "n_gpus": world, "frames_timed": frames,
+        }
+
+    out = {}
+    if args.render_frames > 0:
+        g = make_grid(dev, args.grid, args.sh_degree, seed=42, storage=args.storage)
+        cfg = rf.SHVoxGridRenderConfig(args.samples, bounds, perturb_sampled_points=True, white_bkgd=True)
+        out["fwd_render"] = legs(rf.VolumetricModel(g, rf.render_sh_voxel_grid, cfg, device=dev), args.samples, args.render_frames)
+        del g
+        torch.cuda.empty_cache()
+    if args.highres_frames > 0:
+        hg = make_grid(dev, 256, args.sh_degree, seed=11, sparse=True, storage=args.storage)
+        hg.build_occupancy()
+        hcfg = rf.SHVoxGridRenderConfig(512, bounds, perturb_sampled_points=True, white_bkgd=True)
+        out["highres_render"] = legs(rf.VolumetricModel(hg, rf.render_sh_voxel_grid, hcfg, device=dev), 512, args.highres_frames, use_occupancy_mask=True)
+        del hg
+        torch.cuda.empty_cache()
+    return out
+
+
+def train_leg_at_reference_final_stage(args, dev, dataset, bounds):
+    """The training iteration at the operating point the reference's CLI ENDS at: a 256^3 SH-2 grid, 512 samples per ray, 16384 rays
+    (train_sh_based_voxel_grid_with_posed_images.py:55,88-90; modules/trainers.py:125-129: 32^3 -> 64^3 -> 128^3 -> 256^3).  Same step,
+    same images, U(-1,1) initialisation; 470 M parameters: the optimizer's 24 B per parameter (11.3 GB) dominate.  A reporting leg
+    beside the headline (BASELINE.json quotes its metric on 128^3)."""
+    G2, S2, R = 256, 512, args.rays
+    C = 3 * (args.sh_degree + 1) ** 2 + 1
+    grid = make_grid(dev, G2, args.sh_degree, seed=42, storage="split")
+    cfg = rf.SHVoxGridRenderConfig(S2, bounds, perturb_sampled_points=True, white_bkgd=True)
+    model = rf.VolumetricModel(grid, rf.render_sh_voxel_grid, cfg, device=dev)
+    stepper = TrainStepper(model, R, learning_rate=0.03, apply_diffuse_render_regularization=True, ray_selection="keyed", data_parallel=False)
+    executor = stepper.fused and stepper.merged_bricks
+    torch.manual_seed(4321)
+    batches = dataset.image_batches(args.images)
+    for _ in range(3):
+        stepper.step(dataset, next(batches))
+    steps = args.train256_steps
+    timed_idx = sorted({0, steps // 2, steps - 1}) if executor else []
+    events = [ops.StepEvents() for _ in timed_idx]
+    counts = torch.zeros((max(1, len(timed_idx)), 2), dtype=torch.int64, device=dev)
+    used_keys = torch.zeros((max(1, len(timed_idx)), 2), dtype=torch.int64, device=dev)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    k = 0
+    for i in range(steps):
+        on = k < len(timed_idx) and i == timed_idx[k]
+        stepper.step_events = events[k] if on else None
+        stepper.step(dataset, next(batches))
+        if on:
+            ex = stepper._exec["tensors"]
+            for j in (0, 1):  # (device-side: no sync)
+                off = ex[f"pass{j}"]["offsets"]
+                counts[k, j].copy_(off[-1] - off[0], non_blocking=True)
+                used_keys[k, j].copy_((off[1:] > off[:-1]).sum(), non_blocking=True)
+            k += 1
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / steps
+    stepper.step_events = None
+    kernels = {}
+    if events:
+        per = [e.elapsed_ms() for e in events]
+        kernels = {name: float(np.mean([p_[name] for p_ in per])) for name in per[0]}
+    rec = counts.cpu().numpy().astype(np.float64).mean(axis=0)
+    nkeys = int(stepper._exec["tensors"]["pass0"]["offsets"].numel() - 1) if executor else None
+    nparam = G2**3 * C
+    bricks_ms = kernels.get("brick_accumulate")
+    brick_bytes = rec[0] * 4 * ops.expanded_record_floats(grid) + rec[1] * 4 * ops.expanded_record_floats(grid, True) + nparam * 24
+    leg = {
+        "workload": f"the reference CLI's final stage: {G2}^3 SH-{args.sh_degree} ReLU field (U(-1,1) init), {R} random distinct pixels of the {args.images} images per step, {S2} jittered samples/ray, "
+                    "specular+diffuse fwd+bwd, L1+L1, Adam in the brick flush (one library call per step)",
+        "ms_per_step": dt * 1e3, "ray_samples_per_s": 2 * R * S2 / dt, "steps": steps, "warmup": 3,
+        "parameters": nparam, "optimizer_bytes_per_step": nparam * 24, "brick_nodes": "4x8x8" if getattr(stepper, "brick_size", 8) == rf.ops.BRICK_4X8X8 else f"{int(getattr(stepper, 'brick_size', 8))}^3", "backward": stepper.backward,
+        "kernels_ms": kernels,
+        "records_per_step": {"specular": float(rec[0]), "diffuse": float(rec[1])},
+        "key_tables": None if nkeys is None else {"keys": nkeys, "non_empty_specular": float(used_keys[:, 0].double().mean().item()), "non_empty_diffuse": float(used_keys[:, 1].double().mean().item())},
+        "brick_pass": None if not bricks_ms else {"avg_launch_ms": bricks_ms, "compulsory_bytes": brick_bytes, "frac_of_hbm_peak": frac(brick_bytes, bricks_ms, "train_256 brick pass"),
+                                                 "frac_of_achievable": brick_bytes / 1e9 / (bricks_ms / 1e3) / HBM_ACHIEVABLE_GBS, "share_of_step": bricks_ms / (dt * 1e3)},
+        "oracle_checked_by": "tests/test_hip_baseline_size.py::test_bench_train_step_against_oracle_at_baseline_size[256-...]",
+    }
+    stepper.flat.detach()
+    del stepper, model, grid
+    torch.cuda.empty_cache()
+    return leg
+
+
+def run_guarded(fn, timeout_s, dev):
+    """``fn()`` on a helper thread, waited for at most ``timeout_s``: (result, None), or (None, why) when it raised or is still
+    running -- a collective another rank never enters must not cost the line of a run whose timed region is already done."""
+    import threading
+
+    box = {}
+
+    def body():
+        try:
+            torch.cuda.set_device(dev)
+            box["result"] = fn()
+        except BaseException as exc:  # noqa: BLE001
+            box["error"] = f"{type(exc).__name__}: {exc}"
+
+    th = threading.Thread(target=body, daemon=True)
+    th.start()
+    th.join(timeout_s)
+    if th.is_alive():
+        return None, f"not finished after {timeout_s:.0f} s (abandoned; the process leaves without joining the group's shutdown)"
+    if "error" in box:
+        return None, box["error"]
+    return box.get("result"), None
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -497,6 +672,7 @@ def main():
     ap.add_argument("--cpu-rays", type=int, default=2048, help="rays of the cpu_baseline training sample (0 = skip the CPU baseline)")
     ap.add_argument("--cpu-full-rays", type=int, default=16384, help="rays of the cpu_baseline's full training batch (SURVEY 8d cfg3; one timed step, ~20 s; 0 = skip)")
     ap.add_argument("--cpu-fwd-rays", type=int, default=32768, help="rays of the cpu_baseline forward-only chunk (SURVEY 8d: one parallel_rays_chunk_size chunk)")
+    ap.add_argument("--train256-steps", type=int, default=10, help="steps timed for the train_256 leg: the iteration at the reference CLI's final stage, 256^3 / 512 samples (0 = skip)")
     ap.add_argument("--dropin-steps", type=int, default=20, help="steps timed for the strict drop-in configuration (0 = skip)")
     ap.add_argument("--storage", choices=["split", "bricked", "reference"], default="split",
                     help="HBM layout of the grid: split = MI355X-native (what the trainer uses), reference = the reference's two tensors")
@@ -589,7 +765,7 @@ def main():
             # units really processed: samples whose features are gathered = in-box, positive density, T != 0; counted by a
             # save-forward of a ray subset is not possible at frame size, so the record predicate is evaluated on the device
             # by the training-style forward of a 65536-ray sample of the frame and scaled
-            sub = rf.flatten_rays(rf.cast_rays(intr, pose, dev))[:: (H * W) // 65536][:65536]
+            sub = rf.flatten_rays(rf.cast_rays(intr, pose, dev))[:: max(1, (H * W) // 65536)][:65536]
             nb = ops.brick_counts(g2, 8)
             hist = torch.zeros(nb[0] * nb[1] * nb[2] * 8, dtype=torch.int32, device=dev)
             flags = ops.render_flags(True, False, False, False)
@@ -716,6 +892,7 @@ def main():
                             merge_bricks=False if exchange == "dense" and (world > 1 or args.dp_style_step) else None, exchange=exchange)
 
     stepper = make_stepper(args.exchange)
+    multi_fwd, multi_fwd_error, leave_hard = None, None, False
     exchange_fallback = os.environ.get("RF_BENCH_FALLBACK_REASON")  # (the supervisor's: why earlier attempts were abandoned)
     supervised = bool(os.environ.get("RF_BENCH_WORKER")) and os.environ.get("RF_BENCH_LAST_ATTEMPT") != "1"
     torch.manual_seed(1234 + rank)  # every rank draws its own rays
@@ -860,9 +1037,24 @@ def main():
         _mark("done")
         if not owner:  # reduce-scatter + all-gather (or all-reduce) of the flat bucket: 2 (N-1)/N x bucket bytes sent per rank per step
             exchange_bytes = int(2 * (world - 1) / world * stepper.flat.flat_grad.numel() * 4)
-        # every rank leaves the group together, BEFORE rank 0 starts its single-process reporting legs
-        torch.distributed.barrier()
-        torch.distributed.destroy_process_group()
+        # ---- the forward legs on all N GPUs (fwd_render.multi_gpu / highres_render.multi_gpu), BEHIND the committed training
+        # result and under a guard of their own: should a rank not come back from them, the line is printed without them.
+        # Then every rank leaves the group together, BEFORE rank 0 starts its single-process reporting legs.
+        def forward_legs_and_goodbye():
+            if os.environ.get("RF_BENCH_INJECT_FORWARD_LEGS_HANG") == str(rank):  # (test hook: this rank never enters the legs' collectives)
+                time.sleep(10**6)
+            legs_ = multi_gpu_forward_legs(args, dev, rank, world, intr, bounds) if (args.render_frames > 0 or args.highres_frames > 0) else {}
+            torch.distributed.barrier()
+            torch.distributed.destroy_process_group()
+            return legs_
+
+        multi_fwd, multi_fwd_error = run_guarded(forward_legs_and_goodbye, float(os.environ.get("RF_BENCH_FORWARD_LEGS_TIMEOUT_S", "150")), dev)
+        if multi_fwd_error is not None:
+            print(f"[rank {rank}] multi-GPU forward legs: {multi_fwd_error}", file=sys.stderr, flush=True)
+            leave_hard = True  # (a helper thread may still sit in a collective: no interpreter shutdown, no process-group destructor)
+            if rank != 0:
+                os._exit(0)
+            args.cpu_rays = 0  # (the line, quickly: RCCL's own watchdog ends a process whose collective never completes)
     elif torch.distributed.is_initialized():  # --dp-style-step: the 1-rank group
         torch.distributed.destroy_process_group()
         rfdist.FORCE_COLLECTIVES = False
@@ -1008,6 +1200,10 @@ def main():
             "note": "data-parallel-style step: specular forward + emit + brick pass -> [gradient exchange of `rest` overlapped with] diffuse forward + emit + base-channel brick pass -> exchange of `base` -> (sharded) Adam",
         }
 
+    train_256 = None
+    if args.train256_steps > 0 and world == 1 and not args.dp_style_step:
+        train_256 = train_leg_at_reference_final_stage(args, dev, dataset, bounds)
+
     baseline = None
     if args.cpu_rays > 0:
         baseline = cpu_baseline(grid, (rays.origins.cpu(), rays.directions.cpu()), pixels.cpu(), S, args.cpu_rays, args.cpu_fwd_rays, args.cpu_threads, n_full=args.cpu_full_rays)
@@ -1072,9 +1268,19 @@ def main():
         "fwd_render": fwd_render,
         "highres_render": highres,
         "strict_dropin": dropin,
+        "train_256": train_256,
         "roofline_model_errors": MODEL_ERRORS,
     }
-    print(json.dumps(line))
+    if world > 1:
+        # fwd_render / highres_render of a multi-GPU run: rank 0's single-GPU figures + what all N GPUs did together
+        for key, asked in (("fwd_render", args.render_frames > 0), ("highres_render", args.highres_frames > 0)):
+            leg = (multi_fwd or {}).get(key)
+            if not asked or (leg is None and multi_fwd_error is None):
+                continue
+            line[key] = dict(line[key] or {}, multi_gpu=leg if leg is not None else {"error": multi_fwd_error})
+    print(json.dumps(line), flush=True)
+    if leave_hard:
+        os._exit(0)
 
 
 if __name__ == "__main__":

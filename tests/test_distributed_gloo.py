@@ -70,6 +70,13 @@ def _worker(rank, world, port, result_dir):
     lo, hi = rfdist.shard_range(10)
     full = rfdist.all_gather_rows(rows[lo:hi] * 1.0)
     assert torch.equal(full, rows)
+    # ... with the row counts known from the shard rule (what VolumetricModel.render passes): one all-gather, no count exchange;
+    # ragged (11 rows) and even (12 rows) splits
+    for total in (11, 12):
+        rows = torch.arange(total * 6, dtype=torch.float32).reshape(total, 6)
+        lo, hi = rfdist.shard_range(total)
+        sizes = [b_ - a_ for a_, b_ in (rfdist.shard_range(total, r2, world) for r2 in range(world))]
+        assert torch.equal(rfdist.all_gather_rows(rows[lo:hi], sizes), rows)
     b = torch.full((4,), float(rank))
     rfdist.broadcast_(b, src=0)
     assert torch.equal(b, torch.zeros(4))

@@ -62,12 +62,14 @@ def _oracle_step(dens, feat, rays, pixels, t_rands, cam, G, S):
 
 
 @pytest.mark.parametrize("fuse_optimizer", [False, True])
-def test_bench_train_step_against_oracle_at_baseline_size(hip_device, fuse_optimizer):
+@pytest.mark.parametrize("G,S,n", [(128, 256, 2048), (256, 512, 1024)])
+def test_bench_train_step_against_oracle_at_baseline_size(hip_device, fuse_optimizer, G, S, n):
     """The path bench.py times -- TrainStepper(fused=True, backward='binned') on split storage at 128^3 / SH-2 / 256 jittered
     samples -- against the oracle's autograd + torch.optim.Adam on the same 2048 rays and the same jitter: losses, the whole
     flat gradient (fuse_optimizer=False keeps the gradient bucket) and the parameters after the Adam update
-    (fuse_optimizer=True: the update happens inside the brick flush, no gradient bucket exists)."""
-    G, S, n = 128, 256, 2048
+    (fuse_optimizer=True: the update happens inside the brick flush, no gradient bucket exists).
+    And at the operating point the reference's CLI ends at (bench.py's ``train_256`` leg): 256^3 / SH-2 / 512 samples
+    (train_sh_based_voxel_grid_with_posed_images.py:55,88-90) -- 470 M parameters, 2^19 (brick, flags) keys."""
     grid, dens, feat = _uniform_grid(hip_device, G, 27, 42, "split")
     rays, cam = _frame_rays(hip_device, n, 3)
     pixels = T(hash_uniform((n, 3), 9, 0.0, 1.0)).to(hip_device)

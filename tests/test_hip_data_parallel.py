@@ -188,8 +188,81 @@ def test_trainer_under_data_parallelism_writes_consistent_checkpoints(tmp_path):
     assert sorted(n for n in os.listdir(tmp_path) if n.startswith("ok")) == [f"ok{r}" for r in range(world)]
 
 
+# ---- the multi-rank FORWARD render: VolumetricModel.render(data_parallel=True) (counterpart of modules/volumetric_model.py:143-172) -----
+def _frame_worker(rank, world, port, result_dir):
+    """Every rank renders its ``shard_range`` of an odd frame (47 x 61 pixels: the cuts fall in the middle of a pixel row AND in the
+    middle of an 8 x 8 tile row) against its replica of the grid and the [n, 6] results are all-gathered: the frame every rank ends up
+    with must equal the single-process frame BIT FOR BIT -- a pixel does not depend on how a frame is cut into calls, in either
+    frame kernel -- on both branches of ``render``: the one-launch branch (rays and keyed jitter generated in-kernel; ray packets and
+    the per-ray kernel) and the chunk loop (ragged chunks inside the shard), device and host outputs, with the occupancy mask."""
+    from thr3ed_atom_amd.voxels import VoxelGrid
+    from tests.helpers import sparse_scene_grid
+
+    os.environ.update(RANK=str(rank), LOCAL_RANK="0", WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dev = torch.device("cuda", 0)
+    torch.cuda.set_device(dev)
+    cam = hotdog_like_camera()
+    dims = (20, 16, 24)
+    dens, feat = sparse_scene_grid(dims, 27, 5)
+    grid = VoxelGrid(dens.to(dev), feat.to(dev), rf.VoxelSize(*(3.0 / d for d in dims)), density_preactivation=torch.nn.Identity(),
+                     density_postactivation=torch.nn.ReLU(), expected_density_scale=100.0 / 3.0, tunable=False, storage="split")
+    intr = rf.CameraIntrinsics(47, 61, 70.0)
+    pose = rf.pose_spherical(35.0, -25.0, cam["radius"])
+    bounds = rf.CameraBounds(cam["near"], cam["far"])
+    cfg = rf.SHVoxGridRenderConfig(40, bounds, perturb_sampled_points=True, white_bkgd=True)
+    model = rf.VolumetricModel(grid, rf.render_sh_voxel_grid, cfg, device=dev)
+
+    def same(a, b):  # bit for bit, every output (disparity is NaN on rays that hit nothing, accumulate.py:85-88: NaN == NaN here)
+        pairs = [(a.colour, b.colour), (a.depth, b.depth)] + [(a.extra[k], b.extra[k]) for k in sorted(a.extra)]
+        return sorted(a.extra) == sorted(b.extra) and all(torch.equal(torch.nan_to_num(x.to(dev), nan=-7.0), torch.nan_to_num(y.to(dev), nan=-7.0)) for x, y in pairs)
+
+    # the single-process frames first (no process group yet: data_parallel=True is then the plain render)
+    singles = {}
+    for tiles in ("1", "0"):
+        os.environ["RF_FRAME_TILES"] = tiles
+        for mask in (False, True):
+            torch.manual_seed(4)  # (the jitter key comes from torch's CPU generator: the same state on every rank)
+            singles[tiles, mask] = model.render(pose, intr, data_parallel=True, use_occupancy_mask=mask)
+    assert same(singles["1", False], singles["1", True]) and same(singles["0", False], singles["0", True])  # the mask is exact
+    torch.manual_seed(4)
+    single_chunked = model.render(pose, intr, parallel_rays_chunk_size=300, perturb_sampled_points=False, consume_reference_rng=True)
+    dist.init_process_group(backend="gloo", rank=rank, world_size=world)
+    try:
+        lo, hi = rfdist.shard_range(47 * 61)
+        assert rank == 0 or (lo % 61 != 0 and (lo // 61) % 8 != 0)  # the cut: inside a pixel row, inside a tile row
+        for tiles in ("1", "0"):
+            os.environ["RF_FRAME_TILES"] = tiles
+            for mask in (False, True):
+                torch.manual_seed(4)
+                frame = model.render(pose, intr, data_parallel=True, use_occupancy_mask=mask)
+                assert frame.colour.shape == (47, 61, 3) and frame.depth.shape == (47, 61, 1)
+                assert same(frame, singles[tiles, mask]), f"sharded one-launch frame differs (tiles={tiles}, mask={mask})"
+        # the chunk loop (asked for by consume_reference_rng): ragged chunks of 300 rays inside every shard; device and host outputs
+        for gpu_render in (True, False):
+            torch.manual_seed(4)
+            frame = model.render(pose, intr, parallel_rays_chunk_size=300, data_parallel=True, gpu_render=gpu_render, perturb_sampled_points=False, consume_reference_rng=True)
+            assert frame.colour.device.type == ("cuda" if gpu_render else "cpu")
+            assert same(frame, single_chunked), "sharded chunk-loop frame differs"
+        # every rank holds the same frame
+        mine = frame.colour.to(dev).contiguous()
+        every = [torch.empty_like(mine) for _ in range(world)]
+        dist.all_gather(every, mine)
+        assert all(torch.equal(every[0], e) for e in every)
+        open(os.path.join(result_dir, f"ok{rank}"), "w").write("ok")
+    finally:
+        os.environ.pop("RF_FRAME_TILES", None)
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_sharded_frame_render_equals_the_single_process_frame(tmp_path, world):
+    assert torch.cuda.is_available()
+    mp.spawn(_frame_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    assert sorted(os.listdir(tmp_path)) == [f"ok{r}" for r in range(world)]
+
+
 # ---- bench.py --gpus N: the supervised multi-GPU run (top of bench.py) --------------------------------------------------------------
-def _bench_two_ranks(extra_env, timeout=900):
+def _bench_two_ranks(extra_env, timeout=900, render_frames=0):
     """``python bench.py --gpus 2`` the way the driver launches N > 1 -- it re-executes itself as two ranks under torch.distributed.run,
     every rank a supervisor with the benchmark in a child process -- on ONE GPU over gloo (RF_SINGLE_DEVICE / RF_DIST_BACKEND), small
     workload.  Returns (completed process, the JSON lines it printed)."""
@@ -202,7 +275,7 @@ def _bench_two_ranks(extra_env, timeout=900):
     for name in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "RF_BENCH_WORKER", "RF_BENCH_RUN_DIR"):
         env.pop(name, None)
     cmd = [sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "3", "--windows", "1", "--second-point-rays", "8192", "--grid", "64", "--rays", "4096",
-           "--samples", "64", "--image-size", "200", "--cpu-rays", "0", "--render-frames", "0", "--highres-frames", "0", "--dropin-steps", "0"]
+           "--samples", "64", "--image-size", "200", "--cpu-rays", "0", "--render-frames", str(render_frames), "--highres-frames", "0", "--dropin-steps", "0"]
     r = subprocess.run(cmd, cwd=root, env=env, capture_output=True, text=True, timeout=timeout)
     return r, [json.loads(ln) for ln in r.stdout.splitlines() if ln.startswith("{")]
 
@@ -211,12 +284,26 @@ def test_bench_two_ranks_supervised(hip_device):
     """The undisturbed run: attempt 0 (owner-computes, interleaved halves, all-gathers in flight across the iteration boundary)
     validates itself on its first three iterations and is the configuration that gets timed; the world size in the line is counted
     by a collective."""
-    r, lines = _bench_two_ranks({})
+    r, lines = _bench_two_ranks({}, render_frames=2)
     assert r.returncode == 0 and len(lines) == 1, (r.returncode, r.stdout[-1500:], r.stderr[-3000:])
     d = lines[0]["distributed"]
     assert lines[0]["n_gpus"] == 2 and d["world_size_seen_by_collectives"] == 2 and d["exchange"] == "owner" and d["owner_halves"] == 2
     assert d["exchange_fallback_reason"] is None and d["replicas_bit_identical"] is True
     assert lines[0]["ms_per_step_windows"]["windows"] == 1 and lines[0]["second_weak_scaling_point"]["rays_per_gpu_per_step"] == 8192
+    # the forward legs on BOTH ranks (north_star: forward throughput "at 1/2/4/8 GPUs"): frame-parallel throughput and the sharded
+    # frame's latency, the latter checked against the single-GPU frame inside the run
+    m = lines[0]["fwd_render"]["multi_gpu"]
+    assert m["n_gpus"] == 2 and m["frame_parallel"]["ray_samples_per_s"] > 0 and m["sharded_frame"]["ms_per_frame"] > 0
+    assert m["sharded_frame"]["equals_single_gpu_frame_bit_for_bit"] is True
+
+
+def test_bench_two_ranks_forward_legs_cannot_cost_the_line(hip_device):
+    """A rank that never comes back from the multi-GPU forward legs (they run behind the committed training result, under a guard of their
+    own): the line is printed without them and says so."""
+    r, lines = _bench_two_ranks({"RF_BENCH_INJECT_FORWARD_LEGS_HANG": "1", "RF_BENCH_FORWARD_LEGS_TIMEOUT_S": "20"}, render_frames=1)
+    assert r.returncode == 0 and len(lines) == 1, (r.returncode, r.stdout[-1500:], r.stderr[-3000:])
+    assert lines[0]["n_gpus"] == 2 and lines[0]["distributed"]["replicas_bit_identical"] is True and lines[0]["value"] > 0
+    assert "not finished" in lines[0]["fwd_render"]["multi_gpu"]["error"]
 
 
 @pytest.mark.parametrize("inject", ["hang", "failure", "death"])

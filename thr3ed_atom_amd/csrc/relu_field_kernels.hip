@@ -1399,8 +1399,11 @@ __global__ __launch_bounds__(kBlock, RF_TILE_WAVES) void render_frame_tile_kerne
 
   const int i_raw = row0 + ty * 8 + (lane >> 3), j_raw = tx * 8 + (lane & 7);
   const int i = min(i_raw, r.H - 1), j = min(j_raw, r.W - 1);
-  const long long ray = ((long long)i * r.W + j) - r.ray0;
-  const bool lane_valid = i_raw < r.H && j_raw < r.W && ray >= 0 && ray < r.n;
+  const long long ray_raw = ((long long)i * r.W + j) - r.ray0;
+  const bool lane_valid = i_raw < r.H && j_raw < r.W && ray_raw >= 0 && ray_raw < r.n;
+  // (lanes off the frame or outside the call's pixel range march along with a clamped index: a caller-supplied jitter table
+  // [num_rays, S] is only ever read inside its rows; they never write)
+  const long long ray = min(max(ray_raw, 0ll), (long long)r.n - 1);
   const RayState st = tile_ray(g, r, flags, i, j);
   const bool white = flags & RF_FLAG_WHITE_BKGD;
   const bool use_occ = (flags & RF_FLAG_OCCUPANCY_SKIP) && g.occ != nullptr;
@@ -4109,6 +4112,8 @@ int rf_exp_gather_sorted(const RFGrid* grid, const float* records_sorted_dev, co
 static bool frame_uses_packets(const RFGrid* grid, const GridArgs& g, const RFCamera* cam, uint32_t flags) {
   const int K = grid->num_features / 3;
   if (!(g.layout == RF_LAYOUT_SPLIT && (K == 9 || K == 1) && g.Z >= 4 && g.Y >= 4 && g.X >= 4 && (g.dstride & 3) == 0 && (K == 1 || (g.fstride & 3) == 0))) return false;
+  // (the window is fetched as 16-byte quads: both tensors must start on a 16-byte boundary)
+  if ((((uintptr_t)grid->densities_dev | (uintptr_t)(K == 1 ? nullptr : grid->features_dev)) & 15u) != 0) return false;
   if (const char* e = getenv("RF_FRAME_TILES")) return atoi(e) != 0;
   float dist2 = 0.0f, vmin = 1e30f;
   for (int a = 0; a < 3; ++a) {

@@ -1,13 +1,19 @@
 """Data-parallel rendering/training across the GPUs of one node: one process per GPU over RCCL/xGMI.
 
-The reference has no distributed code at all (single process, single device).  Rays are independent, so
-the path shards naturally: every rank renders its own ray batch against a replicated grid; training adds
-exactly ONE exchange per iteration over the flat gradient bucket (``FlatGrid.flat_grad``: 234.9 MB at 128^3 /
-SH degree 2): either an all-reduce (average) after which every rank applies the identical Adam update, or --
-the trainer's default -- its two halves around a SHARDED Adam (ZeRO stage 1): reduce-scatter of the gradients,
-every rank updates only its 1/N of the parameters, all-gather of the updated parameters.  Same bytes on the
-links, 1/N of the optimizer's 1.6 GB of HBM traffic per rank, and the replicas stay bit-identical either way.
+The reference has no distributed code at all (single process, single device).  Rays are independent, so the path shards
+naturally: every rank renders its own ray batch against a replicated grid.  Frames: ``shard_range`` + ``all_gather_rows`` (the
+[n, 6] per-ray results; VolumetricModel.render(data_parallel=True)).  Training adds exactly ONE exchange per iteration, in one of
+two forms (trainers.TrainStepper(exchange=...)):
 
+* ``"owner"`` -- the trainer's default where the binned adjoint applies: OWNER-COMPUTES.  The ranks exchange what their adjoints
+  produce, gradient RECORDS already sorted by brick (``exchange_slices`` / ``fast_exchange``: an all-to-all of record slices, after
+  an all-gather of the offset tables), every rank sums all ranks' records for its own x-slabs of bricks with Adam in the flush, and
+  the updated parameters are all-gathered in place (``fast_all_gather_in_place`` / ``all_gather_chunks_``).
+* ``"dense"`` -- the fall-back for grids the owner step does not cover: the flat gradient bucket (``FlatGrid.flat_grad``: 234.9 MB
+  at 128^3 / SH degree 2) goes through a reduce-scatter (average), every rank applies Adam to its 1/N of the parameters (ZeRO
+  stage 1) and the updated parameters are all-gathered; ``all_reduce_mean_`` + identical Adam everywhere when sharding is off.
+
+The replicas stay bit-identical in every form.
 Backend "nccl" is RCCL on ROCm; "gloo" is used by the CPU tests of the collective wiring.
 """
 import os
@@ -299,20 +305,29 @@ def shard_range(total: int, rank_: Optional[int] = None, world: Optional[int] = 
     return start, start + base + (1 if r < rem else 0)
 
 
-def all_gather_rows(local: Tensor) -> Tensor:
-    """Concatenate per-rank row blocks (possibly of different lengths) along dim 0 on every rank."""
+def all_gather_rows(local: Tensor, sizes: Optional[list] = None) -> Tensor:
+    """Concatenate per-rank row blocks (possibly of different lengths) along dim 0 on every rank.  ``sizes`` = every rank's row
+    count when the caller knows them (the shards of a frame: ``shard_range``) -- the exchange is then ONE all-gather of equal padded
+    blocks, with no host round trip; without it the counts are exchanged first."""
     w = world_size()
     if w == 1:
         return local
-    sizes = [torch.zeros(1, dtype=torch.int64, device=local.device) for _ in range(w)]
-    dist.all_gather(sizes, torch.tensor([local.shape[0]], dtype=torch.int64, device=local.device))
-    sizes = [int(s.item()) for s in sizes]
+    if sizes is None:
+        counts = [torch.zeros(1, dtype=torch.int64, device=local.device) for _ in range(w)]
+        dist.all_gather(counts, torch.tensor([local.shape[0]], dtype=torch.int64, device=local.device))
+        sizes = [int(s.item()) for s in counts]
+    assert len(sizes) == w and sizes[rank()] == local.shape[0], (sizes, rank(), tuple(local.shape))
     width = max(sizes)
-    padded = torch.zeros((width,) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
-    padded[: local.shape[0]] = local
-    parts = [torch.empty_like(padded) for _ in range(w)]
-    dist.all_gather(parts, padded)
-    return torch.cat([p[:s] for p, s in zip(parts, sizes)], dim=0)
+    if local.shape[0] == width:
+        padded = local.contiguous()
+    else:
+        padded = torch.zeros((width,) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
+        padded[: local.shape[0]] = local
+    every = torch.empty((w, width) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
+    all_gather_rows_equal(every, padded)
+    if all(s == width for s in sizes):
+        return every.reshape((w * width,) + tuple(local.shape[1:]))
+    return torch.cat([every[r, :s] for r, s in enumerate(sizes)], dim=0)
 
 
 def replica_checksum(flat: Tensor) -> Tensor:

@@ -158,8 +158,10 @@ def render_sh_voxel_grid_frame(
     """The pixels [first_ray, first_ray + num_rays) of a whole posed-camera frame (row-major; default all of it) in ONE kernel
     launch: what ``VolumetricModel.render`` does per chunk -- cast_rays, slice, ``torch.rand``, render, concatenate
     (reference modules/volumetric_model.py:143-172) -- with the rays and the stratified jitter generated inside the kernel.
-    Inference only (no autograd); results do not depend on how a frame is split into calls.  ``render_config.jitter`` must be
-    "keyed" when ``perturb_sampled_points`` is set (a torch.rand table would have to be materialised: use the chunked path)."""
+    Inference only (no autograd); results do not depend on how a frame is split into calls.  Configurations that ask for torch's own
+    random streams -- ``consume_reference_rng``, or ``perturb_sampled_points`` with ``jitter="torch"`` (a torch.rand table per chunk) --
+    are served the way ``VolumetricModel.render`` serves them: cast_rays, then ``render_sh_voxel_grid`` on chunks of
+    ``parallel_rays_chunk_size`` rays of the range, concatenated (the reference's loop, volumetric_model.py:152-172)."""
     from .ops import render_flags, render_frame_raw
 
     voxel_grid = as_kernel_grid(voxel_grid)
@@ -167,11 +169,12 @@ def render_sh_voxel_grid_frame(
     jitter = None
     # (the reference's own config class has neither ``jitter`` nor ``use_occupancy_mask`` nor ``consume_reference_rng``)
     use_occupancy = bool(getattr(render_config, "use_occupancy_mask", False))
-    if getattr(render_config, "consume_reference_rng", False):
-        raise ValueError("render_sh_voxel_grid_frame draws no per-chunk torch.randn: with consume_reference_rng use the chunked path")
+    jitter_kind = getattr(render_config, "jitter", "keyed")
+    if jitter_kind not in ("keyed", "torch"):
+        raise ValueError("SHVoxGridRenderConfig.jitter must be 'keyed' or 'torch'")
+    if getattr(render_config, "consume_reference_rng", False) or (render_config.perturb_sampled_points and jitter_kind != "keyed"):
+        return _render_frame_in_chunks(voxel_grid, camera_intrinsics, camera_pose, render_config, first_ray, num_rays)
     if render_config.perturb_sampled_points:
-        if getattr(render_config, "jitter", "keyed") != "keyed":
-            raise ValueError("render_sh_voxel_grid_frame draws its jitter inside the kernel: SHVoxGridRenderConfig.jitter must be 'keyed'")
         jitter = KeyedJitter(draw_jitter_key(), 0)
     if use_occupancy and not voxel_grid.occupancy_current():
         voxel_grid.build_occupancy()
@@ -183,3 +186,23 @@ def render_sh_voxel_grid_frame(
         float(np.float32(bounds.near)), float(np.float32(bounds.far)), flags, jitter, first_ray=first_ray, num_rays=num_rays,
     )
     return RenderOut(colour=colour, depth=depth, extra={EXTRA_DISPARITY: disparity, EXTRA_ACCUMULATED_WEIGHTS: acc})
+
+
+def _render_frame_in_chunks(voxel_grid, camera_intrinsics, camera_pose, render_config, first_ray: int, num_rays: Optional[int]) -> RenderOut:
+    """``render_sh_voxel_grid_frame`` for the configurations that draw from torch's generators per chunk (above): the reference's
+    chunk loop (modules/volumetric_model.py:152-172) over the pixel range, under no_grad."""
+    from .ops import cast_rays_hip
+    from .render_interface import collate_rendered_output
+
+    height, width, focal = camera_intrinsics
+    total = int(height) * int(width)
+    count = total - int(first_ray) if num_rays is None else int(num_rays)
+    if first_ray < 0 or count < 0 or first_ray + count > total:
+        raise RuntimeError(f"render_sh_voxel_grid_frame: bad shape (pixels [{first_ray}, {first_ray + count}) of a {height} x {width} frame)")
+    device = voxel_grid.kernel_tensors()[0].device
+    o, d = cast_rays_hip(int(height), int(width), float(focal), camera_pose.rotation, camera_pose.translation, device)
+    flat = Rays(o.reshape(-1, 3)[first_ray : first_ray + count], d.reshape(-1, 3)[first_ray : first_ray + count])
+    chunk = max(1, int(getattr(render_config, "parallel_rays_chunk_size", 32768) or count or 1))
+    with torch.no_grad():
+        chunks = [render_sh_voxel_grid(voxel_grid, flat[s : s + chunk], render_config, first_ray=first_ray + s) for s in range(0, max(count, 1), chunk)]
+    return collate_rendered_output(chunks)

@@ -134,14 +134,11 @@ class VolumetricModel:
             with torch.no_grad():
                 out = render_sh_voxel_grid_frame(self._thre3d_repr, camera_intrinsics, camera_pose, cfg, first_ray=lo, num_rays=hi - lo)
             if dp:
-                keys = sorted(out.extra.keys())
-                packed = torch.cat([out.colour, out.depth] + [out.extra[k] for k in keys], dim=-1)
-                packed = rfdist.all_gather_rows(packed)
-                assert packed.shape[0] == total_rays
-                out = RenderOut(packed[:, :3], packed[:, 3:4], {k: packed[:, 4 + i : 5 + i] for i, k in enumerate(keys)})
+                out = self._gather_frame_shards(out, total_rays)
             return reshape_rendered_output(out, camera_intrinsics)
         flat = flatten_rays(cast_rays(camera_intrinsics, camera_pose, self._device))
-        if data_parallel and rfdist.world_size() > 1:
+        dp = data_parallel and rfdist.world_size() > 1
+        if dp:
             # rays are independent: every rank renders one contiguous range of the frame against its own replica of
             # the grid; the only exchange is the gather of the [n, 6] per-ray results at the end
             lo, hi = rfdist.shard_range(total_rays)
@@ -156,17 +153,27 @@ class VolumetricModel:
         with torch.no_grad():
             for start in starts:
                 out = self.render_rays(flat[start : start + chunk], parallel_points_chunk_size, **kwargs)
-                if not gpu_render:
+                if not gpu_render and not dp:
                     out = out.to(torch.device("cpu"))
                 chunks.append(out)
         out = collate_rendered_output(chunks)
-        if data_parallel and rfdist.world_size() > 1:
-            keys = sorted(out.extra.keys())
-            packed = torch.cat([out.colour, out.depth] + [out.extra[k] for k in keys], dim=-1)
-            packed = rfdist.all_gather_rows(packed)
-            assert packed.shape[0] == total_rays
-            out = RenderOut(packed[:, :3], packed[:, 3:4], {k: packed[:, 4 + i : 5 + i] for i, k in enumerate(keys)})
+        if dp:
+            out = self._gather_frame_shards(out, total_rays)  # (on the device, whatever ``gpu_render`` says: RCCL moves device memory)
+            if not gpu_render:
+                out = out.to(torch.device("cpu"))
         return reshape_rendered_output(out, camera_intrinsics)
+
+    @staticmethod
+    def _gather_frame_shards(out: RenderOut, total_rays: int) -> RenderOut:
+        """every rank's rows of a frame (``shard_range`` of its flat rays) -> the whole frame on every rank: ONE all-gather of the
+        packed [n, 3 + 1 + extras] per-ray results; the row counts follow from the shard rule, nothing else is exchanged"""
+        world = rfdist.world_size()
+        sizes = [hi - lo for lo, hi in (rfdist.shard_range(total_rays, r, world) for r in range(world))]
+        keys = sorted(out.extra.keys())
+        packed = torch.cat([out.colour, out.depth] + [out.extra[k] for k in keys], dim=-1)
+        packed = rfdist.all_gather_rows(packed, sizes)
+        assert packed.shape[0] == total_rays
+        return RenderOut(packed[:, :3], packed[:, 3:4], {k: packed[:, 4 + i : 5 + i] for i, k in enumerate(keys)})
 
 
 def create_volumetric_model_from_saved_model(
