@@ -871,16 +871,20 @@ def main():
         dt = dropin_leg("keyed")
         dt_rand = dropin_leg("keyed", jitter="torch")
         dt_randperm = dropin_leg("randperm", jitter="torch")
+        dt_randperm_blocks = dropin_leg("randperm_blocks", jitter="torch")
         dropin = {
             "workload": "the same iteration the way a reference user gets it: VoxelGrid in the reference's two tensors (its nn.Parameters; forward passes gather from a split-layout "
-            "shadow), render_sh_voxel_grid as a torch.autograd.Function per render (rf_render_forward / binned adjoint as record lists), SHVoxGridRenderConfig defaults (stratified "
-            "jitter drawn inside the kernel from a per-call key: the law of torch.rand(N, S) without the tensor), the trainer's L1 + MSE lines as one autograd.Function launch per render, "
+            "shadow), both renders of the iteration as ONE torch.autograd.Function (VolumetricModel.render_rays_pair: rf_render_forward_pair / offsets + adjoints of both record lists in two "
+            "launches; $RF_AUTOGRAD_PAIR=0: one node per render), SHVoxGridRenderConfig defaults (stratified "
+            "jitter drawn inside the kernel from a per-call key: the law of torch.rand(N, S) without the tensor), the trainer's L1 + MSE lines of both renders as one autograd.Function launch, "
             "FusedAdam.step = ONE brick pass with Adam in its flush that writes the shadow AND the Parameters' own layout; the batch = distinct uniformly random pixels by the keyed "
             "bijection (the law of torch.randperm(P)[:R] without sorting 5.12 M keys)",
             "ms_per_step": dt * 1e3,
             "ray_samples_per_s": 2 * R * S / dt,
             "ms_per_step_with_torch_rand_jitter": dt_rand * 1e3,
             "ms_per_step_with_torch_rand_jitter_and_torch_randperm_selection": dt_randperm * 1e3,
+            # torch.randperm's own draws without one 5.12 M-key permutation PER ITERATION: one per block of floor(P / R) iterations, consumed in slices
+            "ms_per_step_with_torch_rand_jitter_and_torch_randperm_per_block_selection": dt_randperm_blocks * 1e3,
             "steps": args.dropin_steps,
             "warmup": 5,
         }

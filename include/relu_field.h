@@ -15,8 +15,10 @@
  *  - All pointers named *_dev are DEVICE pointers owned by the caller (PyTorch allocations); the library
  *    never allocates, frees or retains them.  All tensors are contiguous float32 unless a stride is given.
  *  - Every call only ENQUEUES work on `stream` (a hipStream_t passed as void*); no implicit synchronisation.
- *  - Re-entrant, no global state.  Return value: RF_OK (0) or a negative RF_ERR_* code; nothing is thrown
- *    across the ABI.  rf_error_string() maps a code to text.
+ *  - Re-entrant: no mutable state is shared between calls.  What the library keeps per process is read-only after its first
+ *    use: tuning knobs read from the environment ($RF_FRAME_TILES, $RF_FWD_PAIR, $RF_EMIT_PAIR, $RF_BRICK_STAGGER, $RF_FAR_ADDRESSING -- A/B switches,
+ *    unset in production) and the cached result of one-time hipFuncSetAttribute calls (dynamic LDS size of the brick kernels).
+ *    Return value: RF_OK (0) or a negative RF_ERR_* code; nothing is thrown across the ABI.  rf_error_string() maps a code to text.
  *  - Gradient buffers are ACCUMULATED into (+=) with float32 hardware atomics; the caller zero-fills them
  *    (or keeps accumulating across several renders, which is autograd's semantics).
  */
@@ -470,6 +472,34 @@ enum {
 #define RF_TRAIN_STEP_EVENTS 11
 
 int rf_train_step(const RFGrid* grid, const RFTrainStep* step, void* stream);
+
+/* ---- the two renders of an iteration, PAIRED, as separate calls ---------------------------------------------------------
+ * The reference's iteration renders the same rays twice -- vol_mod.render_rays(rays) and vol_mod.render_rays(rays,
+ * render_diffuse=True), each with its own jitter draw (modules/trainers.py:306, 323-325) -- and back-propagates the sum of the two
+ * L1 losses (:311, 329-330, 338).  A host that keeps autograd in charge (torch.autograd.Function: one node for the PAIR of
+ * renders, one for the pair of losses) enqueues the iteration's launches one by one instead of through rf_train_step:
+ *
+ *   rf_render_forward_pair              both saving forward renders in ONE launch ([0] specular, [1] render_diffuse; the second
+ *                                       finds the base records of its corners on chip).  Both outs must carry the four cache
+ *                                       buffers; key_hist_dev counts the records per key as in rf_render_forward.
+ *   rf_l1_loss_grad_pair                the two losses in ONE launch and ready to use: out_dev[5] = (loss[0] + loss[1], loss[0],
+ *                                       mse[0], loss[1], mse[1]) -- means, written by the last workgroup to finish;
+ *                                       grad_colour_dev[i] as rf_l1_loss_grad.  workspace_dev: 8 floats, zero before the first
+ *                                       use, left zero (the kernel cleans up after itself; one workspace per stream).
+ *   rf_bin_offsets_pair                 rf_bin_offsets for both lists in one launch
+ *   rf_render_backward_emit_direct_pair both adjoints as records in ONE launch (rf_render_backward_emit_direct twice); upstream
+ *                                       gradients of the colours only (passes[i].grad_colour_dev), like every reference use.
+ *
+ * Every array argument holds TWO entries.  RF_ERR_UNSUPPORTED when the two renders do not pair up (different ray counts, flags
+ * that do not say specular / render_diffuse): the caller then launches them one by one.  (Added to ABI version 4 compatibly: no
+ * existing struct or signature changed.) */
+int rf_render_forward_pair(const RFGrid* grid, const RFRayBatch* rays, const uint32_t* flags, const RFRenderOut* outs, void* stream);
+int rf_l1_loss_grad_pair(const float* const* colour_dev, const float* target_dev, int64_t num_rays, float scale,
+                         float* const* grad_colour_dev, float* workspace_dev, float* out_dev, void* stream);
+int rf_bin_offsets_pair(const int32_t* const* hist_dev, int32_t num_keys, int64_t* const* offsets_dev, int32_t* const* cursor_dev,
+                        void* stream);
+int rf_render_backward_emit_direct_pair(const RFGrid* grid, const RFRayBatch* rays, const uint32_t* flags,
+                                        const RFPassScratch* passes, void* stream);
 
 #ifdef __cplusplus
 }

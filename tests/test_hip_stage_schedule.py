@@ -61,7 +61,7 @@ class _Follower:
             self.opt = torch.optim.Adam([{"params": list(grid.parameters()), "lr": lr}], betas=(0.9, 0.999))
             self.sched = torch.optim.lr_scheduler.ExponentialLR(self.opt, gamma=self.gamma)
         else:
-            self.stepper = TrainStepper(self.model, int(self.g["config"][4]), learning_rate=lr, fused=self.kind != "autograd", data_parallel=False,
+            self.stepper = TrainStepper(self.model, int(self.g["config"][4]), learning_rate=lr, fused=not self.kind.startswith("autograd"), data_parallel=False,
                                         deterministic=getattr(self, "deterministic", False), backward="binned" if getattr(self, "deterministic", False) else "auto")
             self.sched = ExponentialLR(self.stepper.optimizer, self.gamma)
 
@@ -73,6 +73,15 @@ class _Follower:
             st = self.stepper.step_on(rays, pixels, t_rand=(t_spec, t_diff))
             return float(st.specular_loss), float(st.diffuse_loss)
         cfg = self.model.render_config
+        if self.kind == "autograd_pair":  # both renders as ONE autograd node, both loss lines as one (what TrainStepper(fused=False) runs)
+            from thr3ed_atom_amd import ops
+
+            spec_out, diff_out = rf.render_sh_voxel_grid_pair(self.grid, rays, cfg, t_rands=(t_spec, t_diff))
+            total, spec, _, diff, _ = ops.l1_loss_pair_with_mse(spec_out.colour, diff_out.colour, pixels)
+            self.stepper.optimizer.zero_grad()
+            total.backward()
+            self.stepper.optimizer.step()
+            return float(spec), float(diff)
         spec = torch.nn.functional.l1_loss(rf.render_sh_voxel_grid(self.grid, rays, cfg, t_rand=t_spec).colour, pixels)
         import dataclasses
 
@@ -138,7 +147,8 @@ _POLICY_MIN_BRICKS = {"binned-on-every-grid": "0", "production": None, "switch":
     ("fused", "split", "binned-on-every-grid"), ("fused", "bricked", "binned-on-every-grid"), ("autograd", "reference", "binned-on-every-grid"),
     ("torch_optim", "reference", "binned-on-every-grid"),
     ("fused", "split", "production"), ("autograd", "reference", "production"), ("torch_optim", "reference", "production"),
-    ("fused", "split", "switch"), ("autograd", "reference", "switch")])
+    ("fused", "split", "switch"), ("autograd", "reference", "switch"),
+    ("autograd_pair", "reference", "binned-on-every-grid"), ("autograd_pair", "reference", "switch"), ("autograd_pair", "split", "production")])
 def test_g9b_trained_field_through_the_stage_transition(hip_device, monkeypatch, kind, storage, policy):
     """What float32 allows to be asserted, and what it does not.  Adam turns rounding-level differences of near-zero gradients into
     full-size steps and the L1 loss flips the sign of a pixel's gradient at |error| ~ 1e-7, so two float32 evaluations of this

@@ -35,7 +35,7 @@ def relu_grid(dev, dens, feat, G, rho=100.0 / 3.0, tunable=True, storage="refere
 
 
 @pytest.mark.parametrize("policy", ["binned-on-every-grid", "production"])
-@pytest.mark.parametrize("fused", [True, False])
+@pytest.mark.parametrize("fused", [True, False, "autograd-unpaired"])
 @pytest.mark.parametrize("storage", ["reference", "split", "bricked"])
 def test_g9_reference_trainer_trajectory(hip_device, monkeypatch, storage, fused, policy):
     """TrainStepper fed the batches the REAL reference trainer selected reproduces its losses and parameters.  ``policy``:
@@ -44,6 +44,9 @@ def test_g9_reference_trainer_trajectory(hip_device, monkeypatch, storage, fused
     (modules/trainers.py:278-341)."""
     if policy == "production":
         monkeypatch.delenv("RF_AUTO_BINNED_MIN_BRICKS", raising=False)
+    if fused == "autograd-unpaired":  # (fused=False renders the iteration's pair as ONE autograd node by default: here one node per render)
+        monkeypatch.setattr(ops, "PAIR_RENDERS", False)
+        fused = False
     g = load_golden("g9_trainer_trajectory.npz")
     G, deg, hw, n_img, n_rays, steps, S = (int(v) for v in g["config"])
     F = 3 * (deg + 1) ** 2
@@ -438,6 +441,23 @@ def test_keyed_ray_selection(hip_device):
     torch.manual_seed(3)
     r2, p2 = stepper.select(data, ids)
     assert torch.equal(r1.origins, r2.origins) and torch.equal(p1, p2) and len(r1) == 512
+    # "randperm_blocks": ONE torch.randperm per block of floor(P / R) iterations, consumed in consecutive slices: the batches of a
+    # block are disjoint slices of that permutation (rays / pixels of exactly those entries), the block after it draws a new one
+    stepper = TrainStepper(model, 1500, 0.03, ray_selection="randperm_blocks")
+    torch.manual_seed(5)
+    expect = torch.randperm(4 * hw, dtype=torch.long, device=hip_device)
+    torch.manual_seed(5)
+    seen = []
+    for k in range(4):  # 4 x 1500 = 6000 of the 6400 pixels: one block
+        r, p = stepper.select(data, ids)
+        sel = expect[1500 * k : 1500 * (k + 1)]
+        ro, rd = ops.cast_selected_rays_hip(H, W, f, data.poses[ids.to(hip_device)], sel)
+        assert torch.equal(r.origins, ro) and torch.equal(r.directions, rd)
+        assert torch.equal(p, data.pixels[ids.to(hip_device)[sel // hw] * hw + sel % hw])
+        seen.append(sel)
+    assert len(torch.unique(torch.cat(seen))) == 6000
+    r, _ = stepper.select(data, ids)  # 400 entries are left: a new permutation
+    assert stepper._perm_block[1] == 1500 and len(r) == 1500
 
 
 def _binned_gradients(grid, rays, cfg, target, device, diffuse_too=True, accumulate=False, binning="sort", brick=8):
@@ -1050,6 +1070,72 @@ def test_autograd_trainer_with_deferred_gradients_equals_the_fused_step(hip_devi
         np.testing.assert_allclose(b.cpu().numpy(), a.cpu().numpy(), rtol=2e-4, atol=2e-6 * float(a.abs().max()))
     flat.zero_grad()
     assert flat.pending == []
+
+
+@pytest.mark.parametrize("storage,bucket", [("split", "none"), ("reference", "none"), ("bricked", "flat"), ("reference", "deferred")])
+def test_paired_autograd_node_equals_the_two_single_nodes(hip_device, monkeypatch, storage, bucket):
+    """``render_sh_voxel_grid_pair`` / ``VolumetricModel.render_rays_pair`` (both renders of an iteration as ONE autograd node: one
+    forward launch, offsets + adjoints in two) against the two single nodes: the same jitter draws (keyed from torch's CPU generator, in
+    the same order), outputs bit for bit (the pair kernel runs the single kernels' per-ray code), gradients to the order of the cursor
+    atomics -- into fresh tensors, into a flat bucket, as pending lists of a deferred bucket --, upstream gradients of depth and
+    accumulated weight (the un-paired adjoints behind the paired forward), and the paired loss against torch's."""
+    monkeypatch.setattr(ops, "AUTOGRAD_BACKWARD", "binned")
+    cam = hotdog_like_camera()
+    dims = (24, 20, 28)
+    rays = rf.flatten_rays(rf.cast_rays(rf.CameraIntrinsics(37, 41, 50.0), rf.pose_spherical(25.0, -35.0, cam["radius"]), hip_device))
+    n = len(rays)
+    target = T(hash_uniform((n, 3), 19, 0.0, 1.0)).to(hip_device)
+    cfg = rf.SHVoxGridRenderConfig(48, rf.CameraBounds(cam["near"], cam["far"]), perturb_sampled_points=True, white_bkgd=True)
+
+    def fresh():
+        dens, feat = procedural_grid(dims, 27, 5)
+        grid = rf.VoxelGrid(dens.to(hip_device), feat.to(hip_device), rf.VoxelSize(*(3.0 / d for d in dims)), density_preactivation=torch.nn.Identity(),
+                            density_postactivation=torch.nn.ReLU(), expected_density_scale=30.0, tunable=True, storage=storage)
+        flat = None if bucket == "none" else FlatGrid(grid, deferred=bucket == "deferred")
+        return grid, flat, rf.VolumetricModel(grid, rf.render_sh_voxel_grid, cfg, device=hip_device)
+
+    def grads(grid, flat):
+        if flat is not None and flat.deferred:
+            assert len(flat.pending) == 2
+            flat.materialize()
+        return [t.detach().clone() for t in grid.reference_gradients()]
+
+    for upstream in ("colours", "depth-and-acc"):
+        results = []
+        for paired in (True, False):
+            grid, flat, model = fresh()
+            torch.manual_seed(11)
+            if paired:
+                spec, diff = model.render_rays_pair(rays)
+                assert spec.colour.grad_fn is diff.colour.grad_fn is not None and "Pair" in type(spec.colour.grad_fn).__name__
+            else:
+                spec, diff = model.render_rays(rays), model.render_rays(rays, render_diffuse=True)
+            if upstream == "colours":
+                total, l0, mse0, l1, mse1 = ops.l1_loss_pair_with_mse(spec.colour, diff.colour, target)
+                ref_l0, ref_l1 = torch.nn.functional.l1_loss(spec.colour.detach(), target), torch.nn.functional.l1_loss(diff.colour.detach(), target)
+                np.testing.assert_allclose([float(l0), float(l1), float(total)], [float(ref_l0), float(ref_l1), float(ref_l0 + ref_l1)], rtol=2e-6)
+                np.testing.assert_allclose([float(mse0), float(mse1)], [float(torch.nn.functional.mse_loss(spec.colour.detach(), target)),
+                                                                         float(torch.nn.functional.mse_loss(diff.colour.detach(), target))], rtol=2e-6)
+            else:
+                total = torch.nn.functional.l1_loss(spec.colour, target) + spec.depth.square().mean() + 0.3 * diff.extra["accumulated_weight"].sum() / n
+            total.backward()
+            results.append((spec, diff, grads(grid, flat), float(total)))
+        (s0, d0, g0, t0), (s1, d1, g1, t1) = results
+        for a, b in ((s0, s1), (d0, d1)):
+            assert torch.equal(a.colour, b.colour) and torch.equal(a.depth, b.depth) and torch.equal(a.extra["accumulated_weight"], b.extra["accumulated_weight"])
+        assert abs(t0 - t1) <= 1e-6 * abs(t1)
+        for a, b in zip(g0, g1):
+            assert float(b.abs().max()) > 0
+            np.testing.assert_allclose(a.cpu().numpy(), b.cpu().numpy(), rtol=3e-4, atol=3e-6 * float(b.abs().max()))
+    # the paired loss cleans its workspace up after itself: any number of calls, the gradient of its sum = the two L1 gradients
+    c0 = s0.colour.detach().clone().requires_grad_(True)
+    c1 = d0.colour.detach().clone().requires_grad_(True)
+    for _ in range(3):
+        total, l0, _, l1, _ = ops.l1_loss_pair_with_mse(c0, c1, target)
+    np.testing.assert_allclose(float(total), float(torch.nn.functional.l1_loss(c0, target) + torch.nn.functional.l1_loss(c1, target)), rtol=2e-6)
+    (2.0 * total).backward()
+    np.testing.assert_allclose(c0.grad.cpu().numpy(), (2.0 * torch.sign(c0.detach() - target) / (3 * n)).cpu().numpy(), rtol=1e-6)
+    np.testing.assert_allclose(c1.grad.cpu().numpy(), (2.0 * torch.sign(c1.detach() - target) / (3 * n)).cpu().numpy(), rtol=1e-6)
 
 
 _PAIR_SCRIPT = r"""

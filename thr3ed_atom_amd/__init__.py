@@ -33,7 +33,7 @@ from .voxels import (  # noqa: F401
     create_voxel_grid_from_saved_info_dict,
     scale_voxel_grid_with_required_output_size,
 )
-from .renderers import SHVoxGridRenderConfig, density2occupancy_pb, render_sh_voxel_grid, render_sh_voxel_grid_frame  # noqa: F401
+from .renderers import SHVoxGridRenderConfig, density2occupancy_pb, render_sh_voxel_grid, render_sh_voxel_grid_frame, render_sh_voxel_grid_pair  # noqa: F401
 from .volumetric_model import VolumetricModel, cast_rays, create_volumetric_model_from_saved_model  # noqa: F401
 from .composable import (  # noqa: F401  (the path at the granularity of the reference's plug-in points)
     SampledPointsOnRays,

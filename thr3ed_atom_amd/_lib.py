@@ -25,6 +25,7 @@ FLAG_RENDER_DIFFUSE = 2
 FLAG_AABB_SAMPLING = 4
 FLAG_OCCUPANCY_SKIP = 8
 FLAG_JITTER_KEYED = 16
+ERR_UNSUPPORTED = -3  # RF_ERR_UNSUPPORTED
 STEP_FORWARD = 1
 STEP_EMIT = 2
 STEP_BRICKS = 4
@@ -66,6 +67,10 @@ EXPORTED_SYMBOLS = [
     "rf_l1_loss_grad",
     "rf_adam_step",
     "rf_train_step",
+    "rf_render_forward_pair",
+    "rf_l1_loss_grad_pair",
+    "rf_bin_offsets_pair",
+    "rf_render_backward_emit_direct_pair",
 ]
 
 
@@ -298,6 +303,11 @@ def load() -> C.CDLL:
     lib.rf_build_occupancy.argtypes = [C.POINTER(RFGrid), f32, vp, vp]
     lib.rf_l1_loss_grad.argtypes = [vp, vp, i64, f32, vp, vp, vp]
     lib.rf_adam_step.argtypes = [vp, vp, vp, vp, i64, f32, f32, f32, f32, i32, i32, vp]
+    # the paired entry points: every array argument holds two entries ([0] specular, [1] render_diffuse)
+    lib.rf_render_forward_pair.argtypes = [C.POINTER(RFGrid), C.POINTER(RFRayBatch), C.POINTER(u32), C.POINTER(RFRenderOut), vp]
+    lib.rf_l1_loss_grad_pair.argtypes = [C.POINTER(vp), vp, i64, f32, C.POINTER(vp), vp, vp, vp]
+    lib.rf_bin_offsets_pair.argtypes = [C.POINTER(vp), i32, C.POINTER(vp), C.POINTER(vp), vp]
+    lib.rf_render_backward_emit_direct_pair.argtypes = [C.POINTER(RFGrid), C.POINTER(RFRayBatch), C.POINTER(u32), C.POINTER(RFPassScratch), vp]
     for name in EXPORTED_SYMBOLS:
         if name not in ("rf_error_string",):
             getattr(lib, name).restype = C.c_int64 if name == "rf_brick_split_scratch_bytes" else C.c_int

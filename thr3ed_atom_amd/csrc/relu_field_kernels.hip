@@ -3692,6 +3692,32 @@ __global__ void l1_loss_grad_kernel(L1Sets sets, const float* __restrict__ targe
   l1_loss_grad_body(sets, target, n3, gscale, blockIdx.y, blockIdx.x, gridDim.x);
 }
 
+// rf_l1_loss_grad_pair: both losses in one launch, finished by the LAST workgroup: the block partial sums go to a workspace (4 sums +
+// a ticket counter) with atomics; the workgroup that draws the last ticket reads the totals back (atomics again: the same coherence
+// point), writes the five means and leaves the workspace zeroed for the next call.
+__global__ void l1_loss_pair_kernel(L1Sets sets, const float* __restrict__ target, long long n3, float gscale, float inv_n3, float* __restrict__ out) {
+  l1_loss_grad_body(sets, target, n3, gscale, blockIdx.y, blockIdx.x, gridDim.x);  // (its thread 0 added this block's sums)
+  if (threadIdx.x == 0) {
+    float* ws = sets.sums[0];  // [0..3] sums (sets.sums[1] = ws + 2), [4] ticket counter
+    unsigned int* ticket = reinterpret_cast<unsigned int*>(ws + 4);
+    __threadfence();
+    const unsigned int total = gridDim.x * gridDim.y;
+    if (atomicAdd(ticket, 1u) == total - 1u) {
+      __threadfence();
+      float v[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) v[i] = atomicExch(ws + i, 0.0f);  // read and clear
+      atomicExch(ticket, 0u);
+      const float l0 = v[0] * inv_n3, l1 = v[2] * inv_n3;
+      out[0] = l0 + l1;
+      out[1] = l0;
+      out[2] = v[1] * inv_n3;
+      out[3] = l1;
+      out[4] = v[3] * inv_n3;
+    }
+  }
+}
+
 // rf_train_step: the losses of both renders AND the offsets of both record lists -- everything between the forward passes and the
 // adjoints -- in one launch (1024-thread workgroups; blockIdx.y 0, 1: loss of render 0, 1; 2, 3: offsets of list 0, 1)
 __global__ __launch_bounds__(1024) void loss_and_offsets_kernel(L1Sets sets, const float* __restrict__ target, long long n3, float gscale,
@@ -4331,6 +4357,22 @@ static int emit_pair_impl(const RFGrid* grid, const RFRayBatch* const rays[2], c
   return launch_status();
 }
 
+int rf_render_forward_pair(const RFGrid* grid, const RFRayBatch* rays, const uint32_t* flags, const RFRenderOut* outs, void* stream) {
+  if (!grid || !rays || !flags || !outs) return RF_ERR_NULL_POINTER;
+  const RFRayBatch* const rr[2] = {&rays[0], &rays[1]};
+  const RFRenderOut* const oo[2] = {&outs[0], &outs[1]};
+  if (rays[0].camera || rays[1].camera) return RF_ERR_UNSUPPORTED;  // (ray lists: the renders of a training iteration)
+  return forward_pair_impl(grid, rr, flags, oo, stream);
+}
+
+int rf_render_backward_emit_direct_pair(const RFGrid* grid, const RFRayBatch* rays, const uint32_t* flags, const RFPassScratch* passes, void* stream) {
+  if (!grid || !rays || !flags || !passes) return RF_ERR_NULL_POINTER;
+  if (passes[0].out.brick_size != passes[1].out.brick_size) return RF_ERR_BAD_SHAPE;
+  const RFRayBatch* const rr[2] = {&rays[0], &rays[1]};
+  const RFPassScratch* const pp[2] = {&passes[0], &passes[1]};
+  return emit_pair_impl(grid, rr, flags, pp, stream);
+}
+
 int rf_render_backward_emit_direct(const RFGrid* grid, const RFRayBatch* rays, uint32_t flags, const RFRenderOut* fwd,
                                    const RFRenderGrads* grads, int32_t brick_size, int32_t* cursor_dev,
                                    float* records_sorted_dev, int32_t* hist_clear_dev, void* stream) {
@@ -4385,6 +4427,14 @@ static int bin_offsets_impl(const int32_t* const hist[2], int64_t* const offsets
   }
   hipLaunchKernelGGL(bin_offsets_kernel, dim3((num_keys + 1023) / 1024, nlists), dim3(1024), 0, (hipStream_t)stream, l, num_keys);
   return launch_status();
+}
+
+int rf_bin_offsets_pair(const int32_t* const* hist_dev, int32_t num_keys, int64_t* const* offsets_dev, int32_t* const* cursor_dev, void* stream) {
+  if (!hist_dev || !offsets_dev || !cursor_dev) return RF_ERR_NULL_POINTER;
+  const int32_t* h[2] = {hist_dev[0], hist_dev[1]};
+  int64_t* o[2] = {offsets_dev[0], offsets_dev[1]};
+  int32_t* c[2] = {cursor_dev[0], cursor_dev[1]};
+  return bin_offsets_impl(h, o, c, 2, num_keys, stream);
 }
 
 int rf_bin_offsets(const int32_t* hist_dev, int32_t num_keys, int64_t* offsets_dev, int32_t* cursor_dev, void* stream) {
@@ -4763,6 +4813,23 @@ int rf_l1_loss_grad(const float* colour_dev, const float* target_dev, int64_t nu
   sets.grad[0] = grad_colour_dev;
   sets.sums[0] = sums_dev;
   return l1_loss_grad_impl(sets, 1, target_dev, num_rays, scale, stream);
+}
+
+int rf_l1_loss_grad_pair(const float* const* colour_dev, const float* target_dev, int64_t num_rays, float scale,
+                         float* const* grad_colour_dev, float* workspace_dev, float* out_dev, void* stream) {
+  if (!colour_dev || !grad_colour_dev || !target_dev || !workspace_dev || !out_dev) return RF_ERR_NULL_POINTER;
+  if (num_rays <= 0) return RF_ERR_BAD_SHAPE;
+  L1Sets sets = {};
+  for (int i = 0; i < 2; ++i) {
+    if (!colour_dev[i] || !grad_colour_dev[i]) return RF_ERR_NULL_POINTER;
+    sets.colour[i] = colour_dev[i];
+    sets.grad[i] = grad_colour_dev[i];
+    sets.sums[i] = workspace_dev + 2 * i;
+  }
+  const long long n3 = (long long)num_rays * 3;
+  hipLaunchKernelGGL(l1_loss_pair_kernel, dim3(grid_1d(n3, kBlock * 8, 32), 2), dim3(kBlock), 0, (hipStream_t)stream, sets, target_dev, n3,
+                     scale / (float)n3, 1.0f / (float)n3, out_dev);
+  return launch_status();
 }
 
 int rf_adam_step(float* param_dev, float* grad_dev, float* exp_avg_dev, float* exp_avg_sq_dev, int64_t numel,

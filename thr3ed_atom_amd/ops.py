@@ -347,6 +347,83 @@ def render_backward_emit_direct_raw(grid: VoxelGrid, origins: Tensor, directions
     _lib.check(rc, "rf_render_backward_emit_direct")
 
 
+def _render_out(n: int, num_samples: int, dev, save: bool, key_hist: Optional[Tensor], brick_size: int):
+    """fresh output (and cache) tensors of one render + their RFRenderOut"""
+    f32 = dict(dtype=torch.float32, device=dev)
+    colour, depth, acc, disparity = torch.empty((n, 3), **f32), torch.empty((n, 1), **f32), torch.empty((n, 1), **f32), torch.empty((n, 1), **f32)
+    out = _lib.RFRenderOut()
+    out.colour_dev, out.depth_dev, out.acc_dev, out.disparity_dev = colour.data_ptr(), depth.data_ptr(), acc.data_ptr(), disparity.data_ptr()
+    caches = None
+    if save:
+        caches = (torch.empty((n, num_samples, 4), **f32), torch.empty((n, num_samples), **f32), torch.empty((n,), dtype=torch.int32, device=dev),
+                  torch.empty((n, (num_samples + 63) // 64), dtype=torch.int64, device=dev))
+        out.sample_cache_dev, out.trans_cache_dev, out.stop_cache_dev, out.chunk_mask_dev = (t.data_ptr() for t in caches)
+        if key_hist is not None:
+            out.key_hist_dev, out.brick_size = key_hist.data_ptr(), int(brick_size)
+    return (colour, depth, acc, disparity), caches, out
+
+
+def render_forward_pair_raw(grid: VoxelGrid, origins: Tensor, directions: Tensor, t_rands, num_samples: int, near: float, far: float, flags,
+                            key_hists, brick_size: int = 8):
+    """Enqueue rf_render_forward_pair: BOTH saving forward renders of a training iteration over the same rays -- [0] specular,
+    [1] render_diffuse, each with its own jitter (``t_rands[i]``: None, a [N, S] tensor or a KeyedJitter) and its own record counters
+    ``key_hists[i]`` -- in ONE launch (modules/trainers.py:306, 323-325).  Returns ((colour, depth, acc, disparity), caches) per render.
+    No autograd.  Raises like the single call; ``None`` when the library says the two renders do not pair up."""
+    lib = _lib.load()
+    for name, t in (("ray origins", origins), ("ray directions", directions)):
+        _require_hip(t, name)
+    n, dev = origins.shape[0], origins.device
+    rf_grid = grid.forward_rf_grid(use_occupancy=bool(flags[0] & _lib.FLAG_OCCUPANCY_SKIP))
+    rays, outs, fl = (_lib.RFRayBatch * 2)(), (_lib.RFRenderOut * 2)(), (C.c_uint32 * 2)()
+    results, keep = [], []
+    for i in range(2):
+        rb, tv = _ray_batch(origins, directions, num_samples, near, far, t_rands[i])
+        tensors, caches, out = _render_out(n, num_samples, dev, True, key_hists[i], brick_size)
+        rays[i], outs[i], fl[i] = rb, out, _jitter_flags(flags[i], t_rands[i])
+        results.append((tensors, caches))
+        keep.append(tv)
+    with _span(f"render_forward[{_variant(grid, flags[0])}+diffuse,save]", dev):
+        rc = lib.rf_render_forward_pair(C.byref(rf_grid), rays, fl, outs, _stream(dev))
+    if rc == _lib.ERR_UNSUPPORTED:
+        return None
+    _lib.check(rc, "rf_render_forward_pair")
+    return results
+
+
+def render_backward_emit_direct_pair_raw(grid: VoxelGrid, origins: Tensor, directions: Tensor, t_rands, num_samples: int, near: float, far: float, flags,
+                                         caches2, g_colours, brick_size: int, hists, offsets2: Tensor, cursor2: Tensor, records2) -> bool:
+    """The adjoints of both renders as record lists: ONE launch for the offsets of both lists (rf_bin_offsets_pair) and ONE for both
+    emits (rf_render_backward_emit_direct_pair); the forward pass's counters ``hists[i]`` are cleared for their next use.
+    ``offsets2`` [2, nkeys + 1] int64, ``cursor2`` [2, nkeys] int32, ``records2[i]`` [N * S, expanded_record_floats].  Returns False
+    (nothing launched but the offsets) when the library says the two adjoints do not pair up."""
+    lib = _lib.load()
+    dev = origins.device
+    nkeys = int(hists[0].numel())
+    vp2 = C.c_void_p * 2
+    with _span("bin_offsets[both]", dev):
+        rc = lib.rf_bin_offsets_pair(vp2(hists[0].data_ptr(), hists[1].data_ptr()), nkeys, vp2(offsets2[0].data_ptr(), offsets2[1].data_ptr()),
+                                     vp2(cursor2[0].data_ptr(), cursor2[1].data_ptr()), _stream(dev))
+    _lib.check(rc, "rf_bin_offsets_pair")
+    rf_grid = grid.to_rf_grid(use_occupancy=bool(flags[0] & _lib.FLAG_OCCUPANCY_SKIP))
+    rays, passes, fl = (_lib.RFRayBatch * 2)(), (_lib.RFPassScratch * 2)(), (C.c_uint32 * 2)()
+    keep = []
+    for i in range(2):
+        rb, tv = _ray_batch(origins, directions, num_samples, near, far, t_rands[i])
+        keep.append(tv)
+        rays[i], fl[i] = rb, _jitter_flags(flags[i], t_rands[i])
+        ps = passes[i]
+        cache, tcache, stop, cmask = caches2[i]
+        ps.out.sample_cache_dev, ps.out.trans_cache_dev, ps.out.stop_cache_dev, ps.out.chunk_mask_dev = cache.data_ptr(), tcache.data_ptr(), stop.data_ptr(), cmask.data_ptr()
+        ps.out.key_hist_dev, ps.out.brick_size = hists[i].data_ptr(), int(brick_size)
+        ps.grad_colour_dev, ps.cursor_dev, ps.offsets_dev, ps.records_sorted_dev = g_colours[i].data_ptr(), cursor2[i].data_ptr(), offsets2[i].data_ptr(), records2[i].data_ptr()
+    with _span(f"render_backward_emit_direct[{_variant(grid, flags[0])}+diffuse]", dev):
+        rc = lib.rf_render_backward_emit_direct_pair(C.byref(rf_grid), rays, fl, passes, _stream(dev))
+    if rc == _lib.ERR_UNSUPPORTED:
+        return False
+    _lib.check(rc, "rf_render_backward_emit_direct_pair")
+    return True
+
+
 def bin_offsets(hist: Tensor, offsets: Tensor, cursor: Tensor) -> Tensor:
     """``hist`` (records per key) -> ``offsets`` [len + 1] (int64 exclusive prefix sums) and ``cursor`` (int32 copy)."""
     lib = _lib.load()
@@ -479,6 +556,9 @@ def brick_split_scratch(grid: VoxelGrid, num_bricks: int, parts: int) -> Tensor:
 # reference-storage iteration of bench.py's strict drop-in leg: 2.79 -> 1.99 ms with the diffuse adjoint binned as well), atomic
 # otherwise.
 AUTOGRAD_BACKWARD = "auto"
+# the two renders of a training iteration as ONE autograd node where it applies (relu_field_render_pair); $RF_AUTOGRAD_PAIR=0 / False:
+# always the two single nodes (A/B runs, tests)
+PAIR_RENDERS = os.environ.get("RF_AUTOGRAD_PAIR", "1") != "0"
 AUTOGRAD_BINNED_MAX_BYTES = 1 << 30
 AUTOGRAD_BRICK_SIZE = 8
 
@@ -641,6 +721,117 @@ class _ReluFieldRender(torch.autograd.Function):
         return ret_d, ret_f, None, None, None, None, None, None, None, None, None
 
 
+class _ReluFieldRenderPair(torch.autograd.Function):
+    """BOTH renders of a training iteration -- ``render_rays(rays)`` and ``render_rays(rays, render_diffuse=True)``
+    (modules/trainers.py:306, 323-325), each with its own jitter -- as ONE autograd node: one forward launch
+    (rf_render_forward_pair), and a backward of two launches (offsets of both record lists, both adjoints) whose record lists go to
+    the deferred bucket's optimizer or through ONE brick pass into the gradient tensors.  Used where the single op would take the binned
+    adjoint (``_autograd_uses_bricks``); outputs (colour, depth, acc, disparity) x 2."""
+
+    @staticmethod
+    def forward(ctx, first, second, origins, directions, t_rand0, t_rand1, grid: VoxelGrid, num_samples, near, far, flags0, flags1):
+        for t in (first, second):
+            if t is not None:
+                _require_hip(t, "grid tensor")
+        origins = origins.detach().to(torch.float32).contiguous()
+        directions = directions.detach().to(torch.float32).contiguous()
+        n, S = origins.shape[0], int(num_samples)
+        t_rands, keyed = [], []
+        for t in (t_rand0, t_rand1):
+            k = t if isinstance(t, KeyedJitter) else None
+            if k is None and t is not None:
+                _require_hip(t, "t_rand")
+                t = t.detach().to(torch.float32).contiguous()
+                if tuple(t.shape) != (n, S):
+                    raise ValueError(f"t_rand must be [{n}, {S}], got {tuple(t.shape)}")
+            keyed.append(k)
+            t_rands.append(None if k is not None else t)
+        brick_size = _autograd_brick_size(grid)
+        nb = brick_counts(grid, brick_size)
+        hists = [_take_hist(origins.device, nb[0] * nb[1] * nb[2] * 8) for _ in range(2)]
+        flags = (int(flags0), int(flags1))
+        res = render_forward_pair_raw(grid, origins, directions, [keyed[i] if keyed[i] is not None else t_rands[i] for i in range(2)], S, float(near), float(far), flags,
+                                      hists, brick_size)
+        if res is None:
+            raise RuntimeError("rf_render_forward_pair: the two renders do not pair up (flags must say specular, render_diffuse)")
+        ctx.grid, ctx.flags, ctx.keyed, ctx.hists, ctx.brick_size = grid, flags, keyed, hists, brick_size
+        ctx.num_samples, ctx.near, ctx.far = S, float(near), float(far)
+        ctx.has_rand = [t is not None for t in t_rands]
+        ctx.has_second = second is not None
+        saved = [first] + ([second] if second is not None else []) + [origins, directions]
+        for (_, caches), t in zip(res, t_rands):
+            saved += list(caches)
+            if t is not None:
+                saved.append(t)
+        ctx.save_for_backward(*saved)
+        outs = tuple(res[0][0]) + tuple(res[1][0])
+        ctx.mark_non_differentiable(outs[3], outs[7])
+        ctx.set_materialize_grads(False)
+        return outs
+
+    @staticmethod
+    def backward(ctx, gc0, gd0, ga0, _gq0, gc1, gd1, ga1, _gq1):
+        saved = list(ctx.saved_tensors)
+        first = saved.pop(0)
+        second = saved.pop(0) if ctx.has_second else None
+        origins, directions = saved.pop(0), saved.pop(0)
+        caches2, t_rands = [], []
+        for i in range(2):
+            caches2.append(tuple(saved[:4]))
+            del saved[:4]
+            t_rands.append(saved.pop(0) if ctx.has_rand[i] else ctx.keyed[i])
+        grid: VoxelGrid = ctx.grid
+        if ctx.hists is None:
+            raise RuntimeError("a render pair can be back-propagated once (its record counters were consumed by the first backward pass)")
+        cur_first, cur_second = grid.kernel_tensors()
+        if cur_first.data_ptr() != first.data_ptr() or (second is not None and cur_second.data_ptr() != second.data_ptr()):
+            raise RuntimeError("the VoxelGrid's tensors were replaced between forward and backward")
+
+        def prep(g):
+            return None if g is None else g.detach().to(torch.float32).contiguous()
+
+        dev, n, S = origins.device, origins.shape[0], ctx.num_samples
+        hists, nkeys = ctx.hists, int(ctx.hists[0].numel())
+        offsets2 = torch.empty((2, nkeys + 1), dtype=torch.int64, device=dev)
+        cursor2 = torch.empty((2, nkeys), dtype=torch.int32, device=dev)
+        records2 = [torch.empty((n * S, expanded_record_floats(grid, bool(i))), dtype=torch.float32, device=dev) for i in range(2)]
+        g_colours, g_depths, g_accs = [prep(gc0), prep(gc1)], [prep(gd0), prep(gd1)], [prep(ga0), prep(ga1)]
+        colours_only = all(g is not None for g in g_colours) and all(g is None for g in g_depths + g_accs)
+        paired = colours_only and render_backward_emit_direct_pair_raw(grid, origins, directions, t_rands, S, ctx.near, ctx.far, ctx.flags, caches2, g_colours,
+                                                                       ctx.brick_size, hists, offsets2, cursor2, records2)
+        if not paired:  # upstream gradients of depth / accumulated weight, or an unused render: one adjoint at a time (the general kernel)
+            for i in range(2):
+                if not colours_only:
+                    bin_offsets(hists[i], offsets2[i], cursor2[i])
+                if g_colours[i] is None and g_depths[i] is None and g_accs[i] is None:
+                    g_colours[i] = torch.zeros((n, 3), dtype=torch.float32, device=dev)  # (an unused render: its records are zeros)
+                render_backward_emit_direct_raw(grid, origins, directions, t_rands[i], S, ctx.near, ctx.far, ctx.flags[i], caches2[i], g_colours[i], g_depths[i], g_accs[i],
+                                                ctx.brick_size, cursor2[i], records2[i], hist_clear=hists[i])
+        for h in hists:
+            _return_hist(h)
+        ctx.hists = None
+        lists = [(records2[0], offsets2[0], False), (records2[1], offsets2[1], True)]
+        bucket = getattr(grid, "_grad_bucket", None)
+        if bucket is not None and bucket.matches(first, second):
+            if getattr(bucket, "deferred", False) and ctx.brick_size == bucket.brick_size:
+                bucket.pending.extend(lists)  # the sorted lists ARE the gradient: the optimizer sums all lists of the iteration
+                ret_d, ret_f = bucket.autograd_return()
+                return (ret_d, ret_f) + (None,) * 10
+            if ctx.brick_size != AUTOGRAD_BRICK_SIZE:
+                raise RuntimeError("the grid's deferred gradient bucket was replaced between forward and backward")
+            gd, gf = bucket.views_for_accumulation()
+            ret_d, ret_f = bucket.autograd_return()
+            brick_accumulate_raw(grid, AUTOGRAD_BRICK_SIZE, lists, gd, gf, accumulate=True)
+            return (ret_d, ret_f) + (None,) * 10
+        if ctx.brick_size != AUTOGRAD_BRICK_SIZE:
+            raise RuntimeError("the grid's deferred gradient bucket was replaced between forward and backward")
+        # fresh gradient tensors, OVERWRITTEN by the one brick pass over both lists (the specular list covers every element)
+        gd = torch.empty_like(first)
+        gf = None if second is None else torch.empty_like(second)
+        brick_accumulate_raw(grid, AUTOGRAD_BRICK_SIZE, lists, gd, gf, accumulate=False)
+        return (gd, gf) + (None,) * 10
+
+
 class _GridQuery(torch.autograd.Function):
     @staticmethod
     def forward(ctx, first, second, points, grid: VoxelGrid):
@@ -797,6 +988,56 @@ class _L1LossWithMSE(torch.autograd.Function):
         return grad * g_loss, None
 
 
+_L1_PAIR_WORKSPACE: Dict[Tuple[str, int], Tensor] = {}
+
+
+class _L1LossPairWithMSE(torch.autograd.Function):
+    """The loss lines of an iteration (modules/trainers.py:311-317, 329-336) for BOTH renders in ONE launch (rf_l1_loss_grad_pair):
+    returns [5] = (L1(specular) + L1(diffuse), L1(specular), MSE(specular), L1(diffuse), MSE(diffuse)) as views of one tensor the
+    kernel's last workgroup writes; differentiable through the FIRST (the sum, w.r.t. both colours)."""
+
+    @staticmethod
+    def forward(ctx, colour0, colour1, target):
+        c0 = colour0.detach().to(torch.float32).contiguous()
+        c1 = colour1.detach().to(c0.device, torch.float32).contiguous()
+        tg = target.detach().to(c0.device, torch.float32).contiguous()
+        if not (c0.shape == c1.shape == tg.shape) or c0.dim() != 2 or c0.shape[1] != 3 or c0.shape[0] < 1:
+            raise ValueError(f"l1_loss_pair_with_mse takes [N, 3] colours and targets, got {tuple(colour0.shape)}, {tuple(colour1.shape)} and {tuple(target.shape)}")
+        dev = c0.device
+        key = (str(dev), torch.cuda.current_stream(dev).cuda_stream)  # (one self-cleaning workspace per stream: zero between calls)
+        ws = _L1_PAIR_WORKSPACE.get(key)
+        if ws is None:
+            ws = _L1_PAIR_WORKSPACE[key] = torch.zeros(8, dtype=torch.float32, device=dev)
+        grads = torch.empty((2,) + tuple(c0.shape), dtype=torch.float32, device=dev)
+        out = torch.empty(5, dtype=torch.float32, device=dev)
+        vp2 = C.c_void_p * 2
+        with _span("l1_loss_grad[both]", dev):
+            rc = _lib.load().rf_l1_loss_grad_pair(vp2(c0.data_ptr(), c1.data_ptr()), tg.data_ptr(), c0.shape[0], 1.0, vp2(grads[0].data_ptr(), grads[1].data_ptr()),
+                                                  ws.data_ptr(), out.data_ptr(), _stream(dev))
+        _lib.check(rc, "rf_l1_loss_grad_pair")
+        ctx.save_for_backward(grads)
+        total, l0, mse0, l1, mse1 = out.unbind(0)
+        ctx.mark_non_differentiable(l0, mse0, l1, mse1)
+        ctx.set_materialize_grads(False)
+        return total, l0, mse0, l1, mse1
+
+    @staticmethod
+    def backward(ctx, g_total, *_unused):
+        if g_total is None:
+            return None, None, None
+        (grads,) = ctx.saved_tensors
+        g = grads * g_total  # (one launch for both renders' upstream gradients)
+        return g[0], g[1], None
+
+
+def l1_loss_pair_with_mse(colour_specular: Tensor, colour_diffuse: Tensor, target: Tensor):
+    """(L1(specular) + L1(diffuse) -- differentiable --, L1(specular), MSE(specular), L1(diffuse), MSE(diffuse)): both renders of an
+    iteration against the same target pixels, one launch."""
+    _require_hip(colour_specular, "colour")
+    _require_hip(colour_diffuse, "colour")
+    return _L1LossPairWithMSE.apply(colour_specular, colour_diffuse, target)
+
+
 def l1_loss_with_mse(colour: Tensor, target: Tensor) -> Tuple[Tensor, Tensor]:
     """(mean L1 loss -- differentiable w.r.t. ``colour`` --, mean squared error) of [N, 3] colours against their targets, one launch."""
     _require_hip(colour, "colour")
@@ -834,6 +1075,29 @@ def relu_field_render(
     return _ReluFieldRender.apply(
         ta, tb, origins, directions, t_rand, grid, int(num_samples), float(near), float(far), flags, need_grad
     )
+
+
+def relu_field_render_pair(grid: VoxelGrid, origins: Tensor, directions: Tensor, num_samples: int, near: float, far: float, t_rands=(None, None),
+                           white_bkgd: bool = False, optimized_sampling: bool = False, use_occupancy: bool = False):
+    """``relu_field_render(...)`` and ``relu_field_render(..., render_diffuse=True)`` on the same rays -- the two renders of a training
+    iteration (modules/trainers.py:306, 323-325) -- returned as two (colour, depth, acc, disparity) tuples.  Where a gradient is asked
+    for and the single op would take the binned adjoint, the pair is ONE autograd node (one forward launch, two backward launches);
+    otherwise it is the two single ops, in the reference's order.  ``t_rands``: the two renders' jitter (each None, [N, S] or KeyedJitter)."""
+    grid = as_kernel_grid(grid)
+    if origins.dim() != 2 or origins.shape != directions.shape or origins.shape[-1] != 3:
+        raise AssertionError("the render op works with FLAT rays [N, 3] only")
+    if int(num_samples) < 1:
+        raise ValueError("num_samples must be >= 1")
+    if use_occupancy and not grid.occupancy_current():
+        grid.build_occupancy()
+    flags = [render_flags(white_bkgd, diffuse, optimized_sampling, use_occupancy) for diffuse in (False, True)]
+    ta, tb = grid.kernel_tensors()
+    need_grad = torch.is_grad_enabled() and (ta.requires_grad or (tb is not None and tb.requires_grad))
+    n = origins.shape[0]
+    if (PAIR_RENDERS and need_grad and n > 0 and _autograd_uses_bricks(grid, flags[0], n, int(num_samples)) and _autograd_uses_bricks(grid, flags[1], n, int(num_samples))):
+        o = _ReluFieldRenderPair.apply(ta, tb, origins, directions, t_rands[0], t_rands[1], grid, int(num_samples), float(near), float(far), flags[0], flags[1])
+        return o[:4], o[4:]
+    return tuple(_ReluFieldRender.apply(ta, tb, origins, directions, t_rands[i], grid, int(num_samples), float(near), float(far), flags[i], need_grad) for i in range(2))
 
 
 # --------------------------------------------------------------------------------------------

@@ -147,6 +147,52 @@ def render_sh_voxel_grid(
     return RenderOut(colour=colour, depth=depth, extra={EXTRA_DISPARITY: disparity, EXTRA_ACCUMULATED_WEIGHTS: acc})
 
 
+def render_sh_voxel_grid_pair(voxel_grid: VoxelGrid, rays: Rays, render_config: SHVoxGridRenderConfig, parallel_points_chunk_size: Optional[int] = None, t_rands=(None, None)):
+    """The two renders of a training iteration on the same flat rays -- ``render_sh_voxel_grid(grid, rays, cfg)`` and the same call with
+    ``render_diffuse=True``, each with its own jitter draw, in the reference's order (modules/trainers.py:306, 323-325) -- as
+    (specular RenderOut, diffuse RenderOut).  Where the fused kernels apply and a gradient will be asked for, the pair is ONE
+    autograd node: one forward launch, and a backward of two launches instead of four (ops.relu_field_render_pair); the outputs and
+    the RNG consumption are those of the two single calls.  ``render_config.render_diffuse`` is ignored (the pair is both)."""
+    import copy
+
+    if not fused_kernels_apply(voxel_grid, render_config):
+        cfgs = []
+        for diffuse in (False, True):
+            cfg = copy.copy(render_config)
+            cfg.render_diffuse = diffuse
+            cfgs.append(cfg)
+        return tuple(render_sh_voxel_grid(voxel_grid, rays, cfg, parallel_points_chunk_size, t_rand=t) for cfg, t in zip(cfgs, t_rands))
+    voxel_grid = as_kernel_grid(voxel_grid)
+    origins, directions = rays.origins, rays.directions
+    assert origins.dim() == directions.dim() == 2, "the render interface only works with FLAT rays"
+    num_samples, n = int(render_config.num_samples_per_ray), origins.shape[0]
+    jitters = []
+    for given in t_rands:  # (the draws of the two single calls, in their order)
+        t = given
+        if not render_config.perturb_sampled_points:
+            t = None
+        elif t is None:
+            kind = getattr(render_config, "jitter", "keyed")
+            if kind == "torch":
+                t = torch.rand(n, num_samples, dtype=torch.float32, device=origins.device)
+            elif kind == "keyed":
+                t = KeyedJitter(draw_jitter_key(), 0)
+            else:
+                raise ValueError("SHVoxGridRenderConfig.jitter must be 'keyed' or 'torch'")
+        if getattr(render_config, "consume_reference_rng", False):
+            torch.randn(n, num_samples, dtype=torch.float32, device=origins.device)
+        jitters.append(t)
+    from .ops import relu_field_render_pair
+
+    bounds = render_config.camera_bounds
+    outs = relu_field_render_pair(
+        voxel_grid, origins, directions, num_samples, float(np.float32(bounds.near)), float(np.float32(bounds.far)), t_rands=tuple(jitters),
+        white_bkgd=bool(render_config.white_bkgd), optimized_sampling=bool(render_config.optimized_sampling),
+        use_occupancy=bool(getattr(render_config, "use_occupancy_mask", False)),
+    )
+    return tuple(RenderOut(colour=c, depth=d, extra={EXTRA_DISPARITY: q, EXTRA_ACCUMULATED_WEIGHTS: a}) for c, d, a, q in outs)
+
+
 def render_sh_voxel_grid_frame(
     voxel_grid: VoxelGrid,
     camera_intrinsics,

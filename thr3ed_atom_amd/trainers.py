@@ -245,9 +245,13 @@ class TrainStepper:
         ``ray_selection``: "randperm" draws torch.randperm over all B*H*W pixels exactly like the reference
         (utils/misc.py:123) and keeps the first ``ray_batch_size``; "keyed" draws the same kind of sample
         (distinct, uniformly random pixels) with one fused kernel (rf_select_rays_and_pixels) keyed from torch's
-        CPU generator -- no 5-million-key sort per iteration."""
-        if ray_selection not in ("keyed", "randperm"):
-            raise ValueError("ray_selection must be 'keyed' or 'randperm'")
+        CPU generator -- no 5-million-key sort per iteration; "randperm_blocks" is for users who want torch.randperm's own draws
+        without paying one per iteration (0.42 ms for 5.12 M pixels, more than half a step): ONE torch.randperm over all B*H*W pixels
+        per block of floor(B*H*W / ray_batch_size) iterations, consumed in consecutive slices -- every iteration's batch is still
+        ``ray_batch_size`` distinct uniformly random pixels; batches of one block do not repeat a pixel (sampling without replacement
+        across the block, where the reference re-draws independently per iteration)."""
+        if ray_selection not in ("keyed", "randperm", "randperm_blocks"):
+            raise ValueError("ray_selection must be 'keyed', 'randperm' or 'randperm_blocks'")
         self.ray_selection = ray_selection
         # fused=True runs the iteration as a fixed sequence of launches (forward, loss+gradient, backward per
         # render, then Adam which also clears the gradient bucket) without building an autograd graph;
@@ -364,12 +368,26 @@ class TrainStepper:
             o, d, px = select_rays_and_pixels_hip(intr.height, intr.width, float(intr.focal), dataset.poses, image_ids, dataset.pixels, hi - lo, key, first_index=lo)
             return Rays(o, d), px
         image_ids = image_ids.to(dev)
-        perm = torch.randperm(image_ids.numel() * hw, dtype=torch.long)[lo:hi].to(dev) if self.global_batch else torch.randperm(image_ids.numel() * hw, dtype=torch.long, device=dev)[:total]
+        if self.ray_selection == "randperm_blocks" and not self.global_batch:
+            block = getattr(self, "_perm_block", None)
+            if block is None or block[0].numel() != image_ids.numel() * hw or block[1] + total > block[0].numel():
+                block = self._perm_block = [torch.randperm(image_ids.numel() * hw, dtype=torch.long, device=dev), 0]
+            perm = block[0][block[1] : block[1] + total]
+            block[1] += total
+        else:
+            perm = torch.randperm(image_ids.numel() * hw, dtype=torch.long)[lo:hi].to(dev) if self.global_batch else torch.randperm(image_ids.numel() * hw, dtype=torch.long, device=dev)[:total]
         poses = dataset.poses[image_ids]
         origins, directions = cast_selected_rays_hip(intr.height, intr.width, float(intr.focal), poses, perm)
         b = torch.div(perm, hw, rounding_mode="floor")
         pixels = dataset.pixels[image_ids[b] * hw + (perm - b * hw)]
         return Rays(origins, directions), pixels
+
+    def _unit_gradient(self, loss: Tensor) -> Tensor:
+        """the seed of ``loss.backward()`` -- a one of the loss's shape -- kept between iterations (autograd would fill a fresh one per call)"""
+        one = getattr(self, "_one", None)
+        if one is None or one.device != loss.device or one.shape != loss.shape:
+            one = self._one = torch.ones_like(loss)
+        return one
 
     def _jitter_first(self) -> int:
         """Offset of this rank's rays in the keyed jitter streams: its position in the global batch (0 unless ``global_batch``)."""
@@ -410,15 +428,21 @@ class TrainStepper:
         # (The diffuse render, its loss and its adjoint on a side stream -- so that the two forward kernels and the two adjoints share
         # the machine like the fused step's paired launches -- measured no gain: 0.822 against 0.812 ms per iteration; each kernel
         # fills the machine by itself.  docs/experiments.md D.)
-        spec = vol_mod.render_rays(rays).colour
-        total, spec_mse = ops.l1_loss_with_mse(spec, pixels)
-        spec_loss, diff_loss, diff_mse = total.detach(), None, None
-        if self.diffuse:
-            diff = vol_mod.render_rays(rays, render_diffuse=True).colour
-            dl, diff_mse = ops.l1_loss_with_mse(diff, pixels)
-            total = total + dl
-            diff_loss = dl.detach()
-        total.backward()
+        if self.diffuse and ops.PAIR_RENDERS:
+            # both renders as ONE autograd node and both loss lines as one (VolumetricModel.render_rays_pair, ops.l1_loss_pair_with_mse):
+            # the launches of the fused step's pairs -- one forward, one loss, [backward:] one offsets, one emit -- under autograd
+            spec_out, diff_out = vol_mod.render_rays_pair(rays)
+            total, spec_loss, spec_mse, diff_loss, diff_mse = ops.l1_loss_pair_with_mse(spec_out.colour, diff_out.colour, pixels)
+        else:
+            spec = vol_mod.render_rays(rays).colour
+            total, spec_mse = ops.l1_loss_with_mse(spec, pixels)
+            spec_loss, diff_loss, diff_mse = total.detach(), None, None
+            if self.diffuse:
+                diff = vol_mod.render_rays(rays, render_diffuse=True).colour
+                dl, diff_mse = ops.l1_loss_with_mse(diff, pixels)
+                total = total + dl
+                diff_loss = dl.detach()
+        total.backward(self._unit_gradient(total))
         if self.data_parallel:
             rfdist.all_reduce_mean_(self.flat.flat_grad)
         self.optimizer.step()

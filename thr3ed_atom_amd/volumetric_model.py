@@ -23,7 +23,7 @@ from .constants import (
 from . import distributed as rfdist
 from .ops import cast_rays_hip
 from .render_interface import Rays, RenderOut, collate_rendered_output, flatten_rays, reshape_rendered_output
-from .renderers import RenderConfig, RenderProcedure, render_sh_voxel_grid, render_sh_voxel_grid_frame, fused_kernels_apply
+from .renderers import RenderConfig, RenderProcedure, render_sh_voxel_grid, render_sh_voxel_grid_frame, render_sh_voxel_grid_pair, fused_kernels_apply
 
 
 def cast_rays(camera_intrinsics: CameraIntrinsics, pose: CameraPose, device=None) -> Rays:
@@ -96,6 +96,15 @@ class VolumetricModel:
         """Differentiable render of flat rays; kwargs override render-config fields for this call."""
         cfg = self._update_render_config(self._render_config, kwargs)
         return self._render_procedure(self._thre3d_repr, rays, cfg, parallel_points_chunk_size)
+
+    def render_rays_pair(self, rays: Rays, parallel_points_chunk_size: Optional[int] = None, **kwargs) -> Tuple[RenderOut, RenderOut]:
+        """``(render_rays(rays, **kwargs), render_rays(rays, render_diffuse=True, **kwargs))`` -- the two renders of a training
+        iteration (reference modules/trainers.py:306, 323-325; an extension of this build) -- with the HIP procedure as ONE autograd
+        node (renderers.render_sh_voxel_grid_pair); any other procedure is simply called twice."""
+        if self._render_procedure is render_sh_voxel_grid:
+            cfg = self._update_render_config(self._render_config, kwargs)
+            return render_sh_voxel_grid_pair(self._thre3d_repr, rays, cfg, parallel_points_chunk_size)
+        return self.render_rays(rays, parallel_points_chunk_size, **kwargs), self.render_rays(rays, parallel_points_chunk_size, **dict(kwargs, render_diffuse=True))
 
     def render(
         self,
