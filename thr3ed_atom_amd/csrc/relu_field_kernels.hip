@@ -1382,17 +1382,40 @@ __device__ __forceinline__ RayState tile_ray(const GridArgs& g, const RayArgs& r
   return st;
 }
 
+// z_of for a frame: the keyed jitter or none (frames with a caller-supplied jitter TABLE are the per-ray kernel's: rf_render_forward)
+__device__ __forceinline__ float tile_z(const RayState& st, const RayArgs& r, int s) {
+  const int sc = min(s, r.S - 1);
+  const float u = r.jitter ? jitter_uniform(st.jseed, sc) : 0.0f;
+  return z_sample(r.tvals, r.jitter != 0, u, sc, r.S, st.near, st.far);
+}
+
 // (A variant pipelined over the sample index -- the window of sample s + 1 requested into registers before sample s is interpolated, two
 // waves per SIMD with up to 256 registers each -- measured SLOWER: 2.54 against 2.01 ms per 800 x 800 x 256 frame; at four waves per SIMD it
 // spills 176 registers.  Four resident waves hide the window's round trip better than one wave's own prefetch.)
-template <bool REST>
-__global__ __launch_bounds__(kBlock, RF_TILE_WAVES) void render_frame_tile_kernel(GridArgs g, RayArgs r, OutArgs out, uint32_t flags, int row0, int tile_rows, int tiles_x) {
-  __shared__ __attribute__((aligned(16))) vf4 s_base[kWavesPerBlock][kWave];
-  __shared__ __attribute__((aligned(16))) vf4 s_rest[kWavesPerBlock][REST ? kWave * 6 : 1];
+// Tile of a wave.  WPB waves per workgroup (nothing is shared between them: WPB = 1 lets the dispatcher place every tile by itself);
+// XCD_ROWS: workgroup b runs on XCD b % 8 (observed placement, used for speed only: MI355X_MICROARCH.md, workgroup dispatch) -- the
+// map gives each XCD whole tile rows, interleaved (row = 8 * group + b % 8), so that a tile's neighbours along its row fetch their
+// windows through the same L2 while the eight XCDs still share every part of the picture (the heavy tiles sit in its middle).
+// Measured (profiles/r06_frame_tile_sched.txt), 800 x 800: WPB 1 + XCD rows against WPB 4 + linear: 128^3 / 256 samples 1.69-1.73
+// against 1.70-1.75 ms, 256^3 / 512 samples with the mask 1.52-1.55 against 1.62-1.66 ms; either switch alone: no gain.
+template <bool REST, int WPB, bool XCD_ROWS>
+__global__ __launch_bounds__(kWave * WPB, RF_TILE_WAVES) void render_frame_tile_kernel(GridArgs g, RayArgs r, OutArgs out, uint32_t flags, int row0, int tile_rows, int tiles_x) {
+  __shared__ __attribute__((aligned(16))) vf4 s_base[WPB][kWave];
+  __shared__ __attribute__((aligned(16))) vf4 s_rest[WPB][REST ? kWave * 6 : 1];
   const int lane = threadIdx.x & (kWave - 1);
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const int tile = (int)blockIdx.x * kWavesPerBlock + wave;
-  const int ty = tile / tiles_x, tx = tile - ty * tiles_x;
+  int ty, tx;
+  if constexpr (XCD_ROWS) {
+    const int segs_x = (tiles_x + WPB - 1) / WPB;  // workgroups per tile row
+    const int b = (int)blockIdx.x, group = b / (8 * segs_x), within = b - group * (8 * segs_x);
+    ty = group * 8 + (within & 7);
+    tx = (within >> 3) * WPB + wave;
+    if (tx >= tiles_x) return;
+  } else {
+    const int tile = (int)blockIdx.x * WPB + wave;
+    ty = tile / tiles_x;
+    tx = tile - ty * tiles_x;
+  }
   if (ty >= tile_rows) return;
   vf4* my_base = s_base[wave];
   vf4* my_rest = s_rest[wave];
@@ -1401,15 +1424,25 @@ __global__ __launch_bounds__(kBlock, RF_TILE_WAVES) void render_frame_tile_kerne
   const int i = min(i_raw, r.H - 1), j = min(j_raw, r.W - 1);
   const long long ray_raw = ((long long)i * r.W + j) - r.ray0;
   const bool lane_valid = i_raw < r.H && j_raw < r.W && ray_raw >= 0 && ray_raw < r.n;
-  // (lanes off the frame or outside the call's pixel range march along with a clamped index: a caller-supplied jitter table
-  // [num_rays, S] is only ever read inside its rows; they never write)
-  const long long ray = min(max(ray_raw, 0ll), (long long)r.n - 1);
+  // (the output index; the <true> instantiations sit at their 128-register budget and park these two registers in scratch memory
+  // ACROSS the march -- one store before it, one load behind it per wave, nothing inside; every attempt to rebuild the index after
+  // the march instead moved a spill INTO the loop)
+  const long long ray = ray_raw;
   const RayState st = tile_ray(g, r, flags, i, j);
   const bool white = flags & RF_FLAG_WHITE_BKGD;
   const bool use_occ = (flags & RF_FLAG_OCCUPANCY_SKIP) && g.occ != nullptr;
   float Y[16];
   if constexpr (REST) sh_basis<9>(st.d[0] / st.dnorm, st.d[1] / st.dnorm, st.d[2] / st.dnorm, Y);  // v = d / |d| (process.py:53)
-  const BoxSpan span = box_span(st, r, g);
+  // the ray's parameter interval inside the box, widened by the per-ray kernel's margins (slab interval, one stratum of jitter) -- two
+  // registers for the march: [z_lo, z_hi], empty for lanes that never write and rays that miss the box
+  float z_lo = kInfinity, z_hi = -kInfinity;
+  {
+    const BoxSpan span = box_span(st, r, g);
+    if (lane_valid && span.hits) {
+      z_lo = (span.t_in - span.margin) - span.zpad;
+      z_hi = (span.t_out + span.margin) + span.zpad;
+    }
+  }
 
   float T = 1.0f;
   float part_c[3] = {0.f, 0.f, 0.f};
@@ -1419,18 +1452,18 @@ __global__ __launch_bounds__(kBlock, RF_TILE_WAVES) void render_frame_tile_kerne
   bool rest_hot = true;  // (wave-uniform) did the previous step with live lanes need colours?
 
   for (int s = 0; s < r.S; ++s) {
-    // ---- can any ray of the tile be inside the box at this sample index?  (the per-ray kernel's margins: slab interval of the ray,
-    // one stratum of jitter; a sample outside contributes exactly nothing -- sigma = 0, alpha = 0, w = 0, T unchanged)
+    // ---- can any ray of the tile be inside the box at this sample index?  (a sample outside contributes exactly nothing --
+    // sigma = 0, alpha = 0, w = 0, T unchanged)
     {
       const float zc = z_uniform(st.near, st.far, r.tvals[s]);
-      const bool maybe = lane_valid && span.hits && !(zc + span.zpad < span.t_in - span.margin || zc - span.zpad > span.t_out + span.margin);
+      const bool maybe = zc >= z_lo && zc <= z_hi;
       if (__ballot(maybe) == 0ull) {
         z_ready = false;
         continue;
       }
     }
-    if (!z_ready) z_cur = z_of(st, r, ray, s);
-    const float z_next = z_of(st, r, ray, s + 1);
+    if (!z_ready) z_cur = tile_z(st, r, s);
+    const float z_next = tile_z(st, r, s + 1);
     const Sample sm = sample_at(st, r, g, s, z_cur, z_next);
     z_cur = z_next;
     z_ready = true;
@@ -4191,16 +4224,32 @@ int rf_render_forward(const RFGrid* grid, const RFRayBatch* rays, uint32_t flags
   const int K = grid->num_features / 3;
   // frames of a posed camera (rays generated in-kernel, inference only): ray packets where frame_uses_packets() says so
   if (rays->camera && !save) {
-    const bool tiles = frame_uses_packets(grid, g, rays->camera, flags);
+    const bool tiles = !rays->t_rand_dev && frame_uses_packets(grid, g, rays->camera, flags);
     if (tiles) {
       const int W = rays->camera->width;
       const int row0 = (int)(rays->first_ray / W), row1 = (int)((rays->first_ray + rays->num_rays - 1) / W);
       const int tile_rows = (row1 - row0) / 8 + 1, tiles_x = (W + 7) / 8;
-      const unsigned tblocks = (unsigned)(((long long)tile_rows * tiles_x + kWavesPerBlock - 1) / kWavesPerBlock);
-      if (K == 9 && !diffuse)
-        hipLaunchKernelGGL((render_frame_tile_kernel<true>), dim3(tblocks), dim3(kBlock), 0, st, g, r, o, flags, row0, tile_rows, tiles_x);
-      else
-        hipLaunchKernelGGL((render_frame_tile_kernel<false>), dim3(tblocks), dim3(kBlock), 0, st, g, r, o, flags, row0, tile_rows, tiles_x);
+      // (scheduling of the tiles: $RF_TILE_WPB = waves per workgroup, 1 or 4; $RF_TILE_XCD_ROWS = 0 / 1: A/B switches, read once)
+      static const int wpb = [] {
+        const char* e = getenv("RF_TILE_WPB");
+        return (e && atoi(e) == 4) ? 4 : 1;
+      }();
+      static const bool xcd_rows = [] {
+        const char* e = getenv("RF_TILE_XCD_ROWS");
+        return e ? atoi(e) != 0 : true;
+      }();
+      const bool rest = K == 9 && !diffuse;
+      const long long wgs = xcd_rows ? (long long)((tile_rows + 7) / 8) * 8 * ((tiles_x + wpb - 1) / wpb) : ((long long)tile_rows * tiles_x + wpb - 1) / wpb;
+#define RF_TILE_LAUNCH(REST_, WPB_, XR_)                                                                                                         \
+  hipLaunchKernelGGL((render_frame_tile_kernel<REST_, WPB_, XR_>), dim3((unsigned)wgs), dim3(kWave * WPB_), 0, st, g, r, o, flags, row0, tile_rows, tiles_x)
+      if (rest) {
+        if (wpb == 4) { if (xcd_rows) RF_TILE_LAUNCH(true, 4, true); else RF_TILE_LAUNCH(true, 4, false); }
+        else { if (xcd_rows) RF_TILE_LAUNCH(true, 1, true); else RF_TILE_LAUNCH(true, 1, false); }
+      } else {
+        if (wpb == 4) { if (xcd_rows) RF_TILE_LAUNCH(false, 4, true); else RF_TILE_LAUNCH(false, 4, false); }
+        else { if (xcd_rows) RF_TILE_LAUNCH(false, 1, true); else RF_TILE_LAUNCH(false, 1, false); }
+      }
+#undef RF_TILE_LAUNCH
       return launch_status();
     }
   }
