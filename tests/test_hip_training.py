@@ -324,7 +324,7 @@ def full_size(hip_device):
     return model, pose, rf.CameraIntrinsics(800, 800, 1111.111), cam
 
 
-def test_full_size_chunking_permutation_and_background_properties(full_size, hip_device):
+def test_full_size_chunking_permutation_and_background_properties(full_size, hip_device, monkeypatch):
     model, pose, intr, cam = full_size
     whole = model.render(pose, intr, parallel_rays_chunk_size=None)
     chunked = model.render(pose, intr, parallel_rays_chunk_size=32768)
@@ -337,12 +337,21 @@ def test_full_size_chunking_permutation_and_background_properties(full_size, hip
     sub = model.render_rays(rays[perm])
     # any ray order gives the same per-ray result: bit for bit on the per-ray kernel, to summation order against the frame's ray packets
     assert float((sub.colour - whole.colour.reshape(-1, 3)[perm]).abs().max()) <= 2e-6
-    os.environ["RF_FRAME_TILES"] = "0"
-    try:
-        per_ray_frame = model.render(pose, intr, parallel_rays_chunk_size=None)
-    finally:
-        del os.environ["RF_FRAME_TILES"]
+    monkeypatch.setenv("RF_FRAME_TILES", "0")
+    per_ray_frame = model.render(pose, intr, parallel_rays_chunk_size=None)
+    monkeypatch.undo()  # (whatever the variable was before the test, it is that again)
     assert torch.equal(sub.colour, per_ray_frame.colour.reshape(-1, 3)[perm])
+    # the packet kernel's own self-consistency on the default path: the same pixels through other cuts of the frame (first_ray / num_rays
+    # that start inside a pixel row and inside a tile row) are the same bits -- a pixel does not depend on its tile-mates
+    import dataclasses
+
+    cfg = dataclasses.replace(model.render_config, perturb_sampled_points=True)  # (keyed jitter: indexed by the pixel, not by the call)
+    torch.manual_seed(77)
+    ref = rf.render_sh_voxel_grid_frame(model.thre3d_repr, intr, pose, cfg)
+    for first, count in ((800 * 3 + 5, 123457), (800 * 397 + 399, 800 * 11 + 3), (800 * 800 - 1, 1)):
+        torch.manual_seed(77)
+        part = rf.render_sh_voxel_grid_frame(model.thre3d_repr, intr, pose, cfg, first_ray=first, num_rays=count)
+        assert torch.equal(part.colour, ref.colour[first : first + count]) and torch.equal(part.depth, ref.depth[first : first + count])
     black = model.render(pose, intr, parallel_rays_chunk_size=None, white_bkgd=False)
     acc = whole.extra["accumulated_weight"]
     assert torch.equal(acc, black.extra["accumulated_weight"]) and torch.equal(whole.depth, black.depth)

@@ -157,13 +157,6 @@ struct GradArgs {
 
 constexpr short kNoBrick = -1;  // sorts in front of every (brick, flags) key
 
-#ifdef RF_EXP_TICKET
-// Development build (tools/exp_ticket.sh): the forward pass's per-key counter atomic made RETURNING, its result --
-// the sample's rank inside its key class -- parked per cached sample; the adjoint's record position is then offsets[key] + rank, a plain
-// load, and its returning cursor atomic disappears.  The rank buffers ([2][N * S] ints, specular / diffuse) are handed over through
-// rf_exp_set_ticket_buffers so that the experiment needs no ABI change.
-__device__ int* g_exp_ticket[2];
-#endif
 
 
 // 16-byte load/store at 4-byte alignment (a corner's 27 features start at a multiple of 108 B)
@@ -968,11 +961,7 @@ __device__ __forceinline__ void render_forward_ray(const GridArgs& g, const RayA
     // a sample needs its colour only if it can contribute: inside, T != 0 and (under ReLU) sigma != 0
     const bool need = live && (T != 0.0f) && !(g.mode == RF_DENSITY_RELU && sigma == 0.0f);
     const unsigned long long mask = __ballot(need);
-#ifdef RF_EXP_NO_P1  // development build (tools/exp_bin_once.sh): the march without the feature gather -- what a density-only forward pass costs
-    const int count = 0;
-#else
     const int count = fast_base ? 0 : __popcll(mask);
-#endif
     const int slot = __popcll(mask & ((1ull << lane) - 1ull));
     if (need && !fast_base) {
       uint32_t* e = my_entry + slot * kEntryFwd;
@@ -1123,14 +1112,7 @@ __device__ __forceinline__ void render_forward_ray(const GridArgs& g, const RayA
           out.tcache[idx] = T;
       }
       my_cmask = (lane == (chunk & (kWave - 1))) ? mask : my_cmask;
-#ifdef RF_EXP_TICKET
-      if (out.hist) {
-        const int rank = add_key_runs<true>(out.hist, need ? brick_key(sm.cell.i0, g, out.brick_shift, out.nby, out.nbz) : -1, lane);
-        if (need) g_exp_ticket[DIFFUSE ? 1 : 0][ray * (long long)r.S + chunk * kWave + slot] = rank;
-      }
-#else
       if (out.hist) add_key_runs<false>(out.hist, need ? brick_key(sm.cell.i0, g, out.brick_shift, out.nby, out.nbz) : -1, lane);
-#endif
     }
     wave_lds_fence();
     if (T_carry == 0.0f) break;  // every later weight is exactly 0
@@ -1887,9 +1869,6 @@ __device__ __forceinline__ void render_emit_direct_ray(const GridArgs& g, const 
   for (int c0 = nchunks - 1; c0 >= 0; c0 -= G) {
     float4 cv[G];
     float Tc[G], zz[G], zn[G];
-#ifdef RF_EXP_TICKET
-    int tk[G];
-#endif
     unsigned long long cm[G];
     // -- A0: the masks of the cached samples of chunks c0, c0 - 1, ...: a chunk without any is skipped
 #pragma unroll
@@ -1916,9 +1895,6 @@ __device__ __forceinline__ void render_emit_direct_ray(const GridArgs& g, const 
       const long long idx = cached_slot(ray, r.S, chunk, cm[u], lane);
       cv[u] = load_f4<RF_NT_CACHE_LOAD>(reinterpret_cast<const float4*>(fwd.cache) + idx);
       Tc[u] = RF_NT_CACHE_LOAD ? __builtin_nontemporal_load(fwd.tcache + idx) : fwd.tcache[idx];
-#ifdef RF_EXP_TICKET
-      tk[u] = g_exp_ticket[DIFFUSE ? 1 : 0][idx];
-#endif
       zq[u] = z_requests(r, s);
     }
 #pragma unroll
@@ -1947,10 +1923,6 @@ __device__ __forceinline__ void render_emit_direct_ray(const GridArgs& g, const 
       ix[u][2] = sm.cell.idx[2];
       counted[u] = (cm[u] >> lane) & 1ull;
       const int key = counted[u] ? brick_key(sm.cell.i0, g, gr.brick_shift, gr.nby, gr.nbz) : -1;
-#ifdef RF_EXP_TICKET
-      base_[u] = gr.cursor[max(key, 0)];  // (never advanced in this build: the start of the key class)
-      continue;
-#endif
       // one atomic per RUN of equal keys (add_key_runs, split: the returned base is only combined in phase B)
       const bool active = key >= 0;
       const int prev = __shfl_up(key, 1);
@@ -1992,11 +1964,7 @@ __device__ __forceinline__ void render_emit_direct_ray(const GridArgs& g, const 
         g_pre = g_sigma * (1.0f - exp_fast(-sigma));  // softplus'(x) = sigmoid(x) = 1 - exp(-softplus(x))
       else
         g_pre = g_sigma;
-#ifdef RF_EXP_TICKET
-      const int pos = base_[u] + tk[u];
-#else
       const int pos = __shfl(base_[u], hl_[u]) + (lane - hl_[u]);
-#endif
       if (have) {
         // (a counted sample is inside the box; its record is written even when its gradient happens to vanish)
         const float graw[3] = {(w * gC[0]) * (c[0] * (1.0f - c[0])), (w * gC[1]) * (c[1] * (1.0f - c[1])), (w * gC[2]) * (c[2] * (1.0f - c[2]))};
@@ -3930,82 +3898,6 @@ unsigned grid_1d(long long n, int block, long long cap = 256LL * 16) {
 
 }  // namespace
 
-#ifdef RF_EXP_GATHER
-// Development build only (tools/exp_bin_once.sh; DESIGN "bin once, use twice" go / no-go): the specular feature gather fed by a list of
-// samples SORTED BY BRICK instead of by ray -- one workgroup per brick walks the brick's own samples (the keys of its lower nodes: two
-// runs of four key classes), 8 lanes per sample like P1 of the forward pass (lane 0 and 7 idle at SH degree 2), every lane four
-// consecutive `rest` coefficients of each of the 8 corners, per-sample SH basis from the record's viewing direction, 12 B of raw RGB
-// out per sample.  Reads the compact 48-byte gradient records of a training step as stand-ins for sample records (same index quad,
-// same direction).  Not a product path: the border handling is simplified (corners clamped), nothing consumes the output.
-template <int K>
-__global__ __launch_bounds__(256) void exp_gather_sorted_kernel(GridArgs g, const float4* __restrict__ rec, const long long* __restrict__ offsets,
-                                                                int nby, int nbz, float* __restrict__ out) {
-  constexpr int KR = K - 1, LC = (KR + 3) / 4, R = 3 * KR;
-  const int b = blockIdx.x;
-  const int bz = b % nbz, by = (b / nbz) % nby, bx = b / (nbz * nby);
-  const int sub = threadIdx.x & 7, grp = threadIdx.x >> 3;  // 32 samples per pass
-  const int t = sub - 1;
-  const int c = t / LC, q = t - c * LC;
-  const bool active = sub >= 1 && c < 3;
-  const int first = c * KR + 4 * q;
-  const int off = min(max(first, 0), R - 4);
-  const unsigned int strideB = (unsigned int)g.fstride * 4u;
-  for (int fx = 0; fx < 2; ++fx) {
-    const int key0 = (int)((__umul24(__umul24((unsigned)((bx << 1) | fx), (unsigned)nby) + (unsigned)by, (unsigned)nbz) + (unsigned)bz) << 2);
-    const long long begin = offsets[key0], end = offsets[key0 + 4];
-    for (long long i = begin + grp; i < end; i += 32) {
-      const float4 q0 = rec[3 * i], q1 = rec[3 * i + 1], q2 = rec[3 * i + 2];
-      float Y[16];
-      sh_basis<K>(q1.w, q2.x, q2.y, Y);
-      const float idx[3] = {q0.x, q0.y, q0.z};
-      const int dims3[3] = {g.X, g.Y, g.Z};
-      int i0[3];
-      float w0[3], w1[3];
-#pragma unroll
-      for (int a = 0; a < 3; ++a) {
-        const float f = floorf(idx[a]);
-        i0[a] = min(max((int)f, 0), dims3[a] - 2);
-        w1[a] = idx[a] - f;
-        w0[a] = 1.0f - w1[a];
-      }
-      const unsigned int lin0 = node_lin(g, i0[0], i0[1], i0[2]);
-      vf2 a01 = {0.f, 0.f}, a23 = {0.f, 0.f};
-      if (active) {
-        const unsigned int o0 = __umul24(lin0, strideB) + g.feat_off + (unsigned int)off * 4u;
-        const unsigned int sx = __umul24(g.step[0], strideB), sy = __umul24(g.step[1], strideB), sz = __umul24(g.step[2], strideB);
-        f4u v[8];
-#pragma unroll
-        for (int k = 0; k < 8; ++k) {
-          const unsigned int o = o0 + ((k & 1) ? sx : 0u) + ((k & 2) ? sy : 0u) + ((k & 4) ? sz : 0u);
-          v[k] = *reinterpret_cast<const f4u*>(g.base + (size_t)o);
-        }
-#pragma unroll
-        for (int k = 0; k < 8; ++k) {
-          const float wk = ((k & 1) ? w1[0] : w0[0]) * ((k & 2) ? w1[1] : w0[1]) * ((k & 4) ? w1[2] : w0[2]);
-          const vf2 lo = {v[k].v[0], v[k].v[1]}, hi = {v[k].v[2], v[k].v[3]}, wv = {wk, wk};
-          a01 = __builtin_elementwise_fma(lo, wv, a01);
-          a23 = __builtin_elementwise_fma(hi, wv, a23);
-        }
-      }
-      float p[4] = {0.f, 0.f, 0.f, 0.f};
-      if (active) {
-        const float acc[4] = {a01.x, a01.y, a23.x, a23.y};
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          const int rr = off + j;
-          const bool own = rr >= first && rr < min(first + 4, (c + 1) * KR);
-          float yb = 0.0f;
-#pragma unroll
-          for (int k = 1; k < K; ++k) yb = (own && rr - c * KR + 1 == k) ? Y[k] : yb;
-          p[j] = yb * acc[j];
-        }
-      }
-      const float sum = rest_colour_sums<K>(p);
-      if (active && q == LC - 1) out[3 * i + c] = sum;
-    }
-  }
-}
-#endif
 
 extern "C" {
 
@@ -4141,25 +4033,7 @@ static int brick_geometry(const RFGrid* grid, int brick_size, int* shift, int nb
   return (total * 8 - 1 <= (short_keys ? 0x7fffLL : (1LL << 21) - 1)) ? RF_OK : RF_ERR_UNSUPPORTED;
 }
 
-#ifdef RF_EXP_TICKET
-int rf_exp_set_ticket_buffers(int* specular_dev, int* diffuse_dev) {
-  int* h[2] = {specular_dev, diffuse_dev};
-  return hipMemcpyToSymbol(HIP_SYMBOL(g_exp_ticket), h, sizeof(h)) == hipSuccess ? RF_OK : RF_ERR_LAUNCH;
-}
-#endif
 
-#ifdef RF_EXP_GATHER
-// development builds only (see exp_gather_sorted_kernel)
-int rf_exp_gather_sorted(const RFGrid* grid, const float* records_sorted_dev, const int64_t* offsets_dev, int32_t brick_size, float* out_rgb_dev, void* stream) {
-  if (!grid || !records_sorted_dev || !offsets_dev || !out_rgb_dev) return RF_ERR_NULL_POINTER;
-  const GridArgs g = to_args(grid);
-  int shift, nb[3];
-  if (brick_geometry(grid, brick_size, &shift, nb, false) != RF_OK || g.F != 27 || g.layout == RF_LAYOUT_REFERENCE || !g.near32) return RF_ERR_UNSUPPORTED;
-  hipLaunchKernelGGL((exp_gather_sorted_kernel<9>), dim3(nb[0] * nb[1] * nb[2]), dim3(256), 0, (hipStream_t)stream, g, reinterpret_cast<const float4*>(records_sorted_dev),
-                     reinterpret_cast<const long long*>(offsets_dev), nb[1], nb[2], out_rgb_dev);
-  return launch_status();
-}
-#endif
 
 // Which kernel renders a frame of a posed camera (RFRayBatch.camera, no sample cache): ray packets -- one wave per 8 x 8 pixel tile,
 // render_frame_tile_kernel -- where a tile's rays stay within ~2 voxels of each other at the volume's centre (8 pixels x distance /
@@ -4905,21 +4779,6 @@ int rf_adam_step(float* param_dev, float* grad_dev, float* exp_avg_dev, float* e
 }
 
 int rf_train_step(const RFGrid* grid, const RFTrainStep* step, void* stream) {
-#ifdef RF_EXP_TICKET
-  {  // (development build: the rank buffers of the experiment, grown on demand)
-    static int* bufs[2] = {nullptr, nullptr};
-    static long long cap = 0;
-    const long long need = step ? (long long)step->num_rays * step->num_samples : 0;
-    if (need > cap) {
-      for (int i = 0; i < 2; ++i) {
-        if (bufs[i]) (void)hipFree(bufs[i]);
-        if (hipMalloc(&bufs[i], (size_t)need * sizeof(int)) != hipSuccess) return RF_ERR_LAUNCH;
-      }
-      cap = need;
-      if (rf_exp_set_ticket_buffers(bufs[0], bufs[1]) != RF_OK) return RF_ERR_LAUNCH;
-    }
-  }
-#endif
   if (!grid || !step) return RF_ERR_NULL_POINTER;
   if (step->num_rays == 0) return RF_OK;
   if (!step->origins_dev || !step->directions_dev || !step->pixels_dev || !step->loss_sums_dev) return RF_ERR_NULL_POINTER;

@@ -1,6 +1,9 @@
 # "Bin once, use twice" go / no-go (GPU box, repo root): (a) today's forward pair, (b) the same launch without the specular feature gather
 # (-DRF_EXP_NO_P1: the density-only march of both renders), (c) the brick-sorted feature gather (tools/exp_bin_once.py).
-FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -fPIC -shared -I include thr3ed_atom_amd/csrc/relu_field_kernels.hip"
+# (the experiment's hooks live in a patch since round 6 -- the product source carries no development code: applied to a scratch copy here;
+# the patch was cut against the round-5 source, re-cut it if it no longer applies)
+mkdir -p /tmp/rf_exp && cp thr3ed_atom_amd/csrc/relu_field_kernels.hip /tmp/rf_exp/ && (cd /tmp/rf_exp && patch -p3 relu_field_kernels.hip < $OLDPWD/tools/experiments/r05_exp_ticket_gather_nop1.patch) || exit 1
+FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -fPIC -shared -I include /tmp/rf_exp/relu_field_kernels.hip"
 /opt/rocm/bin/hipcc $FLAGS -DRF_EXP_NO_P1 -o tools/exp_nop1.so || exit 1
 /opt/rocm/bin/hipcc $FLAGS -DRF_EXP_GATHER -o tools/exp_gather.so || exit 1
 for lib in thr3ed_atom_amd/csrc/librelu_field_hip.so tools/exp_nop1.so; do

@@ -1,6 +1,9 @@
 # VERDICT r04 item 2a (GPU box, repo root): the adjoint's returning cursor atomic replaced by offsets[key] + a rank the forward pass's
 # (now returning) counter atomic left per cached sample.  A/B of the bench step, product build against -DRF_EXP_TICKET, alternating.
-FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -fPIC -shared -I include thr3ed_atom_amd/csrc/relu_field_kernels.hip"
+# (the experiment's hooks live in a patch since round 6 -- the product source carries no development code: applied to a scratch copy here;
+# the patch was cut against the round-5 source, re-cut it if it no longer applies)
+mkdir -p /tmp/rf_exp && cp thr3ed_atom_amd/csrc/relu_field_kernels.hip /tmp/rf_exp/ && (cd /tmp/rf_exp && patch -p3 relu_field_kernels.hip < $OLDPWD/tools/experiments/r05_exp_ticket_gather_nop1.patch) || exit 1
+FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -fPIC -shared -I include /tmp/rf_exp/relu_field_kernels.hip"
 /opt/rocm/bin/hipcc $FLAGS -DRF_EXP_TICKET -o tools/exp_ticket.so || exit 1
 for rep in 1 2 3; do
 for lib in thr3ed_atom_amd/csrc/librelu_field_hip.so tools/exp_ticket.so; do
