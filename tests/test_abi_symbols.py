@@ -157,7 +157,7 @@ def test_product_path_raises_without_gpu_tensors():
 
 def test_frame_kernel_dispatch_rule_needs_no_gpu(lib, monkeypatch):
     """rf_frame_render_kernel (host-side only): frames go to the ray-packet kernel where an 8 x 8 pixel tile's footprint at the
-    volume's centre is at most 2 voxels (3 with the occupancy mask) on split storage of SH degree 0 / 2, else to the per-ray kernel;
+    volume's centre is at most 2 voxels (3 with the occupancy mask) on split storage, else to the per-ray kernel;
     $RF_FRAME_TILES overrides where the packet kernel exists.  The bench configurations: configs[1] -> packets, configs[4] -> packets
     only with the mask."""
     import ctypes as C
@@ -196,7 +196,10 @@ def test_frame_kernel_dispatch_rule_needs_no_gpu(lib, monkeypatch):
     assert choice(grid_of(256, occ=True), cam, 0) == 0                      # (a mask that the render does not use)
     assert choice(grid_of(128), cam_of(88.9)) == 0                          # a 64-pixel camera: a tile spans many voxels
     assert choice(grid_of(128, layout="reference"), cam) == 0               # no packet kernel for the reference layout
-    assert choice(grid_of(128, F=12), cam) == 0                             # ... nor for SH degree 1
+    assert choice(grid_of(128, F=12), cam) == 1 and choice(grid_of(128, F=48), cam) == 1  # SH degree 1 / 3: the generic rest path (round 6)
+    misaligned = grid_of(128)
+    misaligned.densities_dev += 4
+    assert choice(misaligned, cam) == 0                                     # the base records are fetched as aligned 16-byte quads
     assert choice(grid_of(64, F=3), cam_of(1111.111)) == 1                  # degree 0: the base-record instantiation
     monkeypatch.setenv("RF_FRAME_TILES", "0")
     assert choice(grid_of(128), cam) == 0

@@ -1190,7 +1190,7 @@ __global__ __launch_bounds__(kBlock, RF_FWD_WAVES) void render_forward_pair_kern
 // sigmoid -- is the per-ray kernel's, value for value; only the order in which a ray's weighted samples are ADDED differs
 // (sequential here, per-lane partial sums + a butterfly there), so the two kernels agree to summation order, not bit for bit.
 // A pixel's result does not depend on the other pixels of its tile or on how a frame is cut into calls.
-// Split / bricked storage, SH degree 2 (REST) or the base record alone (degree 0, render_diffuse).
+// Split / bricked storage, every SH degree (degree 2 = the tuned path; the base record alone for degree 0 and render_diffuse).
 // =============================================================================================
 #ifndef RF_TILE_WAVES
 #define RF_TILE_WAVES 4
@@ -1342,6 +1342,63 @@ __device__ __forceinline__ void tile_interpolate_rest(const TileCell& tc, const 
   }
 }
 
+// SH degree 1 / 3 (K = 4 / 16): rest records of 3 (K - 1) = 9 / 45 floats -- not whole quads, 4-byte aligned.  Always fetched on
+// demand (after the densities said that a lane needs colours): whole quads by 16-byte loads at 4-byte alignment, the odd float by
+// itself (nothing is read behind a record: the last node's record ends the tensor), stored as kQ = 3 / 12 quads per window slot.
+template <int K>
+struct TileRestGeneric {
+  static constexpr int kKR = K - 1, kF = 3 * kKR, kFull = kF / 4, kRem = kF % 4, kQ = (kF + 3) / 4;
+};
+template <int K>
+__device__ __forceinline__ void tile_window_rest_generic(const GridArgs& g, unsigned int lin, vf4* my_rest, int lane) {
+  using R = TileRestGeneric<K>;
+  const float* rp = g.feat + (size_t)lin * (size_t)g.fstride;
+  f4u q[R::kFull];
+  float tail[R::kRem > 0 ? R::kRem : 1];
+#pragma unroll
+  for (int t = 0; t < R::kFull; ++t) q[t] = *reinterpret_cast<const f4u*>(rp + 4 * t);
+#pragma unroll
+  for (int t = 0; t < R::kRem; ++t) tail[t] = rp[4 * R::kFull + t];
+  vf4* d = my_rest + lane * R::kQ;
+#pragma unroll
+  for (int t = 0; t < R::kFull; ++t) d[t] = vf4{q[t].v[0], q[t].v[1], q[t].v[2], q[t].v[3]};
+  if constexpr (R::kRem > 0) d[R::kFull] = vf4{tail[0], R::kRem > 1 ? tail[R::kRem > 1 ? 1 : 0] : 0.0f, R::kRem > 2 ? tail[R::kRem > 2 ? 2 : 0] : 0.0f, 0.0f};
+}
+// element c * (K - 1) + (k - 1) of the record, summed over the corners with fused multiply-adds in corner order, then basis * sum,
+// added up pairwise
+template <int K>
+__device__ __forceinline__ void tile_interpolate_rest_generic(const TileCell& tc, const int nk[8], const vf4* my_rest, const float Y[16], float raw[3]) {
+  using R = TileRestGeneric<K>;
+  vf2 a2[2 * R::kQ];
+#pragma unroll
+  for (int t = 0; t < 2 * R::kQ; ++t) a2[t] = vf2{0.f, 0.f};
+#pragma unroll
+  for (int k = 0; k < 8; ++k) {
+    const vf2 wk = {tc.w[k], tc.w[k]};
+#pragma unroll
+    for (int t = 0; t < R::kQ; ++t) {
+      const vf4 v = my_rest[nk[k] * R::kQ + t];
+      a2[2 * t] = __builtin_elementwise_fma(vf2{v[0], v[1]}, wk, a2[2 * t]);
+      a2[2 * t + 1] = __builtin_elementwise_fma(vf2{v[2], v[3]}, wk, a2[2 * t + 1]);
+    }
+  }
+#pragma unroll
+  for (int c = 0; c < 3; ++c) {
+    float p[16];
+#pragma unroll
+    for (int jj = 0; jj < 16; ++jj) {
+      const int el = c * R::kKR + (jj < R::kKR ? jj : 0);
+      const float av = (el & 1) ? a2[el >> 1].y : a2[el >> 1].x;
+      p[jj] = jj < R::kKR ? Y[1 + (jj < R::kKR ? jj : 0)] * av : 0.0f;
+    }
+#pragma unroll
+    for (int w = 8; w >= 1; w >>= 1)
+#pragma unroll
+      for (int jj = 0; jj < w; ++jj) p[jj] = p[jj] + p[jj + w];
+    raw[c] = raw[c] + p[0];
+  }
+}
+
 // this lane's ray of the tile: pixel (i, j), cast_rays fused (utils/misc.py:12-50) -- lanes off the frame or outside the pixel
 // range of the call compute on a clamped pixel and never write
 __device__ __forceinline__ RayState tile_ray(const GridArgs& g, const RayArgs& r, uint32_t flags, int i, int j) {
@@ -1380,10 +1437,15 @@ __device__ __forceinline__ float tile_z(const RayState& st, const RayArgs& r, in
 // windows through the same L2 while the eight XCDs still share every part of the picture (the heavy tiles sit in its middle).
 // Measured (profiles/r06_frame_tile_sched.txt), 800 x 800: WPB 1 + XCD rows against WPB 4 + linear: 128^3 / 256 samples 1.69-1.73
 // against 1.70-1.75 ms, 256^3 / 512 samples with the mask 1.52-1.55 against 1.62-1.66 ms; either switch alone: no gain.
-template <bool REST, int WPB, bool XCD_ROWS>
-__global__ __launch_bounds__(kWave * WPB, RF_TILE_WAVES) void render_frame_tile_kernel(GridArgs g, RayArgs r, OutArgs out, uint32_t flags, int row0, int tile_rows, int tiles_x) {
+// K = the coefficients per colour that are read: 1 (SH degree 0, render_diffuse: the base record alone), 4, 9, 16.  K = 9 is the tuned
+// path (rest records = six aligned quads, prefetched with the base records where the previous step needed colours); K = 4 / 16 use the
+// generic rest path above (K = 16: 46 accumulator registers per lane -- two waves per SIMD instead of four).
+template <int K, int WPB, bool XCD_ROWS>
+__global__ __launch_bounds__(kWave * WPB, (K == 16 ? 2 : RF_TILE_WAVES)) void render_frame_tile_kernel(GridArgs g, RayArgs r, OutArgs out, uint32_t flags, int row0, int tile_rows, int tiles_x) {
+  constexpr bool REST = K > 1;
+  constexpr int kRestQuads = K == 9 ? 6 : (K > 1 ? TileRestGeneric<K>::kQ : 0);
   __shared__ __attribute__((aligned(16))) vf4 s_base[WPB][kWave];
-  __shared__ __attribute__((aligned(16))) vf4 s_rest[WPB][REST ? kWave * 6 : 1];
+  __shared__ __attribute__((aligned(16))) vf4 s_rest[WPB][REST ? kWave * kRestQuads : 1];
   const int lane = threadIdx.x & (kWave - 1);
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   int ty, tx;
@@ -1414,7 +1476,7 @@ __global__ __launch_bounds__(kWave * WPB, RF_TILE_WAVES) void render_frame_tile_
   const bool white = flags & RF_FLAG_WHITE_BKGD;
   const bool use_occ = (flags & RF_FLAG_OCCUPANCY_SKIP) && g.occ != nullptr;
   float Y[16];
-  if constexpr (REST) sh_basis<9>(st.d[0] / st.dnorm, st.d[1] / st.dnorm, st.d[2] / st.dnorm, Y);  // v = d / |d| (process.py:53)
+  if constexpr (REST) sh_basis<K>(st.d[0] / st.dnorm, st.d[1] / st.dnorm, st.d[2] / st.dnorm, Y);  // v = d / |d| (process.py:53)
   // the ray's parameter interval inside the box, widened by the per-ray kernel's margins (slab interval, one stratum of jitter) -- two
   // registers for the march: [z_lo, z_hi], empty for lanes that never write and rays that miss the box
   float z_lo = kInfinity, z_hi = -kInfinity;
@@ -1468,10 +1530,14 @@ __global__ __launch_bounds__(kWave * WPB, RF_TILE_WAVES) void render_frame_tile_
         const unsigned int lin = tile_window_node(g, O, lane);
         TileWindow wdw;
         tile_window_load_base(wdw, g, lin);
-        const bool with_rest = REST && rest_hot;  // (wave-uniform)
-        if (with_rest) tile_window_load_rest(wdw, g, lin);
+        const bool with_rest = K == 9 && rest_hot;  // (wave-uniform)
+        if constexpr (K == 9) {
+          if (with_rest) tile_window_load_rest(wdw, g, lin);
+        }
         my_base[lane] = wdw.b;
-        if (with_rest) tile_window_store_rest(wdw, my_rest, lane);
+        if constexpr (K == 9) {
+          if (with_rest) tile_window_store_rest(wdw, my_rest, lane);
+        }
         wave_lds_fence();
         int nk[8];
         const bool covered = tile_interpolate_base(pending, tc, O, my_base, g, T, nk, sigma, raw, need);
@@ -1479,12 +1545,18 @@ __global__ __launch_bounds__(kWave * WPB, RF_TILE_WAVES) void render_frame_tile_
           const bool mine = covered && need;
           if (__ballot(mine) != 0ull) {
             step_needs_rest = true;
-            if (!with_rest) {
-              tile_window_load_rest(wdw, g, lin);
-              tile_window_store_rest(wdw, my_rest, lane);
+            if constexpr (K == 9) {
+              if (!with_rest) {
+                tile_window_load_rest(wdw, g, lin);
+                tile_window_store_rest(wdw, my_rest, lane);
+                wave_lds_fence();
+              }
+              if (mine) tile_interpolate_rest(tc, nk, my_rest, Y, raw);
+            } else {
+              tile_window_rest_generic<K>(g, lin, my_rest, lane);
               wave_lds_fence();
+              if (mine) tile_interpolate_rest_generic<K>(tc, nk, my_rest, Y, raw);
             }
-            if (mine) tile_interpolate_rest(tc, nk, my_rest, Y, raw);
           }
         }
         wave_lds_fence();  // (the next round overwrites the window)
@@ -4040,13 +4112,13 @@ static int brick_geometry(const RFGrid* grid, int brick_size, int* shift, int nb
 // focal length against the smallest voxel edge; 3 voxels with the occupancy mask, whose live lanes are few): beyond that the
 // 4 x 4 x 4-node window has to be moved several times per step and the per-ray kernel wins.  Measured, 800 x 800: 128^3 / 256 samples
 // (1.3 voxels) 1.78 against 2.80 ms; 256^3 / 512 samples (2.6 voxels) 1.70 against 2.05 ms with the mask, 3.12 against 2.90 ms without.
-// The packet kernel exists for split / bricked storage and SH degree 0 / 2.  $RF_FRAME_TILES = 1 / 0 forces /
+// The packet kernel exists for split / bricked storage (a grid in the reference's tensors is rendered from its split shadow), every SH degree.  $RF_FRAME_TILES = 1 / 0 forces /
 // forbids it where it exists (A/B runs, tests).
 static bool frame_uses_packets(const RFGrid* grid, const GridArgs& g, const RFCamera* cam, uint32_t flags) {
   const int K = grid->num_features / 3;
-  if (!(g.layout == RF_LAYOUT_SPLIT && (K == 9 || K == 1) && g.Z >= 4 && g.Y >= 4 && g.X >= 4 && (g.dstride & 3) == 0 && (K == 1 || (g.fstride & 3) == 0))) return false;
-  // (the window is fetched as 16-byte quads: both tensors must start on a 16-byte boundary)
-  if ((((uintptr_t)grid->densities_dev | (uintptr_t)(K == 1 ? nullptr : grid->features_dev)) & 15u) != 0) return false;
+  if (!(g.layout == RF_LAYOUT_SPLIT && (K == 1 || K == 4 || K == 9 || K == 16) && g.Z >= 4 && g.Y >= 4 && g.X >= 4 && (g.dstride & 3) == 0 && (K != 9 || (g.fstride & 3) == 0))) return false;
+  // (the window is fetched as 16-byte quads: the base tensor -- and the degree-2 rest tensor -- must start on a 16-byte boundary)
+  if ((((uintptr_t)grid->densities_dev | (uintptr_t)(K == 9 ? grid->features_dev : nullptr)) & 15u) != 0) return false;
   if (const char* e = getenv("RF_FRAME_TILES")) return atoi(e) != 0;
   float dist2 = 0.0f, vmin = 1e30f;
   for (int a = 0; a < 3; ++a) {
@@ -4112,16 +4184,23 @@ int rf_render_forward(const RFGrid* grid, const RFRayBatch* rays, uint32_t flags
         const char* e = getenv("RF_TILE_XCD_ROWS");
         return e ? atoi(e) != 0 : true;
       }();
-      const bool rest = K == 9 && !diffuse;
-      const long long wgs = xcd_rows ? (long long)((tile_rows + 7) / 8) * 8 * ((tiles_x + wpb - 1) / wpb) : ((long long)tile_rows * tiles_x + wpb - 1) / wpb;
-#define RF_TILE_LAUNCH(REST_, WPB_, XR_)                                                                                                         \
-  hipLaunchKernelGGL((render_frame_tile_kernel<REST_, WPB_, XR_>), dim3((unsigned)wgs), dim3(kWave * WPB_), 0, st, g, r, o, flags, row0, tile_rows, tiles_x)
-      if (rest) {
-        if (wpb == 4) { if (xcd_rows) RF_TILE_LAUNCH(true, 4, true); else RF_TILE_LAUNCH(true, 4, false); }
-        else { if (xcd_rows) RF_TILE_LAUNCH(true, 1, true); else RF_TILE_LAUNCH(true, 1, false); }
+      const int KT = diffuse ? 1 : K;  // coefficients per colour that are read
+      const bool sched_default = KT == 4 || KT == 16;  // (the degree-1 / 3 instantiations exist in the default scheduling only)
+      const int wpb_ = sched_default ? 1 : wpb;
+      const bool xr_ = sched_default ? true : xcd_rows;
+      const long long wgs = xr_ ? (long long)((tile_rows + 7) / 8) * 8 * ((tiles_x + wpb_ - 1) / wpb_) : ((long long)tile_rows * tiles_x + wpb_ - 1) / wpb_;
+#define RF_TILE_LAUNCH(K_, WPB_, XR_)                                                                                                            \
+  hipLaunchKernelGGL((render_frame_tile_kernel<K_, WPB_, XR_>), dim3((unsigned)wgs), dim3(kWave * WPB_), 0, st, g, r, o, flags, row0, tile_rows, tiles_x)
+      if (KT == 4) {
+        RF_TILE_LAUNCH(4, 1, true);
+      } else if (KT == 16) {
+        RF_TILE_LAUNCH(16, 1, true);
+      } else if (KT == 9) {
+        if (wpb == 4) { if (xcd_rows) RF_TILE_LAUNCH(9, 4, true); else RF_TILE_LAUNCH(9, 4, false); }
+        else { if (xcd_rows) RF_TILE_LAUNCH(9, 1, true); else RF_TILE_LAUNCH(9, 1, false); }
       } else {
-        if (wpb == 4) { if (xcd_rows) RF_TILE_LAUNCH(false, 4, true); else RF_TILE_LAUNCH(false, 4, false); }
-        else { if (xcd_rows) RF_TILE_LAUNCH(false, 1, true); else RF_TILE_LAUNCH(false, 1, false); }
+        if (wpb == 4) { if (xcd_rows) RF_TILE_LAUNCH(1, 4, true); else RF_TILE_LAUNCH(1, 4, false); }
+        else { if (xcd_rows) RF_TILE_LAUNCH(1, 1, true); else RF_TILE_LAUNCH(1, 1, false); }
       }
 #undef RF_TILE_LAUNCH
       return launch_status();

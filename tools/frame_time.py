@@ -34,4 +34,16 @@ for name, G, S, sparse, over, deg in (("cfg1", 128, 256, False, {}, 2), ("cfg4_m
     out[name] = {"kernel_ms": round(kms, 4), "wall_ms": round(wall * 1e3, 4)}
     del model, grid
     torch.cuda.empty_cache()
+# SH degree 1 / 3 (round 6: the packet kernel's generic rest path) against the per-ray kernel ($RF_FRAME_TILES is read per call)
+for deg in (1, 3):
+    grid = bench.make_grid(dev, 128, deg, seed=42, storage="split")
+    cfg = rf.SHVoxGridRenderConfig(256, bounds, perturb_sampled_points=True, white_bkgd=True)
+    model = rf.VolumetricModel(grid, rf.render_sh_voxel_grid, cfg, device=dev)
+    for tiles in ("1", "0"):
+        os.environ["RF_FRAME_TILES"] = tiles
+        wall, kms, launches = bench.time_frames(lambda: model.render(pose, intr), frames, kernel=f"render_forward[sh{deg},frame]")
+        out[f"cfg1_sh{deg}_{'packets' if tiles == '1' else 'per_ray'}"] = {"kernel_ms": round(kms, 4), "wall_ms": round(wall * 1e3, 4)}
+    os.environ.pop("RF_FRAME_TILES", None)
+    del model, grid
+    torch.cuda.empty_cache()
 print(json.dumps(out))
