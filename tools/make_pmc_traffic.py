@@ -114,7 +114,8 @@ def main():
                 continue  # (a harness probe on other inputs -- e.g. the sample-count probe of the fwd_render leg --, not a kernel of the timed steps)
             out[bname] = entry(by["FETCH_SIZE"][kname], by["WRITE_SIZE"][kname])
     # (frames: the ray-packet kernel where the library dispatches it -- the bench's 800 x 800 frames at 128^3 --, else the per-ray kernel)
-    frame = "render_frame_tile_kernel<true>" if by["FETCH_SIZE"].get("render_frame_tile_kernel<true>") else "render_forward_kernel<9, false, false>"
+    tile_names = [k for k in by["FETCH_SIZE"] if k.startswith("render_frame_tile_kernel<9") or k == "render_frame_tile_kernel<true>"]
+    frame = tile_names[0] if tile_names else "render_forward_kernel<9, false, false>"
     f, w = by["FETCH_SIZE"].get(frame, []), by["WRITE_SIZE"].get(frame, [])
     g, n = args.gt_frames, args.frames_per_leg
     for i, leg in enumerate(("init_field", "traversal")):
