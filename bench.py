@@ -248,6 +248,7 @@ from thr3ed_atom_amd.trainers import PosedImagesInMemory, TrainStepper  # noqa: 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md)
 HBM_ACHIEVABLE_GBS = 6300.0  # what a streaming kernel measures on it (same guide): the second denominator of the roofline line
 L2_PEAK_TBS = 34.5  # aggregate L2 bandwidth, same guide
+LDS_READ_PEAK_TBS = 150.0  # aggregate ds_read_b128 rate, same guide
 NEAR = float(np.float32(2.0) * 0.9)  # hotdog-like bounds, SURVEY.md 8d
 FAR = float(np.float32(6.0) * 1.1)
 RADIUS = 4.0311
@@ -775,6 +776,7 @@ def main():
             del hist, sub
             alg = gathered * 8 * C * 4 + (inside_sub - gathered) * 8 * 4 * 4 + H * W * 12  # features | density only | outputs (rays are generated in-kernel)
             counter = pmc.get(f"{kname}:{leg}", {}).get("hbm_bytes_per_launch")
+            packets = frame_kernel_of(g2, intr, False).startswith("render_frame_tile_kernel")
             legs[leg] = {
                 "density_scale": g2.expected_density_scale,
                 "frame_kernel": frame_kernel_of(g2, intr, False),
@@ -791,7 +793,11 @@ def main():
                 # not move these bytes through L2 at all: a tile fetches its neighbourhood once per step and the per-sample gathers
                 # are LDS reads; the figure is then an EFFECTIVE rate on SURVEY 8d's per-sample byte model, comparable across rounds.)
                 "effective_TBps_processed": alg / 1e12 / (kms / 1e3),
-                "frac_of_l2_peak_processed": alg / 1e12 / (kms / 1e3) / L2_PEAK_TBS,
+                # which ceiling those bytes move against depends on the kernel that served the frame: the ray-packet kernel reads them
+                # out of LDS (ds_read_b128: ~150 TB/s aggregate, MI355X_MICROARCH.md) -- and is bound by vector-ALU issue, not by any
+                # bandwidth (profiles/r06_frame_packets_counters.md: VALU 78 % busy, LDS pipe 70 %) --, the per-ray kernel through L1 / L2
+                "frac_of_lds_read_peak": (alg / 1e12 / (kms / 1e3) / LDS_READ_PEAK_TBS) if packets else None,
+                "frac_of_l2_peak_processed": None if packets else alg / 1e12 / (kms / 1e3) / L2_PEAK_TBS,
                 "counter_GB_per_launch": None if counter is None else counter / 1e9,
                 "frac_hbm": None if counter is None else frac(counter, kms, f"fwd_render.{leg} (counters)"),
             }

@@ -18,6 +18,16 @@ This file depends on torch, numpy, ctypes and the reference package only -- NOT 
 
 The one other edit the reference needs: the identity assert of the trainer (modules/trainers.py:116-122) must accept the new
 procedure, e.g. `vol_mod.render_procedure in (render_sh_voxel_grid, render_sh_voxel_grid_hip)`.
+
+Optional second edit, for the trainer's iteration (modules/trainers.py:306-330 renders the same rays twice: specular, then
+`render_diffuse=True`): `render_sh_voxel_grid_pair_hip(voxel_grid, rays, render_config)` returns both RenderOuts from ONE autograd
+node -- one forward launch (rf_render_forward_pair), and a backward of three (rf_bin_offsets_pair, rf_render_backward_emit_direct_pair,
+one rf_brick_accumulate over both record lists) instead of six.
+
+Forward passes of a training-size render and frames gather from a split-layout COPY of the grid (see _split_shadow).  The copy follows
+the module's tensors through their data pointers and autograd version counters; a write that bumps neither (`p.data.copy_(...)`,
+`p.data.clamp_()`, a raw-pointer kernel) must be followed by `invalidate_split_shadow(voxel_grid)`.  `release_split_shadow(voxel_grid)`
+frees the copy (235 MB at 128^3 / SH-2, 1.9 GB at 256^3) when training ends; RELU_FIELD_HIP_SPLIT_SHADOW=0 never makes one.
 """
 import ctypes as C
 import os
@@ -64,6 +74,11 @@ class RFBrickList(C.Structure):
     _fields_ = [("records_sorted_dev", C.c_void_p), ("offsets_dev", C.c_void_p), ("render_diffuse", C.c_int32)]
 
 
+class RFPassScratch(C.Structure):
+    _fields_ = [("out", RFRenderOut), ("grad_colour_dev", C.c_void_p), ("cursor_dev", C.c_void_p), ("offsets_dev", C.c_void_p),
+                ("records_sorted_dev", C.c_void_p), ("t_rand_dev", C.c_void_p), ("jitter_key", C.c_uint64)]
+
+
 # backward: "auto" = the binned adjoint for SH degree >= 2, at least 2^20 samples and at least RELU_FIELD_HIP_MIN_BRICKS (256) bricks of
 # 8^3 nodes -- the measured crossover, see _use_binned_adjoint --, else float atomics; "atomic" / "binned" force one
 BACKWARD = os.environ.get("RELU_FIELD_HIP_BACKWARD", "auto")
@@ -98,6 +113,12 @@ def _library():
         lib.rf_render_backward_emit_direct.argtypes = [C.POINTER(RFGrid), C.POINTER(RFRayBatch), C.c_uint32, C.POINTER(RFRenderOut), C.POINTER(RFRenderGrads),
                                                        C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
         lib.rf_brick_accumulate.argtypes = [C.POINTER(RFGrid), C.c_int32, C.POINTER(RFBrickList), C.c_int32, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p]
+        # the paired entry points (every array argument holds two entries: [0] specular, [1] render_diffuse)
+        vp2 = C.POINTER(C.c_void_p)
+        lib.rf_render_forward_pair.restype = lib.rf_bin_offsets_pair.restype = lib.rf_render_backward_emit_direct_pair.restype = C.c_int
+        lib.rf_render_forward_pair.argtypes = [C.POINTER(RFGrid), C.POINTER(RFRayBatch), C.POINTER(C.c_uint32), C.POINTER(RFRenderOut), C.c_void_p]
+        lib.rf_bin_offsets_pair.argtypes = [vp2, C.c_int32, vp2, vp2, C.c_void_p]
+        lib.rf_render_backward_emit_direct_pair.argtypes = [C.POINTER(RFGrid), C.POINTER(RFRayBatch), C.POINTER(C.c_uint32), C.POINTER(RFPassScratch), C.c_void_p]
         if lib.rf_abi_version() != RF_ABI_VERSION:
             raise RuntimeError(f"{_LIB_PATH}: ABI version {lib.rf_abi_version()}, this binding was written for {RF_ABI_VERSION}")
         _lib = lib
@@ -270,6 +291,108 @@ def render_sh_voxel_grid_hip(voxel_grid, rays: Rays, render_config, parallel_poi
     return RenderOut(colour=colour, depth=depth, extra={EXTRA_DISPARITY: disparity, EXTRA_ACCUMULATED_WEIGHTS: acc})
 
 
+# ---- the two renders of a training iteration (modules/trainers.py:306, 323-325) as ONE autograd node ---------------------------------
+class _RenderPairFunction(torch.autograd.Function):
+    """forward: rf_render_forward_pair (both saving renders of the same rays in one launch, each with its own jitter table and its own
+    per-key record counters); backward: rf_bin_offsets_pair + rf_render_backward_emit_direct_pair + ONE rf_brick_accumulate over both
+    record lists, which OVERWRITES the gradient tensors (the specular list covers every element).  Upstream gradients of the two
+    colours only -- every reference use; anything else raises (use two calls of render_sh_voxel_grid_hip)."""
+
+    @staticmethod
+    def forward(ctx, densities, features, origins, directions, t_vals, t_rand0, t_rand1, voxel_grid, num_samples, near, far, flags, nkeys):
+        lib, dev, n = _library(), origins.device, origins.shape[0]
+        grid = _describe_grid(voxel_grid, densities, features)
+        rays, outs, fl = (RFRayBatch * 2)(), (RFRenderOut * 2)(), (C.c_uint32 * 2)(flags & ~RF_FLAG_RENDER_DIFFUSE, flags | RF_FLAG_RENDER_DIFFUSE)
+        results, saved = [], []
+        for i, t_rand in enumerate((t_rand0, t_rand1)):
+            rays[i] = RFRayBatch(origins.data_ptr(), directions.data_ptr(), n, num_samples, near, far, t_vals.data_ptr(), None if t_rand is None else t_rand.data_ptr(), 0, 0, None)
+            colour = torch.empty((n, 3), dtype=torch.float32, device=dev)
+            depth, acc, disparity = (torch.empty((n, 1), dtype=torch.float32, device=dev) for _ in range(3))
+            caches = (torch.empty((n, num_samples, 4), dtype=torch.float32, device=dev), torch.empty((n, num_samples), dtype=torch.float32, device=dev),
+                      torch.empty((n,), dtype=torch.int32, device=dev), torch.empty((n, (num_samples + 63) // 64), dtype=torch.int64, device=dev),
+                      torch.zeros(nkeys, dtype=torch.int32, device=dev))
+            outs[i] = RFRenderOut(colour.data_ptr(), depth.data_ptr(), acc.data_ptr(), disparity.data_ptr(), caches[0].data_ptr(), caches[1].data_ptr(), caches[2].data_ptr(),
+                                  caches[3].data_ptr(), caches[4].data_ptr(), BRICK)
+            results += [colour, depth, acc, disparity]
+            saved += list(caches)
+        fgrid, keep = _split_shadow(voxel_grid, densities, features, grid) if int(features.shape[-1]) in (3, 27) else (grid, None)
+        _check(lib.rf_render_forward_pair(C.byref(fgrid), rays, fl, outs, torch.cuda.current_stream(dev).cuda_stream), "rf_render_forward_pair")
+        del keep
+        ctx.voxel_grid, ctx.args, ctx.has_rand = voxel_grid, (num_samples, near, far, int(fl[0]), int(fl[1])), (t_rand0 is not None, t_rand1 is not None)
+        ctx.save_for_backward(densities, features, origins, directions, t_vals, *saved, *[t for t in (t_rand0, t_rand1) if t is not None])
+        ctx.mark_non_differentiable(results[3], results[7])
+        ctx.set_materialize_grads(False)
+        return tuple(results)
+
+    @staticmethod
+    def backward(ctx, gc0, gd0, ga0, _gq0, gc1, gd1, ga1, _gq1):
+        if gc0 is None or gc1 is None or any(g is not None for g in (gd0, ga0, gd1, ga1)):
+            raise RuntimeError("render_sh_voxel_grid_pair_hip back-propagates the two colours only (the trainer's use); use two calls of render_sh_voxel_grid_hip")
+        lib = _library()
+        saved = list(ctx.saved_tensors)
+        densities, features, origins, directions, t_vals = saved[:5]
+        caches = [saved[5:10], saved[10:15]]
+        rands = saved[15:]
+        num_samples, near, far, fl0, fl1 = ctx.args
+        dev, n = origins.device, origins.shape[0]
+        grid = _describe_grid(ctx.voxel_grid, densities, features)
+        nkeys = caches[0][4].numel()
+        offsets = torch.empty((2, nkeys + 1), dtype=torch.int64, device=dev)
+        cursor = torch.empty((2, nkeys), dtype=torch.int32, device=dev)
+        records = [torch.empty((n * num_samples, int(lib.rf_expanded_record_floats(f))), dtype=torch.float32, device=dev) for f in (int(features.shape[-1]), 3)]
+        g_colours = [g.detach().to(torch.float32).contiguous() for g in (gc0, gc1)]
+        stream = torch.cuda.current_stream(dev).cuda_stream
+        vp2 = C.c_void_p * 2
+        _check(lib.rf_bin_offsets_pair(vp2(caches[0][4].data_ptr(), caches[1][4].data_ptr()), nkeys, vp2(offsets[0].data_ptr(), offsets[1].data_ptr()),
+                                       vp2(cursor[0].data_ptr(), cursor[1].data_ptr()), stream), "rf_bin_offsets_pair")
+        rays, passes, fl = (RFRayBatch * 2)(), (RFPassScratch * 2)(), (C.c_uint32 * 2)(fl0, fl1)
+        for i in range(2):
+            t_rand = rands.pop(0) if ctx.has_rand[i] else None
+            rays[i] = RFRayBatch(origins.data_ptr(), directions.data_ptr(), n, num_samples, near, far, t_vals.data_ptr(), None if t_rand is None else t_rand.data_ptr(), 0, 0, None)
+            c = caches[i]
+            passes[i].out = RFRenderOut(None, None, None, None, c[0].data_ptr(), c[1].data_ptr(), c[2].data_ptr(), c[3].data_ptr(), c[4].data_ptr(), BRICK)
+            passes[i].grad_colour_dev, passes[i].cursor_dev, passes[i].offsets_dev, passes[i].records_sorted_dev = (
+                g_colours[i].data_ptr(), cursor[i].data_ptr(), offsets[i].data_ptr(), records[i].data_ptr())
+        _check(lib.rf_render_backward_emit_direct_pair(C.byref(grid), rays, fl, passes, stream), "rf_render_backward_emit_direct_pair")
+        grad_d, grad_f = torch.empty_like(densities), torch.empty_like(features)
+        lists = (RFBrickList * 2)(RFBrickList(records[0].data_ptr(), offsets[0].data_ptr(), 0), RFBrickList(records[1].data_ptr(), offsets[1].data_ptr(), 1))
+        _check(lib.rf_brick_accumulate(C.byref(grid), BRICK, lists, 2, grad_d.data_ptr(), grad_f.data_ptr(), 0, stream), "rf_brick_accumulate")
+        return (grad_d, grad_f) + (None,) * 11
+
+
+def render_sh_voxel_grid_pair_hip(voxel_grid, rays: Rays, render_config, parallel_points_chunk_size=None):
+    """(render_sh_voxel_grid_hip(grid, rays, cfg), render_sh_voxel_grid_hip(grid, rays, cfg with render_diffuse=True)) -- the two renders
+    of modules/trainers.py:306, 323-325, with the same torch.rand draws in the same order -- as ONE autograd node where the binned adjoint
+    applies (a training batch on an SH degree >= 2 grid, a gradient will be asked for); otherwise simply the two calls."""
+    import copy
+
+    densities, features = voxel_grid.densities, voxel_grid.features
+    n, s = int(rays.origins.shape[0]), int(render_config.num_samples_per_ray)
+    need_grad = torch.is_grad_enabled() and (densities.requires_grad or features.requires_grad)
+    nkeys = _use_binned_adjoint(features, n, s) if (need_grad and rays.origins.is_cuda) else 0
+    if not nkeys:
+        diffuse = copy.copy(render_config)
+        diffuse.render_diffuse = True
+        plain = copy.copy(render_config)
+        plain.render_diffuse = False
+        return render_sh_voxel_grid_hip(voxel_grid, rays, plain), render_sh_voxel_grid_hip(voxel_grid, rays, diffuse)
+    if render_config.density2occupancy.__name__ != "density2occupancy_pb" or render_config.radiance_hdr_tone_map is not torch.sigmoid:
+        raise ValueError("render_sh_voxel_grid_pair_hip: only density2occupancy_pb / torch.sigmoid are implemented")
+    if render_config.stochastic_density_noise_std != 0.0:
+        raise ValueError("render_sh_voxel_grid_pair_hip: stochastic_density_noise_std must be 0.0")
+    origins = rays.origins.detach().to(torch.float32).contiguous()
+    directions = rays.directions.detach().to(torch.float32).contiguous()
+    assert origins.dim() == 2 and directions.shape == origins.shape, "the render interface only works with FLAT rays"
+    if not (densities.is_cuda and densities.is_contiguous() and features.is_contiguous() and densities.dtype == features.dtype == torch.float32):
+        raise RuntimeError("the VoxelGrid's tensors must be contiguous float32 on the HIP device")
+    t_vals = torch.linspace(0.0, 1.0, s, dtype=torch.float32).to(origins.device)
+    t_rands = [torch.rand(n, s, dtype=torch.float32, device=origins.device) if render_config.perturb_sampled_points else None for _ in range(2)]  # sample.py:63, twice
+    flags = (RF_FLAG_WHITE_BKGD if render_config.white_bkgd else 0) | (RF_FLAG_AABB_SAMPLING if render_config.optimized_sampling else 0)
+    near, far = float(np.float32(render_config.camera_bounds.near)), float(np.float32(render_config.camera_bounds.far))
+    o = _RenderPairFunction.apply(densities, features, origins, directions, t_vals, t_rands[0], t_rands[1], voxel_grid, s, near, far, flags, nkeys)
+    return tuple(RenderOut(colour=o[4 * i], depth=o[4 * i + 1], extra={EXTRA_DISPARITY: o[4 * i + 3], EXTRA_ACCUMULATED_WEIGHTS: o[4 * i + 2]}) for i in range(2))
+
+
 # ---- whole frames (modules/volumetric_model.py:143-172) in ONE launch --------------------------------------------------------------
 # The frame loop of VolumetricModel.render -- cast_rays, slices of parallel_rays_chunk_size, one procedure call per chunk, concatenate
 # -- as one library call: rays and stratified jitter are generated inside the kernel (RFRayBatch.camera), and on frames whose 8 x 8
@@ -281,7 +404,25 @@ import weakref
 _FRAME_SHADOWS = weakref.WeakKeyDictionary()
 
 
+SPLIT_SHADOW = os.environ.get("RELU_FIELD_HIP_SPLIT_SHADOW", "1") != "0"
+
+
+def invalidate_split_shadow(voxel_grid) -> None:
+    """Call after a write to the grid's tensors that bumps neither their data pointer nor their autograd version counter
+    (``p.data.copy_(...)``, ``p.data.clamp_()``, a raw-pointer kernel): the next forward pass re-makes the split copy."""
+    sh = _FRAME_SHADOWS.get(voxel_grid)
+    if sh is not None:
+        sh["stamp"] = None
+
+
+def release_split_shadow(voxel_grid) -> None:
+    """Free the split copy of the grid (as large as the grid itself); the next forward pass that wants one makes it again."""
+    _FRAME_SHADOWS.pop(voxel_grid, None)
+
+
 def _split_shadow(voxel_grid, densities, features, reference_grid):
+    if not SPLIT_SHADOW:
+        return reference_grid, None
     f = int(features.shape[-1])
     stamp = (densities.data_ptr(), features.data_ptr(), densities._version, features._version, tuple(features.shape))
     sh = _FRAME_SHADOWS.get(voxel_grid)
@@ -328,7 +469,7 @@ def render_frame_hip(voxel_grid, camera_intrinsics, camera_pose, render_config, 
         cam.pose[4 * i + 3] = float(trans[i])
     grid = _describe_grid(voxel_grid, densities, features)
     keep = None
-    if int(features.shape[-1]) in (3, 27):  # (the layouts the packet kernel gathers from; other degrees: the per-ray kernel on the grid's own tensors)
+    if int(features.shape[-1]) in (3, 12, 27, 48):  # (the layout the packet kernel gathers from: SH degree 0 .. 3)
         grid, keep = _split_shadow(voxel_grid, densities, features, grid)
     s = int(render_config.num_samples_per_ray)
     t_vals = torch.linspace(0.0, 1.0, s, dtype=torch.float32).to(dev)

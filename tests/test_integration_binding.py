@@ -56,7 +56,7 @@ def test_binding_struct_mirrors_match_the_library(monkeypatch):
     rh = _load_binding(monkeypatch, with_reference=False)
     lib = rh._library()
     lib.rf_abi_struct_size.argtypes = [C.c_int]
-    for which, mirror in ((0, rh.RFGrid), (1, rh.RFRayBatch), (2, rh.RFRenderOut), (3, rh.RFRenderGrads), (4, rh.RFBrickList), (6, rh.RFCamera)):
+    for which, mirror in ((0, rh.RFGrid), (1, rh.RFRayBatch), (2, rh.RFRenderOut), (3, rh.RFRenderGrads), (4, rh.RFBrickList), (6, rh.RFCamera), (8, rh.RFPassScratch)):
         assert lib.rf_abi_struct_size(which) == C.sizeof(mirror) == C.sizeof(_lib.ABI_STRUCTS[which])
     assert lib.rf_abi_struct_size(99) == -1
     for which, mirror in enumerate(_lib.ABI_STRUCTS):  # the package's own mirrors (also checked at load time)
@@ -178,3 +178,73 @@ def test_binding_frame_entry_equals_the_ray_list_procedure(hip_device, monkeypat
         assert float((frame.extra["accumulated_weight"].reshape(-1, 1) - ref.extra["accumulated_weight"]).abs().max()) <= 2e-6
         assert torch.equal(part.colour, frame.colour.reshape(-1, 3)[300:800]) and torch.equal(part.depth, frame.depth.reshape(-1, 1)[300:800])
     assert float(frame.colour.min()) < 0.95
+
+
+@pytest.mark.gpu
+def test_binding_pair_procedure_equals_two_calls_and_follows_golden_g7(hip_device, monkeypatch):
+    """integration/renderers_hip.py::render_sh_voxel_grid_pair_hip -- the two renders of modules/trainers.py:306, 323-325 as ONE autograd node
+    (rf_render_forward_pair; backward: rf_bin_offsets_pair + rf_render_backward_emit_direct_pair + one rf_brick_accumulate over both lists)
+    -- on the reference's own grid type: the outputs of the two single calls bit for bit (the same torch.rand draws in the same order), the
+    gradient of L1 + L1 like theirs and, jitter off, like the reference's own (golden G7: specular + diffuse gradients added)."""
+    import thr3ed_atom_amd as rf
+
+    monkeypatch.setenv("RELU_FIELD_HIP_BACKWARD", "binned")
+    rh = _load_binding(monkeypatch, with_reference=False)
+    g7 = load_golden("g7_grid16_render.npz")
+    cam = hotdog_like_camera()
+    dens, feat = procedural_grid((16, 16, 16), 27, 81)
+    rays = rf.Rays(torch.from_numpy(g7["origins"]).to(hip_device), torch.from_numpy(g7["directions"]).to(hip_device))
+    target = torch.from_numpy(g7["target"]).to(hip_device)
+
+    def run(paired, perturb):
+        grid = _ReferenceLikeGrid(dens.to(hip_device), feat.to(hip_device), (3.0 / 16,) * 3, (0.0, 0.0, 0.0), torch.nn.Identity(), torch.nn.ReLU(), float(g7["rho"])).to(hip_device)
+        cfg = rf.SHVoxGridRenderConfig(48, rf.CameraBounds(cam["near"], cam["far"]), perturb_sampled_points=perturb, white_bkgd=True)
+        torch.manual_seed(9)
+        if paired:
+            spec, diff = rh.render_sh_voxel_grid_pair_hip(grid, rays, cfg)
+            assert spec.colour.grad_fn is diff.colour.grad_fn
+        else:
+            import dataclasses
+
+            spec = rh.render_sh_voxel_grid_hip(grid, rays, cfg)
+            diff = rh.render_sh_voxel_grid_hip(grid, rays, dataclasses.replace(cfg, render_diffuse=True))
+        (torch.nn.functional.l1_loss(spec.colour, target) + torch.nn.functional.l1_loss(diff.colour, target)).backward()
+        return spec, diff, grid.densities.grad.cpu().numpy(), grid.features.grad.cpu().numpy()
+
+    for perturb in (True, False):
+        a, b = run(True, perturb), run(False, perturb)
+        for x, y in ((a[0], b[0]), (a[1], b[1])):
+            assert torch.equal(x.colour, y.colour) and torch.equal(x.depth, y.depth) and torch.equal(x.extra["accumulated_weight"], y.extra["accumulated_weight"])
+        for x, y in ((a[2], b[2]), (a[3], b[3])):
+            np.testing.assert_allclose(x, y, rtol=3e-4, atol=3e-6 * np.abs(y).max())
+    np.testing.assert_allclose(a[0].colour.detach().cpu().numpy(), g7["relu_spec_colour"], rtol=0, atol=1e-5)
+    np.testing.assert_allclose(a[1].colour.detach().cpu().numpy(), g7["relu_diffuse_colour"], rtol=0, atol=1e-5)
+    for ours, ref in ((a[2], g7["relu_spec_gd"] + g7["relu_diffuse_gd"]), (a[3], g7["relu_spec_gf"] + g7["relu_diffuse_gf"])):
+        np.testing.assert_allclose(ours, ref, rtol=2e-4, atol=2e-6 * np.abs(ref).max())
+
+
+@pytest.mark.gpu
+def test_binding_split_shadow_hooks(hip_device, monkeypatch):
+    """The split-layout copy that forward passes of the binding gather from follows the module's tensors through data pointers and version
+    counters; a write that bumps neither (``p.data.mul_``) needs ``invalidate_split_shadow``; ``release_split_shadow`` frees the copy."""
+    import thr3ed_atom_amd as rf
+
+    rh = _load_binding(monkeypatch, with_reference=False)
+    g7 = load_golden("g7_grid16_render.npz")
+    cam = hotdog_like_camera()
+    dens, feat = procedural_grid((16, 16, 16), 27, 81)
+    grid = _ReferenceLikeGrid(dens.to(hip_device), feat.to(hip_device), (3.0 / 16,) * 3, (0.0, 0.0, 0.0), torch.nn.Identity(), torch.nn.ReLU(), float(g7["rho"])).to(hip_device)
+    cfg = rf.SHVoxGridRenderConfig(48, rf.CameraBounds(cam["near"], cam["far"]), perturb_sampled_points=False, white_bkgd=True)
+    rays = rf.Rays(torch.from_numpy(g7["origins"]).to(hip_device), torch.from_numpy(g7["directions"]).to(hip_device))
+    with torch.no_grad():
+        first = rh.render_sh_voxel_grid_hip(grid, rays, cfg).colour.clone()
+        grid._features.data.mul_(-1.0)  # (no version bump, same storage)
+        stale = rh.render_sh_voxel_grid_hip(grid, rays, cfg).colour.clone()
+        assert torch.equal(stale, first)  # the documented constraint ...
+        rh.invalidate_split_shadow(grid)
+        fresh = rh.render_sh_voxel_grid_hip(grid, rays, cfg).colour.clone()
+        assert not torch.equal(fresh, first)  # ... and its remedy
+        assert grid in rh._FRAME_SHADOWS
+        rh.release_split_shadow(grid)
+        assert grid not in rh._FRAME_SHADOWS
+        assert torch.equal(rh.render_sh_voxel_grid_hip(grid, rays, cfg).colour, fresh)
