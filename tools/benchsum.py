@@ -13,7 +13,7 @@ if r:
     for k, v in r["by_kernel"].items():
         print("  ", k, {a: (round(b, 4) if isinstance(b, float) else b) for a, b in v.items()})
 if l.get("fwd_render"):
-    print("fwd", {k: (round(v["ms_per_frame"], 3), round(v["kernel_ms_per_frame"], 3), round(v["frac_of_l2_peak_processed"], 3)) for k, v in l["fwd_render"].items() if isinstance(v, dict)})
+    print("fwd", {k: (round(v["ms_per_frame"], 3), round(v["kernel_ms_per_frame"], 3), round(v.get("frac_of_lds_read_peak") or v.get("frac_of_l2_peak_processed") or 0.0, 3)) for k, v in l["fwd_render"].items() if isinstance(v, dict)})
 if l.get("highres_render"):
     print("highres mask/no mask", round(l["highres_render"]["ms_per_frame_occupancy_mask"], 3), round(l["highres_render"]["ms_per_frame_no_mask"], 3))
 if l.get("strict_dropin"):
