@@ -206,3 +206,52 @@ def test_frame_kernel_dispatch_rule_needs_no_gpu(lib, monkeypatch):
     monkeypatch.setenv("RF_FRAME_TILES", "1")
     assert choice(grid_of(256), cam) == 1 and choice(grid_of(128, layout="reference"), cam) == 0
     assert lib.rf_frame_render_kernel(C.byref(grid_of(128)), None, 0) == -1
+
+
+def test_paired_entry_points_validate_before_any_launch(lib):
+    """rf_render_forward_pair / rf_l1_loss_grad_pair / rf_bin_offsets_pair / rf_render_backward_emit_direct_pair (round 6: the two renders
+    of an iteration as separate calls): argument errors come back as codes, and RF_ERR_UNSUPPORTED says "these two do not pair up"."""
+    import ctypes as C
+
+    g = _lib.RFGrid()
+    g.densities_dev, g.features_dev = 16, 32
+    g.dims[0], g.dims[1], g.dims[2] = 16, 16, 16
+    g.num_features, g.density_stride, g.feature_stride, g.layout = 27, 4, 24, 1
+    rays, outs, flags = (_lib.RFRayBatch * 2)(), (_lib.RFRenderOut * 2)(), (C.c_uint32 * 2)(0, _lib.FLAG_RENDER_DIFFUSE)
+    assert lib.rf_render_forward_pair(C.byref(g), None, flags, outs, None) == -1
+    for i in range(2):
+        rays[i].origins_dev = rays[i].directions_dev = rays[i].t_vals_dev = 64
+        rays[i].num_rays, rays[i].num_samples = 8, 16
+    assert lib.rf_render_forward_pair(C.byref(g), rays, flags, outs, None) == -1  # output buffers missing
+    for i in range(2):
+        outs[i].colour_dev = outs[i].depth_dev = outs[i].acc_dev = outs[i].disparity_dev = 64
+    assert lib.rf_render_forward_pair(C.byref(g), rays, flags, outs, None) == -3  # no sample caches: not the pair's business
+    for i in range(2):
+        outs[i].sample_cache_dev = outs[i].trans_cache_dev = outs[i].stop_cache_dev = outs[i].chunk_mask_dev = 64
+    wrong = (C.c_uint32 * 2)(_lib.FLAG_RENDER_DIFFUSE, 0)
+    assert lib.rf_render_forward_pair(C.byref(g), rays, wrong, outs, None) == -3  # [0] specular, [1] render_diffuse
+    rays[1].num_rays = 9
+    assert lib.rf_render_forward_pair(C.byref(g), rays, flags, outs, None) == -3  # different ray counts
+    rays[1].num_rays = 8
+    cam = _lib.RFCamera()
+    rays[0].camera = C.pointer(cam)
+    assert lib.rf_render_forward_pair(C.byref(g), rays, flags, outs, None) == -3  # frames are not paired
+    rays[0].num_rays = rays[1].num_rays = 0
+    rays[0].camera = None
+    assert lib.rf_render_forward_pair(C.byref(g), rays, flags, outs, None) == 0  # zero rays: nothing to do
+    # losses
+    vp2 = C.c_void_p * 2
+    assert lib.rf_l1_loss_grad_pair(None, 64, 8, 1.0, vp2(64, 64), 64, 64, None) == -1
+    assert lib.rf_l1_loss_grad_pair(vp2(64, None), 64, 8, 1.0, vp2(64, 64), 64, 64, None) == -1
+    assert lib.rf_l1_loss_grad_pair(vp2(64, 64), 64, 0, 1.0, vp2(64, 64), 64, 64, None) == -2
+    # offsets
+    assert lib.rf_bin_offsets_pair(None, 64, vp2(64, 64), vp2(64, 64), None) == -1
+    assert lib.rf_bin_offsets_pair(vp2(64, 64), 0, vp2(64, 64), vp2(64, 64), None) == -2
+    assert lib.rf_bin_offsets_pair(vp2(64, None), 64, vp2(64, 64), vp2(64, 64), None) == -1
+    # adjoints
+    passes = (_lib.RFPassScratch * 2)()
+    assert lib.rf_render_backward_emit_direct_pair(C.byref(g), rays, flags, None, None) == -1
+    passes[0].out.brick_size, passes[1].out.brick_size = 8, 4
+    assert lib.rf_render_backward_emit_direct_pair(C.byref(g), rays, flags, passes, None) == -2  # one brick size for both lists
+    passes[1].out.brick_size = 8
+    assert lib.rf_render_backward_emit_direct_pair(C.byref(g), rays, flags, passes, None) == -1  # cursors / records / gradients missing
