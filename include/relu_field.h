@@ -170,7 +170,8 @@ int rf_cast_rays(int32_t height, int32_t width, float focal, const float* rotati
  * modules/volumetric_model.py:143-172): 1 = ray packets (one wavefront per 8 x 8 pixel tile, the tile's 4 x 4 x 4-node neighbourhood
  * staged through LDS once per sample index), 0 = one wavefront per ray; negative = error code.  The packet kernel is chosen where a
  * tile's footprint at the volume's centre stays within 2 voxels (3 with RF_FLAG_OCCUPANCY_SKIP and a mask), on split / bricked
- * storage of SH degree 0 / 2; $RF_FRAME_TILES = 1 / 0 in the environment forces / forbids it.  Both kernels compute a pixel with the
+ * storage with a 16-byte aligned base tensor, every SH degree, keyed jitter or none (a frame with a jitter TABLE goes to the per-ray
+ * kernel); $RF_FRAME_TILES = 1 / 0 in the environment forces / forbids it.  Both kernels compute a pixel with the
  * same per-sample arithmetic and differ in the order a ray's weighted samples are added (<= 2e-6 on colours).  Host-side only: no
  * device access.  (Added to ABI version 4 compatibly: no existing struct or signature changed.) */
 int rf_frame_render_kernel(const RFGrid* grid, const RFCamera* camera, uint32_t flags);

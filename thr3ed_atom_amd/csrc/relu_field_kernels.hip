@@ -1433,10 +1433,13 @@ __device__ __forceinline__ float tile_z(const RayState& st, const RayArgs& r, in
 // spills 176 registers.  Four resident waves hide the window's round trip better than one wave's own prefetch.)
 // Tile of a wave.  WPB waves per workgroup (nothing is shared between them: WPB = 1 lets the dispatcher place every tile by itself);
 // XCD_ROWS: workgroup b runs on XCD b % 8 (observed placement, used for speed only: MI355X_MICROARCH.md, workgroup dispatch) -- the
-// map gives each XCD whole tile rows, interleaved (row = 8 * group + b % 8), so that a tile's neighbours along its row fetch their
-// windows through the same L2 while the eight XCDs still share every part of the picture (the heavy tiles sit in its middle).
+// map gives each XCD whole tile rows, interleaved (row = 8 * group + b % 8): a tile's neighbours along its row go through the same
+// L2 while the eight XCDs still share every part of the picture (the heavy tiles sit in its middle).
 // Measured (profiles/r06_frame_tile_sched.txt), 800 x 800: WPB 1 + XCD rows against WPB 4 + linear: 128^3 / 256 samples 1.69-1.73
-// against 1.70-1.75 ms, 256^3 / 512 samples with the mask 1.52-1.55 against 1.62-1.66 ms; either switch alone: no gain.
+// against 1.70-1.75 ms, 256^3 / 512 samples with the mask 1.52-1.55 against 1.62-1.66 ms; either switch alone: no gain.  The gain is
+// placement granularity (a workgroup of four tiles holds its LDS and slot until its slowest tile is done), not cache locality: the
+// counters show MORE L2 requests with one wave per workgroup (the four tiles no longer share a CU's L1) at the same kernel time --
+// memory is not what this kernel waits for (profiles/r06_frame_packets_counters.md).
 // K = the coefficients per colour that are read: 1 (SH degree 0, render_diffuse: the base record alone), 4, 9, 16.  K = 9 is the tuned
 // path (rest records = six aligned quads, prefetched with the base records where the previous step needed colours); K = 4 / 16 use the
 // generic rest path above (K = 16: 46 accumulator registers per lane -- two waves per SIMD instead of four).
