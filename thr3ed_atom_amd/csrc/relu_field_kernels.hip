@@ -1195,6 +1195,16 @@ __global__ __launch_bounds__(kBlock, RF_FWD_WAVES) void render_forward_pair_kern
 #ifndef RF_TILE_WAVES
 #define RF_TILE_WAVES 4
 #endif
+// LDS layout of the window: node (x, y, z) of the 4 x 4 x 4 window sits in slot x * kTileXS + y * 4 + z.  A ds_read_b128 covers four of
+// the 64 banks: with 16-byte base records two slots collide when they differ by a multiple of 16, with the 96-byte rest records by a
+// multiple of 8.  The plain stride 16 makes every pair of nodes one step apart in x collide (41 % of the LDS pipe's active cycles
+// were bank conflicts: profiles/r06_frame_packets_counters.md); with stride 18 no two DIFFERENT nodes of a unit neighbourhood
+// (offsets in {-1, 0, 1}^3) collide, in either record size: 18 dx + 4 dy + dz is never 0 mod 8 for them.
+constexpr int kTileXS = 18;
+constexpr int kTileSlots = (3 * kTileXS + 16 + 3) / 4 * 4;  // (whole multiples of four slots)
+// slot of the node lane 16 x + 4 y + z loads: lane + x (kTileXS - 16).  (Written out at its three uses: as a function the same expression
+// sends the K = 9 instantiation from 2 to 34 spilled registers -- the kernel sits on its 128-register budget.)
+#define RF_TILE_SLOT(lane) ((lane) + ((lane) >> 4) * (kTileXS - 16))
 __device__ __forceinline__ int wave_min_i32(int x) {
   auto step = [](int v, auto ctrl_tag, auto mask_tag) {
     constexpr int CTRL = decltype(ctrl_tag)::value, MASK = decltype(mask_tag)::value;
@@ -1279,7 +1289,7 @@ __device__ __forceinline__ void tile_window_load_rest(TileWindow& wdw, const Gri
   wdw.q5 = *reinterpret_cast<const vf4*>(rp + 80);
 }
 __device__ __forceinline__ void tile_window_store_rest(const TileWindow& wdw, vf4* my_rest, int lane) {
-  vf4* d = my_rest + lane * 6;
+  vf4* d = my_rest + RF_TILE_SLOT(lane) * 6;
   d[0] = wdw.q0;
   d[1] = wdw.q1;
   d[2] = wdw.q2;
@@ -1295,8 +1305,8 @@ __device__ __forceinline__ bool tile_interpolate_base(bool pending, const TileCe
   const int l0[3] = {tc.c0[0] - O[0], tc.c0[1] - O[1], tc.c0[2] - O[2]};
   // (O is the minimum over the waiting lanes unless the anchor pulled it up: then the lanes below it wait for another round)
   const bool covered = pending && l0[0] >= 0 && l0[1] >= 0 && l0[2] >= 0 && l0[0] + tc.e[0] <= 3 && l0[1] + tc.e[1] <= 3 && l0[2] + tc.e[2] <= 3;
-  const int n0 = (l0[0] * 4 + l0[1]) * 4 + l0[2];
-  const int ex = tc.e[0] * 16, ey = tc.e[1] * 4, ez = tc.e[2];
+  const int n0 = l0[0] * kTileXS + l0[1] * 4 + l0[2];
+  const int ex = tc.e[0] * kTileXS, ey = tc.e[1] * 4, ez = tc.e[2];
 #pragma unroll
   for (int k = 0; k < 8; ++k) nk[k] = n0 + ((k & 1) ? ex : 0) + ((k & 2) ? ey : 0) + ((k & 4) ? ez : 0);
   if (covered) {
@@ -1370,7 +1380,7 @@ __device__ __forceinline__ void tile_window_rest_generic(const GridArgs& g, unsi
   for (int t = 0; t < R::kFull; ++t) q[t] = *reinterpret_cast<const f4u*>(rp + 4 * t);
 #pragma unroll
   for (int t = 0; t < R::kRem; ++t) tail[t] = rp[4 * R::kFull + t];
-  vf4* d = my_rest + lane * R::kQ;
+  vf4* d = my_rest + RF_TILE_SLOT(lane) * R::kQ;
 #pragma unroll
   for (int t = 0; t < R::kFull; ++t) d[t] = vf4{q[t].v[0], q[t].v[1], q[t].v[2], q[t].v[3]};
   if constexpr (R::kRem > 0) d[R::kFull] = vf4{tail[0], R::kRem > 1 ? tail[R::kRem > 1 ? 1 : 0] : 0.0f, R::kRem > 2 ? tail[R::kRem > 2 ? 2 : 0] : 0.0f, 0.0f};
@@ -1459,8 +1469,8 @@ template <int K, int WPB, bool XCD_ROWS>
 __global__ __launch_bounds__(kWave * WPB, (K == 16 ? 2 : RF_TILE_WAVES)) void render_frame_tile_kernel(GridArgs g, RayArgs r, OutArgs out, uint32_t flags, int row0, int tile_rows, int tiles_x) {
   constexpr bool REST = K > 1;
   constexpr int kRestQuads = K == 9 ? 6 : (K > 1 ? TileRestGeneric<K>::kQ : 0);
-  __shared__ __attribute__((aligned(16))) vf4 s_base[WPB][kWave];
-  __shared__ __attribute__((aligned(16))) vf4 s_rest[WPB][REST ? kWave * kRestQuads : 1];
+  __shared__ __attribute__((aligned(16))) vf4 s_base[WPB][kTileSlots];
+  __shared__ __attribute__((aligned(16))) vf4 s_rest[WPB][REST ? kTileSlots * kRestQuads : 1];
   const int lane = threadIdx.x & (kWave - 1);
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   int ty, tx;
@@ -1557,7 +1567,7 @@ __global__ __launch_bounds__(kWave * WPB, (K == 16 ? 2 : RF_TILE_WAVES)) void re
         if constexpr (K == 9) {
           if (with_rest) tile_window_load_rest(wdw, g, lin);
         }
-        my_base[lane] = wdw.b;
+        my_base[RF_TILE_SLOT(lane)] = wdw.b;
         if constexpr (K == 9) {
           if (with_rest) tile_window_store_rest(wdw, my_rest, lane);
         }
