@@ -164,3 +164,27 @@ def test_g11_density_noise_like_the_reference(hip_device, tag, mode, over):
         ok = np.isfinite(ref)
         np.testing.assert_allclose(ours[ok], ref[ok], rtol=1e-5, atol=2e-5)
     assert 0.2 < float((~torch.isfinite(drawn.extra["accumulated_weight"])).float().mean()) < 0.8
+
+
+def test_render_pair_on_a_composed_configuration_is_the_two_single_renders(hip_device):
+    """``render_sh_voxel_grid_pair`` / ``VolumetricModel.render_rays_pair`` (the two renders of an iteration, modules/trainers.py:306,
+    323-325) on a configuration the fused kernels do not implement (a non-default tone map): the composed path, twice, with the same
+    jitter draws in the same order -- outputs and gradients of the two single calls."""
+    dens, feat = procedural_grid((8, 8, 8), 27, 61)
+    rays = rf.Rays(T(np.tile(np.array([[0.2, 0.1, 4.0]], dtype=np.float32), (50, 1))).to(hip_device),
+                   torch.nn.functional.normalize(T(np.random.RandomState(3).randn(50, 3).astype(np.float32) * 0.15 + np.array([0.0, 0.0, -1.0], dtype=np.float32)), dim=-1).to(hip_device))
+    cfg = rf.SHVoxGridRenderConfig(24, rf.CameraBounds(2.0, 6.0), perturb_sampled_points=True, white_bkgd=True, radiance_hdr_tone_map=torch.tanh, jitter="torch")
+    results = []
+    for paired in (True, False):
+        grid = make_grid(hip_device, dens, feat, 8, 10.0, tunable=True)
+        model = rf.VolumetricModel(grid, rf.render_sh_voxel_grid, cfg, device=hip_device)
+        torch.manual_seed(17)
+        if paired:
+            spec, diff = model.render_rays_pair(rays)
+        else:
+            spec, diff = model.render_rays(rays), model.render_rays(rays, render_diffuse=True)
+        (spec.colour.square().mean() + diff.colour.mean()).backward()
+        results.append((spec.colour.detach(), diff.colour.detach(), grid.densities.grad.clone(), grid.features.grad.clone()))
+    for a, b in zip(*results):
+        assert torch.equal(a, b)
+    assert float(results[0][2].abs().max()) > 0 and not torch.equal(results[0][0], results[0][1])
