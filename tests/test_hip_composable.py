@@ -185,6 +185,9 @@ def test_render_pair_on_a_composed_configuration_is_the_two_single_renders(hip_d
             spec, diff = model.render_rays(rays), model.render_rays(rays, render_diffuse=True)
         (spec.colour.square().mean() + diff.colour.mean()).backward()
         results.append((spec.colour.detach(), diff.colour.detach(), grid.densities.grad.clone(), grid.features.grad.clone()))
-    for a, b in zip(*results):
-        assert torch.equal(a, b)
+    for k, (a, b) in enumerate(zip(*results)):
+        if k < 2:
+            assert torch.equal(a, b)
+        else:  # (the point query's adjoint scatters with float atomics: equal to summation order)
+            np.testing.assert_allclose(a.cpu().numpy(), b.cpu().numpy(), rtol=2e-4, atol=2e-6 * float(b.abs().max()))
     assert float(results[0][2].abs().max()) > 0 and not torch.equal(results[0][0], results[0][1])
