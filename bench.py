@@ -537,6 +537,20 @@ def multi_gpu_forward_legs(args, dev, rank, world, intr, bounds):
 
         cfg_ = model._update_render_config(model.render_config, over)
         dt_rows = timed(lambda: render_sh_voxel_grid_frame(model.thre3d_repr, intr, pose, cfg_, first_ray=lo, num_rays=hi - lo), frames)
+        # the same sharded frame served by the per-ray kernel ($RF_FRAME_TILES is read per call): a packet tile's march is ~0.5 ms long
+        # whatever the launch size, so a rank's share of a frame stops shrinking with N once its tiles no longer fill the machine, while the
+        # per-ray kernel's time follows the shard (one MI355X, shard of 1/8 of this frame: 0.62 against 0.47 ms, configs[4]: 1.00 against
+        # 0.45 -- profiles/r06_sharded_frame_shard_times.json).  The default keeps ONE kernel per frame whatever N is (the sharded frame is
+        # then the single-GPU frame bit for bit); this figure says what the other choice would buy at this N.
+        keep_env = os.environ.get("RF_FRAME_TILES")
+        os.environ["RF_FRAME_TILES"] = "0"
+        try:
+            dt_sh_per_ray = timed(lambda: model.render(pose, intr, data_parallel=True, **over), frames)
+        finally:
+            if keep_env is None:
+                os.environ.pop("RF_FRAME_TILES", None)
+            else:
+                os.environ["RF_FRAME_TILES"] = keep_env
         # the sharded frame IS the single-GPU frame (jitter off for the comparison; every rank checks the frame it ended up with)
         a = model.render(pose, intr, data_parallel=True, perturb_sampled_points=False, **over)
         b = model.render(pose, intr, perturb_sampled_points=False, **over)
@@ -547,7 +561,8 @@ def multi_gpu_forward_legs(args, dev, rank, world, intr, bounds):
                                "frames_per_s": world / dt_fp, "rays_per_s": world * H * W / dt_fp, "ray_samples_per_s": world * H * W * S_ / dt_fp},
             "sharded_frame": {"what": "ONE pose, VolumetricModel.render(data_parallel=True): every rank renders its contiguous shard of the pixels, one all-gather of the [n, 6] results "
                               "(every rank ends up with the whole frame); max over ranks", "ms_per_frame": dt_sh * 1e3, "rays_per_s": H * W / dt_sh, "ray_samples_per_s": H * W * S_ / dt_sh,
-                              "ms_per_frame_without_the_gather": dt_rows * 1e3, "equals_single_gpu_frame_bit_for_bit": bool(int(same.item()))},
+                              "ms_per_frame_without_the_gather": dt_rows * 1e3, "equals_single_gpu_frame_bit_for_bit": bool(int(same.item())),
+                              "ms_per_frame_with_the_per_ray_kernel": dt_sh_per_ray * 1e3},
             "n_gpus": world, "frames_timed": frames,
         }
 
