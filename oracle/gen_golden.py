@@ -357,6 +357,37 @@ def g7_g8_end_to_end():
     save("g7_grid16_render.npz", near=np.float64(cam["near"]), far=np.float64(cam["far"]), rho=np.float64(rho), **out)
 
 
+def g13_last_sample_inside():
+    """A far plane INSIDE the volume: the last sample of every ray carries the reference's 1e10 |d| interval (accumulate.py:49-52) and
+    lies in the grid, so its density gradient is delta exp(-sigma delta) x activation slope -- with softplus densities around 1e-9
+    (raw ~ -0.65 at rho 100/3) an ordinary-sized number built from one huge and two tiny factors.  Found by the randomised sweep
+    (tests/parity_fuzz.py); pinned against the reference here, all three density modes."""
+    dens, feat = procedural_grid((8, 8, 8), 12, 131)
+    o = torch.from_numpy(hash_uniform((160, 3), 132))
+    o = o / o.norm(dim=-1, keepdim=True) * 3.2
+    d = torch.from_numpy(hash_uniform((160, 3), 133)) * 0.5 - o
+    d = d / d.norm(dim=-1, keepdim=True)
+    rays = Rays(o, d)
+    target = torch.from_numpy(hash_uniform((160, 3), 134, 0.0, 1.0))
+    bounds = CameraBounds(1.0, 3.4)
+    out = {"origins": o, "directions": d, "target": target}
+    for mode in ("softplus", "abs", "relu"):
+        rho = 1.0 if mode == "abs" else 100.0 / 3.0
+        grid = make_grid(dens, feat, (3.0 / 8,) * 3, mode=mode, rho=rho, tunable=True)
+        cfg = SHVoxGridRenderConfig(num_samples_per_ray=24, camera_bounds=bounds, perturb_sampled_points=False, white_bkgd=True)
+        res, loss, gd, gf = run_render(grid, rays, cfg, target)
+        out[f"{mode}_colour"] = res.colour
+        out[f"{mode}_depth"] = res.depth
+        out[f"{mode}_acc"] = res.extra["accumulated_weight"]
+        out[f"{mode}_loss"] = loss
+        out[f"{mode}_gd"] = gd
+        out[f"{mode}_gf"] = gf
+        grid64 = make_grid(dens.double(), feat.double(), (3.0 / 8,) * 3, mode=mode, rho=rho, tunable=True)
+        _, _, gd64, _ = run_render(grid64, rays, cfg, target, torch.float64)
+        out[f"{mode}_f64_gd"] = gd64.float()
+    save("g13_last_sample_inside.npz", near=np.float64(1.0), far=np.float64(3.4), **out)
+
+
 def g11_density_noise():
     """stochastic_density_noise_std != 0 (accumulate.py:58-62): with perturb_sampled_points off the render's only RNG draw is
     torch.randn(N, S), so the noise table is reproducible from the seed and stored beside the outputs."""
@@ -492,6 +523,7 @@ if __name__ == "__main__":
         "g10": g10_single_cube,
         "g11": g11_density_noise,
         "g12": g12_plugins,
+        "g13": g13_last_sample_inside,
     }
     for name, fn in jobs.items():
         if not wanted or name in wanted:

@@ -1,0 +1,170 @@
+"""Randomised parity sweep of the HIP path against the oracle (GPU box): python tools/fuzz_parity.py [--cases N] [--seed S] [--kind rays|frames|all]
+(the case generators live here so that tests/test_hip_parity_fuzz.py can replay a fixed set; tools/fuzz_parity.py is the command line)
+
+Every case draws a configuration the parametrised tests do not enumerate -- grid dims 2..22 per axis (also below the packet
+kernel's 4-node minimum), anisotropic voxels, off-centre location, SH degree, density mode, storage, diffuse / AABB sampling /
+background, 1..150 samples, rays that start inside the volume or miss it, odd frame sizes, partial pixel ranges, occupancy mask,
+either frame kernel -- and holds the result to the bars of tests/test_hip_parity.py (colour / acc 1e-5, depth 2e-5, gradients to
+float32 summation order).  The oracle is the checker (test infrastructure); failures are printed with the case's seed."""
+import argparse
+import os
+import sys
+import traceback
+
+import numpy as np
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import thr3ed_atom_amd as rf  # noqa: E402
+from oracle import relu_field_oracle as orc  # noqa: E402
+from tests.helpers import hash_uniform, procedural_grid  # noqa: E402
+
+TOL = 1e-5
+FORCE_MODE = ""
+ACTS = {"relu": (torch.nn.Identity(), torch.nn.ReLU()), "softplus": (torch.nn.Identity(), torch.nn.Softplus()), "abs": (torch.abs, torch.nn.Identity())}
+
+
+def make_grid(dev, dens, feat, voxel, loc, mode, rho, storage, tunable):
+    return rf.VoxelGrid(dens.clone().to(dev), feat.clone().to(dev), rf.VoxelSize(*voxel), rf.VoxelGridLocation(*loc), density_preactivation=ACTS[mode][0],
+                        density_postactivation=ACTS[mode][1], expected_density_scale=rho, tunable=tunable, storage=storage)
+
+
+def draw_common(rng):
+    dims = tuple(int(rng.integers(2, 23)) for _ in range(3))
+    deg = int(rng.integers(0, 4))
+    mode = str(rng.choice(["relu", "relu", "softplus", "abs"]))
+    if FORCE_MODE:
+        mode = FORCE_MODE
+    storage = str(rng.choice(["reference", "split", "bricked"]))
+    extent = [float(rng.uniform(1.5, 3.5)) for _ in range(3)]
+    voxel = tuple(e / d for e, d in zip(extent, dims))
+    loc = tuple(float(rng.uniform(-0.3, 0.3)) for _ in range(3))
+    rho = 1.0 if mode == "abs" else float(rng.choice([1.0, 9.0, 100.0 / 3.0]))
+    return dims, deg, mode, storage, voxel, loc, rho
+
+
+def case_rays(rng, dev, seed):
+    dims, deg, mode, storage, voxel, loc, rho = draw_common(rng)
+    F = 3 * (deg + 1) ** 2
+    dens, feat = procedural_grid(dims, F, seed % 100000)
+    n = int(rng.integers(1, 400))
+    S = int(rng.choice([1, 2, 3, 17, 40, 63, 64, 65, 128, 150]))
+    o = torch.from_numpy(hash_uniform((n, 3), seed + 1))
+    radius = torch.from_numpy(hash_uniform((n, 1), seed + 2, 0.2, 5.0))  # some origins INSIDE the volume
+    o = o / o.norm(dim=-1, keepdim=True).clamp_min(1e-3) * radius
+    d = torch.from_numpy(hash_uniform((n, 3), seed + 3)) * 1.5 - o
+    d = d / d.norm(dim=-1, keepdim=True).clamp_min(1e-3) * (1.0 + 0.2 * torch.from_numpy(hash_uniform((n, 1), seed + 4)))
+    near, far = float(rng.uniform(0.05, 2.0)), float(rng.uniform(4.0, 7.0))
+    diffuse, opt, white, perturb = bool(rng.integers(2)), bool(rng.integers(2)), bool(rng.integers(2)), bool(rng.integers(2))
+    t_rand = torch.from_numpy(hash_uniform((n, S), seed + 5, 0.0, 1.0)) if perturb else None
+    target = torch.from_numpy(hash_uniform((n, 3), seed + 6, 0.0, 1.0))
+    backward = str(rng.choice(["atomic", "binned"]))
+    desc = f"rays dims={dims} deg={deg} mode={mode} storage={storage} n={n} S={S} diffuse={diffuse} opt={opt} white={white} perturb={perturb} backward={backward} near={near:.2f}"
+    grid = make_grid(dev, dens, feat, voxel, loc, mode, rho, storage, True)
+    cfg = rf.SHVoxGridRenderConfig(S, rf.CameraBounds(near, far), perturb_sampled_points=perturb, optimized_sampling=opt, white_bkgd=white, render_diffuse=diffuse)
+    from thr3ed_atom_amd import ops
+
+    ops.AUTOGRAD_BACKWARD = backward
+    try:
+        out = rf.render_sh_voxel_grid(grid, rf.Rays(o.to(dev), d.to(dev)), cfg, None, t_rand=None if t_rand is None else t_rand.to(dev))
+        loss = torch.nn.functional.l1_loss(out.colour, target.to(dev)) + 0.1 * out.depth.mean() + 0.05 * out.extra["accumulated_weight"].mean()
+        loss.backward()
+    finally:
+        ops.AUTOGRAD_BACKWARD = "auto"
+    dc, fc = dens.clone().requires_grad_(True), feat.clone().requires_grad_(True)
+    ref = orc.render(dc, fc, o, d, orc.make_aabb(dims, voxel, loc), near, far, S, rho, mode, white_bkgd=white, render_diffuse=diffuse, optimized_sampling=opt, t_rand=t_rand)
+    ref_loss = torch.nn.functional.l1_loss(ref["colour"], target) + 0.1 * ref["depth"].mean() + 0.05 * ref["acc"].mean()
+    ref_loss.backward()
+    cpu = lambda t: t.detach().cpu().numpy()
+    np.testing.assert_allclose(cpu(out.colour), ref["colour"].detach().numpy(), rtol=0, atol=TOL, err_msg=desc)
+    np.testing.assert_allclose(cpu(out.depth), ref["depth"].detach().numpy(), rtol=0, atol=2 * TOL * max(1.0, far / 6.6), err_msg=desc)
+    np.testing.assert_allclose(cpu(out.extra["accumulated_weight"]), ref["acc"].detach().numpy(), rtol=0, atol=TOL, err_msg=desc)
+    gd, gf = grid.reference_gradients()
+    gd_ref, gf_ref = dc.grad.numpy(), fc.grad.numpy()
+    np.testing.assert_allclose(cpu(gd), gd_ref, rtol=5e-4, atol=5e-6 * max(np.abs(gd_ref).max(), 1e-12), err_msg=desc)
+    np.testing.assert_allclose(cpu(gf), gf_ref, rtol=5e-4, atol=5e-6 * max(np.abs(gf_ref).max(), 1e-12), err_msg=desc)
+    return desc
+
+
+def case_frames(rng, dev, seed):
+    dims, deg, mode, storage, voxel, loc, rho = draw_common(rng)
+    F = 3 * (deg + 1) ** 2
+    dens, feat = procedural_grid(dims, F, seed % 100000)
+    H, W = int(rng.integers(1, 50)), int(rng.integers(1, 50))
+    focal = float(rng.choice([20.0, 60.0, 300.0, 900.0]))
+    S = int(rng.choice([1, 5, 40, 64, 97]))
+    tiles = str(rng.choice(["0", "1"]))
+    white, diffuse, opt = bool(rng.integers(2)), bool(rng.integers(2)), bool(rng.integers(2))
+    occ = bool(rng.integers(2)) and mode == "relu"
+    pose = rf.pose_spherical(float(rng.uniform(0, 360)), float(rng.uniform(-80, 10)), float(rng.uniform(2.5, 5.0)))
+    near, far = float(rng.uniform(0.3, 2.0)), float(rng.uniform(5.5, 8.0))
+    desc = f"frame dims={dims} deg={deg} mode={mode} storage={storage} HxW={H}x{W} focal={focal} S={S} tiles={tiles} white={white} diffuse={diffuse} opt={opt} occ={occ}"
+    grid = make_grid(dev, dens, feat, voxel, loc, mode, rho, storage, False)
+    intr = rf.CameraIntrinsics(H, W, focal)
+    cfg = rf.SHVoxGridRenderConfig(S, rf.CameraBounds(near, far), perturb_sampled_points=False, optimized_sampling=opt, white_bkgd=white, render_diffuse=diffuse,
+                                   use_occupancy_mask=occ)
+    if occ:
+        grid.build_occupancy()
+    os.environ["RF_FRAME_TILES"] = tiles
+    try:
+        frame = rf.render_sh_voxel_grid_frame(grid, intr, pose, cfg)
+    finally:
+        os.environ.pop("RF_FRAME_TILES", None)
+    flat = rf.flatten_rays(rf.cast_rays(intr, pose, dev))
+    ref = orc.render(dens, feat, flat.origins.cpu(), flat.directions.cpu(), orc.make_aabb(dims, voxel, loc), near, far, S, rho, mode, white_bkgd=white,
+                     render_diffuse=diffuse, optimized_sampling=opt)
+    err_c = float((frame.colour.reshape(-1, 3).cpu() - ref["colour"]).abs().max())
+    err_a = float((frame.extra["accumulated_weight"].reshape(-1, 1).cpu() - ref["acc"]).abs().max())
+    err_d = float((frame.depth.reshape(-1, 1).cpu() - ref["depth"]).abs().max())
+    assert err_c <= TOL and err_a <= TOL and err_d <= 2 * TOL * max(1.0, far / 6.6), f"{desc}: colour {err_c:.2e} acc {err_a:.2e} depth {err_d:.2e}"
+    return desc
+
+
+def case_seed(run_seed: int, i: int) -> int:
+    return run_seed * 1000003 + i * 7919
+
+
+def run_case(run_seed: int, i: int, kind: str, dev, mode: str = "") -> str:
+    """case i of the run: its description; raises AssertionError on a parity miss"""
+    global FORCE_MODE
+    FORCE_MODE = mode
+    seed = case_seed(run_seed, i)
+    rng = np.random.default_rng(seed)
+    if kind == "all":
+        kind = "rays" if i % 2 == 0 else "frames"
+    try:
+        return (case_rays if kind == "rays" else case_frames)(rng, dev, seed)
+    finally:
+        FORCE_MODE = ""
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--cases", type=int, default=200)
+    ap.add_argument("--seed", type=int, default=1)
+    ap.add_argument("--kind", default="all")
+    ap.add_argument("--verbose", action="store_true")
+    ap.add_argument("--only", default="", help="comma-separated case indices (re-run failures)")
+    ap.add_argument("--mode", default="", help="restrict the density mode (relu / softplus / abs)")
+    a = ap.parse_args()
+    dev = torch.device("cuda:0")
+    fails = 0
+    only = {int(x) for x in a.only.split(",") if x}
+    for i in range(a.cases):
+        if only and i not in only:
+            continue
+        try:
+            desc = run_case(a.seed, i, a.kind, dev, a.mode)
+            if a.verbose:
+                print("ok  ", i, desc, flush=True)
+        except Exception as e:  # noqa: BLE001
+            fails += 1
+            print(f"FAIL case {i} seed {case_seed(a.seed, i)} kind {a.kind}: {type(e).__name__}: {str(e)[:1500]}", flush=True)
+            if not isinstance(e, AssertionError):
+                traceback.print_exc()
+    print(f"fuzz_parity: {a.cases - fails} / {a.cases} cases passed (seed {a.seed}, kind {a.kind})")
+    sys.exit(1 if fails else 0)
+
+
+if __name__ == "__main__":
+    main()

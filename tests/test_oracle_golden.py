@@ -229,6 +229,24 @@ def test_g7_grid16_end_to_end_and_grads(tag, mode, over):
     np.testing.assert_allclose(gf.numpy(), g[f"{tag}_gf"], rtol=1e-4, atol=1e-8)
 
 
+@pytest.mark.parametrize("mode", ["softplus", "abs", "relu"])
+def test_g13_last_sample_inside_the_volume(mode):
+    """A far plane inside the volume: the last sample of every ray (interval 1e10 |d|, accumulate.py:49-52) lies in the grid and
+    carries a density gradient made of one huge and two tiny factors.  The oracle against the reference's own output."""
+    g = load_golden("g13_last_sample_inside.npz")
+    dens, feat = procedural_grid((8, 8, 8), 12, 131)
+    kw = dict(origins=T(g["origins"]), directions=T(g["directions"]), aabb=orc.make_aabb((8, 8, 8), (3.0 / 8,) * 3), near=float(g["near"]), far=float(g["far"]),
+              num_samples=24, density_scale=1.0 if mode == "abs" else 100.0 / 3.0, density_mode=mode, white_bkgd=True)
+    out, loss, gd, gf = _l1_grads(dens, feat, kw, T(g["target"]))
+    assert torch.equal(out["colour"], T(g[f"{mode}_colour"])) and torch.equal(out["depth"], T(g[f"{mode}_depth"])) and torch.equal(out["acc"], T(g[f"{mode}_acc"]))
+    assert loss.item() == float(g[f"{mode}_loss"])
+    np.testing.assert_allclose(gd.numpy(), g[f"{mode}_gd"], rtol=1e-4, atol=1e-8)
+    np.testing.assert_allclose(gf.numpy(), g[f"{mode}_gf"], rtol=1e-4, atol=1e-8)
+    # the regime is real: every ray ENDS inside the box
+    end = T(g["origins"]) + float(g["far"]) * T(g["directions"])
+    assert bool((end.abs() < 1.5).all())
+
+
 NOISE_CASES = [("relu", "relu", {}), ("relu_diffuse_black", "relu", {"render_diffuse": True, "white_bkgd": False}), ("softplus", "softplus", {})]
 
 

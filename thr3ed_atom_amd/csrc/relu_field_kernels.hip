@@ -256,6 +256,14 @@ __device__ __forceinline__ float wave_sum(float x) {
 // own CPU (SLEEF) and GPU (libdevice) paths differ from each other by as much; the parity bar is 1e-5.
 __device__ __forceinline__ float exp_fast(float x) { return __builtin_amdgcn_exp2f(x * 1.44269504088896340736f); }
 __device__ __forceinline__ float sigmoidf_(float x) { return __builtin_amdgcn_rcpf(1.0f + exp_fast(-x)); }
+// softplus'(x) = sigmoid(x) = 1 - exp(-softplus(x)), from the cached activated density s = softplus(x) >= 0, to RELATIVE accuracy: a
+// sample far below the surface has s ~ 1e-9 and 1 - exp(-s) cancels to 0 in float32, but the last sample of a ray carries
+// delta = 1e10 |d| (accumulate.py:49-52), so its d alpha / d sigma is ~1e10 and the product is an ordinary gradient that the reference
+// (ATen's softplus backward: z / (z + 1), z = exp(x)) gets right.  Below 0.25 the alternating series, six terms (next term / s < 5e-8).
+__device__ __forceinline__ float softplus_slope(float s) {
+  if (s < 0.25f) return s * (1.0f - s * (0.5f - s * (1.0f / 6.0f - s * (1.0f / 24.0f - s * (1.0f / 120.0f - s * (1.0f / 720.0f))))));
+  return 1.0f - exp_fast(-s);
+}
 
 // ---------------------------------------------------------------------------------------------
 // sampling (rendering/volumetric/sample.py:39-68)
@@ -1802,9 +1810,13 @@ __global__ __launch_bounds__(kBlock) void render_backward_kernel(GridArgs g, Ray
         T = Tl;
       }
     }
-    const float alpha = 1.0f - exp_fast(-(sigma * sm.delta));
+    // (T_{i+1} e_i is the sample's OWN term of d L / d sigma_i = delta_i (T_i exp(-sigma_i delta_i) e_i - sum_{j>i} w_j e_j): with the
+    // exponential itself, not 1 - alpha -- that difference cancels to a relative error of 6e-8 / exp(-x), which the 1e10-long interval
+    // of a ray's last sample (accumulate.py:49-52) turns into per cents of its gradient when the sample lies inside the volume)
+    const float E = exp_fast(-(sigma * sm.delta));
+    const float alpha = 1.0f - E;
     const float w = alpha * T;
-    const float Tn = T * (1.0f - alpha);
+    const float Tn = T * E;
     float c[3], e = gD * sm.z + gA;
 #pragma unroll
     for (int ch = 0; ch < 3; ++ch) {
@@ -1821,7 +1833,7 @@ __global__ __launch_bounds__(kBlock) void render_backward_kernel(GridArgs g, Ray
     if (g.mode == RF_DENSITY_RELU)
       g_pre = (sigma > 0.0f) ? g_sigma : 0.0f;
     else if (g.mode == RF_DENSITY_SOFTPLUS)
-      g_pre = g_sigma * (1.0f - exp_fast(-sigma));  // softplus'(x) = sigmoid(x) = 1 - exp(-softplus(x))
+      g_pre = g_sigma * softplus_slope(sigma);
     else
       g_pre = g_sigma;
     float g_raw[3];
@@ -2047,9 +2059,10 @@ __device__ __forceinline__ void render_emit_direct_ray(const GridArgs& g, const 
       const bool have = counted[u];
       const float sigma = have ? cv[u].w : 0.0f;
       const float T = have ? Tc[u] : 0.0f;
-      const float alpha = 1.0f - exp_fast(-(sigma * dl[u]));
+      const float E = exp_fast(-(sigma * dl[u]));  // (the own term uses the exponential itself: see render_backward_kernel)
+      const float alpha = 1.0f - E;
       const float w = alpha * T;
-      const float Tn = T * (1.0f - alpha);
+      const float Tn = T * E;
       const float raw[3] = {cv[u].x, cv[u].y, cv[u].z};
       float c[3], e = gD * zz[u] + gA;
 #pragma unroll
@@ -2066,7 +2079,7 @@ __device__ __forceinline__ void render_emit_direct_ray(const GridArgs& g, const 
       if (g.mode == RF_DENSITY_RELU)
         g_pre = (sigma > 0.0f) ? g_sigma : 0.0f;
       else if (g.mode == RF_DENSITY_SOFTPLUS)
-        g_pre = g_sigma * (1.0f - exp_fast(-sigma));  // softplus'(x) = sigmoid(x) = 1 - exp(-softplus(x))
+        g_pre = g_sigma * softplus_slope(sigma);
       else
         g_pre = g_sigma;
       const int pos = __shfl(base_[u], hl_[u]) + (lane - hl_[u]);
