@@ -120,6 +120,98 @@ def case_frames(rng, dev, seed):
     return desc
 
 
+def case_train(rng, dev, seed):
+    """Two training iterations (TrainStepper: fused or autograd-driven, either adjoint, either brick shape, Adam in the brick flush or
+    from a gradient bucket) against the oracle's autograd + torch.optim.Adam on the same rays, pixels and jitter."""
+    from thr3ed_atom_amd.trainers import TrainStepper
+
+    dims = tuple(int(rng.integers(4, 21)) for _ in range(3))
+    deg = int(rng.integers(0, 4))
+    mode = str(rng.choice(["relu", "relu", "softplus", "abs"]))
+    if FORCE_MODE:
+        mode = FORCE_MODE
+    storage = str(rng.choice(["reference", "split", "bricked"]))
+    voxel = tuple(3.0 / d for d in dims)
+    rho = 1.0 if mode == "abs" else float(rng.choice([5.0, 100.0 / 3.0]))
+    F = 3 * (deg + 1) ** 2
+    dens, feat = procedural_grid(dims, F, seed % 100000)
+    n = int(rng.choice([1, 3, 37, 64, 130, 257]))
+    # (not fewer than 17 samples here: with 2 or 3 the 1e10-long last interval often lies inside the volume and the float32 forward
+    # rounding of the REFERENCE itself shows as 1e-4 relative noise on small gradients -- tools/debug_train_case.py: HIP and the float32
+    # oracle are equally far from the float64 oracle there -- which Adam's normalised update turns into parameter differences above the
+    # allowance below; that regime is held to the gradient bar by the ray cases and golden G13)
+    S = int(rng.choice([17, 33, 40, 64, 70]))
+    fused = bool(rng.integers(2))
+    backward = str(rng.choice(["atomic", "binned"]))
+    fuse_opt = bool(rng.integers(2)) if (fused and backward == "binned") else None
+    white, diffuse_reg = bool(rng.integers(2)), bool(rng.integers(2))
+    if fuse_opt and (storage == "reference" or deg not in (0, 2) or not diffuse_reg):
+        fuse_opt = False  # (Adam in the brick flush: the merged pass over both renders' lists, split / bricked storage, SH degree 0 or 2)
+    perturb = fused  # (a jitter TABLE is taken by the fused step only; the autograd-driven step is compared without jitter)
+    brick = None if not (fused and backward == "binned") else [None, 4, 8][int(rng.integers(3))]
+    lr = 0.03
+    desc = (f"train dims={dims} deg={deg} mode={mode} storage={storage} n={n} S={S} fused={fused} backward={backward} fuse_optimizer={fuse_opt} brick={brick} "
+            f"white={white} diffuse_reg={diffuse_reg}")
+    o = torch.from_numpy(hash_uniform((n, 3), seed + 1))
+    o = o / o.norm(dim=-1, keepdim=True).clamp_min(1e-3) * 4.0
+    d = torch.from_numpy(hash_uniform((n, 3), seed + 3)) * 1.2 - o
+    d = d / d.norm(dim=-1, keepdim=True)
+    pixels = torch.from_numpy(hash_uniform((n, 3), seed + 6, 0.0, 1.0))
+    near, far = 1.8, 6.6
+    grid = make_grid(dev, dens, feat, voxel, (0.0, 0.0, 0.0), mode, rho, storage, True)
+    cfg = rf.SHVoxGridRenderConfig(S, rf.CameraBounds(near, far), perturb_sampled_points=perturb, white_bkgd=white)
+    model = rf.VolumetricModel(grid, rf.render_sh_voxel_grid, cfg, device=dev)
+    kw = dict(fused=fused, backward=backward, apply_diffuse_render_regularization=diffuse_reg, data_parallel=False)
+    if fuse_opt is not None:
+        kw["fuse_optimizer"] = fuse_opt
+    if brick is not None:
+        kw["brick_size"] = brick
+    stepper = TrainStepper(model, n, learning_rate=lr, **kw)
+    cd, cf = dens.clone().requires_grad_(True), feat.clone().requires_grad_(True)
+    opt = torch.optim.Adam([{"params": [cd, cf], "lr": lr}], betas=(0.9, 0.999))
+    aabb = orc.make_aabb(dims, voxel)
+    rays = rf.Rays(o.to(dev), d.to(dev))
+    firm, grads = None, []
+    for it in range(2):
+        t_rands = [torch.from_numpy(hash_uniform((n, S), seed + 10 + 2 * it + i, 0.0, 1.0)).clamp_(0.0, 1.0 - 2.0**-24) for i in range(2)]
+        stats = stepper.step_on(rays, pixels.to(dev), t_rand=[t.to(dev) for t in t_rands] if perturb else None)
+        opt.zero_grad()
+        losses = []
+        for k, diffuse in enumerate((False, True) if diffuse_reg else (False,)):
+            out = orc.render(cd, cf, o, d, aabb, near, far, S, rho, mode, white_bkgd=white, render_diffuse=diffuse, t_rand=t_rands[k] if perturb else None)
+            losses.append(torch.nn.functional.l1_loss(out["colour"], pixels))
+        sum(losses).backward()
+        np.testing.assert_allclose(float(stats.specular_loss), losses[0].item(), rtol=5e-5, atol=1e-7, err_msg=desc + f" it={it}")
+        if diffuse_reg:
+            np.testing.assert_allclose(float(stats.diffuse_loss), losses[1].item(), rtol=5e-5, atol=1e-7, err_msg=desc + f" it={it}")
+        g_now = torch.cat([cd.grad.reshape(-1), cf.grad.reshape(-1)]).clone()
+        grads.append(g_now)
+        firm_now = g_now.abs() > max(1e-6, 1e-3 * float(g_now.abs().max()))
+        firm = firm_now if firm is None else (firm & firm_now)
+        opt.step()
+    torch.cuda.synchronize()
+    ours = torch.cat([grid.densities.detach().reshape(-1), grid.features.detach().reshape(-1)]).cpu()
+    ref = torch.cat([cd.detach().reshape(-1), cf.detach().reshape(-1)])
+    err = (ours - ref).abs()
+    # Adam normalises the step: a parameter whose gradient is summation noise may move by a whole update in the other direction; every
+    # parameter with a firm gradient in both iterations must agree tightly (the criterion of test_bench_train_step_against_oracle_...).
+    # "Tightly" scales with the conditioning of the second update's first moment, 0.09 g1 + 0.1 g2: where the two iterations' gradients
+    # nearly cancel, float32 summation-order noise of the gradients (taken as 3e-4 relative, atomics included) is amplified by
+    # cond = (0.09 |g1| + 0.1 |g2|) / |0.09 g1 + 0.1 g2|
+    assert float(err.max()) <= 2 * 2 * lr + 1e-6, f"{desc}: max parameter error {float(err.max()):.3e}"
+    num = 0.09 * grads[0].abs() + 0.1 * grads[1].abs()
+    cond = num / (0.09 * grads[0] + 0.1 * grads[1]).abs().clamp_min(1e-30)
+    allowed = (2e-5 + lr * 3e-4 * cond).clamp_max(2 * lr)
+    # ... for all but a handful of them: a sample within ~1e-6 of the ReLU kink (or of the box faces) falls on the other side once the
+    # two parameter sets differ by the first iteration's rounding, which changes the gradients of its 8 corners discontinuously -- the
+    # reference trainer's own run-to-run behaviour (docs/experiments.md C); a systematic error shows on whole fractions of the grid
+    if bool(firm.any()):
+        inside = (err[firm] <= allowed[firm]).float().mean()
+        assert float(inside) >= 0.995, f"{desc}: only {float(inside):.4f} of the {int(firm.sum())} firm-gradient parameters within the allowance (max error {float(err[firm].max()):.3e})"
+    assert float((err <= 5e-5).float().mean()) >= 0.97, f"{desc}: only {float((err <= 5e-5).float().mean()):.4f} of the parameters within 5e-5"
+    return desc
+
+
 def case_seed(run_seed: int, i: int) -> int:
     return run_seed * 1000003 + i * 7919
 
@@ -133,7 +225,7 @@ def run_case(run_seed: int, i: int, kind: str, dev, mode: str = "") -> str:
     if kind == "all":
         kind = "rays" if i % 2 == 0 else "frames"
     try:
-        return (case_rays if kind == "rays" else case_frames)(rng, dev, seed)
+        return {"rays": case_rays, "frames": case_frames, "train": case_train}[kind](rng, dev, seed)
     finally:
         FORCE_MODE = ""
 

@@ -21,6 +21,14 @@ def test_randomised_parity_sweep(hip_device, run_seed, first):
         parity_fuzz.run_case(run_seed, i, "all", hip_device)
 
 
+def test_randomised_training_iterations(hip_device):
+    """Two iterations of TrainStepper in randomly drawn set-ups (fused / autograd-driven, atomic / binned adjoint, cubic and 4 x 8 x 8
+    bricks, Adam in the brick flush or from the bucket, every SH degree / density mode / storage, ragged batches, partial bricks) against
+    the oracle's autograd + torch.optim.Adam."""
+    for i in range(40):
+        parity_fuzz.run_case(11, i, "train", hip_device)
+
+
 @pytest.mark.parametrize("run_seed,i,kind,mode", [(1, 138, "all", ""), (1, 268, "all", ""), (1, 284, "all", ""), (1, 292, "all", ""), (2, 251, "rays", "softplus")])
 def test_last_sample_inside_the_volume_softplus_density_gradient(hip_device, run_seed, i, kind, mode):
     desc = parity_fuzz.run_case(run_seed, i, kind, hip_device, mode)
