@@ -212,6 +212,122 @@ def case_train(rng, dev, seed):
     return desc
 
 
+def case_misc(rng, dev, seed):
+    """The smaller entry points in random set-ups: point queries (+ adjoint), the stage transition, the keyed batch selection, frames cut
+    into pixel ranges with the in-kernel jitter."""
+    from thr3ed_atom_amd import ops
+
+    what = str(rng.choice(["query", "upsample", "select", "ranges"]))
+    dims, deg, mode, storage, voxel, loc, rho = draw_common(rng)
+    F = 3 * (deg + 1) ** 2
+    if what == "query":
+        dens, feat = procedural_grid(dims, F, seed % 100000)
+        m = int(rng.integers(1, 3000))
+        lo = np.array([l - 0.5 * v * d_ for l, v, d_ in zip(loc, voxel, dims)], dtype=np.float32)
+        hi = np.array([l + 0.5 * v * d_ for l, v, d_ in zip(loc, voxel, dims)], dtype=np.float32)
+        u = hash_uniform((m, 3), seed + 1, -0.2, 1.2)  # in, out and (below) on the faces of the box
+        pts = lo + (hi - lo) * u
+        face = hash_uniform((m,), seed + 2, 0.0, 1.0) < 0.15
+        axis = (hash_uniform((m,), seed + 3, 0.0, 3.0)).astype(np.int64).clip(0, 2)
+        side = hash_uniform((m,), seed + 4, 0.0, 1.0) < 0.5
+        eps = hash_uniform((m,), seed + 5, -1e-4, 1e-4)
+        rows = np.nonzero(face)[0]
+        pts[rows, axis[rows]] = np.where(side[rows], lo[axis[rows]], hi[axis[rows]]) + eps[rows]
+        pts = torch.from_numpy(pts.astype(np.float32))
+        desc = f"query dims={dims} deg={deg} mode={mode} storage={storage} points={m}"
+        grid = make_grid(dev, dens, feat, voxel, loc, mode, rho, storage, True)
+        out = grid(pts.to(dev))
+        gout = torch.from_numpy(hash_uniform((m, F + 1), seed + 6))
+        (out * gout.to(dev)).sum().backward()
+        cd, cf = dens.clone().requires_grad_(True), feat.clone().requires_grad_(True)
+        aabb = orc.make_aabb(dims, voxel, loc)
+        ref = orc.voxel_grid_forward(cd, cf, pts, aabb, rho, mode)
+        (ref * gout).sum().backward()
+        o_, r_ = out.detach().cpu().numpy(), ref.detach().numpy()
+        assert np.array_equal(o_[:, :F], r_[:, :F]), desc + ": interpolated features are not bit-identical"
+        if mode == "softplus":
+            np.testing.assert_allclose(o_[:, F], r_[:, F], rtol=2e-6, atol=1e-7, err_msg=desc)
+        else:
+            assert np.array_equal(o_[:, F], r_[:, F]), desc + ": densities are not bit-identical"
+        assert np.array_equal(grid.test_inside_volume(pts.to(dev)).cpu().numpy().reshape(-1), orc.inside_aabb(pts, aabb).numpy().reshape(-1)), desc
+        gd, gf = grid.reference_gradients()
+        for ours, refg in ((gd, cd.grad), (gf, cf.grad)):
+            np.testing.assert_allclose(ours.detach().cpu().numpy(), refg.numpy(), rtol=1e-4, atol=1e-5 * max(float(refg.abs().max()), 1e-12), err_msg=desc)
+        return desc
+    if what == "upsample":
+        src = tuple(int(rng.integers(2, 13)) for _ in range(3))
+        dst = tuple(int(rng.integers(2, 31)) for _ in range(3))
+        dens, feat = procedural_grid(src, F, seed % 100000)
+        desc = f"upsample {src} -> {dst} deg={deg} storage={storage}"
+        grid = make_grid(dev, dens, feat, tuple(3.0 / d_ for d_ in src), (0.0, 0.0, 0.0), "relu", 3.0, storage, False)
+        up = rf.scale_voxel_grid_with_required_output_size(grid, dst)
+        ref = torch.from_numpy(orc.trilinear_upsample_recipe(torch.cat([feat, dens], dim=-1).numpy(), dst, vector_width=8))
+        assert up.grid_dims == tuple(dst) and up.storage == storage, desc
+        assert torch.equal(up.features.detach().cpu(), ref[..., :-1]) and torch.equal(up.densities.detach().cpu(), ref[..., -1:]), desc + ": not bit-identical"
+        return desc
+    if what == "select":
+        H, W, M = int(rng.integers(1, 60)), int(rng.integers(1, 60)), int(rng.integers(1, 7))
+        nsel = int(rng.integers(1, M + 1))
+        ids = torch.from_numpy(rng.choice(M, nsel, replace=False).astype(np.int64))
+        P = nsel * H * W
+        n = int(rng.integers(1, P + 1))
+        first = int(rng.integers(0, P - n + 1))
+        key = int(rng.integers(0, 2**63 - 1)) * 2 + int(rng.integers(0, 2))
+        focal = float(rng.uniform(10.0, 900.0))
+        poses = torch.stack([torch.cat([p.rotation, p.translation], dim=1) for p in
+                             (rf.pose_spherical(float(rng.uniform(0, 360)), float(rng.uniform(-80, 10)), 4.0) for _ in range(M))]).to(dev)
+        table = torch.from_numpy(hash_uniform((M * H * W, 3), seed + 1, 0.0, 1.0)).to(dev)
+        desc = f"select HxW={H}x{W} images={nsel}/{M} n={n} first={first}"
+        o, d, px, idx = ops.select_rays_and_pixels_hip(H, W, focal, poses, ids, table, n, key, return_index=True, first_index=first)
+        want = orc.keyed_permutation(np.arange(first, first + n), P, key)
+        assert np.array_equal(idx.cpu().numpy(), want), desc + ": indices differ from the restated bijection"
+        assert len(np.unique(want)) == n, desc
+        hw = H * W
+        img = ids.to(dev)[idx // hw]
+        assert torch.equal(px, table[img * hw + idx % hw]), desc + ": pixels"
+        ro, rd = ops.cast_selected_rays_hip(H, W, focal, poses[ids.to(dev)], idx)
+        assert torch.equal(o, ro) and torch.equal(d, rd), desc + ": rays"
+        return desc
+    # "ranges": a frame with the in-kernel (keyed) jitter, whole and cut into three pixel ranges, either kernel; and against the oracle
+    # fed with the restated jitter table
+    dens, feat = procedural_grid(dims, F, seed % 100000)
+    H, W = int(rng.integers(1, 45)), int(rng.integers(1, 45))
+    focal = float(rng.choice([30.0, 80.0, 400.0]))
+    S = int(rng.choice([3, 33, 64, 80]))
+    tiles = str(rng.choice(["0", "1"]))
+    pose = rf.pose_spherical(float(rng.uniform(0, 360)), float(rng.uniform(-80, 10)), float(rng.uniform(3.0, 5.0)))
+    near, far = 1.0, 7.0
+    desc = f"ranges dims={dims} deg={deg} mode={mode} storage={storage} HxW={H}x{W} focal={focal} S={S} tiles={tiles}"
+    grid = make_grid(dev, dens, feat, voxel, loc, mode, rho, storage, False)
+    intr = rf.CameraIntrinsics(H, W, focal)
+    cfg = rf.SHVoxGridRenderConfig(S, rf.CameraBounds(near, far), perturb_sampled_points=True, white_bkgd=True)
+    n = H * W
+    cuts = sorted(int(c) for c in rng.integers(0, n + 1, size=2))
+    os.environ["RF_FRAME_TILES"] = tiles
+    try:
+        torch.manual_seed(seed % 2**31)
+        key = ops.draw_jitter_key()
+        torch.manual_seed(seed % 2**31)
+        whole = rf.render_sh_voxel_grid_frame(grid, intr, pose, cfg)
+        parts = []
+        for a_, b_ in ((0, cuts[0]), (cuts[0], cuts[1]), (cuts[1], n)):
+            if b_ > a_:
+                torch.manual_seed(seed % 2**31)
+                parts.append(rf.render_sh_voxel_grid_frame(grid, intr, pose, cfg, first_ray=a_, num_rays=b_ - a_))
+    finally:
+        os.environ.pop("RF_FRAME_TILES", None)
+    for name in ("colour", "depth"):
+        cat = torch.cat([getattr(p, name).reshape(-1, getattr(p, name).shape[-1]) for p in parts])
+        assert torch.equal(cat, getattr(whole, name).reshape(cat.shape)), desc + f": {name} depends on how the frame is cut ({cuts})"
+    flat = rf.flatten_rays(rf.cast_rays(intr, pose, dev))
+    table = torch.from_numpy(orc.keyed_jitter(key, 0, n, S))
+    ref = orc.render(dens, feat, flat.origins.cpu(), flat.directions.cpu(), orc.make_aabb(dims, voxel, loc), near, far, S, rho, mode, white_bkgd=True, t_rand=table)
+    err_c = float((whole.colour.reshape(-1, 3).cpu() - ref["colour"]).abs().max())
+    err_d = float((whole.depth.reshape(-1, 1).cpu() - ref["depth"]).abs().max())
+    assert err_c <= TOL and err_d <= 2.5 * TOL, f"{desc}: colour {err_c:.2e} depth {err_d:.2e}"
+    return desc
+
+
 def case_seed(run_seed: int, i: int) -> int:
     return run_seed * 1000003 + i * 7919
 
@@ -225,7 +341,7 @@ def run_case(run_seed: int, i: int, kind: str, dev, mode: str = "") -> str:
     if kind == "all":
         kind = "rays" if i % 2 == 0 else "frames"
     try:
-        return {"rays": case_rays, "frames": case_frames, "train": case_train}[kind](rng, dev, seed)
+        return {"rays": case_rays, "frames": case_frames, "train": case_train, "misc": case_misc}[kind](rng, dev, seed)
     finally:
         FORCE_MODE = ""
 

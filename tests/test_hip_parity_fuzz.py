@@ -29,6 +29,15 @@ def test_randomised_training_iterations(hip_device):
         parity_fuzz.run_case(11, i, "train", hip_device)
 
 
+def test_randomised_small_entry_points(hip_device):
+    """Point queries with their adjoint (bit-identical interpolation, points on the faces of the box), the stage transition at random
+    size ratios (bit-identical to the restated ATen kernel), the keyed batch selection against its numpy restatement, frames with the
+    in-kernel jitter cut into pixel ranges (bit-identical to the whole frame, either kernel) and against the oracle fed with the
+    restated jitter table."""
+    for i in range(60):
+        parity_fuzz.run_case(21, i, "misc", hip_device)
+
+
 @pytest.mark.parametrize("run_seed,i,kind,mode", [(1, 138, "all", ""), (1, 268, "all", ""), (1, 284, "all", ""), (1, 292, "all", ""), (2, 251, "rays", "softplus")])
 def test_last_sample_inside_the_volume_softplus_density_gradient(hip_device, run_seed, i, kind, mode):
     desc = parity_fuzz.run_case(run_seed, i, kind, hip_device, mode)
