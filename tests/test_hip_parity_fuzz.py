@@ -38,6 +38,18 @@ def test_randomised_small_entry_points(hip_device):
         parity_fuzz.run_case(21, i, "misc", hip_device)
 
 
+@pytest.mark.parametrize("cases", [list(range(0, 24)), [28, 33, 49, 73, 222, 229, 257, 316, 364, 376]], ids=["first-24", "found"])
+def test_rays_of_255_to_5000_samples(hip_device, cases):
+    """Sample counts around the kernels' internal group sizes (64-sample chunks, 64 chunk masks = 4096 samples per mask group) and at
+    the reference's default render count (render_num_samples_per_ray = 1024) and beyond, held to the float64-anchored bar: the HIP result
+    may be as far from the float64 oracle as 3 x the float32 reference's own worst error of the batch + the bar.  The "found" cases are
+    the ones the sweep failed on before the transmittance scan carried 1 - prod E beside prod E (slowly varying density: the doubling
+    steps of a product scan round all lanes alike, 1e-5 of transmittance lost per 1000 samples) and before exp(-x) near 1 came from
+    the series instead of v_exp_f32."""
+    for i in cases:
+        parity_fuzz.run_case(42, i, "long", hip_device)
+
+
 @pytest.mark.parametrize("run_seed,i,kind,mode", [(1, 138, "all", ""), (1, 268, "all", ""), (1, 284, "all", ""), (1, 292, "all", ""), (2, 251, "rays", "softplus")])
 def test_last_sample_inside_the_volume_softplus_density_gradient(hip_device, run_seed, i, kind, mode):
     desc = parity_fuzz.run_case(run_seed, i, kind, hip_device, mode)

@@ -232,6 +232,31 @@ __device__ __forceinline__ float wave_incl_scan_mul(float x) {
   return x;
 }
 
+// Inclusive prefix of a chunk's transmittance factors E_j = 1 - alpha_j, carried in BOTH forms: e = prod E_j and a = 1 - prod E_j (joined
+// as a' = a_prefix + a e_prefix).  The product alone is as accurate as torch.cumprod's sequential one in the worst case, but not on
+// the rays that matter at high sample counts: with a slowly varying density the factors of neighbouring samples are (nearly) the SAME
+// float, the first doubling step rounds all of them the same way and the later steps multiply that error by 32 per chunk -- coherent
+// over a ray, where the sequential product's roundings are not: 1000 samples of alpha ~ 1e-4 left the transmittance 1e-5 low (accumulated
+// weight of a ray that ends inside the volume 0.99999 instead of 1, depth 6e-5 off: tests/parity_fuzz.py kind "long"; the float32
+// reference is within 1e-6 of the float64 value there).  In the `a` form the same roundings are relative to a ~ 1e-4 .. 1e-2, not to 1.
+// prefix_transmittance() takes 1 - a while a < 1/4 and the product beyond (exact zeros behind an opaque sample stay exact; a ray
+// passes through few chunks in that regime).  24 VALU instructions per chunk instead of 6.
+__device__ __forceinline__ void wave_incl_scan_trans(float& e, float& a) {
+  auto step = [&](auto ctrl_tag, auto mask_tag) {
+    constexpr int CTRL = decltype(ctrl_tag)::value, MASK = decltype(mask_tag)::value;
+    const float ep = dpp_move<CTRL, MASK>(1.0f, e), ap = dpp_move<CTRL, MASK>(0.0f, a);
+    a = __builtin_fmaf(a, ep, ap);
+    e = e * ep;
+  };
+  step(std::integral_constant<int, kDppRowShr1>{}, std::integral_constant<int, 0xf>{});
+  step(std::integral_constant<int, kDppRowShr2>{}, std::integral_constant<int, 0xf>{});
+  step(std::integral_constant<int, kDppRowShr4>{}, std::integral_constant<int, 0xf>{});
+  step(std::integral_constant<int, kDppRowShr8>{}, std::integral_constant<int, 0xf>{});
+  step(std::integral_constant<int, kDppRowBcast15>{}, std::integral_constant<int, 0xa>{});
+  step(std::integral_constant<int, kDppRowBcast31>{}, std::integral_constant<int, 0xc>{});
+}
+__device__ __forceinline__ float prefix_transmittance(float e, float a) { return (a < 0.25f) ? 1.0f - a : e; }
+
 __device__ __forceinline__ float read_lane(float x, int lane) {
   return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, x), lane));
 }
@@ -256,6 +281,23 @@ __device__ __forceinline__ float wave_sum(float x) {
 // own CPU (SLEEF) and GPU (libdevice) paths differ from each other by as much; the parity bar is 1e-5.
 __device__ __forceinline__ float exp_fast(float x) { return __builtin_amdgcn_exp2f(x * 1.44269504088896340736f); }
 __device__ __forceinline__ float sigmoidf_(float x) { return __builtin_amdgcn_rcpf(1.0f + exp_fast(-x)); }
+// alpha = 1 - exp(-x), x = sigma * delta >= 0 (density2occupancy_pb, accumulate.py:24-28), the way the REFERENCE's float32 arithmetic
+// produces it: E = exp(-x) correctly rounded, alpha = 1 - E (an exact subtraction: alpha is a multiple of 2^-24 and 1 - alpha == E, so
+// that weights alpha_i T_i and transmittances T_i E_i telescope without a bias).  v_exp_f32 is a one-ulp exponential: at the small x of
+// densely sampled rays (1000+ samples: x ~ 1e-3) its errors in E near 1 showed as 3..8e-5 on depth at 4000 .. 5000 samples per ray, where the
+// float32 reference stays within 2e-6 of the float64 value (tests/parity_fuzz.py, kind "long").  Below 1/16: E = 1 - (x - x^2/2 + ... ),
+// the series to 2e-9 relative, i.e. the correctly rounded exponential in all but a handful of cases.  (alpha taken from the series
+// itself is MORE accurate than the reference's -- and then 1 - alpha is rounded, with the same sign sample after sample where the
+// density varies slowly: accumulated weights of opaque rays came out 1.5e-5 short of 1.  Measured, not kept.)
+__device__ __forceinline__ float occupancy_alpha(float x, float& E) {
+  float t = __builtin_fmaf(-x, 1.0f / 120.0f, 1.0f / 24.0f);
+  t = __builtin_fmaf(-x, t, 1.0f / 6.0f);
+  t = __builtin_fmaf(-x, t, 0.5f);
+  t = __builtin_fmaf(-x, t, 1.0f);
+  const float big = exp_fast(-x);
+  E = (x < 0.0625f) ? __builtin_fmaf(-x, t, 1.0f) : big;
+  return 1.0f - E;
+}
 // softplus'(x) = sigmoid(x) = 1 - exp(-softplus(x)), from the cached activated density s = softplus(x) >= 0, to RELATIVE accuracy: a
 // sample far below the surface has s ~ 1e-9 and 1 - exp(-s) cancels to 0 in float32, but the last sample of a ray carries
 // delta = 1e10 |d| (accumulate.py:49-52), so its d alpha / d sigma is ~1e10 and the product is an ordinary gradient that the reference
@@ -957,9 +999,11 @@ __device__ __forceinline__ void render_forward_ray(const GridArgs& g, const RayA
         sigma = interp_density(cn, g, pre);
       }
     }
-    const float alpha = 1.0f - exp_fast(-(sigma * sm.delta));  // density2occupancy_pb, accumulate.py:24-28
-    const float one_minus = 1.0f - alpha;
-    const float incl = wave_incl_scan_mul(sm.valid ? one_minus : 1.0f);
+    float one_minus;  // = exp(-sigma delta) = 1 - alpha exactly
+    const float alpha = occupancy_alpha(sigma * sm.delta, one_minus);  // density2occupancy_pb, accumulate.py:24-28
+    float incl_e = sm.valid ? one_minus : 1.0f, incl_a = sm.valid ? alpha : 0.0f;
+    wave_incl_scan_trans(incl_e, incl_a);
+    const float incl = prefix_transmittance(incl_e, incl_a);
     const float excl = dpp_move<kDppWaveShr1, 0xf>(1.0f, incl);  // lane i <- lane i-1, lane 0 <- 1
     const float T = T_carry * excl;
     const float w = alpha * T;
@@ -1607,7 +1651,8 @@ __global__ __launch_bounds__(kWave * WPB, (K == 16 ? 2 : RF_TILE_WAVES)) void re
       rest_hot = step_needs_rest;
     }
     // ---- compositing, this ray's own recurrence (accumulate.py:63-88)
-    const float alpha = 1.0f - exp_fast(-(sigma * sm.delta));
+    float E;
+    const float alpha = occupancy_alpha(sigma * sm.delta, E);
     const float wgt = alpha * T;
     if (need) {
       part_c[0] += wgt * sigmoidf_(raw[0]);
@@ -1616,7 +1661,7 @@ __global__ __launch_bounds__(kWave * WPB, (K == 16 ? 2 : RF_TILE_WAVES)) void re
     }
     part_acc += wgt;
     part_depth += wgt * sm.z;
-    T = T * (1.0f - alpha);
+    T = T * E;
     if (__ballot(lane_valid && T != 0.0f) == 0ull) break;  // every later weight of every ray of the tile is exactly 0
   }
   if (lane_valid) {
@@ -1813,8 +1858,8 @@ __global__ __launch_bounds__(kBlock) void render_backward_kernel(GridArgs g, Ray
     // (T_{i+1} e_i is the sample's OWN term of d L / d sigma_i = delta_i (T_i exp(-sigma_i delta_i) e_i - sum_{j>i} w_j e_j): with the
     // exponential itself, not 1 - alpha -- that difference cancels to a relative error of 6e-8 / exp(-x), which the 1e10-long interval
     // of a ray's last sample (accumulate.py:49-52) turns into per cents of its gradient when the sample lies inside the volume)
-    const float E = exp_fast(-(sigma * sm.delta));
-    const float alpha = 1.0f - E;
+    float E;
+    const float alpha = occupancy_alpha(sigma * sm.delta, E);
     const float w = alpha * T;
     const float Tn = T * E;
     float c[3], e = gD * sm.z + gA;
@@ -2059,8 +2104,8 @@ __device__ __forceinline__ void render_emit_direct_ray(const GridArgs& g, const 
       const bool have = counted[u];
       const float sigma = have ? cv[u].w : 0.0f;
       const float T = have ? Tc[u] : 0.0f;
-      const float E = exp_fast(-(sigma * dl[u]));  // (the own term uses the exponential itself: see render_backward_kernel)
-      const float alpha = 1.0f - E;
+      float E;  // (the own term uses the exponential itself: see render_backward_kernel)
+      const float alpha = occupancy_alpha(sigma * dl[u], E);
       const float w = alpha * T;
       const float Tn = T * E;
       const float raw[3] = {cv[u].x, cv[u].y, cv[u].z};

@@ -1,0 +1,46 @@
+"""debug aid: one "long" ray case of tests/parity_fuzz.py, per-ray errors against the float64 oracle, with switches"""
+import os, sys
+import numpy as np, torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import thr3ed_atom_amd as rf
+from oracle import relu_field_oracle as orc
+from tests import parity_fuzz as pf
+from tests.helpers import hash_uniform, procedural_grid
+
+run_seed, i = int(sys.argv[1]), int(sys.argv[2])
+over = dict(a.split("=") for a in sys.argv[3:])
+seed = pf.case_seed(run_seed, i)
+rng = np.random.default_rng(seed)
+pf.LONG_RAYS = True
+dims, deg, mode, storage, voxel, loc, rho = pf.draw_common(rng)
+F = 3 * (deg + 1) ** 2
+dens, feat = procedural_grid(dims, F, seed % 100000)
+n = int(rng.integers(1, 400)); S = int(rng.choice([1, 2, 3, 17, 40, 63, 64, 65, 128, 150]))
+n = int(rng.integers(1, 24)); S = int(rng.choice([255, 256, 257, 1000, 1024, 4095, 4096, 4097, 4160, 5000]))
+o = torch.from_numpy(hash_uniform((n, 3), seed + 1)); radius = torch.from_numpy(hash_uniform((n, 1), seed + 2, 0.2, 5.0))
+o = o / o.norm(dim=-1, keepdim=True).clamp_min(1e-3) * radius
+d = torch.from_numpy(hash_uniform((n, 3), seed + 3)) * 1.5 - o
+d = d / d.norm(dim=-1, keepdim=True).clamp_min(1e-3) * (1.0 + 0.2 * torch.from_numpy(hash_uniform((n, 1), seed + 4)))
+if rng.integers(4) == 0:
+    zero = torch.from_numpy(hash_uniform((n, 3), seed + 7, 0.0, 1.0) < 0.3); zero[:, 0] &= ~(zero[:, 1] & zero[:, 2]); d = torch.where(zero, torch.zeros_like(d), d)
+near, far = float(rng.uniform(0.05, 2.0)), float(rng.uniform(4.0, 7.0))
+diffuse, opt, white, perturb = bool(rng.integers(2)), bool(rng.integers(2)), bool(rng.integers(2)), bool(rng.integers(2))
+if "opt" in over: opt = over["opt"] == "1"
+if "perturb" in over: perturb = over["perturb"] == "1"
+if "S" in over: S = int(over["S"])
+storage = over.get("storage", storage)
+t_rand = torch.from_numpy(hash_uniform((n, S), seed + 5, 0.0, 1.0)) if perturb else None
+print(dims, deg, mode, storage, "n", n, "S", S, "diffuse", diffuse, "opt", opt, "white", white, "perturb", perturb, "near/far", near, far)
+dev = torch.device("cuda:0")
+grid = pf.make_grid(dev, dens, feat, voxel, loc, mode, rho, storage, False)
+cfg = rf.SHVoxGridRenderConfig(S, rf.CameraBounds(near, far), perturb_sampled_points=perturb, optimized_sampling=opt, white_bkgd=white, render_diffuse=diffuse)
+out = rf.render_sh_voxel_grid(grid, rf.Rays(o.to(dev), d.to(dev)), cfg, None, t_rand=None if t_rand is None else t_rand.to(dev))
+aabb = orc.make_aabb(dims, voxel, loc)
+r32 = orc.render(dens, feat, o, d, aabb, near, far, S, rho, mode, white_bkgd=white, render_diffuse=diffuse, optimized_sampling=opt, t_rand=t_rand)
+r64 = orc.render(dens.double(), feat.double(), o.double(), d.double(), aabb, near, far, S, rho, mode, white_bkgd=white, render_diffuse=diffuse, optimized_sampling=opt,
+                 t_rand=None if t_rand is None else t_rand.double())
+for name, ours in (("acc", out.extra["accumulated_weight"]), ("depth", out.depth), ("colour", out.colour)):
+    h = ours.detach().cpu().double().reshape(n, -1); a = r32[name].double().reshape(n, -1); b = r64[name].reshape(n, -1)
+    print(name, "per ray |hip-f64|:", " ".join(f"{float(v):.1e}" for v in (h - b).abs().max(1).values), "\n     |ref32-f64|:", " ".join(f"{float(v):.1e}" for v in (a - b).abs().max(1).values))
+print("acc f64:", " ".join(f"{float(v):.6f}" for v in r64["acc"].reshape(-1)))
+print("depth f64:", " ".join(f"{float(v):.4f}" for v in r64["depth"].reshape(-1)))
