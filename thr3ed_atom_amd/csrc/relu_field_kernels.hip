@@ -4,7 +4,7 @@
 // phases that re-shape the wave instead of launching separate kernels:
 //
 //   P0  lanes = samples   z, point, AABB test, 8-corner density gather (+rho, +ReLU), alpha, wave-level
-//                         exclusive product scan -> transmittance T and weight w.  Samples whose
+//                         exclusive transmittance scan (wave_incl_scan_trans) -> T and weight w.  Samples whose
 //                         contribution is exactly zero (outside the box, sigma == 0 under ReLU, T == 0)
 //                         are dropped; the survivors are compacted into an LDS work list.
 //   P1  lanes = channels  LPS lanes cooperate on one sample: each lane fetches 4 consecutive feature
@@ -220,18 +220,6 @@ __device__ __forceinline__ float dpp_move(float old, float src) {
 constexpr int kDppRowShr1 = 0x111, kDppRowShr2 = 0x112, kDppRowShr4 = 0x114, kDppRowShr8 = 0x118;
 constexpr int kDppRowBcast15 = 0x142, kDppRowBcast31 = 0x143, kDppWaveShr1 = 0x138, kDppWaveShl1 = 0x130;
 
-// inclusive prefix product over the 64 lanes: 4 row_shr steps inside each row of 16, then row_bcast:15 / :31
-// (gfx9 DPP) to fold the rows -- 12 VALU instructions, no LDS traffic
-__device__ __forceinline__ float wave_incl_scan_mul(float x) {
-  x = x * dpp_move<kDppRowShr1, 0xf>(1.0f, x);
-  x = x * dpp_move<kDppRowShr2, 0xf>(1.0f, x);
-  x = x * dpp_move<kDppRowShr4, 0xf>(1.0f, x);
-  x = x * dpp_move<kDppRowShr8, 0xf>(1.0f, x);
-  x = x * dpp_move<kDppRowBcast15, 0xa>(1.0f, x);
-  x = x * dpp_move<kDppRowBcast31, 0xc>(1.0f, x);
-  return x;
-}
-
 // Inclusive prefix of a chunk's transmittance factors E_j = 1 - alpha_j, carried in BOTH forms: e = prod E_j and a = 1 - prod E_j (joined
 // as a' = a_prefix + a e_prefix).  The product alone is as accurate as torch.cumprod's sequential one in the worst case, but not on
 // the rays that matter at high sample counts: with a slowly varying density the factors of neighbouring samples are (nearly) the SAME
@@ -240,7 +228,8 @@ __device__ __forceinline__ float wave_incl_scan_mul(float x) {
 // weight of a ray that ends inside the volume 0.99999 instead of 1, depth 6e-5 off: tests/parity_fuzz.py kind "long"; the float32
 // reference is within 1e-6 of the float64 value there).  In the `a` form the same roundings are relative to a ~ 1e-4 .. 1e-2, not to 1.
 // prefix_transmittance() takes 1 - a while a < 1/4 and the product beyond (exact zeros behind an opaque sample stay exact; a ray
-// passes through few chunks in that regime).  24 VALU instructions per chunk instead of 6.
+// passes through few chunks in that regime).  DPP (gfx9): 4 row_shr steps inside each row of 16 lanes, then row_bcast:15 / :31 to fold
+// the rows; 24 VALU instructions per chunk (the product alone took 6), no LDS traffic.
 __device__ __forceinline__ void wave_incl_scan_trans(float& e, float& a) {
   auto step = [&](auto ctrl_tag, auto mask_tag) {
     constexpr int CTRL = decltype(ctrl_tag)::value, MASK = decltype(mask_tag)::value;
