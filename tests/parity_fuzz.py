@@ -115,6 +115,9 @@ def case_frames(rng, dev, seed):
     H, W = int(rng.integers(1, 50)), int(rng.integers(1, 50))
     focal = float(rng.choice([20.0, 60.0, 300.0, 900.0]))
     S = int(rng.choice([1, 5, 40, 64, 97]))
+    if LONG_RAYS:
+        H, W = int(rng.integers(1, 13)), int(rng.integers(1, 13))
+        S = int(rng.choice([256, 1000, 1024, 4096, 4100, 5000]))
     tiles = str(rng.choice(["0", "1"]))
     white, diffuse, opt = bool(rng.integers(2)), bool(rng.integers(2)), bool(rng.integers(2))
     occ = bool(rng.integers(2)) and mode == "relu"
@@ -135,6 +138,15 @@ def case_frames(rng, dev, seed):
     flat = rf.flatten_rays(rf.cast_rays(intr, pose, dev))
     ref = orc.render(dens, feat, flat.origins.cpu(), flat.directions.cpu(), orc.make_aabb(dims, voxel, loc), near, far, S, rho, mode, white_bkgd=white,
                      render_diffuse=diffuse, optimized_sampling=opt)
+    if LONG_RAYS:  # the float64-anchored rule (see case_rays)
+        r64 = orc.render(dens.double(), feat.double(), flat.origins.cpu().double(), flat.directions.cpu().double(), orc.make_aabb(dims, voxel, loc), near, far, S, rho, mode,
+                         white_bkgd=white, render_diffuse=diffuse, optimized_sampling=opt)
+        for name, ours, bar in (("colour", frame.colour.reshape(-1, 3), TOL), ("depth", frame.depth.reshape(-1, 1), 2 * TOL * max(1.0, far / 6.6)),
+                                ("acc", frame.extra["accumulated_weight"].reshape(-1, 1), TOL)):
+            noise = float((ref[name].double() - r64[name]).abs().max())
+            worst = float((ours.cpu().double() - r64[name]).abs().max())
+            assert worst <= 3.0 * noise + bar, f"{desc}: {name} is {worst:.2e} from the float64 value; the float32 reference is {noise:.2e} from it"
+        return desc
     err_c = float((frame.colour.reshape(-1, 3).cpu() - ref["colour"]).abs().max())
     err_a = float((frame.extra["accumulated_weight"].reshape(-1, 1).cpu() - ref["acc"]).abs().max())
     err_d = float((frame.depth.reshape(-1, 1).cpu() - ref["depth"]).abs().max())
@@ -358,9 +370,9 @@ def run_case(run_seed: int, i: int, kind: str, dev, mode: str = "") -> str:
     """case i of the run: its description; raises AssertionError on a parity miss (kind "long" = ray cases with 255..5000 samples)"""
     global FORCE_MODE, LONG_RAYS
     FORCE_MODE = mode
-    LONG_RAYS = kind == "long"
-    if kind == "long":
-        kind = "rays"
+    LONG_RAYS = kind in ("long", "longframes")
+    if kind in ("long", "longframes"):
+        kind = "rays" if kind == "long" else "frames"
     seed = case_seed(run_seed, i)
     rng = np.random.default_rng(seed)
     if kind == "all":
