@@ -362,6 +362,57 @@ def case_misc(rng, dev, seed):
     return desc
 
 
+def _renamed_occupancy(densities, deltas):  # the default law under another name: un-fusable, so the render is COMPOSED
+    return 1.0 - torch.exp(-(densities * deltas))
+
+
+def case_composed(rng, dev, seed):
+    """render_sh_voxel_grid with callables the fused kernels do not recognise (the default laws, re-stated): the composed path --
+    rf_grid_query in the middle of torch ops, through autograd -- against the oracle, forward and gradients."""
+    from thr3ed_atom_amd.renderers import fused_kernels_apply
+
+    dims, deg, mode, storage, voxel, loc, rho = draw_common(rng)
+    F = 3 * (deg + 1) ** 2
+    dens, feat = procedural_grid(dims, F, seed % 100000)
+    n = int(rng.integers(1, 300))
+    S = int(rng.choice([2, 3, 17, 40, 64, 65, 128]))
+    o = torch.from_numpy(hash_uniform((n, 3), seed + 1))
+    o = o / o.norm(dim=-1, keepdim=True).clamp_min(1e-3) * torch.from_numpy(hash_uniform((n, 1), seed + 2, 0.2, 5.0))
+    d = torch.from_numpy(hash_uniform((n, 3), seed + 3)) * 1.5 - o
+    d = d / d.norm(dim=-1, keepdim=True).clamp_min(1e-3) * (1.0 + 0.2 * torch.from_numpy(hash_uniform((n, 1), seed + 4)))
+    near, far = float(rng.uniform(0.05, 2.0)), float(rng.uniform(4.0, 7.0))
+    diffuse, opt, white, perturb = bool(rng.integers(2)), bool(rng.integers(2)), bool(rng.integers(2)), bool(rng.integers(2))
+    which = int(rng.integers(1, 4))  # bit 0: occupancy law renamed, bit 1: tone map re-stated
+    t_rand = torch.from_numpy(hash_uniform((n, S), seed + 5, 0.0, 1.0)) if perturb else None
+    target = torch.from_numpy(hash_uniform((n, 3), seed + 6, 0.0, 1.0))
+    desc = f"composed dims={dims} deg={deg} mode={mode} storage={storage} n={n} S={S} diffuse={diffuse} opt={opt} white={white} perturb={perturb} callables={which}"
+    grid = make_grid(dev, dens, feat, voxel, loc, mode, rho, storage, True)
+    kw = {}
+    if which & 1:
+        kw["density2occupancy"] = _renamed_occupancy
+    if which & 2:
+        kw["radiance_hdr_tone_map"] = lambda x: torch.sigmoid(x)
+    cfg = rf.SHVoxGridRenderConfig(S, rf.CameraBounds(near, far), perturb_sampled_points=perturb, optimized_sampling=opt, white_bkgd=white, render_diffuse=diffuse, **kw)
+    assert not fused_kernels_apply(grid, cfg), desc
+    out = rf.render_sh_voxel_grid(grid, rf.Rays(o.to(dev), d.to(dev)), cfg, None, t_rand=None if t_rand is None else t_rand.to(dev))
+    loss = torch.nn.functional.l1_loss(out.colour, target.to(dev)) + 0.1 * out.depth.mean() + 0.05 * out.extra["accumulated_weight"].mean()
+    loss.backward()
+    dc, fc = dens.clone().requires_grad_(True), feat.clone().requires_grad_(True)
+    ref = orc.render(dc, fc, o, d, orc.make_aabb(dims, voxel, loc), near, far, S, rho, mode, white_bkgd=white, render_diffuse=diffuse, optimized_sampling=opt, t_rand=t_rand)
+    ref_loss = torch.nn.functional.l1_loss(ref["colour"], target) + 0.1 * ref["depth"].mean() + 0.05 * ref["acc"].mean()
+    ref_loss.backward()
+    cpu = lambda t: t.detach().cpu().numpy()
+    zmax = max(far, float(ref["depth"].detach().abs().max()))
+    np.testing.assert_allclose(cpu(out.colour), ref["colour"].detach().numpy(), rtol=0, atol=TOL, err_msg=desc)
+    np.testing.assert_allclose(cpu(out.depth), ref["depth"].detach().numpy(), rtol=0, atol=2 * TOL * max(1.0, zmax / 6.6), err_msg=desc)
+    np.testing.assert_allclose(cpu(out.extra["accumulated_weight"]), ref["acc"].detach().numpy(), rtol=0, atol=TOL, err_msg=desc)
+    gd, gf = grid.reference_gradients()
+    gd_ref, gf_ref = dc.grad.numpy(), fc.grad.numpy()
+    np.testing.assert_allclose(cpu(gd), gd_ref, rtol=5e-4, atol=5e-6 * max(np.abs(gd_ref).max(), 1e-12), err_msg=desc)
+    np.testing.assert_allclose(cpu(gf), gf_ref, rtol=5e-4, atol=5e-6 * max(np.abs(gf_ref).max(), 1e-12), err_msg=desc)
+    return desc
+
+
 def case_seed(run_seed: int, i: int) -> int:
     return run_seed * 1000003 + i * 7919
 
@@ -378,7 +429,7 @@ def run_case(run_seed: int, i: int, kind: str, dev, mode: str = "") -> str:
     if kind == "all":
         kind = "rays" if i % 2 == 0 else "frames"
     try:
-        return {"rays": case_rays, "frames": case_frames, "train": case_train, "misc": case_misc}[kind](rng, dev, seed)
+        return {"rays": case_rays, "frames": case_frames, "train": case_train, "misc": case_misc, "composed": case_composed}[kind](rng, dev, seed)
     finally:
         FORCE_MODE = ""
 

@@ -38,6 +38,13 @@ def test_randomised_small_entry_points(hip_device):
         parity_fuzz.run_case(21, i, "misc", hip_device)
 
 
+def test_randomised_composed_renders(hip_device):
+    """render_sh_voxel_grid with callables the fused kernels do not recognise (the default occupancy law / tone map re-stated under other
+    names): the COMPOSED path -- rf_grid_query between torch ops, through autograd -- against the oracle, forward and gradients."""
+    for i in range(40):
+        parity_fuzz.run_case(71, i, "composed", hip_device)
+
+
 @pytest.mark.parametrize("cases", [list(range(0, 24)), [28, 33, 49, 73, 222, 229, 257, 316, 364, 376]], ids=["first-24", "found"])
 def test_rays_of_255_to_5000_samples(hip_device, cases):
     """Sample counts around the kernels' internal group sizes (64-sample chunks, 64 chunk masks = 4096 samples per mask group) and at
