@@ -175,6 +175,9 @@ def case_train(rng, dev, seed):
     # oracle are equally far from the float64 oracle there -- which Adam's normalised update turns into parameter differences above the
     # allowance below; that regime is held to the gradient bar by the ray cases and golden G13)
     S = int(rng.choice([17, 33, 40, 64, 70]))
+    if LONG_RAYS:  # (the adjoints' chunk-mask groups: 64 masks = 4096 samples)
+        n = int(rng.choice([1, 3, 17, 40]))
+        S = int(rng.choice([256, 1000, 4096, 4100, 4200]))
     fused = bool(rng.integers(2))
     backward = str(rng.choice(["atomic", "binned"]))
     fuse_opt = bool(rng.integers(2)) if (fused and backward == "binned") else None
@@ -421,9 +424,9 @@ def run_case(run_seed: int, i: int, kind: str, dev, mode: str = "") -> str:
     """case i of the run: its description; raises AssertionError on a parity miss (kind "long" = ray cases with 255..5000 samples)"""
     global FORCE_MODE, LONG_RAYS
     FORCE_MODE = mode
-    LONG_RAYS = kind in ("long", "longframes")
-    if kind in ("long", "longframes"):
-        kind = "rays" if kind == "long" else "frames"
+    LONG_RAYS = kind in ("long", "longframes", "longtrain")
+    if LONG_RAYS:
+        kind = {"long": "rays", "longframes": "frames", "longtrain": "train"}[kind]
     seed = case_seed(run_seed, i)
     rng = np.random.default_rng(seed)
     if kind == "all":
