@@ -101,6 +101,13 @@ def case_rays(rng, dev, seed):
         np.testing.assert_allclose(cpu(out.colour), ref["colour"].detach().numpy(), rtol=0, atol=TOL, err_msg=desc)
         np.testing.assert_allclose(cpu(out.depth), ref["depth"].detach().numpy(), rtol=0, atol=2 * TOL * max(1.0, zmax / 6.6), err_msg=desc)
         np.testing.assert_allclose(cpu(out.extra["accumulated_weight"]), ref["acc"].detach().numpy(), rtol=0, atol=TOL, err_msg=desc)
+    # disparity = 1 / max(1e-10, depth / acc): NaN exactly where the reference's is (acc == 0), else the same quotient
+    disp, disp_ref = cpu(out.extra["disparity"]).reshape(-1), ref["disparity"].detach().numpy().reshape(-1)
+    assert np.array_equal(np.isnan(disp), np.isnan(disp_ref)), desc + ": NaN pattern of the disparity"
+    # (compared where the quotient is not a ratio of rounding noise: acc > 1e-2 and depth / acc > 1e-3)
+    firm = (~np.isnan(disp_ref)) & (ref["acc"].detach().numpy().reshape(-1) > 1e-2) & (np.nan_to_num(disp_ref, nan=np.inf) < 1e3)
+    if firm.any() and not LONG_RAYS:
+        np.testing.assert_allclose(disp[firm], disp_ref[firm], rtol=2e-3, atol=1e-6, err_msg=desc + " (disparity)")
     gd, gf = grid.reference_gradients()
     gd_ref, gf_ref = dc.grad.numpy(), fc.grad.numpy()
     np.testing.assert_allclose(cpu(gd), gd_ref, rtol=5e-4, atol=5e-6 * max(np.abs(gd_ref).max(), 1e-12), err_msg=desc)
