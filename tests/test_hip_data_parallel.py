@@ -140,6 +140,18 @@ def test_four_processes_owner_computes_on_one_gpu(tmp_path, grid_size, halves):
     assert sorted(os.listdir(tmp_path)) == [f"ok{r}" for r in range(world)]
 
 
+@pytest.mark.parametrize("grid_size,halves", [(64, 1), (128, 2)])
+def test_eight_processes_owner_computes_on_one_gpu(tmp_path, grid_size, halves):
+    """EIGHT ranks -- the world size of BASELINE configs[3], where the owner step is at its limits: 8 full-width + 8 base-channel lists per
+    brick pass (the most a launch takes), two workgroups per owned brick, seven foreign slices per receive buffer.  64^3: one x-slab of
+    bricks per rank.  128^3 (the bench grid): sixteen slabs owned in two interleaved halves, the pipelined step the first attempt of
+    ``bench.py --gpus 8`` runs.  Both must equal the single-process run and keep the replicas bit-identical."""
+    assert torch.cuda.is_available()
+    world = 8
+    mp.spawn(_worker, args=(world, _free_port(), str(tmp_path), "owner", True, True, grid_size, halves), nprocs=world, join=True)
+    assert sorted(os.listdir(tmp_path)) == [f"ok{r}" for r in range(world)]
+
+
 def _trainer_worker(rank, world, port, result_dir):
     """the whole trainer (two stages, a checkpoint every 7 iterations but a synchronising summary only every 100) under data parallelism:
     checkpoints are written while parameter all-gathers of the owner-computes step may still be in flight -- state_dict() has to wait
