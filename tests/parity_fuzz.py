@@ -423,6 +423,135 @@ def case_composed(rng, dev, seed):
     return desc
 
 
+class ReferenceLikeGrid(torch.nn.Module):
+    """A module with exactly the attributes the reference's VoxelGrid has (thre3d_reprs/voxels.py:93-124) and none of this package's:
+    what `VolumetricModel(thre3d_repr=<reference grid>, ...)` hands to a render procedure."""
+
+    def __init__(self, densities, features, voxel_size, location, pre, post, rho):
+        super().__init__()
+        self._densities = torch.nn.Parameter(densities)
+        self._features = torch.nn.Parameter(features)
+        self._density_preactivation, self._density_postactivation = pre, post
+        self._feature_preactivation = self._feature_postactivation = torch.nn.Identity()
+        self._radiance_transfer_function = None
+        self._grid_location, self._voxel_size, self._expected_density_scale, self._tunable = location, voxel_size, rho, True
+        self.width_x, self.depth_y, self.height_z = densities.shape[:3]
+        half = [n_ * v / 2 for n_, v in zip(densities.shape[:3], voxel_size)]
+        self._aabb = tuple((c - h, c + h) for c, h in zip(location, half))
+
+    densities = property(lambda self: self._densities)
+    features = property(lambda self: self._features)
+    aabb = property(lambda self: self._aabb)
+
+
+_BINDING = {}
+
+
+def load_binding(backward: str):
+    """integration/renderers_hip.py (the file a maintainer adds to the reference) imported against stand-ins for the three reference
+    names it needs -- the reference itself does not exist on the GPU box --, one instance per adjoint policy (read at import)."""
+    import importlib.util
+    import types
+
+    from thr3ed_atom_amd import _lib, constants
+
+    if backward in _BINDING:
+        return _BINDING[backward]
+    names = ["thre3d_atom", "thre3d_atom.rendering", "thre3d_atom.rendering.volumetric", "thre3d_atom.rendering.volumetric.render_interface", "thre3d_atom.utils",
+             "thre3d_atom.utils.constants"]
+    saved = {n_: sys.modules.get(n_) for n_ in names}
+    mods = {n_: types.ModuleType(n_) for n_ in names}
+    mods["thre3d_atom.rendering.volumetric.render_interface"].Rays = rf.Rays
+    mods["thre3d_atom.rendering.volumetric.render_interface"].RenderOut = rf.RenderOut
+    mods["thre3d_atom.utils.constants"].EXTRA_DISPARITY = constants.EXTRA_DISPARITY
+    mods["thre3d_atom.utils.constants"].EXTRA_ACCUMULATED_WEIGHTS = constants.EXTRA_ACCUMULATED_WEIGHTS
+    env = {k: os.environ.get(k) for k in ("RELU_FIELD_HIP_LIB", "RELU_FIELD_HIP_BACKWARD", "RELU_FIELD_HIP_MIN_BRICKS")}
+    os.environ.update(RELU_FIELD_HIP_LIB=_lib.LIB_PATH, RELU_FIELD_HIP_BACKWARD=backward, RELU_FIELD_HIP_MIN_BRICKS="0")
+    sys.modules.update(mods)
+    try:
+        path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "integration", "renderers_hip.py")
+        spec = importlib.util.spec_from_file_location(f"renderers_hip_fuzz_{backward}", path)
+        mod = importlib.util.module_from_spec(spec)
+        spec.loader.exec_module(mod)
+    finally:
+        for n_, m in saved.items():
+            if m is None:
+                sys.modules.pop(n_, None)
+            else:
+                sys.modules[n_] = m
+        for k, v in env.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+    _BINDING[backward] = mod
+    return mod
+
+
+def case_binding(rng, dev, seed):
+    """The reference-side binding (integration/renderers_hip.py) on a module with the reference VoxelGrid's attributes: the single
+    procedure, the pair procedure and the frame entry, against the oracle."""
+    dims, deg, mode, storage, voxel, loc, rho = draw_common(rng)
+    F = 3 * (deg + 1) ** 2
+    dens, feat = procedural_grid(dims, F, seed % 100000)
+    backward = str(rng.choice(["atomic", "binned"]))
+    rh = load_binding(backward)
+    what = str(rng.choice(["single", "pair", "frame"]))
+    S = int(rng.choice([2, 3, 17, 40, 64, 65, 128]))
+    near, far = float(rng.uniform(0.05, 2.0)), float(rng.uniform(4.0, 7.0))
+    opt, white = bool(rng.integers(2)), bool(rng.integers(2))
+    grid = ReferenceLikeGrid(dens.to(dev), feat.to(dev), voxel, loc, ACTS[mode][0], ACTS[mode][1], rho).to(dev)
+    aabb = orc.make_aabb(dims, voxel, loc)
+    desc = f"binding[{what}] dims={dims} deg={deg} mode={mode} S={S} opt={opt} white={white} backward={backward}"
+    cpu = lambda t: t.detach().cpu().numpy()
+    if what == "frame":
+        H, W = int(rng.integers(1, 40)), int(rng.integers(1, 40))
+        focal = float(rng.choice([30.0, 80.0, 400.0]))
+        diffuse = bool(rng.integers(2))
+        pose = rf.pose_spherical(float(rng.uniform(0, 360)), float(rng.uniform(-80, 10)), float(rng.uniform(3.0, 5.0)))
+        intr = rf.CameraIntrinsics(H, W, focal)
+        cfg = rf.SHVoxGridRenderConfig(S, rf.CameraBounds(near, far), perturb_sampled_points=False, optimized_sampling=opt, white_bkgd=white, render_diffuse=diffuse)
+        out = rh.render_frame_hip(grid, intr, pose, cfg)
+        flat = rf.flatten_rays(rf.cast_rays(intr, pose, dev))
+        ref = orc.render(dens, feat, flat.origins.cpu(), flat.directions.cpu(), aabb, near, far, S, rho, mode, white_bkgd=white, render_diffuse=diffuse, optimized_sampling=opt)
+        err_c = float((out.colour.reshape(-1, 3).cpu() - ref["colour"]).abs().max())
+        err_d = float((out.depth.reshape(-1, 1).cpu() - ref["depth"]).abs().max())
+        assert err_c <= TOL and err_d <= 2 * TOL * max(1.0, far / 6.6), f"{desc} HxW={H}x{W}: colour {err_c:.2e} depth {err_d:.2e}"
+        return desc
+    n = int(rng.integers(1, 300))
+    o = torch.from_numpy(hash_uniform((n, 3), seed + 1))
+    o = o / o.norm(dim=-1, keepdim=True).clamp_min(1e-3) * torch.from_numpy(hash_uniform((n, 1), seed + 2, 0.2, 5.0))
+    d = torch.from_numpy(hash_uniform((n, 3), seed + 3)) * 1.5 - o
+    d = d / d.norm(dim=-1, keepdim=True).clamp_min(1e-3) * (1.0 + 0.2 * torch.from_numpy(hash_uniform((n, 1), seed + 4)))
+    target = torch.from_numpy(hash_uniform((n, 3), seed + 6, 0.0, 1.0))
+    rays = rf.Rays(o.to(dev), d.to(dev))
+    dc, fc = dens.clone().requires_grad_(True), feat.clone().requires_grad_(True)
+    if what == "single":
+        diffuse = bool(rng.integers(2))
+        cfg = rf.SHVoxGridRenderConfig(S, rf.CameraBounds(near, far), perturb_sampled_points=False, optimized_sampling=opt, white_bkgd=white, render_diffuse=diffuse)
+        outs = [rh.render_sh_voxel_grid_hip(grid, rays, cfg)]
+        refs = [orc.render(dc, fc, o, d, aabb, near, far, S, rho, mode, white_bkgd=white, render_diffuse=diffuse, optimized_sampling=opt)]
+    else:
+        cfg = rf.SHVoxGridRenderConfig(S, rf.CameraBounds(near, far), perturb_sampled_points=False, optimized_sampling=opt, white_bkgd=white)
+        outs = list(rh.render_sh_voxel_grid_pair_hip(grid, rays, cfg))
+        refs = [orc.render(dc, fc, o, d, aabb, near, far, S, rho, mode, white_bkgd=white, render_diffuse=df, optimized_sampling=opt) for df in (False, True)]
+    # (the pair procedure back-propagates the two colours only -- the trainer's use -- and says so when anything else carries a gradient)
+    if what == "single":
+        (torch.nn.functional.l1_loss(outs[0].colour, target.to(dev)) + 0.1 * outs[0].depth.mean()).backward()
+        (torch.nn.functional.l1_loss(refs[0]["colour"], target) + 0.1 * refs[0]["depth"].mean()).backward()
+    else:
+        sum(torch.nn.functional.l1_loss(x.colour, target.to(dev)) for x in outs).backward()
+        sum(torch.nn.functional.l1_loss(r_["colour"], target) for r_ in refs).backward()
+    for x, r_ in zip(outs, refs):
+        zmax = max(far, float(r_["depth"].detach().abs().max()))
+        np.testing.assert_allclose(cpu(x.colour), r_["colour"].detach().numpy(), rtol=0, atol=TOL, err_msg=desc)
+        np.testing.assert_allclose(cpu(x.depth), r_["depth"].detach().numpy(), rtol=0, atol=2 * TOL * max(1.0, zmax / 6.6), err_msg=desc)
+    for ours, refg in ((grid.densities.grad, dc.grad), (grid.features.grad, fc.grad)):
+        assert ours is not None, desc + ": no gradient arrived at the module's Parameters"
+        np.testing.assert_allclose(cpu(ours), refg.numpy(), rtol=5e-4, atol=5e-6 * max(float(refg.abs().max()), 1e-12), err_msg=desc)
+    return desc
+
+
 def case_seed(run_seed: int, i: int) -> int:
     return run_seed * 1000003 + i * 7919
 
@@ -439,7 +568,7 @@ def run_case(run_seed: int, i: int, kind: str, dev, mode: str = "") -> str:
     if kind == "all":
         kind = "rays" if i % 2 == 0 else "frames"
     try:
-        return {"rays": case_rays, "frames": case_frames, "train": case_train, "misc": case_misc, "composed": case_composed}[kind](rng, dev, seed)
+        return {"rays": case_rays, "frames": case_frames, "train": case_train, "misc": case_misc, "composed": case_composed, "binding": case_binding}[kind](rng, dev, seed)
     finally:
         FORCE_MODE = ""
 

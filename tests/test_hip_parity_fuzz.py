@@ -45,6 +45,13 @@ def test_randomised_composed_renders(hip_device):
         parity_fuzz.run_case(71, i, "composed", hip_device)
 
 
+def test_randomised_renders_through_the_reference_side_binding(hip_device):
+    """integration/renderers_hip.py -- the file a maintainer adds to the reference -- on a module that has exactly the reference VoxelGrid's
+    attributes: the render procedure, the pair procedure and the frame entry in random set-ups (both adjoint policies), against the oracle."""
+    for i in range(60):
+        parity_fuzz.run_case(101, i, "binding", hip_device)
+
+
 @pytest.mark.parametrize("cases", [list(range(0, 24)), [28, 33, 49, 73, 222, 229, 257, 316, 364, 376]], ids=["first-24", "found"])
 def test_rays_of_255_to_5000_samples(hip_device, cases):
     """Sample counts around the kernels' internal group sizes (64-sample chunks, 64 chunk masks = 4096 samples per mask group) and at
