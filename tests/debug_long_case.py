@@ -1,7 +1,7 @@
-"""debug aid: one "long" ray case of tests/parity_fuzz.py, per-ray errors against the float64 oracle, with switches"""
+"""debug aid (test infrastructure: it calls the oracle; run on a GPU box as `python tests/debug_long_case.py <run seed> <case>`): one "long" ray case of tests/parity_fuzz.py, per-ray errors against the float64 oracle, with switches"""
 import os, sys
 import numpy as np, torch
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))  # (repo root)
 import thr3ed_atom_amd as rf
 from oracle import relu_field_oracle as orc
 from tests import parity_fuzz as pf

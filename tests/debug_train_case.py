@@ -1,7 +1,7 @@
-"""debug aid: gradients of the first iteration of a tests/parity_fuzz.py train case -- HIP vs the float32 oracle vs the float64 oracle"""
+"""debug aid (test infrastructure: it calls the oracle; run on a GPU box as `python tests/debug_train_case.py <run seed> <case>`): gradients of the first iteration of a tests/parity_fuzz.py train case -- HIP vs the float32 oracle vs the float64 oracle"""
 import os, sys
 import numpy as np, torch
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))  # (repo root)
 import thr3ed_atom_amd as rf
 from thr3ed_atom_amd import ops
 from oracle import relu_field_oracle as orc

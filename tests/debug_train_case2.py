@@ -1,7 +1,7 @@
-"""debug aid: replay a tests/parity_fuzz.py train case step by step (parameters after each iteration vs the oracle + torch Adam)"""
+"""debug aid (test infrastructure: it calls the oracle; run on a GPU box as `python tests/debug_train_case2.py <run seed> <case>`): replay a tests/parity_fuzz.py train case step by step (parameters after each iteration vs the oracle + torch Adam)"""
 import os, sys
 import numpy as np, torch
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))  # (repo root)
 import thr3ed_atom_amd as rf
 from oracle import relu_field_oracle as orc
 from tests import parity_fuzz as pf

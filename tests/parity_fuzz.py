@@ -1,5 +1,9 @@
-"""Randomised parity sweep of the HIP path against the oracle (GPU box): python tools/fuzz_parity.py [--cases N] [--seed S] [--kind rays|frames|all]
-(the case generators live here so that tests/test_hip_parity_fuzz.py can replay a fixed set; tools/fuzz_parity.py is the command line)
+"""Randomised parity sweep of the HIP path against the oracle -- test infrastructure (it calls the oracle), on a GPU box:
+
+    python -m tests.parity_fuzz [--cases N] [--seed S] [--kind rays|frames|train|misc|composed|binding|long|longframes|longtrain|all]
+                                [--mode relu|softplus|abs] [--only i,j,...] [--verbose]
+
+tests/test_hip_parity_fuzz.py replays a fixed set of its cases.
 
 Every case draws a configuration the parametrised tests do not enumerate -- grid dims 2..22 per axis (also below the packet
 kernel's 4-node minimum), anisotropic voxels, off-centre location, SH degree, density mode, storage, diffuse / AABB sampling /
@@ -178,7 +182,7 @@ def case_train(rng, dev, seed):
     dens, feat = procedural_grid(dims, F, seed % 100000)
     n = int(rng.choice([1, 3, 37, 64, 130, 257]))
     # (not fewer than 17 samples here: with 2 or 3 the 1e10-long last interval often lies inside the volume and the float32 forward
-    # rounding of the REFERENCE itself shows as 1e-4 relative noise on small gradients -- tools/debug_train_case.py: HIP and the float32
+    # rounding of the REFERENCE itself shows as 1e-4 relative noise on small gradients -- tests/debug_train_case.py: HIP and the float32
     # oracle are equally far from the float64 oracle there -- which Adam's normalised update turns into parameter differences above the
     # allowance below; that regime is held to the gradient bar by the ray cases and golden G13)
     S = int(rng.choice([17, 33, 40, 64, 70]))

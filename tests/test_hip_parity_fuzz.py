@@ -1,4 +1,4 @@
-"""A fixed replay of the randomised parity sweep (tests/parity_fuzz.py; `python tools/fuzz_parity.py` runs it open-ended): configurations
+"""A fixed replay of the randomised parity sweep (tests/parity_fuzz.py; `python -m tests.parity_fuzz` runs it open-ended): configurations
 the parametrised tests do not enumerate -- grid dims 2..22 per axis, anisotropic voxels, off-centre grids, every SH degree / density
 mode / storage, 1..150 samples, rays that start inside the volume, odd frame sizes, either frame kernel, the occupancy mask, either
 adjoint -- against the oracle at the bars of tests/test_hip_parity.py.
