@@ -171,7 +171,9 @@ int rf_cast_rays(int32_t height, int32_t width, float focal, const float* rotati
  * staged through LDS once per sample index), 0 = one wavefront per ray; negative = error code.  The packet kernel is chosen where a
  * tile's footprint at the volume's centre stays within 2 voxels (3 with RF_FLAG_OCCUPANCY_SKIP and a mask), on split / bricked
  * storage with a 16-byte aligned base tensor, every SH degree, keyed jitter or none (a frame with a jitter TABLE goes to the per-ray
- * kernel); $RF_FRAME_TILES = 1 / 0 in the environment forces / forbids it.  Both kernels compute a pixel with the
+ * kernel) and at most 1024 samples per ray (this function does not see the sample count: a frame of more goes to the per-ray kernel
+ * whatever it answers -- a packet lane adds a ray's samples sequentially, and that float32 sum drifts past the parity bar at 4096+);
+ * $RF_FRAME_TILES = 1 / 0 in the environment forces / forbids it within these rules.  Both kernels compute a pixel with the
  * same per-sample arithmetic and differ in the order a ray's weighted samples are added (<= 2e-6 on colours).  Host-side only: no
  * device access.  (Added to ABI version 4 compatibly: no existing struct or signature changed.) */
 int rf_frame_render_kernel(const RFGrid* grid, const RFCamera* camera, uint32_t flags);

@@ -64,6 +64,15 @@ def test_rays_of_255_to_5000_samples(hip_device, cases):
         parity_fuzz.run_case(42, i, "long", hip_device)
 
 
+def test_frames_of_256_to_5000_samples(hip_device):
+    """Frames at high sample counts through either frame kernel (float64-anchored bar).  A packet lane adds its ray's weighted samples
+    one after the other; at 4096+ samples that sequential float32 sum drifts 3..8e-5 on depth where torch.sum's pairwise order keeps
+    the reference within 2e-6, so frames of more than 1024 samples per ray are dispatched to the per-ray kernel (the cases that showed
+    it are among these)."""
+    for i in [154, 320, 349, 397, 445, 469, 619] + list(range(0, 16)):
+        parity_fuzz.run_case(201, i, "longframes", hip_device)
+
+
 @pytest.mark.parametrize("run_seed,i,kind,mode", [(1, 138, "all", ""), (1, 268, "all", ""), (1, 284, "all", ""), (1, 292, "all", ""), (2, 251, "rays", "softplus")])
 def test_last_sample_inside_the_volume_softplus_density_gradient(hip_device, run_seed, i, kind, mode):
     desc = parity_fuzz.run_case(run_seed, i, kind, hip_device, mode)

@@ -4194,6 +4194,7 @@ static int brick_geometry(const RFGrid* grid, int brick_size, int* shift, int nb
 // (1.3 voxels) 1.78 against 2.80 ms; 256^3 / 512 samples (2.6 voxels) 1.70 against 2.05 ms with the mask, 3.12 against 2.90 ms without.
 // The packet kernel exists for split / bricked storage (a grid in the reference's tensors is rendered from its split shadow), every SH degree.  $RF_FRAME_TILES = 1 / 0 forces /
 // forbids it where it exists (A/B runs, tests).
+constexpr int kTileMaxSamples = 1024;  // (the reference's default render_num_samples_per_ray: the largest count the sweep holds the packet kernel to the bar at)
 static bool frame_uses_packets(const RFGrid* grid, const GridArgs& g, const RFCamera* cam, uint32_t flags) {
   const int K = grid->num_features / 3;
   if (!(g.layout == RF_LAYOUT_SPLIT && (K == 1 || K == 4 || K == 9 || K == 16) && g.Z >= 4 && g.Y >= 4 && g.X >= 4 && (g.dstride & 3) == 0 && (K != 9 || (g.fstride & 3) == 0))) return false;
@@ -4250,7 +4251,10 @@ int rf_render_forward(const RFGrid* grid, const RFRayBatch* rays, uint32_t flags
   const int K = grid->num_features / 3;
   // frames of a posed camera (rays generated in-kernel, inference only): ray packets where frame_uses_packets() says so
   if (rays->camera && !save) {
-    const bool tiles = !rays->t_rand_dev && frame_uses_packets(grid, g, rays->camera, flags);
+    // (a packet lane adds its ray's weighted samples one after the other; beyond kTileMaxSamples samples per ray that sequential float32
+    // sum drifts past the parity bar -- 3..8e-5 on depth at 4096+ samples, where torch.sum's pairwise order keeps the reference within
+    // 2e-6 -- so such frames go to the per-ray kernel, whose per-lane sums are 64 times shorter, whatever $RF_FRAME_TILES says)
+    const bool tiles = !rays->t_rand_dev && rays->num_samples <= kTileMaxSamples && frame_uses_packets(grid, g, rays->camera, flags);
     if (tiles) {
       const int W = rays->camera->width;
       const int row0 = (int)(rays->first_ray / W), row1 = (int)((rays->first_ray + rays->num_rays - 1) / W);
