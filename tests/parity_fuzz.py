@@ -26,6 +26,7 @@ from tests.helpers import hash_uniform, procedural_grid  # noqa: E402
 TOL = 1e-5
 FORCE_MODE = ""
 LONG_RAYS = False
+BIG_GRIDS = False
 ACTS = {"relu": (torch.nn.Identity(), torch.nn.ReLU()), "softplus": (torch.nn.Identity(), torch.nn.Softplus()), "abs": (torch.abs, torch.nn.Identity())}
 
 
@@ -171,6 +172,8 @@ def case_train(rng, dev, seed):
     from thr3ed_atom_amd.trainers import TrainStepper
 
     dims = tuple(int(rng.integers(4, 21)) for _ in range(3))
+    if BIG_GRIDS:  # many bricks per axis, partial bricks on every axis: the (brick, flags) key ranges of the binned adjoint
+        dims = tuple(int(rng.integers(4, 73)) for _ in range(3))
     deg = int(rng.integers(0, 4))
     mode = str(rng.choice(["relu", "relu", "softplus", "abs"]))
     if FORCE_MODE:
@@ -562,8 +565,11 @@ def case_seed(run_seed: int, i: int) -> int:
 
 def run_case(run_seed: int, i: int, kind: str, dev, mode: str = "") -> str:
     """case i of the run: its description; raises AssertionError on a parity miss (kind "long" = ray cases with 255..5000 samples)"""
-    global FORCE_MODE, LONG_RAYS
+    global FORCE_MODE, LONG_RAYS, BIG_GRIDS
     FORCE_MODE = mode
+    BIG_GRIDS = kind == "bigtrain"
+    if BIG_GRIDS:
+        kind = "train"
     LONG_RAYS = kind in ("long", "longframes", "longtrain")
     if LONG_RAYS:
         kind = {"long": "rays", "longframes": "frames", "longtrain": "train"}[kind]

@@ -27,6 +27,8 @@ def test_randomised_training_iterations(hip_device):
     the oracle's autograd + torch.optim.Adam."""
     for i in range(40):
         parity_fuzz.run_case(11, i, "train", hip_device)
+    for i in range(12):  # grids of up to 72 nodes per axis: many bricks, partial ones on every axis
+        parity_fuzz.run_case(301, i, "bigtrain", hip_device)
 
 
 def test_randomised_small_entry_points(hip_device):
