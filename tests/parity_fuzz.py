@@ -393,6 +393,9 @@ def case_composed(rng, dev, seed):
     dens, feat = procedural_grid(dims, F, seed % 100000)
     n = int(rng.integers(1, 300))
     S = int(rng.choice([2, 3, 17, 40, 64, 65, 128]))
+    if LONG_RAYS:
+        n = int(rng.integers(1, 24))
+        S = int(rng.choice([256, 1000, 1024, 4096, 5000]))
     o = torch.from_numpy(hash_uniform((n, 3), seed + 1))
     o = o / o.norm(dim=-1, keepdim=True).clamp_min(1e-3) * torch.from_numpy(hash_uniform((n, 1), seed + 2, 0.2, 5.0))
     d = torch.from_numpy(hash_uniform((n, 3), seed + 3)) * 1.5 - o
@@ -420,9 +423,17 @@ def case_composed(rng, dev, seed):
     ref_loss.backward()
     cpu = lambda t: t.detach().cpu().numpy()
     zmax = max(far, float(ref["depth"].detach().abs().max()))
-    np.testing.assert_allclose(cpu(out.colour), ref["colour"].detach().numpy(), rtol=0, atol=TOL, err_msg=desc)
-    np.testing.assert_allclose(cpu(out.depth), ref["depth"].detach().numpy(), rtol=0, atol=2 * TOL * max(1.0, zmax / 6.6), err_msg=desc)
-    np.testing.assert_allclose(cpu(out.extra["accumulated_weight"]), ref["acc"].detach().numpy(), rtol=0, atol=TOL, err_msg=desc)
+    if LONG_RAYS:  # the float64-anchored rule (see case_rays)
+        r64 = orc.render(dens.double(), feat.double(), o.double(), d.double(), orc.make_aabb(dims, voxel, loc), near, far, S, rho, mode, white_bkgd=white,
+                         render_diffuse=diffuse, optimized_sampling=opt, t_rand=None if t_rand is None else t_rand.double())
+        for name, ours, bar in (("colour", out.colour, TOL), ("depth", out.depth, 2 * TOL * max(1.0, zmax / 6.6)), ("acc", out.extra["accumulated_weight"], TOL)):
+            noise = float((ref[name].detach().double() - r64[name]).abs().max())
+            worst = float((ours.detach().cpu().double() - r64[name]).abs().max())
+            assert worst <= 3.0 * noise + bar, f"{desc}: {name} is {worst:.2e} from the float64 value; the float32 reference is {noise:.2e} from it"
+    else:
+        np.testing.assert_allclose(cpu(out.colour), ref["colour"].detach().numpy(), rtol=0, atol=TOL, err_msg=desc)
+        np.testing.assert_allclose(cpu(out.depth), ref["depth"].detach().numpy(), rtol=0, atol=2 * TOL * max(1.0, zmax / 6.6), err_msg=desc)
+        np.testing.assert_allclose(cpu(out.extra["accumulated_weight"]), ref["acc"].detach().numpy(), rtol=0, atol=TOL, err_msg=desc)
     gd, gf = grid.reference_gradients()
     gd_ref, gf_ref = dc.grad.numpy(), fc.grad.numpy()
     np.testing.assert_allclose(cpu(gd), gd_ref, rtol=5e-4, atol=5e-6 * max(np.abs(gd_ref).max(), 1e-12), err_msg=desc)
@@ -570,9 +581,9 @@ def run_case(run_seed: int, i: int, kind: str, dev, mode: str = "") -> str:
     BIG_GRIDS = kind == "bigtrain"
     if BIG_GRIDS:
         kind = "train"
-    LONG_RAYS = kind in ("long", "longframes", "longtrain")
+    LONG_RAYS = kind in ("long", "longframes", "longtrain", "longcomposed")
     if LONG_RAYS:
-        kind = {"long": "rays", "longframes": "frames", "longtrain": "train"}[kind]
+        kind = {"long": "rays", "longframes": "frames", "longtrain": "train", "longcomposed": "composed"}[kind]
     seed = case_seed(run_seed, i)
     rng = np.random.default_rng(seed)
     if kind == "all":

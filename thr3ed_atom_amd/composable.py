@@ -171,13 +171,19 @@ def accumulate_radiance_density_on_rays(processed_points: ProcessedPointsOnRays,
     step = torch.cat([z[..., 1:] - z[..., :-1], torch.full_like(z[..., :1], INFINITY)], dim=-1) * rays.directions.norm(dim=-1, keepdim=True)
     noise = torch.randn(sigma.shape, dtype=sigma.dtype, device=sigma.device) * stochastic_density_noise_std if density_noise is None else density_noise
     alpha = density2occupancy(sigma + noise, step)
-    through = torch.cumprod(torch.cat([torch.ones_like(alpha[:, :1]), 1.0 - alpha], dim=-1), dim=-1)[:, :-1]  # transmittance in front of each sample
+    # transmittance in front of each sample.  The reference's torch.cumprod / torch.sum run on the CPU there: a sequential product and
+    # pairwise sums.  On the device torch scans and reduces in another order, whose float32 roundings are coherent where the density
+    # varies slowly -- 3..6e-5 on depth at 4096+ samples per ray against the CPU reference (tests/parity_fuzz.py, kind "longcomposed") --
+    # so the scan and the three reductions are carried in float64 and rounded once (the products and sums of the float32 per-sample
+    # values: as close to the reference's own float32 results as those are to the exact ones)
+    wide = torch.float64 if alpha.dtype == torch.float32 else alpha.dtype
+    through = torch.cumprod(torch.cat([torch.ones_like(alpha[:, :1]), 1.0 - alpha], dim=-1).to(wide), dim=-1)[:, :-1].to(alpha.dtype)
     weights = alpha * through
-    colour = (radiance_hdr_tone_map(raw_radiance) * weights[..., None]).sum(dim=-2)
-    acc = weights.sum(dim=-1, keepdim=True)
+    colour = (radiance_hdr_tone_map(raw_radiance) * weights[..., None]).sum(dim=-2, dtype=wide).to(alpha.dtype)
+    acc = weights.sum(dim=-1, keepdim=True, dtype=wide).to(alpha.dtype)
     if white_bkgd:
         colour = colour + (1 - acc)
-    depth = (z * weights).sum(dim=-1, keepdim=True)
+    depth = (z * weights).sum(dim=-1, keepdim=True, dtype=wide).to(alpha.dtype)
     disparity = 1.0 / torch.maximum(torch.full_like(acc, ZERO_PLUS), depth / acc)
     extra = {EXTRA_DISPARITY: disparity, EXTRA_ACCUMULATED_WEIGHTS: acc}
     if extra_debug_info:
