@@ -1,4 +1,4 @@
-for rep in 1 2 3; do for lib in tools/exp_old.so tools/exp_new.so; do
+for rep in 1 2 3; do for lib in ${AB_LIBS:-tools/exp_old.so tools/exp_new.so}; do
 RF_LIB_PATH=$PWD/$lib python bench.py --steps 20 --warmup 5 --cpu-rays 0 --dropin-steps 0 --render-frames 8 --highres-frames 4 --windows 0 --second-point-rays 0 --train256-steps 0 2>/dev/null | python -c "
 import json,sys
 l=json.loads([x for x in sys.stdin if x.startswith('{')][0])
