@@ -1246,20 +1246,6 @@ constexpr int kTileSlots = (3 * kTileXS + 16 + 3) / 4 * 4;  // (whole multiples 
 // slot of the node lane 16 x + 4 y + z loads: lane + x (kTileXS - 16).  (Written out at its three uses: as a function the same expression
 // sends the K = 9 instantiation from 2 to 34 spilled registers -- the kernel sits on its 128-register budget.)
 #define RF_TILE_SLOT(lane) ((lane) + ((lane) >> 4) * (kTileXS - 16))
-__device__ __forceinline__ int wave_min_i32(int x) {
-  auto step = [](int v, auto ctrl_tag, auto mask_tag) {
-    constexpr int CTRL = decltype(ctrl_tag)::value, MASK = decltype(mask_tag)::value;
-    return min(v, __builtin_amdgcn_update_dpp(v, v, CTRL, MASK, 0xf, false));
-  };
-  x = step(x, std::integral_constant<int, kDppRowShr1>{}, std::integral_constant<int, 0xf>{});
-  x = step(x, std::integral_constant<int, kDppRowShr2>{}, std::integral_constant<int, 0xf>{});
-  x = step(x, std::integral_constant<int, kDppRowShr4>{}, std::integral_constant<int, 0xf>{});
-  x = step(x, std::integral_constant<int, kDppRowShr8>{}, std::integral_constant<int, 0xf>{});
-  x = step(x, std::integral_constant<int, kDppRowBcast15>{}, std::integral_constant<int, 0xa>{});
-  x = step(x, std::integral_constant<int, kDppRowBcast31>{}, std::integral_constant<int, 0xc>{});
-  return __builtin_amdgcn_readlane(x, kWave - 1);
-}
-
 // a lane's cell in (clamped) node coordinates -- corners_of's rules: lower node c0, step e to the upper node (0 where clamping
 // collapses the two), the 8 trilinear weights with out-of-grid nodes forced to 0
 struct TileCell {
@@ -2767,7 +2753,6 @@ __device__ __forceinline__ void lds_request_f32(float& v, uint32_t addr) {
 __device__ __forceinline__ void lds_request_u8(uint32_t& v, uint32_t addr) {
   asm volatile("ds_read_u8 %0, %1" : "+v"(v) : "v"(addr));
 }
-__device__ __forceinline__ void lds_wait(uint32_t& a) { asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a)); }
 __device__ __forceinline__ void lds_wait(uint32_t& a, uint32_t& b) { asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a), "+v"(b)); }
 __device__ __forceinline__ void lds_wait(float& a, float& b, float& c, float& d, float& e, uint32_t& f) {
   asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a), "+v"(b), "+v"(c), "+v"(d), "+v"(e), "+v"(f));
@@ -2782,9 +2767,8 @@ constexpr int kGatherBatch = 256;  // records per batch (their indices travel as
 constexpr int kGatherWtab = 24;    // rows of the weight table: 3 axes x local node coordinate 0..7
 // Bank conflicts are what bounds the tile loop (6 LDS reads per instruction): table rows are kGatherBatch + 4 words apart, so that
 // the 2 (x, y) or 4 (z) rows the lanes of one record read, and those of the neighbouring record indices of the same instruction,
-// fall into different banks; record rows are padded by two quads (36 / 12 words), so that the four records of an instruction do
-// not all start in the same two bank groups.
-constexpr int kGatherRow = kGatherBatch + 4;
+// fall into different banks (GROW in the kernel); record rows are padded by two quads (36 / 12 words), so that the four records of an
+// instruction do not all start in the same two bank groups.
 // words of a record's row of per-channel values in LDS (C4 = channels rounded up to whole quads)
 __host__ __device__ constexpr int gather_record_words(int C4) { return C4 + 8; }
 typedef float f32x4 __attribute__((ext_vector_type(4)));
